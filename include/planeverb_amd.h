@@ -1,0 +1,186 @@
+/* planeverb_amd.h -- C-ABI of libplaneverb_amd.so (MI355X / gfx950 build of Planeverb's FDTD + IR-analysis path)
+ *
+ * Part 1 is the reference's own flat C-ABI, symbol for symbol -- the functions Unity P/Invokes from
+ * ProjectPlaneverbUnityPlugin (reference: ProjectPlaneverb/PlaneverbUnityPluginAPI/PlaneverbUnity.cpp:12-135,
+ * C# mirror PlaneverbContext.cs:25-60).  A build of the Acoustics module that loads this library instead of
+ * ProjectPlaneverbUnityPlugin.dll needs no source change; pass threadExecutionType = 1 (pv_GPU, the value the
+ * C# enum already defines, PlaneverbConfig.cs:23-29) -- this library has no CPU path and fails loudly without a
+ * HIP device.
+ *
+ * Part 2 (PvAmd*) is an extension: a handle-based, synchronous batch interface to the same solver, used by the
+ * benchmarks, the parity tests and the multi-GPU sharding layer.  It replaces nothing in the reference; it exposes
+ * what the reference's classes Grid / FreeGrid / Analyzer expose to its own Context (PvContext.cpp:63-94).
+ *
+ * Plain C types only.  No C++ exception crosses this boundary: errors are reported by return code
+ * (0 = ok) and PvAmdLastError().
+ */
+#ifndef PLANEVERB_AMD_H
+#define PLANEVERB_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define PVA_EXPORT __attribute__((visibility("default")))
+#else
+#define PVA_EXPORT
+#endif
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Part 1 -- reference C-ABI
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* PlaneverbUnity.cpp:66-76 (returned BY VALUE, 8 floats) */
+typedef struct PlaneverbOutput {
+    float occlusion;        /* dry/obstruction gain; -1 (PV_INVALID_DRY_GAIN) = invalid, PvTypes.h:80 */
+    float wetGain;
+    float rt60;
+    float lowpass;
+    float directionX;
+    float directionY;
+    float sourceDirectionX;
+    float sourceDirectionY;
+} PlaneverbOutput;
+
+/* PlaneverbUnity.cpp:12-20 (no-ops) */
+PVA_EXPORT void UnityPluginLoad(void* unityInterfaces);
+PVA_EXPORT void UnityPluginUnload(void);
+
+/* PlaneverbUnity.cpp:25-40 -> Planeverb::Init (PvContext.cpp:25-32).  Invalid config (res < 275, size 0,
+ * tempFileDir NULL: PvContext.cpp:101-107) leaves the module un-initialised instead of throwing. */
+PVA_EXPORT void PlaneverbInit(float gridSizeX, float gridSizeY, int gridResolution, int gridBoundaryType,
+                              char* tempFileDir, int maxThreadUsage, int threadExecutionType);
+/* PlaneverbUnity.cpp:42-46 */
+PVA_EXPORT void PlaneverbExit(void);
+/* PlaneverbUnity.cpp:48-52 ; -1 when the module is not initialised (EmissionManager.cpp:13) */
+PVA_EXPORT int PlaneverbEmit(float x, float y, float z);
+/* PlaneverbUnity.cpp:54-58 */
+PVA_EXPORT void PlaneverbUpdateEmission(int id, float x, float y, float z);
+/* PlaneverbUnity.cpp:60-64 */
+PVA_EXPORT void PlaneverbEndEmission(int id);
+/* PlaneverbUnity.cpp:78-92 -> Planeverb::GetOutput (FDTD.cpp:16-58); wait-free, O(1) */
+PVA_EXPORT PlaneverbOutput PlaneverbGetOutput(int emissionID);
+/* PlaneverbUnity.cpp:94-107 ; -1 when not initialised (GeometryManager.cpp:20) */
+PVA_EXPORT int PlaneverbAddGeometry(float posX, float posY, float width, float height, float absorption);
+/* PlaneverbUnity.cpp:109-123 */
+PVA_EXPORT void PlaneverbUpdateGeometry(int id, float posX, float posY, float width, float height,
+                                        float absorption);
+/* PlaneverbUnity.cpp:125-129 */
+PVA_EXPORT void PlaneverbRemoveGeometry(int id);
+/* PlaneverbUnity.cpp:131-135 */
+PVA_EXPORT void PlaneverbSetListenerPosition(float x, float y, float z);
+
+/* Extensions to the live module (not in the reference ABI) */
+/* Load a .pv scene (PlaneverbSandbox/src/Editor/Editor.cpp:245-281) into the live module; returns #boxes or <0 */
+PVA_EXPORT int PlaneverbLoadScene(const char* pvPath);
+/* Number of completed simulation iterations since Init (an iteration = FDTD + analysis, PvContext.cpp:74-93) */
+PVA_EXPORT long long PlaneverbIterationCount(void);
+/* Block until at least `count` iterations have completed, or timeoutMs elapsed; returns the iteration count */
+PVA_EXPORT long long PlaneverbWaitIterations(long long count, int timeoutMs);
+/* 1 if the module is initialised */
+PVA_EXPORT int PlaneverbIsRunning(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Part 2 -- batch solver handle (extension)
+ * ---------------------------------------------------------------------------------------------------------- */
+
+typedef struct PvAmdSolver PvAmdSolver;
+
+typedef struct PvAmdInfo {
+    int gx, gy;             /* (int)m_gridSize: result map is gx*gy, cell array (gx+1)*(gy+1)  (Grid.cpp:48-53) */
+    int T;                  /* response length in samples (Grid.cpp:55) */
+    int fs;                 /* sampling rate (Grid.cpp:390-396) */
+    int res;
+    float dx, dt;
+    float efree;            /* FreeGrid energy at 1 m (FreeGrid.cpp:71-94) */
+    int device;
+    int stepsPerLaunch;     /* K: time steps fused per kernel launch */
+    int tileRows, tileCols; /* interior cells per wave tile */
+    int pitch, rows;        /* padded device array geometry (floats per row, rows) */
+    int histRows, histPitch;/* history window geometry */
+    int numGeometry;
+    long long deviceBytes;  /* bytes of HBM held by this solver */
+} PvAmdInfo;
+
+typedef struct PvAmdTimings {
+    float fdtdMs;           /* HIP-event time of the T-step loop (incl. IR record) of the last run */
+    float analysisMs;       /* HIP-event time of both analysis kernels of the last run */
+    float geometryMs;       /* material upload + face-code build, last time it ran */
+    float stepKernelMs;     /* fdtdMs / number of step launches */
+    int stepLaunches;
+    long long histBytesWritten; /* bytes of pr history written by the last run */
+} PvAmdTimings;
+
+/* option keys for PvAmdSetOption (must be set before the first run) */
+enum {
+    PVA_OPT_DENSE_HISTORY = 1, /* 1 = record every tile every step (no zero-tile skipping) */
+    PVA_OPT_NUM_STEPS = 2,     /* override T (extension); 0 = reference value */
+    PVA_OPT_SKIP_ANALYSIS = 3, /* 1 = PvAmdRun does the FDTD loop only */
+    PVA_OPT_USE_GRAPH = 4,     /* 1 = replay the T-step loop from a captured hipGraph */
+    PVA_OPT_STEPS_PER_LAUNCH = 5, /* K: time steps fused per kernel launch (tuning) */
+    PVA_OPT_TILE_ROWS = 6,     /* interior rows of a wave tile (tuning; must pair with a compiled K) */
+    PVA_OPT_NO_FREE_GRID = 7   /* 1 = skip the free-field run (efree = 0; stencil-only use) */
+};
+
+PVA_EXPORT int PvAmdDeviceCount(void);
+PVA_EXPORT const char* PvAmdLastError(void);
+PVA_EXPORT const char* PvAmdVersion(void);
+
+/* Create the grid for a config (Grid::Grid, Grid.cpp:30-117, + FreeGrid, FreeGrid.cpp:6-34) on HIP device
+ * `device`.  PlaneverbCreateGrid is the same function under the name BASELINE.json uses. */
+PVA_EXPORT PvAmdSolver* PvAmdCreate(float gridSizeX, float gridSizeY, int gridResolution, int device);
+PVA_EXPORT PvAmdSolver* PlaneverbCreateGrid(float gridSizeX, float gridSizeY, int gridResolution, int device);
+PVA_EXPORT void PvAmdDestroy(PvAmdSolver* s);
+PVA_EXPORT int PvAmdSetOption(PvAmdSolver* s, int key, long long value);
+PVA_EXPORT int PvAmdGetInfo(PvAmdSolver* s, PvAmdInfo* out);
+
+/* Geometry (Grid::AddAABB / RemoveAABB / UpdateAABB, Grid.cpp:136-303); applied before the next run */
+PVA_EXPORT int PvAmdAddGeometry(PvAmdSolver* s, float posX, float posY, float width, float height,
+                                float absorption);
+PVA_EXPORT int PvAmdUpdateGeometry(PvAmdSolver* s, int id, float posX, float posY, float width, float height,
+                                   float absorption);
+PVA_EXPORT int PvAmdRemoveGeometry(PvAmdSolver* s, int id);
+PVA_EXPORT int PvAmdLoadScene(PvAmdSolver* s, const char* pvPath);
+/* Write the current boxes as a .pv file (Editor.cpp:219-243) */
+PVA_EXPORT int PvAmdSaveScene(PvAmdSolver* s, const char* pvPath);
+
+/* One iteration of the reference's background loop (PvContext.cpp:80-83): GenerateResponse + AnalyzeResponses
+ * for a listener position; synchronous. */
+PVA_EXPORT int PvAmdRun(PvAmdSolver* s, float lx, float ly, float lz);
+/* Enqueue the same work on the solver's stream without waiting; PvAmdSync waits. */
+PVA_EXPORT int PvAmdRunAsync(PvAmdSolver* s, float lx, float ly, float lz);
+PVA_EXPORT int PvAmdSync(PvAmdSolver* s);
+PVA_EXPORT int PvAmdGetTimings(PvAmdSolver* s, PvAmdTimings* out);
+
+/* Analyzer::GetResponseResult + Planeverb::GetOutput (Analyzer.cpp:106-116, FDTD.cpp:16-58) */
+PVA_EXPORT int PvAmdGetOutput(PvAmdSolver* s, float ex, float ey, float ez, PlaneverbOutput* out);
+/* Whole result map: res8 = gx*gy*8 floats in AnalyzerResult order (Analyzer.h:13-21), delay = gx*gy */
+PVA_EXPORT int PvAmdCopyResults(PvAmdSolver* s, float* res8, float* delay);
+/* Planeverb::GetImpulseResponse (FDTD.cpp:60-70): T x {pr, vx, vy} at array cell (cx, cy) */
+PVA_EXPORT int PvAmdGetImpulseResponse(PvAmdSolver* s, int cx, int cy, float* out3T);
+/* Final fields of the last run, (gx+1)*(gy+1) each, reference order (x*(gy+1)+y) */
+PVA_EXPORT int PvAmdCopyFields(PvAmdSolver* s, float* pr, float* vx, float* vy);
+/* Recorded pressure plane of step t (zeros where the history was provably zero and not stored) */
+PVA_EXPORT int PvAmdCopyHistoryPlane(PvAmdSolver* s, int t, float* pr);
+/* Gaussian pulse table (Grid.cpp:12-27), T floats */
+PVA_EXPORT int PvAmdCopyPulse(PvAmdSolver* s, float* out);
+/* Material planes after rasterisation: beta (uint8) and R (float), (gx+1)*(gy+1) each */
+PVA_EXPORT int PvAmdCopyMaterial(PvAmdSolver* s, uint8_t* beta, float* R);
+/* Overwrite the fields the NEXT PvAmdRunSteps starts from (test / benchmark hook; reference order) */
+PVA_EXPORT int PvAmdSetFields(PvAmdSolver* s, const float* pr, const float* vx, const float* vy);
+/* Advance `nsteps` time steps from the current fields without resetting them, without pulse when
+ * withPulse == 0 and without recording history: the raw stencil (used for roofline measurements and for
+ * linearity / equivalence property tests). */
+PVA_EXPORT int PvAmdRunSteps(PvAmdSolver* s, int nsteps, int withPulse, float lx, float lz);
+
+/* PlaneverbDSP reverb-bus split of wetGain by rt60 (PlaneverbDSP/src/PvDSPContext.cpp:165-228) */
+PVA_EXPORT void PvAmdReverbBusGains(float rt60, float wetGain, float* a, float* b, float* c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLANEVERB_AMD_H */

@@ -1,0 +1,342 @@
+"""ctypes binding of libplaneverb_amd.so -- the host-side mirror of Planeverb's interface for the FDTD path.
+
+Two layers, both thin:
+
+* module-level functions `Init / Exit / Emit / UpdateEmission / EndEmission / GetOutput / AddGeometry /
+  UpdateGeometry / RemoveGeometry / SetListenerPosition` with the names, argument meaning and sentinel behaviour of
+  the reference's C++ API (ProjectPlaneverb/include/Planeverb.h:12-47) on top of the flat C-ABI
+  (PlaneverbUnityPluginAPI/PlaneverbUnity.cpp:25-135);
+* `Solver`, the synchronous batch handle (PvAmd* extension) used by the benchmarks, the parity tests and the
+  multi-GPU sharding layer.
+
+There is no CPU implementation behind this module: if the shared library is missing it raises, and if no HIP device
+is visible every call that needs one fails loudly.
+"""
+import ctypes as C
+import os
+from collections import namedtuple
+
+import numpy as np
+
+from .build import LIB_PATH
+
+PV_INVALID_DRY_GAIN = -1.0
+PV_INVALID_ID = -1
+
+PVA_OPT_DENSE_HISTORY = 1
+PVA_OPT_NUM_STEPS = 2
+PVA_OPT_SKIP_ANALYSIS = 3
+PVA_OPT_USE_GRAPH = 4
+PVA_OPT_STEPS_PER_LAUNCH = 5
+PVA_OPT_TILE_ROWS = 6
+PVA_OPT_NO_FREE_GRID = 7
+
+
+class PlaneverbOutput(C.Structure):
+    """PlaneverbUnity.cpp:66-76"""
+    _fields_ = [("occlusion", C.c_float), ("wetGain", C.c_float), ("rt60", C.c_float), ("lowpass", C.c_float),
+                ("directionX", C.c_float), ("directionY", C.c_float), ("sourceDirectionX", C.c_float),
+                ("sourceDirectionY", C.c_float)]
+
+    def as_array(self):
+        return np.array([self.occlusion, self.wetGain, self.rt60, self.lowpass, self.directionX, self.directionY,
+                         self.sourceDirectionX, self.sourceDirectionY], np.float32)
+
+
+class PvAmdInfo(C.Structure):
+    _fields_ = [("gx", C.c_int), ("gy", C.c_int), ("T", C.c_int), ("fs", C.c_int), ("res", C.c_int),
+                ("dx", C.c_float), ("dt", C.c_float), ("efree", C.c_float), ("device", C.c_int),
+                ("stepsPerLaunch", C.c_int), ("tileRows", C.c_int), ("tileCols", C.c_int), ("pitch", C.c_int),
+                ("rows", C.c_int), ("histRows", C.c_int), ("histPitch", C.c_int), ("numGeometry", C.c_int),
+                ("deviceBytes", C.c_longlong)]
+
+
+class PvAmdTimings(C.Structure):
+    _fields_ = [("fdtdMs", C.c_float), ("analysisMs", C.c_float), ("geometryMs", C.c_float),
+                ("stepKernelMs", C.c_float), ("stepLaunches", C.c_int), ("histBytesWritten", C.c_longlong)]
+
+
+# every symbol include/planeverb_amd.h declares: name -> (restype, argtypes)
+_fp = C.POINTER(C.c_float)
+_vp = C.c_void_p
+SYMBOLS = {
+    "UnityPluginLoad": (None, [_vp]),
+    "UnityPluginUnload": (None, []),
+    "PlaneverbInit": (None, [C.c_float, C.c_float, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int]),
+    "PlaneverbExit": (None, []),
+    "PlaneverbEmit": (C.c_int, [C.c_float] * 3),
+    "PlaneverbUpdateEmission": (None, [C.c_int] + [C.c_float] * 3),
+    "PlaneverbEndEmission": (None, [C.c_int]),
+    "PlaneverbGetOutput": (PlaneverbOutput, [C.c_int]),
+    "PlaneverbAddGeometry": (C.c_int, [C.c_float] * 5),
+    "PlaneverbUpdateGeometry": (None, [C.c_int] + [C.c_float] * 5),
+    "PlaneverbRemoveGeometry": (None, [C.c_int]),
+    "PlaneverbSetListenerPosition": (None, [C.c_float] * 3),
+    "PlaneverbLoadScene": (C.c_int, [C.c_char_p]),
+    "PlaneverbIterationCount": (C.c_longlong, []),
+    "PlaneverbWaitIterations": (C.c_longlong, [C.c_longlong, C.c_int]),
+    "PlaneverbIsRunning": (C.c_int, []),
+    "PvAmdDeviceCount": (C.c_int, []),
+    "PvAmdLastError": (C.c_char_p, []),
+    "PvAmdVersion": (C.c_char_p, []),
+    "PvAmdCreate": (_vp, [C.c_float, C.c_float, C.c_int, C.c_int]),
+    "PlaneverbCreateGrid": (_vp, [C.c_float, C.c_float, C.c_int, C.c_int]),
+    "PvAmdDestroy": (None, [_vp]),
+    "PvAmdSetOption": (C.c_int, [_vp, C.c_int, C.c_longlong]),
+    "PvAmdGetInfo": (C.c_int, [_vp, C.POINTER(PvAmdInfo)]),
+    "PvAmdAddGeometry": (C.c_int, [_vp] + [C.c_float] * 5),
+    "PvAmdUpdateGeometry": (C.c_int, [_vp, C.c_int] + [C.c_float] * 5),
+    "PvAmdRemoveGeometry": (C.c_int, [_vp, C.c_int]),
+    "PvAmdLoadScene": (C.c_int, [_vp, C.c_char_p]),
+    "PvAmdSaveScene": (C.c_int, [_vp, C.c_char_p]),
+    "PvAmdRun": (C.c_int, [_vp] + [C.c_float] * 3),
+    "PvAmdRunAsync": (C.c_int, [_vp] + [C.c_float] * 3),
+    "PvAmdSync": (C.c_int, [_vp]),
+    "PvAmdGetTimings": (C.c_int, [_vp, C.POINTER(PvAmdTimings)]),
+    "PvAmdGetOutput": (C.c_int, [_vp] + [C.c_float] * 3 + [C.POINTER(PlaneverbOutput)]),
+    "PvAmdCopyResults": (C.c_int, [_vp, _fp, _fp]),
+    "PvAmdGetImpulseResponse": (C.c_int, [_vp, C.c_int, C.c_int, _fp]),
+    "PvAmdCopyFields": (C.c_int, [_vp, _fp, _fp, _fp]),
+    "PvAmdCopyHistoryPlane": (C.c_int, [_vp, C.c_int, _fp]),
+    "PvAmdCopyPulse": (C.c_int, [_vp, _fp]),
+    "PvAmdCopyMaterial": (C.c_int, [_vp, C.POINTER(C.c_ubyte), _fp]),
+    "PvAmdSetFields": (C.c_int, [_vp, _fp, _fp, _fp]),
+    "PvAmdRunSteps": (C.c_int, [_vp, C.c_int, C.c_int, C.c_float, C.c_float]),
+    "PvAmdReverbBusGains": (None, [C.c_float, C.c_float, _fp, _fp, _fp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libplaneverb_amd.so (built by planeverb_amd.build.build()).  Raises if it is missing: there is no
+    fallback implementation."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error():
+    e = lib().PvAmdLastError()
+    return e.decode() if e else ""
+
+
+class PlaneverbError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise PlaneverbError(last_error())
+
+
+def _f(a):
+    return a.ctypes.data_as(_fp)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# reference-shaped live API (Planeverb.h:12-47)
+# --------------------------------------------------------------------------------------------------------------
+
+Config = namedtuple("PlaneverbConfig", "gridSizeInMeters gridResolution gridBoundaryType tempFileDirectory "
+                                       "maxThreadUsage threadExecutionType")
+pv_CPU, pv_GPU = 0, 1  # PvTypes.h:13-17 / PlaneverbConfig.cs:23-29
+
+
+def Init(config):
+    """Planeverb::Init (PvContext.cpp:25-32).  Raises PlaneverbError where the reference throws."""
+    d = config.tempFileDirectory
+    lib().PlaneverbInit(config.gridSizeInMeters[0], config.gridSizeInMeters[1], config.gridResolution,
+                        config.gridBoundaryType, d.encode() if d is not None else None, config.maxThreadUsage,
+                        config.threadExecutionType)
+    if not lib().PlaneverbIsRunning():
+        raise PlaneverbError(last_error() or "pv_InvalidConfig")
+
+
+def Exit():
+    lib().PlaneverbExit()
+
+
+def Emit(pos):
+    return lib().PlaneverbEmit(*[float(v) for v in pos])
+
+
+def UpdateEmission(eid, pos):
+    lib().PlaneverbUpdateEmission(int(eid), *[float(v) for v in pos])
+
+
+def EndEmission(eid):
+    lib().PlaneverbEndEmission(int(eid))
+
+
+def GetOutput(eid):
+    return lib().PlaneverbGetOutput(int(eid))
+
+
+def AddGeometry(aabb):
+    """aabb = (posX, posY, width, height, absorption), PvMathTypes.h:31-49"""
+    return lib().PlaneverbAddGeometry(*[float(v) for v in aabb])
+
+
+def UpdateGeometry(gid, aabb):
+    lib().PlaneverbUpdateGeometry(int(gid), *[float(v) for v in aabb])
+
+
+def RemoveGeometry(gid):
+    lib().PlaneverbRemoveGeometry(int(gid))
+
+
+def SetListenerPosition(pos):
+    lib().PlaneverbSetListenerPosition(*[float(v) for v in pos])
+
+
+def LoadScene(path):
+    n = lib().PlaneverbLoadScene(path.encode())
+    if n < 0:
+        raise PlaneverbError(last_error())
+    return n
+
+
+def WaitIterations(count, timeout_ms=60000):
+    return lib().PlaneverbWaitIterations(int(count), int(timeout_ms))
+
+
+def IterationCount():
+    return lib().PlaneverbIterationCount()
+
+
+def reverb_bus_gains(rt60, wet):
+    a, b, c = C.c_float(), C.c_float(), C.c_float()
+    lib().PvAmdReverbBusGains(rt60, wet, a, b, c)
+    return a.value, b.value, c.value
+
+
+def device_count():
+    return lib().PvAmdDeviceCount()
+
+
+# --------------------------------------------------------------------------------------------------------------
+# batch solver
+# --------------------------------------------------------------------------------------------------------------
+
+class Solver:
+    """Grid + FreeGrid + Analyzer of one config on one MI355X (PvAmd* handle API)."""
+
+    def __init__(self, size_x, size_y, res, device=0, **options):
+        self._h = lib().PvAmdCreate(float(size_x), float(size_y), int(res), int(device))
+        if not self._h:
+            raise PlaneverbError(last_error())
+        keys = {"dense_history": PVA_OPT_DENSE_HISTORY, "num_steps": PVA_OPT_NUM_STEPS,
+                "skip_analysis": PVA_OPT_SKIP_ANALYSIS, "use_graph": PVA_OPT_USE_GRAPH,
+                "steps_per_launch": PVA_OPT_STEPS_PER_LAUNCH, "tile_rows": PVA_OPT_TILE_ROWS,
+                "no_free_grid": PVA_OPT_NO_FREE_GRID}
+        for k, v in options.items():
+            _check(lib().PvAmdSetOption(self._h, keys[k], int(v)))
+        self.info = PvAmdInfo()
+        _check(lib().PvAmdGetInfo(self._h, self.info))
+        i = self.info
+        self.gx, self.gy, self.T, self.fs, self.dx, self.dt, self.efree = i.gx, i.gy, i.T, i.fs, i.dx, i.dt, i.efree
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().PvAmdDestroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def load_scene(self, path):
+        n = lib().PvAmdLoadScene(self._h, path.encode())
+        if n < 0:
+            raise PlaneverbError(last_error())
+        return n
+
+    def save_scene(self, path):
+        _check(lib().PvAmdSaveScene(self._h, path.encode()))
+
+    def add_geometry(self, aabb):
+        return lib().PvAmdAddGeometry(self._h, *[float(v) for v in aabb])
+
+    def update_geometry(self, gid, aabb):
+        _check(lib().PvAmdUpdateGeometry(self._h, int(gid), *[float(v) for v in aabb]))
+
+    def remove_geometry(self, gid):
+        _check(lib().PvAmdRemoveGeometry(self._h, int(gid)))
+
+    def run(self, listener):
+        _check(lib().PvAmdRun(self._h, *[float(v) for v in listener]))
+
+    def run_async(self, listener):
+        _check(lib().PvAmdRunAsync(self._h, *[float(v) for v in listener]))
+
+    def sync(self):
+        _check(lib().PvAmdSync(self._h))
+
+    def run_steps(self, nsteps, with_pulse=False, listener=(0.0, 0.0, 0.0)):
+        _check(lib().PvAmdRunSteps(self._h, int(nsteps), int(with_pulse), float(listener[0]), float(listener[2])))
+
+    def timings(self):
+        t = PvAmdTimings()
+        _check(lib().PvAmdGetTimings(self._h, t))
+        return t
+
+    def get_output(self, emitter):
+        o = PlaneverbOutput()
+        _check(lib().PvAmdGetOutput(self._h, *[float(v) for v in emitter], o))
+        return o
+
+    def results(self):
+        res = np.empty((self.gx, self.gy, 8), np.float32)
+        delay = np.empty((self.gx, self.gy), np.float32)
+        _check(lib().PvAmdCopyResults(self._h, _f(res), _f(delay)))
+        return res, delay
+
+    def impulse_response(self, cx, cy):
+        out = np.empty((self.T, 3), np.float32)
+        _check(lib().PvAmdGetImpulseResponse(self._h, int(cx), int(cy), _f(out)))
+        return out
+
+    def fields(self):
+        shp = (self.gx + 1, self.gy + 1)
+        pr, vx, vy = (np.empty(shp, np.float32) for _ in range(3))
+        _check(lib().PvAmdCopyFields(self._h, _f(pr), _f(vx), _f(vy)))
+        return pr, vx, vy
+
+    def set_fields(self, pr, vx, vy):
+        a = [np.ascontiguousarray(x, np.float32) for x in (pr, vx, vy)]
+        _check(lib().PvAmdSetFields(self._h, _f(a[0]), _f(a[1]), _f(a[2])))
+
+    def history_plane(self, t):
+        out = np.empty((self.gx + 1, self.gy + 1), np.float32)
+        _check(lib().PvAmdCopyHistoryPlane(self._h, int(t), _f(out)))
+        return out
+
+    def pulse(self):
+        out = np.empty(self.T, np.float32)
+        _check(lib().PvAmdCopyPulse(self._h, _f(out)))
+        return out
+
+    def material(self):
+        shp = (self.gx + 1, self.gy + 1)
+        beta = np.empty(shp, np.uint8)
+        R = np.empty(shp, np.float32)
+        _check(lib().PvAmdCopyMaterial(self._h, beta.ctypes.data_as(C.POINTER(C.c_ubyte)), _f(R)))
+        return beta, R

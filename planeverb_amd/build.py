@@ -1,0 +1,17 @@
+"""Build helpers: compile planeverb_amd/libplaneverb_amd.so (hipcc, gfx950) in-tree."""
+import os
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "libplaneverb_amd.so")
+
+
+def build(force=False, jobs=4):
+    """Compile every HIP/C++ source of the package for gfx950.  Works without a GPU (cross-compile)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", CSRC, "-j%d" % jobs], stdout=subprocess.DEVNULL)
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("build finished but %s is missing" % LIB_PATH)
+    return LIB_PATH

@@ -1,0 +1,343 @@
+// pv_capi.cpp -- extern "C" boundary of libplaneverb_amd.so (declared in include/planeverb_amd.h).
+// No C++ exception leaves this file; the reference's sentinels are kept (-1 ids, occlusion = -1).
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/planeverb_amd.h"
+#include "pv_context.h"
+#include "pv_core.h"
+#include "pv_solver.h"
+
+using namespace pva;
+
+static thread_local std::string g_lastError;
+
+struct PvAmdSolver {
+    Solver* s = nullptr;
+    SolverOptions opt;
+    GridSpec spec;
+    int device = 0;
+    std::string createErr;
+};
+
+static bool ensure(PvAmdSolver* h) {
+    if (!h) {
+        g_lastError = "null solver handle";
+        return false;
+    }
+    if (h->s) return true;
+    h->s = Solver::create(h->spec, h->device, h->opt, &g_lastError);
+    return h->s != nullptr;
+}
+
+static int ret(PvAmdSolver* h, bool ok) {
+    if (ok) return 0;
+    if (h && h->s && !h->s->lastError().empty()) g_lastError = h->s->lastError();
+    return -1;
+}
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------------------------
+// Part 1: reference C-ABI
+// ---------------------------------------------------------------------------------------------------------------
+
+void UnityPluginLoad(void*) {}
+void UnityPluginUnload(void) {}
+
+void PlaneverbInit(float gridSizeX, float gridSizeY, int gridResolution, int gridBoundaryType, char* tempFileDir,
+                   int maxThreadUsage, int threadExecutionType) {
+    try {
+        LiveConfig c;
+        c.sizeX = gridSizeX;
+        c.sizeY = gridSizeY;
+        c.res = gridResolution;
+        c.boundaryType = gridBoundaryType;
+        c.tempDir = tempFileDir;
+        c.maxThreads = maxThreadUsage;
+        c.executionType = threadExecutionType;  // 0 (pv_CPU) and 1 (pv_GPU) both run on the HIP device here
+        std::string err;
+        if (!Context::init(c, &err)) {
+            g_lastError = err;
+            std::fprintf(stderr, "[planeverb_amd] PlaneverbInit failed: %s\n", err.c_str());
+        }
+    } catch (...) {
+        g_lastError = "exception in PlaneverbInit";
+    }
+}
+
+void PlaneverbExit(void) {
+    try {
+        Context::exit();
+    } catch (...) {
+    }
+}
+
+int PlaneverbEmit(float x, float y, float z) {
+    Context* c = Context::get();
+    return c ? c->emit(x, y, z) : -1;
+}
+
+void PlaneverbUpdateEmission(int id, float x, float y, float z) {
+    if (Context* c = Context::get()) c->updateEmission(id, x, y, z);
+}
+
+void PlaneverbEndEmission(int id) {
+    if (Context* c = Context::get()) c->endEmission(id);
+}
+
+PlaneverbOutput PlaneverbGetOutput(int emissionID) {
+    PlaneverbOutput o;
+    std::memset(&o, 0, sizeof(o));
+    Context* c = Context::get();
+    if (!c) {  // FDTD.cpp:22-26
+        o.occlusion = kInvalidDryGain;
+        return o;
+    }
+    const Out8 r = c->getOutput(emissionID);
+    std::memcpy(&o, r.v, sizeof(o));
+    return o;
+}
+
+int PlaneverbAddGeometry(float posX, float posY, float width, float height, float absorption) {
+    Context* c = Context::get();
+    return c ? c->addGeometry(Box{posX, posY, width, height, absorption}) : -1;
+}
+
+void PlaneverbUpdateGeometry(int id, float posX, float posY, float width, float height, float absorption) {
+    if (Context* c = Context::get()) c->updateGeometry(id, Box{posX, posY, width, height, absorption});
+}
+
+void PlaneverbRemoveGeometry(int id) {
+    if (Context* c = Context::get()) c->removeGeometry(id);
+}
+
+void PlaneverbSetListenerPosition(float x, float y, float z) {
+    if (Context* c = Context::get()) c->setListener(x, y, z);
+}
+
+int PlaneverbLoadScene(const char* pvPath) {
+    Context* c = Context::get();
+    if (!c || !pvPath) return -1;
+    std::vector<Box> boxes;
+    if (!loadPv(pvPath, &boxes, &g_lastError)) return -1;
+    for (const Box& b : boxes) c->addGeometry(b);
+    return (int)boxes.size();
+}
+
+long long PlaneverbIterationCount(void) {
+    Context* c = Context::get();
+    return c ? c->iterations() : 0;
+}
+
+long long PlaneverbWaitIterations(long long count, int timeoutMs) {
+    Context* c = Context::get();
+    return c ? c->waitIterations(count, timeoutMs) : 0;
+}
+
+int PlaneverbIsRunning(void) { return Context::get() ? 1 : 0; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Part 2: batch solver handle
+// ---------------------------------------------------------------------------------------------------------------
+
+int PvAmdDeviceCount(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* PvAmdLastError(void) { return g_lastError.c_str(); }
+const char* PvAmdVersion(void) { return "planeverb_amd 0.1 (gfx950)"; }
+
+PvAmdSolver* PvAmdCreate(float gridSizeX, float gridSizeY, int gridResolution, int device) {
+    if (gridResolution < kLowResolution || gridSizeX == 0.f || gridSizeY == 0.f) {
+        g_lastError = "invalid config (pv_InvalidConfig)";  // PvContext.cpp:101-107
+        return nullptr;
+    }
+    int n = PvAmdDeviceCount();
+    if (n <= 0) {
+        g_lastError = "no HIP device: libplaneverb_amd has no CPU path";
+        return nullptr;
+    }
+    if (device < 0 || device >= n) {
+        g_lastError = "HIP device index out of range";
+        return nullptr;
+    }
+    PvAmdSolver* h = new PvAmdSolver();
+    h->spec = makeGridSpec(gridSizeX, gridSizeY, gridResolution);
+    h->device = device;
+    return h;
+}
+
+PvAmdSolver* PlaneverbCreateGrid(float gridSizeX, float gridSizeY, int gridResolution, int device) {
+    return PvAmdCreate(gridSizeX, gridSizeY, gridResolution, device);
+}
+
+void PvAmdDestroy(PvAmdSolver* h) {
+    if (!h) return;
+    delete h->s;
+    delete h;
+}
+
+int PvAmdSetOption(PvAmdSolver* h, int key, long long value) {
+    if (!h) return -1;
+    if (h->s) {
+        g_lastError = "options must be set before the solver is first used";
+        return -1;
+    }
+    switch (key) {
+        case PVA_OPT_DENSE_HISTORY: h->opt.denseHistory = value != 0; break;
+        case PVA_OPT_NUM_STEPS: h->opt.numSteps = (int)value; break;
+        case PVA_OPT_SKIP_ANALYSIS: h->opt.skipAnalysis = value != 0; break;
+        case PVA_OPT_USE_GRAPH: h->opt.useGraph = value != 0; break;
+        case PVA_OPT_STEPS_PER_LAUNCH: h->opt.K = (int)value; break;
+        case PVA_OPT_TILE_ROWS: h->opt.rxi = (int)value; break;
+        case PVA_OPT_NO_FREE_GRID: h->opt.withFreeGrid = value == 0; break;
+        default: g_lastError = "unknown option"; return -1;
+    }
+    return 0;
+}
+
+int PvAmdGetInfo(PvAmdSolver* h, PvAmdInfo* out) {
+    if (!out || !ensure(h)) return -1;
+    const GridSpec& g = h->s->spec();
+    const Geometry& geo = h->s->geometry();
+    std::memset(out, 0, sizeof(*out));
+    out->gx = g.gx;
+    out->gy = g.gy;
+    out->T = h->s->T();
+    out->fs = (int)g.fs;
+    out->res = g.res;
+    out->dx = g.dx;
+    out->dt = g.dt;
+    out->efree = h->s->efree();
+    out->device = h->s->device();
+    out->stepsPerLaunch = h->s->K();
+    out->tileRows = geo.rxi;
+    out->tileCols = geo.wi;
+    out->pitch = geo.pitch;
+    out->rows = geo.rows;
+    out->histRows = h->s->histRows();
+    out->histPitch = h->s->histPitch();
+    out->numGeometry = h->s->numBoxes();
+    out->deviceBytes = h->s->deviceBytes();
+    return 0;
+}
+
+int PvAmdAddGeometry(PvAmdSolver* h, float posX, float posY, float width, float height, float absorption) {
+    if (!ensure(h)) return -1;
+    return h->s->addBox(Box{posX, posY, width, height, absorption});
+}
+
+int PvAmdUpdateGeometry(PvAmdSolver* h, int id, float posX, float posY, float width, float height,
+                        float absorption) {
+    if (!ensure(h)) return -1;
+    return ret(h, h->s->updateBox(id, Box{posX, posY, width, height, absorption}));
+}
+
+int PvAmdRemoveGeometry(PvAmdSolver* h, int id) {
+    if (!ensure(h)) return -1;
+    return ret(h, h->s->removeBox(id));
+}
+
+int PvAmdLoadScene(PvAmdSolver* h, const char* pvPath) {
+    if (!ensure(h) || !pvPath) return -1;
+    std::vector<Box> boxes;
+    if (!loadPv(pvPath, &boxes, &g_lastError)) return -1;
+    for (const Box& b : boxes) h->s->addBox(b);
+    return (int)boxes.size();
+}
+
+int PvAmdSaveScene(PvAmdSolver* h, const char* pvPath) {
+    if (!ensure(h) || !pvPath) return -1;
+    return savePv(pvPath, h->s->boxes(), &g_lastError) ? 0 : -1;
+}
+
+int PvAmdRun(PvAmdSolver* h, float lx, float ly, float lz) {
+    if (!ensure(h)) return -1;
+    return ret(h, h->s->run(lx, ly, lz, true));
+}
+
+int PvAmdRunAsync(PvAmdSolver* h, float lx, float ly, float lz) {
+    if (!ensure(h)) return -1;
+    return ret(h, h->s->run(lx, ly, lz, false));
+}
+
+int PvAmdSync(PvAmdSolver* h) {
+    if (!ensure(h)) return -1;
+    return ret(h, h->s->sync());
+}
+
+int PvAmdGetTimings(PvAmdSolver* h, PvAmdTimings* out) {
+    if (!out || !ensure(h)) return -1;
+    const SolverTimings& t = h->s->timings();
+    out->fdtdMs = t.fdtdMs;
+    out->analysisMs = t.analysisMs;
+    out->geometryMs = t.geometryMs;
+    out->stepLaunches = t.stepLaunches;
+    out->stepKernelMs = t.stepLaunches ? t.fdtdMs / (float)t.stepLaunches : 0.f;
+    out->histBytesWritten = t.histBytesWritten;
+    return 0;
+}
+
+int PvAmdGetOutput(PvAmdSolver* h, float ex, float ey, float ez, PlaneverbOutput* out) {
+    if (!out || !ensure(h)) return -1;
+    float v[8];
+    bool valid = false;
+    if (!h->s->getOutput(ex, ey, ez, v, &valid)) return ret(h, false);
+    if (!valid) {
+        std::memset(out, 0, sizeof(*out));
+        out->occlusion = kInvalidDryGain;
+        return 0;
+    }
+    std::memcpy(out, v, sizeof(*out));
+    return 0;
+}
+
+int PvAmdCopyResults(PvAmdSolver* h, float* res8, float* delay) {
+    if (!ensure(h)) return -1;
+    return ret(h, h->s->copyResults(res8, delay));
+}
+
+int PvAmdGetImpulseResponse(PvAmdSolver* h, int cx, int cy, float* out3T) {
+    if (!out3T || !ensure(h)) return -1;
+    return ret(h, h->s->impulseResponse(cx, cy, out3T));
+}
+
+int PvAmdCopyFields(PvAmdSolver* h, float* pr, float* vx, float* vy) {
+    if (!ensure(h)) return -1;
+    return ret(h, h->s->copyFields(pr, vx, vy));
+}
+
+int PvAmdCopyHistoryPlane(PvAmdSolver* h, int t, float* pr) {
+    if (!pr || !ensure(h)) return -1;
+    return ret(h, h->s->copyHistoryPlane(t, pr));
+}
+
+int PvAmdCopyPulse(PvAmdSolver* h, float* out) {
+    if (!out || !ensure(h)) return -1;
+    return ret(h, h->s->copyPulse(out));
+}
+
+int PvAmdCopyMaterial(PvAmdSolver* h, uint8_t* beta, float* R) {
+    if (!ensure(h)) return -1;
+    return ret(h, h->s->copyMaterial(beta, R));
+}
+
+int PvAmdSetFields(PvAmdSolver* h, const float* pr, const float* vx, const float* vy) {
+    if (!ensure(h)) return -1;
+    return ret(h, h->s->setFields(pr, vx, vy));
+}
+
+int PvAmdRunSteps(PvAmdSolver* h, int nsteps, int withPulse, float lx, float lz) {
+    if (!ensure(h)) return -1;
+    return ret(h, h->s->runSteps(nsteps, withPulse != 0, lx, lz));
+}
+
+void PvAmdReverbBusGains(float rt60, float wetGain, float* a, float* b, float* c) {
+    reverbBusGains(rt60, wetGain, a, b, c);
+}
+
+}  // extern "C"

@@ -1,0 +1,103 @@
+// pv_device.h -- device-side data layout shared by the HIP kernels (pv_kernels.hip) and the host solver.
+//
+// HBM layout (all planes share one padded geometry, SoA):
+//   rows  = G + ntx*RXI + G,  pitch = roundup(G + nty*WI + G, 64) floats
+//   array cell (x, y) of the reference's (gx+1) x (gy+1) grid lives at padded (x + G, y + G);
+//   y is the contiguous dimension (reference index = x*(gy+1) + y, FDTD.cpp:99) so wave lanes run along y.
+//   pr/vx/vy : float32, ping-pong pair (a fused K-step launch reads one set and writes the other)
+//   codes    : uint16 per cell = kxIdx | kyIdx << 8, indices into a 256-entry float LUT that folds beta,
+//              wall admittance Y=(1-R)/(1+R) and the absorbing grid edges into one per-face coefficient
+//   hist     : float32 pr[t][row][col] over a tile-aligned window around the listener (cells that the pulse
+//              cannot have reached are exactly zero and are not stored)
+// The guard band (G cells on every side, plus tile overhang) holds zeros / wall codes and is never written
+// with anything else, so no kernel needs a bounds check.
+#pragma once
+
+#include <cstdint>
+
+namespace pva {
+
+// analysis constants (reference: include/PvTypes.h:83-101), usable in device code
+constexpr float kCDev = 343.21f;
+constexpr float kAudibleThresholdDev = 0.00000316f;
+constexpr float kDistanceGainDev = 0.891251f;
+constexpr float kDelayCloseDev = 5.f;
+
+// LUT layout: beta(cell) == (kxIdx < 128)
+constexpr int kLutAir = 0;        // air|air face: v -= C * grad(p)           (entry = NaN sentinel)
+constexpr int kLutNegBase = 1;    // 1 + p : wall(n)|air(i):  v = -Y[p] * p_i  (p = palette index of cell n)
+constexpr int kLutWall = 128;     // wall|wall face: v = 0
+constexpr int kLutPosBase = 129;  // 129 + p : air(n)|wall(i): v = +Y[p] * p_n (p = palette index of cell i)
+constexpr int kPaletteMax = 127;  // palette index 0 is always R = 0 (Y = 1)
+
+struct Geometry {
+    int gx, gy, NX, NY;
+    int G;           // guard width
+    int rxi, wi;     // tile interior rows / columns
+    int ntx, nty;    // tiles
+    int rows, pitch; // padded plane
+};
+
+// per-run parameters that change with the listener; lives in device memory so a captured graph can be replayed
+struct DynParams {
+    int lrow, lcol;          // listener cell, padded coordinates
+    int histRow0, histCol0;  // padded coordinates of the history window origin (tile aligned)
+    int histTileX0, histTileY0, histTilesX, histTilesY;
+};
+
+struct StepArgs {
+    const float* prIn;
+    const float* vxIn;
+    const float* vyIn;
+    float* prOut;
+    float* vxOut;
+    float* vyOut;
+    const uint16_t* codes;
+    const float* lut;      // 256 floats
+    const float* pulse;    // T floats
+    float* hist;           // window base, plane stride histPlane
+    int* tileFirst;        // per tile: first step block in which the tile was non-zero (INT_MAX = never)
+    const uint8_t* tileClass;   // per tile: 0 = all faces air|air (air kernel), 1 = general kernel
+    const int* generalList;     // tiles for the general kernel: class-1 tiles + tiles holding the listener
+    int numGeneral;
+    const DynParams* dyn;
+    int* errFlag;
+    long long histPlane;   // floats per recorded step
+    long long planeBytes;  // bytes of one padded float plane
+    int histPitch;
+    int pitch;
+    int G;
+    int ntx, nty, ntiles;
+    int t0;                // first global step of this launch
+    int nsteps;            // steps in this launch (<= K)
+    int withPulse;
+    int record;            // write pr history
+    int dense;             // record even all-zero tiles
+    float courant;
+};
+
+struct AnalyzeArgs {
+    const float* hist;
+    const uint16_t* codes;
+    const float* lut;
+    const int* tileFirst;
+    const DynParams* dyn;
+    float* res8;   // gx*gy*8
+    float* delay;  // gx*gy
+    long long histPlane;
+    int histPitch;
+    int pitch, G;
+    int gx, gy;
+    int rxi, wi, nty;
+    int T;
+    int nDir, nDry, nWet, nCut;
+    unsigned fs;
+    int res;
+    float dx;
+    float courant;
+    float efree;
+    float lx, lz;        // listener, metres
+    int lcx, lcy;        // listener cell by reciprocal multiply (Analyzer.cpp:200-201)
+};
+
+}  // namespace pva

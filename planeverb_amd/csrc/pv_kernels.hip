@@ -1,0 +1,719 @@
+// pv_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X, CDNA4): the Planeverb FDTD leapfrog stencil with
+// K time steps fused per launch, pr-history recording, and the per-cell impulse-response analysis.
+//
+// Reference semantics implemented here (paths relative to /root/reference/ProjectPlaneverb):
+//   pv_step_kernel      src/FDTD/FDTD.cpp:122-235   pressure / vx / vy sweeps, edge absorption, record, pulse
+//   pv_codes_kernel     src/FDTD/FDTD.cpp:143-223 + src/FDTD/Grid.cpp:88-108   (beta, Y, edges -> face codes)
+//   pv_encode_kernel    src/DSP/Analyzer.cpp:139-328  onset, dry gain, source direction, lowpass, wet, RT60
+//   pv_direction_kernel src/DSP/Analyzer.cpp:340-431  listener direction by delay-map descent
+//   pv_efree_kernel     src/FDTD/FreeGrid.cpp:96-110  free-field energy sum
+//   pv_ir_kernel        src/FDTD/FDTD.cpp:60-79       impulse response (pr, vx, vy) of one cell
+//
+// Design (MI355X-first, not a translation of the reference's three AoS sweeps):
+//   * memory-bound 5-point staggered stencil, 24 B of state per cell-step; no MFMA.
+//   * one WAVE owns one (RXI+2K) x 64 tile held entirely in VGPRs (SoA pr/vx/vy, one cell column per lane, lanes
+//     along the contiguous y axis); x-neighbours are the lane's own registers, y-neighbours come from lane+-1 by
+//     DPP wave shifts.  No LDS traffic for the fields, no barriers inside the time loop.
+//   * K leapfrog steps are advanced per launch on the tile+halo (overlapped temporal tiling): HBM traffic per
+//     cell-step drops from 24 B to about (12*(1+halo)+12)/K B.
+//   * beta, wall admittance and the absorbing grid edges are folded into one uint16 face-code per cell that indexes
+//     a 256-entry coefficient LUT in LDS; tiles whose faces are all air|air take a branch-free fast path.
+//   * float32 arithmetic in the reference's operation order; compiled with -ffp-contract=off so that
+//     v - C*(p_i - p_n) stays a separate multiply and subtract (bit-identical fields).
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <climits>
+#include <cstdint>
+
+#include "pv_device.h"
+#include "pv_launch.h"
+
+namespace pva {
+
+#ifndef PV_USE_DPP
+#define PV_USE_DPP 1
+#endif
+
+// value held by lane+1 (lane 63 receives an unspecified value; it is always a halo lane)
+__device__ __forceinline__ float laneNext(float v) {
+#if PV_USE_DPP
+    // DPP wave_shl:1 -- dst[i] = src[i+1] across the whole 64-lane wavefront (gfx9 DPP_WF_SL1 = 0x130)
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+#else
+    return __shfl_down(v, 1);
+#endif
+}
+
+// value held by lane-1 (lane 0 receives an unspecified value)
+__device__ __forceinline__ float lanePrev(float v) {
+#if PV_USE_DPP
+    // DPP wave_shr:1 -- dst[i] = src[i-1] (DPP_WF_SR1 = 0x138)
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+#else
+    return __shfl_up(v, 1);
+#endif
+}
+
+// self-test of the lane-shift primitives: out[i] = {laneNext(i), lanePrev(i)}
+__global__ void pv_lane_selftest_kernel(float* out) {
+    const int lane = threadIdx.x;
+    out[lane] = laneNext((float)lane);
+    out[64 + lane] = lanePrev((float)lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// face codes
+// ---------------------------------------------------------------------------------------------------------------
+
+// mat: (gx+1)*(gy+1) bytes, bit0 = beta (Grid.cpp:88-108,229-246), bits 1..7 = palette index of R.
+// One thread per padded cell.  Folds FDTD.cpp:143-223 into one coefficient index per face:
+//   air|air   : v = v - C*(p_i - p_n)                                   (FDTD.cpp:162-163, beta*beta_n = 1)
+//   wall(n)|air(i): v = -Y_n * p_i ; air(n)|wall(i): v = +Y_i * p_n      (FDTD.cpp:165-168)
+//   grid edges: vx[0,y] = -p[0,y], vx[gx,y] = p[gx-1,y], vy likewise     (FDTD.cpp:201-223)
+__global__ void pv_codes_kernel(const uint8_t* __restrict__ mat, uint16_t* __restrict__ codes, Geometry g) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = blockIdx.y;
+    if (col >= g.pitch || row >= g.rows) return;
+    const int x = row - g.G, y = col - g.G;
+    unsigned kx = kLutWall, ky = kLutWall;
+    if (x >= 0 && x < g.NX && y >= 0 && y < g.NY) {
+        const bool ghost = (x == g.gx) || (y == g.gy);
+        const unsigned mi = mat[(size_t)x * g.NY + y];
+        const bool bi = (mi & 1u) && !ghost;
+        const unsigned pi = ghost ? 0u : (mi >> 1);
+        // x face: neighbour n = (x-1, y)
+        if (x == 0) {
+            kx = (bi && y < g.gy) ? (unsigned)kLutNegBase : (unsigned)kLutWall;
+        } else if (x == g.gx) {
+            kx = (y < g.gy) ? (unsigned)kLutPosBase : (unsigned)kLutWall;
+        } else {
+            const unsigned mn = mat[(size_t)(x - 1) * g.NY + y];
+            const bool bn = (mn & 1u) && (y != g.gy);
+            const unsigned pn = (y == g.gy) ? 0u : (mn >> 1);
+            kx = (bi && bn) ? (unsigned)kLutAir
+                            : bi ? kLutNegBase + pn : bn ? kLutPosBase + pi : (unsigned)kLutWall;
+        }
+        // y face: neighbour n = (x, y-1)
+        if (y == 0) {
+            ky = (bi && x < g.gx) ? (unsigned)kLutNegBase : (unsigned)kLutWall;
+        } else if (y == g.gy) {
+            ky = (x < g.gx) ? (unsigned)kLutPosBase : (unsigned)kLutWall;
+        } else {
+            const unsigned mn = mat[(size_t)x * g.NY + (y - 1)];
+            const bool bn = (mn & 1u) && (x != g.gx);
+            const unsigned pn = (x == g.gx) ? 0u : (mn >> 1);
+            ky = (bi && bn) ? (unsigned)kLutAir
+                            : bi ? kLutNegBase + pn : bn ? kLutPosBase + pi : (unsigned)kLutWall;
+        }
+    }
+    codes[(size_t)row * g.pitch + col] = (uint16_t)(kx | (ky << 8));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fused K-step stencil
+// ---------------------------------------------------------------------------------------------------------------
+
+template <int ROWS, bool FAST>
+__device__ __forceinline__ void leapfrogStep(float (&pr)[ROWS], float (&vx)[ROWS], float (&vy)[ROWS],
+                                             const uint32_t (&cd)[(ROWS + 1) / 2], const float* lut,
+                                             const float C) {
+    // pressure sweep, FDTD.cpp:124-141:  p = beta * (p - C * ((vx[x+1] - vx[x]) + (vy[y+1] - vy[y])))
+#pragma unroll
+    for (int r = 0; r < ROWS - 1; ++r) {
+        const float vyR = laneNext(vy[r]);
+        const float div = (vx[r + 1] - vx[r]) + (vyR - vy[r]);
+        const float p = pr[r] - C * div;
+        if (FAST) {
+            pr[r] = p;
+        } else {
+            const uint32_t kxi = (cd[r >> 1] >> (16 * (r & 1))) & 0xffu;
+            pr[r] = (kxi < (uint32_t)kLutWall) ? p : 0.f;
+        }
+    }
+    // velocity sweeps, FDTD.cpp:143-199 (+ edges :201-223 through the face codes)
+#pragma unroll
+    for (int r = ROWS - 1; r >= 1; --r) {
+        const float pi = pr[r], pn = pr[r - 1];
+        const float air = vx[r] - C * (pi - pn);
+        if (FAST) {
+            vx[r] = air;
+        } else {
+            const uint32_t kxi = (cd[r >> 1] >> (16 * (r & 1))) & 0xffu;
+            const float k = lut[kxi];
+            const float wall = k * (pi + pn);
+            vx[r] = (k != k) ? air : wall;
+            // keep the coefficient reads of at most 4 rows in flight (otherwise all ROWS are hoisted and spill)
+            if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const float pi = pr[r];
+        const float pn = lanePrev(pi);
+        const float air = vy[r] - C * (pi - pn);
+        if (FAST) {
+            vy[r] = air;
+        } else {
+            const uint32_t kyi = (cd[r >> 1] >> (16 * (r & 1) + 8)) & 0xffu;
+            const float k = lut[kyi];
+            const float wall = k * (pi + pn);
+            vy[r] = (k != k) ? air : wall;
+            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// Buffer (SRSRC) addressing: every plane is reached through a 128-bit descriptor built from kernel arguments;
+// the per-lane part of an address is the constant lane*4 in voffset and everything wave-uniform (tile origin,
+// row) goes into the scalar soffset, so the 3*ROWS loads / stores of a tile cost no address VGPRs.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ rsrc_t makeRsrc(const void* p, long long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float bufLoadF(rsrc_t r, int voff, int soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bufStoreF(float v, rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+
+// Body shared by the two step kernels.  GENERAL = false: every face of the tile (halo included) is air|air and the
+// listener is not inside it -- no coefficient reads, no pulse.  GENERAL = true: walls / grid edges / listener.
+// They are separate kernels (not one kernel with a wave-uniform branch) so that each gets its own register
+// allocation: the air tile needs 3*ROWS VGPRs plus a handful and must not inherit the general path's pressure.
+template <int K, int RXI, bool GENERAL>
+__device__ __forceinline__ void stepTile(const StepArgs& a, const int tile, const int lane, const float* lut) {
+    constexpr int ROWS = RXI + 2 * K;
+    constexpr int WI = 64 - 2 * K;
+    const int ti = tile / a.nty;
+    const int tj = tile - ti * a.nty;
+    const int row0 = a.G - K + ti * RXI;  // first loaded row / column, padded coordinates
+    const int col0 = a.G - K + tj * WI;
+    const int voff = lane * 4;
+    const int pitchB = a.pitch * 4;
+    const int soff0 = (row0 * a.pitch + col0) * 4;
+
+    const rsrc_t rPrIn = makeRsrc(a.prIn, a.planeBytes), rVxIn = makeRsrc(a.vxIn, a.planeBytes),
+                 rVyIn = makeRsrc(a.vyIn, a.planeBytes);
+
+    float pr[ROWS], vx[ROWS], vy[ROWS];
+    uint32_t cd[(ROWS + 1) / 2];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int so = soff0 + r * pitchB;
+        pr[r] = bufLoadF(rPrIn, voff, so);
+        vx[r] = bufLoadF(rVxIn, voff, so);
+        vy[r] = bufLoadF(rVyIn, voff, so);
+    }
+    if (GENERAL) {
+        const rsrc_t rCodes = makeRsrc(a.codes, a.planeBytes / 2);
+#pragma unroll
+        for (int i = 0; i < (ROWS + 1) / 2; ++i) {
+            const int so = (soff0 >> 1) + (2 * i) * (pitchB >> 1);
+            uint32_t lo = __builtin_amdgcn_raw_buffer_load_b16(rCodes, lane * 2, so, 0);
+            uint32_t hi =
+                (2 * i + 1 < ROWS)
+                    ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rCodes, lane * 2, so + (pitchB >> 1), 0)
+                    : 0u;
+            cd[i] = lo | (hi << 16);
+        }
+    }
+
+    // is anything non-zero in the tile?  (sign bit ignored: -0 from v = -p at the grid edges is still zero)
+    uint32_t nz = 0;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+        nz |= (__float_as_uint(pr[r]) | __float_as_uint(vx[r]) | __float_as_uint(vy[r])) & 0x7fffffffu;
+    bool active = __ballot(nz != 0u) != 0ull;
+
+    const DynParams dyn = *a.dyn;
+    const int lr = dyn.lrow - row0;
+    const int lc = dyn.lcol - col0;
+    const bool hasL = GENERAL && a.withPulse && lr >= 0 && lr < ROWS && lc >= 0 && lc < 64;
+    active = active || hasL;
+
+    const int hti = ti - dyn.histTileX0, htj = tj - dyn.histTileY0;
+    const bool inWin = hti >= 0 && hti < dyn.histTilesX && htj >= 0 && htj < dyn.histTilesY;
+    // once a tile has been active its history is recorded for the rest of the run
+    const bool wasActive = a.record && a.tileFirst[tile] != INT_MAX;
+    const bool rec = a.record && inWin && (active || wasActive || a.dense);
+    if (a.record && active && !inWin && lane == 0) atomicExch(a.errFlag, 1);
+    if (a.record && active && !wasActive && lane == 0) atomicMin(&a.tileFirst[tile], a.t0);
+
+    const float C = a.courant;
+    const bool inCols = lane >= K && lane < 64 - K;
+    const float* hplane = a.hist + (long long)a.t0 * a.histPlane;
+    // history window addressing: soffset = row part (>= 0 for every stored row), voffset = column part
+    const int hpitchB = a.histPitch * 4;
+    const int hsoff0 = (hti * RXI - K) * hpitchB;       // + r*hpitchB with r >= K
+    const int hvoff = (htj * WI - K + lane) * 4;        // >= 0 for the stored lanes (lane >= K)
+
+#pragma unroll 1
+    for (int s = 0; s < a.nsteps; ++s) {
+        if (!GENERAL) {
+            leapfrogStep<ROWS, true>(pr, vx, vy, cd, lut, C);
+        } else {
+            // The face codes and LUT are loop-invariant; left alone, LICM hoists the 2*ROWS coefficient reads out
+            // of the time loop and spills them.  Re-materialise them every step instead (empty asm = opaque).
+            const float* lutS = lut;
+            asm volatile("" : "+v"(lutS));
+#pragma unroll
+            for (int i = 0; i < (ROWS + 1) / 2; ++i) asm volatile("" : "+v"(cd[i]));
+            leapfrogStep<ROWS, false>(pr, vx, vy, cd, lutS, C);
+        }
+
+        // record the pressure of this step before the pulse is injected (FDTD.cpp:226-234)
+        if (rec) {
+            const rsrc_t rH = makeRsrc(hplane, a.histPlane * 4);
+            if (inCols) {
+#pragma unroll
+                for (int r = K; r < ROWS - K; ++r) bufStoreF(pr[r], rH, hvoff, hsoff0 + r * hpitchB);
+            }
+        }
+        hplane += a.histPlane;
+
+        if (GENERAL && hasL) {  // soft source: p[listener] += pulse[t], FDTD.cpp:234
+            const float pv = (lane == lc) ? a.pulse[a.t0 + s] : 0.f;
+            int lrS = lr;  // opaque per step, so the ROWS row-select masks are not hoisted and spilled
+            asm volatile("" : "+s"(lrS));
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) pr[r] += (r == lrS) ? pv : 0.f;
+        }
+    }
+
+    const rsrc_t rPrOut = makeRsrc(a.prOut, a.planeBytes), rVxOut = makeRsrc(a.vxOut, a.planeBytes),
+                 rVyOut = makeRsrc(a.vyOut, a.planeBytes);
+    if (inCols) {
+#pragma unroll
+        for (int r = K; r < ROWS - K; ++r) {
+            const int so = soff0 + r * pitchB;
+            bufStoreF(pr[r], rPrOut, voff, so);
+            bufStoreF(vx[r], rVxOut, voff, so);
+            bufStoreF(vy[r], rVyOut, voff, so);
+        }
+    }
+}
+
+// air tiles: one wave per tile, 4 tiles per 256-thread block; tiles of the other class exit immediately
+template <int K, int RXI, int WPS>
+__global__ __launch_bounds__(256, WPS) void pv_step_air_kernel(const StepArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= a.ntiles) return;
+    if (a.tileClass[tile] != 0) return;
+    if (a.withPulse) {  // the tile(s) holding the listener are on the general kernel's list
+        const int ti = tile / a.nty, tj = tile - ti * a.nty;
+        const int lr = a.dyn->lrow - (a.G - K + ti * RXI), lc = a.dyn->lcol - (a.G - K + tj * (64 - 2 * K));
+        if (lr >= 0 && lr < RXI + 2 * K && lc >= 0 && lc < 64) return;
+    }
+    stepTile<K, RXI, false>(a, tile, lane, nullptr);
+}
+
+// wall / edge / listener tiles, taken from a compact list
+template <int K, int RXI>
+__global__ __launch_bounds__(256, 2) void pv_step_general_kernel(const StepArgs a) {
+    __shared__ float lut[256];
+    lut[threadIdx.x] = a.lut[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int idx = blockIdx.x * 4 + wave;
+    if (idx >= a.numGeneral) return;
+    const int tile = __builtin_amdgcn_readfirstlane(a.generalList[idx]);
+    stepTile<K, RXI, true>(a, tile, lane, lut);
+}
+
+// Per-tile class: 0 = every face code in the tile's loaded region is air|air, 1 = needs the general kernel.
+// One wave per tile.  Tiles of class 1 are also appended to generalList (order irrelevant).
+template <int K, int RXI>
+__global__ __launch_bounds__(256) void pv_tileclass_kernel(const uint16_t* codes, uint8_t* tileClass,
+                                                           int* generalList, int* generalCount, Geometry g) {
+    constexpr int ROWS = RXI + 2 * K;
+    constexpr int WI = 64 - 2 * K;
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= g.ntx * g.nty) return;
+    const int ti = tile / g.nty, tj = tile - ti * g.nty;
+    const size_t base = (size_t)(g.G - K + ti * RXI) * g.pitch + (g.G - K + tj * WI) + lane;
+    uint32_t any = 0;
+    for (int r = 0; r < ROWS; ++r) any |= codes[base + (size_t)r * g.pitch];
+    const bool general = __ballot(any != 0u) != 0ull;
+    if (lane == 0) {
+        tileClass[tile] = general ? 1 : 0;
+        if (general) generalList[atomicAdd(generalCount, 1)] = tile;
+    }
+}
+
+template <int K, int RXI, int WPS>
+static void launchStepT(const StepArgs& a, hipStream_t stream) {
+    const int blocks = (a.ntiles + 3) / 4;
+    hipLaunchKernelGGL((pv_step_air_kernel<K, RXI, WPS>), dim3(blocks), dim3(256), 0, stream, a);
+    if (a.numGeneral > 0) {
+        const int gblocks = (a.numGeneral + 3) / 4;
+        hipLaunchKernelGGL((pv_step_general_kernel<K, RXI>), dim3(gblocks), dim3(256), 0, stream, a);
+    }
+}
+
+template <int K, int RXI>
+static void launchTileClassT(const uint16_t* codes, uint8_t* tileClass, int* list, int* count, const Geometry& g,
+                             hipStream_t stream) {
+    const int blocks = (g.ntx * g.nty + 3) / 4;
+    hipLaunchKernelGGL((pv_tileclass_kernel<K, RXI>), dim3(blocks), dim3(256), 0, stream, codes, tileClass, list,
+                       count, g);
+}
+
+#define PV_STEP_CONFIGS(X) X(4, 32, 3) X(4, 24, 4) X(2, 28, 4) X(1, 30, 4) X(8, 24, 3) X(6, 28, 3) X(3, 26, 4)
+
+void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream) {
+#define X(k, r, w) \
+    if (K == k && rxi == r) return launchStepT<k, r, w>(a, stream);
+    PV_STEP_CONFIGS(X)
+#undef X
+}
+
+void launchTileClass(int K, int rxi, const uint16_t* codes, uint8_t* tileClass, int* list, int* count,
+                     const Geometry& g, hipStream_t stream) {
+#define X(k, r, w) \
+    if (K == k && rxi == r) return launchTileClassT<k, r>(codes, tileClass, list, count, g, stream);
+    PV_STEP_CONFIGS(X)
+#undef X
+}
+
+bool stepConfigSupported(int K, int rxi) {
+#define X(k, r, w) \
+    if (K == k && rxi == r) return true;
+    PV_STEP_CONFIGS(X)
+#undef X
+    return false;
+}
+
+void launchCodes(const uint8_t* mat, uint16_t* codes, const Geometry& g, hipStream_t stream) {
+    dim3 grid((g.pitch + 255) / 256, g.rows);
+    hipLaunchKernelGGL(pv_codes_kernel, grid, dim3(256), 0, stream, mat, codes, g);
+}
+
+void launchLaneSelfTest(float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(pv_lane_selftest_kernel, dim3(1), dim3(64), 0, stream, out);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// impulse-response analysis
+// ---------------------------------------------------------------------------------------------------------------
+
+// libm-equivalents evaluated through double precision and rounded once to float: within 1 ulp of glibc's
+// log10f / powf (which are themselves not correctly rounded), SURVEY.md section 8c "third-party arithmetic".
+__device__ __forceinline__ float pvLog10f(float x) { return (float)log10((double)x); }
+__device__ __forceinline__ float pvPowf(float x, float y) { return (float)pow((double)x, (double)y); }
+
+struct CellHistory {
+    const float* h;     // this cell, step 0
+    long long plane;
+    __device__ __forceinline__ float at(int t) const { return h[(long long)t * plane]; }
+};
+
+// FreeGrid::GetEFreePerR, FreeGrid.cpp:41-59
+__device__ __forceinline__ float efreePerR(float efree, float dx, int lX, int lY, int eX, int eY) {
+    const float lx = (float)lX * dx, ly = (float)lY * dx;
+    const float ex = (float)eX * dx, ey = (float)eY * dx;
+    const float r = sqrtf((ex - lx) * (ex - lx) + (ey - ly) * (ey - ly));
+    if (r == 0.f) return efree;
+    return efree / r;
+}
+
+// One thread per result cell (X, Y); lanes along Y so every history read is a coalesced row segment of one
+// recorded plane.  All sums are sequential float32 accumulations in the reference's order.
+// vx / vy are not stored: they are re-derived from the pressure history with the stencil's own recurrence
+// (v_t = v_{t-1} - C*(p_t[i] - p_t[n]) on air|air faces, k*(p_i + p_n) otherwise), bit-identical to the values
+// the step kernel held.
+__global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
+    const int Y = blockIdx.x * blockDim.x + threadIdx.x;
+    const int X = blockIdx.y;
+    if (Y >= a.gy || X >= a.gx) return;
+    const int s = X * a.gy + Y;
+    const DynParams dyn = *a.dyn;
+
+    const int tile = (X / a.rxi) * a.nty + (Y / a.wi);
+    const int tFirst = a.tileFirst[tile];
+    if (tFirst == INT_MAX || tFirst >= a.T) {  // never reached by the pulse: no onset (Analyzer.cpp:160-165)
+        a.delay[s] = FLT_MAX;
+        return;
+    }
+    const int T = a.T;
+    const int prow = X + a.G, pcol = Y + a.G;
+    const long long hoff = (long long)(prow - dyn.histRow0) * a.histPitch + (pcol - dyn.histCol0);
+    CellHistory hc{a.hist + hoff, a.histPlane};
+    // neighbours for the velocity recurrence; a neighbour tile that became active later (or never) has
+    // unwritten history that is exactly zero by causality
+    int tFx = INT_MAX, tFy = INT_MAX;
+    if (X > 0 && prow - 1 >= dyn.histRow0) tFx = a.tileFirst[((X - 1) / a.rxi) * a.nty + (Y / a.wi)];
+    if (Y > 0 && pcol - 1 >= dyn.histCol0) tFy = a.tileFirst[(X / a.rxi) * a.nty + ((Y - 1) / a.wi)];
+    CellHistory hx{a.hist + hoff - a.histPitch, a.histPlane};
+    CellHistory hy{a.hist + hoff - 1, a.histPlane};
+
+    const uint32_t code = a.codes[(size_t)prow * a.pitch + pcol];
+    const float kx = a.lut[code & 0xffu], ky = a.lut[code >> 8];
+    const bool airX = kx != kx, airY = ky != ky;
+    const float C = a.courant;
+
+    // onset + dry energy + flux, Analyzer.cpp:146-195 (sums run from sample 0; samples before tFirst are zero)
+    int onset = -1, sourceDirEnd = INT_MAX, directEnd = INT_MAX;
+    float Edry = 0.f, fluxX = 0.f, fluxY = 0.f, vx = 0.f, vy = 0.f;
+    for (int t = tFirst; t < T; ++t) {
+        if (t >= directEnd) break;
+        const float p = hc.at(t);
+        const bool needV = t < sourceDirEnd;
+        if (needV) {
+            const float pxn = (t >= tFx) ? hx.at(t) : 0.f;
+            const float pyn = (t >= tFy) ? hy.at(t) : 0.f;
+            const float ax = vx - C * (p - pxn), wx = kx * (p + pxn);
+            const float ay = vy - C * (p - pyn), wy = ky * (p + pyn);
+            vx = airX ? ax : wx;
+            vy = airY ? ay : wy;
+        }
+        if (onset < 0 && fabsf(p) > kAudibleThresholdDev) {
+            onset = t;
+            sourceDirEnd = t + a.nDir;
+            directEnd = t + a.nDry;
+            if (t >= directEnd) break;
+        }
+        Edry += p * p;
+        if (t < sourceDirEnd) {
+            fluxX += p * vx;
+            fluxY += p * vy;
+        }
+    }
+    if (onset < 0) {
+        a.delay[s] = FLT_MAX;
+        return;
+    }
+    a.delay[s] = (float)onset;
+
+    // obstruction gain + source directivity, Analyzer.cpp:197-220
+    const float EfreePr = efreePerR(a.efree, a.dx, a.lcx, a.lcy, X, Y);
+    const float occ = sqrtf(Edry / EfreePr);
+    float norm = sqrtf(fluxX * fluxX + fluxY * fluxY);
+    norm = -1.0f / (norm > 0.0f ? norm : 1.0f);
+    const float sdx = norm * fluxX, sdy = norm * fluxY;
+
+    // low-pass cutoff, Analyzer.cpp:227-230 (std::max(0.001f, g) == (0.001f < g) ? g : 0.001f)
+    const float rr = 1.0f / ((0.001f < occ) ? occ : 0.001f);
+    const float lowpass = -147.f + (18390.f) / (1.f + pvPowf(rr / 12.f, 0.8f));
+
+    // wet gain, Analyzer.cpp:235-247
+    float wetEnergy = 0.f;
+    {
+        int end = directEnd + 1 + a.nWet;
+        if (T < end) end = T;
+        for (int j = directEnd + 1; j < end; ++j) {
+            const float p = hc.at(j);
+            wetEnergy += p * p;
+        }
+    }
+    const float wet = sqrtf(wetEnergy / a.efree);
+
+    // decay time by backward Schroeder integration + linear regression, Analyzer.cpp:282-327
+    float rt60;
+    {
+        const int startingPoint = directEnd + 1;
+        const int endPoint = T - a.nCut;
+        const int regressN = endPoint - startingPoint;
+        const float rn = (float)regressN;
+        const float xmean = (rn - 1.0f) * 0.5f;
+        const float xsum = rn * xmean;
+        const float denominator = (1.0f / 12.0f) * rn * (rn * rn - 1.0f);
+        float edc = 0.f, xysum = 0.f, ysum = 0.f;
+        for (int i = T - 1; i >= endPoint && i >= 0; --i) {
+            const float p = hc.at(i);
+            edc += p * p;
+        }
+        for (int i = endPoint - 1; i >= startingPoint; --i) {
+            const float p = hc.at(i);
+            edc += p * p;
+            const float y = 10.f * pvLog10f(edc);
+            xysum += y * (float)(i - startingPoint);
+            ysum += y;
+        }
+        const float ymean = ysum / rn;
+        const float numerator = xysum - ymean * xsum - xmean * ysum + rn * xmean * ymean;
+        const float slopePerSample = numerator / denominator;
+        const float slopePerSec = slopePerSample * (float)a.fs;
+        rt60 = -60.f / slopePerSec;
+    }
+
+    float* o = a.res8 + 8 * (size_t)s;
+    o[0] = occ;
+    o[1] = wet;
+    o[2] = rt60;
+    o[3] = lowpass;
+    o[6] = sdx;
+    o[7] = sdy;
+}
+
+// Analyzer.cpp:332-337
+__device__ const int kNeighbors[8][2] = {{-1, -1}, {-1, 0}, {-1, 1}, {0, -1}, {0, 1}, {1, -1}, {1, 0}, {1, 1}};
+
+// Analyzer::EncodeListenerDirection, Analyzer.cpp:340-431: walk down the delay map towards the listener until
+// the path is in line of sight; one thread per result cell.
+__global__ __launch_bounds__(256) void pv_direction_kernel(const AnalyzeArgs a) {
+    const int Y = blockIdx.x * blockDim.x + threadIdx.x;
+    const int X = blockIdx.y;
+    if (Y >= a.gy || X >= a.gx) return;
+    const int index = X * a.gy + Y;
+    float loudness = a.res8[8 * (size_t)index];
+    int cur = index;
+    float delay = FLT_MAX;
+    const float samplingRate = (float)a.fs;
+    const float wavelength = kCDev / (float)a.res;
+    const float thresholdDist = 0.3f * wavelength;
+
+    while (delay > kDelayCloseDev && loudness < kDistanceGainDev) {
+        const int r = cur / a.gy, c = cur - r * a.gy;
+        float bestLoud = 0.f, bestDelay = FLT_MAX;
+        for (int i = 0; i < 8; ++i) {
+            const int nr = r + kNeighbors[i][0], nc = c + kNeighbors[i][1];
+            if (nr < 0 || nc < 0 || nr >= a.gx || nc >= a.gy) continue;
+            const int ni = nr * a.gy + nc;
+            const float occ = a.res8[8 * (size_t)ni];
+            const float d = a.delay[ni];
+            if (occ == 0.f) continue;               // Analyzer.cpp:372 (the (unsigned)delay test never fires)
+            if (d < bestDelay && occ > 0.f) {       // strict <: first neighbour wins ties
+                bestLoud = occ;
+                cur = ni;                           // kept even if the step is rejected below (Analyzer.cpp:377)
+                bestDelay = d;
+            }
+        }
+        if (bestDelay == FLT_MAX || bestDelay >= delay) break;
+        delay = bestDelay;
+        loudness = bestLoud;
+        // line-of-sight test, Analyzer.cpp:393-411
+        const float geodesic = kCDev * bestDelay / samplingRate;
+        const int r2 = cur / a.gy, c2 = cur - r2 * a.gy;
+        const float tx = (float)r2 * a.dx - a.lx, ty = (float)c2 * a.dx - a.lz;
+        const float euclid = sqrtf((tx * tx) + (ty * ty));
+        if (fabsf(geodesic - euclid) < thresholdDist) break;
+    }
+    const int r = cur / a.gy, c = cur - r * a.gy;
+    float ox = (float)r * a.dx - a.lx, oy = (float)c * a.dx - a.lz;
+    float len = (ox * ox) + (oy * oy);
+    if (len != 0.f) {
+        len = sqrtf(len);
+        ox /= len;
+        oy /= len;
+    }
+    a.res8[8 * (size_t)index + 4] = ox;
+    a.res8[8 * (size_t)index + 5] = oy;
+}
+
+__global__ void pv_fill_delay_kernel(float* delay, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) delay[i] = FLT_MAX;  // Analyzer.cpp:64-68
+}
+
+void launchAnalysis(const AnalyzeArgs& a, hipStream_t stream) {
+    dim3 grid((a.gy + 255) / 256, a.gx);
+    const int n = a.gx * a.gy;
+    hipLaunchKernelGGL(pv_fill_delay_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a.delay, n);
+    hipLaunchKernelGGL(pv_encode_kernel, grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(pv_direction_kernel, grid, dim3(256), 0, stream, a);
+}
+
+// FreeGrid::CalculateEFree + SimulateFreeFieldEnergy tail, FreeGrid.cpp:86-110: sequential float sum of p^2 over
+// the first n samples at one cell, times the discrete distance r.
+__global__ void pv_efree_kernel(const float* hist, long long plane, long long cellOff, int n, float r,
+                                float* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float e = 0.f;
+    for (int i = 0; i < n; ++i) {
+        const float p = hist[(long long)i * plane + cellOff];
+        e += p * p;
+    }
+    out[0] = e * r;
+}
+
+void launchEfree(const float* hist, long long plane, long long cellOff, int n, float r, float* out,
+                 hipStream_t stream) {
+    hipLaunchKernelGGL(pv_efree_kernel, dim3(1), dim3(64), 0, stream, hist, plane, cellOff, n, r, out);
+}
+
+// Grid::GetResponse, FDTD.cpp:74-79: the (pr, vx, vy) impulse response of one array cell, rebuilt from the
+// pressure history (see pv_encode_kernel).  out = T x 3 floats.
+__global__ void pv_ir_kernel(const AnalyzeArgs a, int X, int Y, float* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const DynParams dyn = *a.dyn;
+    const int prow = X + a.G, pcol = Y + a.G;
+    const int tj = (Y / a.wi), ti = (X / a.rxi);
+    const int tFirst = a.tileFirst[ti * a.nty + tj];
+    const long long hoff = (long long)(prow - dyn.histRow0) * a.histPitch + (pcol - dyn.histCol0);
+    int tFx = INT_MAX, tFy = INT_MAX;
+    if (X > 0 && prow - 1 >= dyn.histRow0) tFx = a.tileFirst[((X - 1) / a.rxi) * a.nty + tj];
+    if (Y > 0 && pcol - 1 >= dyn.histCol0) tFy = a.tileFirst[ti * a.nty + ((Y - 1) / a.wi)];
+    const uint32_t code = a.codes[(size_t)prow * a.pitch + pcol];
+    const float kx = a.lut[code & 0xffu], ky = a.lut[code >> 8];
+    const bool airX = kx != kx, airY = ky != ky;
+    float vx = 0.f, vy = 0.f;
+    for (int t = 0; t < a.T; ++t) {
+        float p = 0.f;
+        if (t >= tFirst) {
+            p = a.hist[(long long)t * a.histPlane + hoff];
+            const float pxn = (t >= tFx) ? a.hist[(long long)t * a.histPlane + hoff - a.histPitch] : 0.f;
+            const float pyn = (t >= tFy) ? a.hist[(long long)t * a.histPlane + hoff - 1] : 0.f;
+            const float ax = vx - a.courant * (p - pxn), wx = kx * (p + pxn);
+            const float ay = vy - a.courant * (p - pyn), wy = ky * (p + pyn);
+            vx = airX ? ax : wx;
+            vy = airY ? ay : wy;
+        }
+        out[3 * t + 0] = p;
+        out[3 * t + 1] = vx;
+        out[3 * t + 2] = vy;
+    }
+}
+
+void launchIr(const AnalyzeArgs& a, int X, int Y, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(pv_ir_kernel, dim3(1), dim3(64), 0, stream, a, X, Y, out);
+}
+
+// gather / scatter between the reference's dense (gx+1)x(gy+1) order and the padded device planes
+__global__ void pv_unpad_kernel(const float* padded, float* dense, Geometry g) {
+    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+    const int x = blockIdx.y;
+    if (y < g.NY && x < g.NX) dense[(size_t)x * g.NY + y] = padded[(size_t)(x + g.G) * g.pitch + (y + g.G)];
+}
+__global__ void pv_pad_kernel(const float* dense, float* padded, Geometry g) {
+    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+    const int x = blockIdx.y;
+    if (y < g.NY && x < g.NX) padded[(size_t)(x + g.G) * g.pitch + (y + g.G)] = dense[(size_t)x * g.NY + y];
+}
+// recorded pressure plane t -> dense order, zero where nothing was stored
+__global__ void pv_histplane_kernel(const AnalyzeArgs a, int t, float* dense, int NX, int NY, int histRows) {
+    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+    const int x = blockIdx.y;
+    if (y >= NY || x >= NX) return;
+    const DynParams dyn = *a.dyn;
+    const int hr = x + a.G - dyn.histRow0, hcn = y + a.G - dyn.histCol0;
+    float v = 0.f;
+    if (hr >= 0 && hr < histRows && hcn >= 0 && hcn < a.histPitch) {
+        const int tF = a.tileFirst[(x / a.rxi) * a.nty + (y / a.wi)];
+        if (t >= tF) v = a.hist[(long long)t * a.histPlane + (long long)hr * a.histPitch + hcn];
+    }
+    dense[(size_t)x * NY + y] = v;
+}
+
+void launchUnpad(const float* padded, float* dense, const Geometry& g, hipStream_t stream) {
+    dim3 grid((g.NY + 255) / 256, g.NX);
+    hipLaunchKernelGGL(pv_unpad_kernel, grid, dim3(256), 0, stream, padded, dense, g);
+}
+void launchPad(const float* dense, float* padded, const Geometry& g, hipStream_t stream) {
+    dim3 grid((g.NY + 255) / 256, g.NX);
+    hipLaunchKernelGGL(pv_pad_kernel, grid, dim3(256), 0, stream, dense, padded, g);
+}
+void launchHistPlane(const AnalyzeArgs& a, int t, float* dense, int NX, int NY, int histRows,
+                     hipStream_t stream) {
+    dim3 grid((NY + 255) / 256, NX);
+    hipLaunchKernelGGL(pv_histplane_kernel, grid, dim3(256), 0, stream, a, t, dense, NX, NY, histRows);
+}
+
+}  // namespace pva

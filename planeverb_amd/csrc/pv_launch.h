@@ -1,0 +1,28 @@
+// pv_launch.h -- host-callable launchers for the kernels in pv_kernels.hip
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "pv_device.h"
+
+namespace pva {
+
+// supported (K steps per launch, interior rows per tile) instantiations of the fused stencil
+bool stepConfigSupported(int K, int rxi);
+void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream);
+void launchTileClass(int K, int rxi, const uint16_t* codes, uint8_t* tileClass, int* list, int* count,
+                     const Geometry& g, hipStream_t stream);
+void launchCodes(const uint8_t* mat, uint16_t* codes, const Geometry& g, hipStream_t stream);
+void launchLaneSelfTest(float* out128, hipStream_t stream);
+void launchAnalysis(const AnalyzeArgs& a, hipStream_t stream);
+void launchEfree(const float* hist, long long plane, long long cellOff, int n, float r, float* out,
+                 hipStream_t stream);
+void launchIr(const AnalyzeArgs& a, int X, int Y, float* out3T, hipStream_t stream);
+void launchUnpad(const float* padded, float* dense, const Geometry& g, hipStream_t stream);
+void launchPad(const float* dense, float* padded, const Geometry& g, hipStream_t stream);
+void launchHistPlane(const AnalyzeArgs& a, int t, float* dense, int NX, int NY, int histRows,
+                     hipStream_t stream);
+
+}  // namespace pva

@@ -1,0 +1,670 @@
+// pv_solver.cpp -- see pv_solver.h
+#include "pv_solver.h"
+
+#include <algorithm>
+#include <chrono>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include "pv_launch.h"
+
+namespace pva {
+
+namespace {
+constexpr int kGuard = 8;  // >= the largest K instantiated in pv_kernels.hip
+inline int roundUp(int v, int m) { return (v + m - 1) / m * m; }
+inline int ceilDiv(int a, int b) { return (a + b - 1) / b; }
+inline int floorDiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+}  // namespace
+
+bool Solver::fail(const std::string& what) {
+    err_ = what;
+    return false;
+}
+
+bool Solver::hipOk(hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    err_ = std::string(what) + ": " + hipGetErrorString(e);
+    return false;
+}
+
+template <typename Tp>
+bool Solver::dalloc(Tp** p, size_t count, bool zero) {
+    const size_t bytes = count * sizeof(Tp);
+    if (!hipOk(hipMalloc((void**)p, bytes), "hipMalloc")) return false;
+    deviceBytes_ += (long long)bytes;
+    if (zero && !hipOk(hipMemsetAsync(*p, 0, bytes, stream_), "hipMemsetAsync")) return false;
+    return true;
+}
+
+Solver* Solver::create(const GridSpec& spec, int device, const SolverOptions& opt, std::string* err) {
+    Solver* s = new Solver();
+    if (!s->init(spec, device, opt)) {
+        if (err) *err = s->err_;
+        delete s;
+        return nullptr;
+    }
+    return s;
+}
+
+bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
+    g_ = spec;
+    opt_ = opt;
+    device_ = device;
+    if (spec.gx < 1 || spec.gy < 1) return fail("grid has no cells");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail("no HIP device: libplaneverb_amd has no CPU path");
+    if (device < 0 || device >= ndev) return fail("HIP device index out of range");
+    if (!hipOk(hipSetDevice(device), "hipSetDevice")) return false;
+    if (!hipOk(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate")) return false;
+    for (auto& e : ev_)
+        if (!hipOk(hipEventCreate(&e), "hipEventCreate")) return false;
+
+    K_ = opt.K > 0 ? opt.K : 4;
+    rxi_ = opt.rxi > 0 ? opt.rxi : 32;
+    if (!stepConfigSupported(K_, rxi_)) return fail("unsupported (stepsPerLaunch, tileRows) configuration");
+    wi_ = 64 - 2 * K_;
+    T_ = opt.numSteps > 0 ? opt.numSteps : g_.T;
+
+    geo_.gx = g_.gx;
+    geo_.gy = g_.gy;
+    geo_.NX = g_.NX;
+    geo_.NY = g_.NY;
+    geo_.G = kGuard;
+    geo_.rxi = rxi_;
+    geo_.wi = wi_;
+    geo_.ntx = ceilDiv(g_.NX, rxi_);
+    geo_.nty = ceilDiv(g_.NY, wi_);
+    geo_.rows = kGuard + geo_.ntx * rxi_ + kGuard;
+    geo_.pitch = roundUp(kGuard + geo_.nty * wi_ + kGuard, 64);
+    const size_t plane = (size_t)geo_.rows * geo_.pitch;
+    if (plane * 4 > (size_t)INT_MAX) return fail("grid too large for 32-bit plane offsets");
+    const int ntiles = geo_.ntx * geo_.nty;
+
+    // lane-shift self test: the stencil relies on DPP wave shifts moving data by exactly one lane
+    {
+        float* d = nullptr;
+        if (!dalloc(&d, 128, true)) return false;
+        launchLaneSelfTest(d, stream_);
+        float h[128];
+        if (!hipOk(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, stream_), "selftest copy")) return false;
+        if (!hipOk(hipStreamSynchronize(stream_), "selftest sync")) return false;
+        hipFree(d);
+        deviceBytes_ -= 128 * 4;
+        for (int i = 0; i < 63; ++i)
+            if (h[i] != (float)(i + 1)) return fail("DPP wave_shl self-test failed");
+        for (int i = 1; i < 64; ++i)
+            if (h[64 + i] != (float)(i - 1)) return fail("DPP wave_shr self-test failed");
+    }
+
+    for (int i = 0; i < 2; ++i) {
+        if (!dalloc(&pr_[i], plane, true) || !dalloc(&vx_[i], plane, true) || !dalloc(&vy_[i], plane, true))
+            return false;
+    }
+    if (!dalloc(&codes_, plane, true)) return false;
+    if (!dalloc(&matDev_, (size_t)g_.NX * g_.NY, true)) return false;
+    if (!dalloc(&lutDev_, 256, true)) return false;
+    if (!dalloc(&pulseDev_, (size_t)std::max(T_, g_.T), true)) return false;
+    if (!dalloc(&tileFirst_, (size_t)ntiles, true)) return false;
+    if (!dalloc(&tileClass_, (size_t)ntiles, true)) return false;
+    listCap_ = ntiles;
+    if (!dalloc(&generalList_, (size_t)listCap_, true)) return false;
+    if (!dalloc(&generalCount_, 1, true)) return false;
+    if (!dalloc(&dynDev_, 1, true)) return false;
+    if (!dalloc(&errFlag_, 1, true)) return false;
+    if (!dalloc(&res8_, (size_t)g_.gx * g_.gy * 8, true)) return false;  // zeroed pool: PvContext.cpp:132
+    if (!dalloc(&delay_, (size_t)g_.gx * g_.gy, true)) return false;
+    scratchCount_ = std::max<size_t>((size_t)3 * std::max(T_, g_.T), (size_t)g_.NX * g_.NY * 3);
+    if (!dalloc(&scratch_, scratchCount_, true)) return false;
+
+    // history window: the pulse moves at most one cell per step along each axis, so after T steps everything
+    // farther than T cells from the listener is still exactly zero and needs no storage
+    {
+        const int reach = T_ + 2;
+        int wtx = geo_.ntx, wty = geo_.nty;
+        if (!opt.denseHistory) {
+            wtx = std::min(geo_.ntx, ceilDiv(2 * reach + 1, rxi_) + 1);
+            wty = std::min(geo_.nty, ceilDiv(2 * reach + 1, wi_) + 1);
+        }
+        histTilesX_ = wtx;
+        histTilesY_ = wty;
+        histRows_ = wtx * rxi_;
+        histPitch_ = roundUp(wty * wi_, 64);
+        histPlane_ = (long long)histRows_ * histPitch_;
+        const long long bytes = histPlane_ * 4 * (long long)T_;
+        if (histPlane_ * 4 > (long long)INT_MAX) return fail("history plane too large for 32-bit offsets");
+        size_t freeB = 0, totalB = 0;
+        hipMemGetInfo(&freeB, &totalB);
+        if ((unsigned long long)bytes + (1ull << 30) > freeB)
+            return fail("not enough HBM for the pressure history (" + std::to_string(bytes >> 20) + " MiB)");
+        if (!hipOk(hipMalloc((void**)&hist_, (size_t)bytes), "hipMalloc history")) return false;
+        deviceBytes_ += bytes;
+    }
+
+    if (!hipOk(hipHostMalloc((void**)&dynHost_, sizeof(DynParams)), "hipHostMalloc")) return false;
+    if (!hipOk(hipHostMalloc((void**)&listHost_, sizeof(int) * (size_t)listCap_), "hipHostMalloc")) return false;
+
+    pulse_ = gaussianPulse(g_);
+    pulse_.resize((size_t)std::max(T_, g_.T), 0.f);  // an extended run (numSteps > T) injects nothing after T
+    if (!hipOk(hipMemcpyAsync(pulseDev_, pulse_.data(), pulse_.size() * 4, hipMemcpyHostToDevice, stream_),
+               "pulse upload"))
+        return false;
+
+    mat_.init(g_);
+    matHost_.assign((size_t)g_.NX * g_.NY, 0);
+    palette_.assign(1, 0.f);
+    paletteIndex_.clear();
+    uint32_t zeroBits = 0;
+    paletteIndex_[zeroBits] = 0;
+    geometryDirty_ = true;
+    if (!applyGeometry()) return false;
+    if (!hipOk(hipStreamSynchronize(stream_), "init sync")) return false;
+
+    if (opt.withFreeGrid) {
+        if (!computeEfree()) return false;
+    }
+    return true;
+}
+
+Solver::~Solver() {
+    if (stream_) hipStreamSynchronize(stream_);
+    for (int i = 0; i < 2; ++i) {
+        if (pr_[i]) hipFree(pr_[i]);
+        if (vx_[i]) hipFree(vx_[i]);
+        if (vy_[i]) hipFree(vy_[i]);
+    }
+    void* ptrs[] = {codes_,     matDev_, lutDev_, pulseDev_, hist_,  tileFirst_, tileClass_, generalList_,
+                    generalCount_, dynDev_, errFlag_, res8_,     delay_, scratch_};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    if (dynHost_) hipHostFree(dynHost_);
+    if (listHost_) hipHostFree(listHost_);
+    for (auto& e : ev_)
+        if (e) hipEventDestroy(e);
+    if (stream_) hipStreamDestroy(stream_);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// geometry
+// ----------------------------------------------------------------------------------------------------------------
+
+int Solver::addBox(const Box& b) {
+    int id;
+    if (boxFree_.empty()) {
+        id = (int)boxTable_.size();
+        boxTable_.push_back(b);
+        boxUsed_.push_back(1);
+    } else {
+        id = boxFree_.back();  // LIFO recycling, GeometryManager.cpp:83-85
+        boxFree_.pop_back();
+        boxTable_[(size_t)id] = b;
+        boxUsed_[(size_t)id] = 1;
+    }
+    mat_.add(b);
+    geometryDirty_ = true;
+    return id;
+}
+
+bool Solver::updateBox(int id, const Box& b) {
+    if (id < 0 || id >= (int)boxTable_.size()) return fail("invalid geometry id");
+    mat_.remove(boxTable_[(size_t)id]);  // UpdateObject = Remove(old) then Add(new), GeometryManager.cpp:112-121
+    boxTable_[(size_t)id] = b;
+    mat_.add(b);
+    geometryDirty_ = true;
+    return true;
+}
+
+bool Solver::removeBox(int id) {
+    if (id < 0 || id >= (int)boxTable_.size()) return fail("invalid geometry id");
+    mat_.remove(boxTable_[(size_t)id]);
+    boxTable_[(size_t)id] = Box{0, 0, 0, 0, 0};  // GeometryManager.cpp:108
+    boxUsed_[(size_t)id] = 0;
+    boxFree_.push_back(id);
+    geometryDirty_ = true;
+    return true;
+}
+
+int Solver::numBoxes() const {
+    int n = 0;
+    for (uint8_t u : boxUsed_) n += u;
+    return n;
+}
+
+std::vector<std::pair<int, Box>> Solver::boxes() const {
+    std::vector<std::pair<int, Box>> out;
+    for (size_t i = 0; i < boxTable_.size(); ++i)
+        if (boxUsed_[i]) out.emplace_back((int)i, boxTable_[i]);
+    return out;
+}
+
+bool Solver::applyGeometry() {
+    if (!geometryDirty_ && mat_.dirtyLo() >= mat_.dirtyHi()) return true;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int lo = mat_.dirtyLo(), hi = mat_.dirtyHi();
+    if (lo < hi) {
+        const auto& beta = mat_.beta();
+        const auto& R = mat_.R();
+        for (int x = lo; x < hi; ++x) {
+            for (int y = 0; y < g_.NY; ++y) {
+                const size_t i = (size_t)x * g_.NY + y;
+                int p = 0;
+                if (R[i] != 0.f) {
+                    uint32_t bits;
+                    std::memcpy(&bits, &R[i], 4);
+                    auto it = paletteIndex_.find(bits);
+                    if (it == paletteIndex_.end()) {
+                        if ((int)palette_.size() >= kPaletteMax)
+                            return fail("more than 127 distinct absorption values in the scene");
+                        p = (int)palette_.size();
+                        palette_.push_back(R[i]);
+                        paletteIndex_[bits] = p;
+                    } else {
+                        p = it->second;
+                    }
+                }
+                matHost_[i] = (uint8_t)((beta[i] ? 1 : 0) | (p << 1));
+            }
+        }
+        if (!hipOk(hipMemcpyAsync(matDev_ + (size_t)lo * g_.NY, matHost_.data() + (size_t)lo * g_.NY,
+                                  (size_t)(hi - lo) * g_.NY, hipMemcpyHostToDevice, stream_),
+                   "material upload"))
+            return false;
+    }
+    // coefficient LUT: Y = (1 - R) / (1 + R), FDTD.cpp:150,156
+    float lut[256];
+    for (float& v : lut) v = 0.f;
+    lut[kLutAir] = std::numeric_limits<float>::quiet_NaN();
+    for (size_t p = 0; p < palette_.size(); ++p) {
+        const float Rv = palette_[p];
+        const float Y = (1.f - Rv) / (1.f + Rv);
+        lut[kLutNegBase + p] = -Y;
+        lut[kLutPosBase + p] = Y;
+    }
+    lut[kLutWall] = 0.f;
+    if (!hipOk(hipMemcpyAsync(lutDev_, lut, sizeof(lut), hipMemcpyHostToDevice, stream_), "lut upload"))
+        return false;
+    launchCodes(matDev_, codes_, geo_, stream_);
+    if (!hipOk(hipMemsetAsync(generalCount_, 0, sizeof(int), stream_), "memset")) return false;
+    launchTileClass(K_, rxi_, codes_, tileClass_, generalList_, generalCount_, geo_, stream_);
+    int count = 0;
+    if (!hipOk(hipMemcpyAsync(&count, generalCount_, sizeof(int), hipMemcpyDeviceToHost, stream_), "count copy"))
+        return false;
+    if (!hipOk(hipStreamSynchronize(stream_), "geometry sync")) return false;
+    wallTiles_.resize((size_t)count);
+    if (count > 0 &&
+        !hipOk(hipMemcpy(wallTiles_.data(), generalList_, sizeof(int) * (size_t)count, hipMemcpyDeviceToHost),
+               "list copy"))
+        return false;
+    std::sort(wallTiles_.begin(), wallTiles_.end());
+    tileClassHost_.resize((size_t)geo_.ntx * geo_.nty);
+    if (!hipOk(hipMemcpy(tileClassHost_.data(), tileClass_, tileClassHost_.size(), hipMemcpyDeviceToHost),
+               "class copy"))
+        return false;
+    mat_.clearDirty();
+    geometryDirty_ = false;
+    dynValid_ = false;
+    tim_.geometryMs =
+        std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return true;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// FreeGrid
+// ----------------------------------------------------------------------------------------------------------------
+
+bool Solver::freeFieldEnergyAt(int cellX, int cellY, int n, float r, float* out) {
+    const long long off = (long long)(cellX + geo_.G - dynCur_.histRow0) * histPitch_ +
+                          (cellY + geo_.G - dynCur_.histCol0);
+    launchEfree(hist_, histPlane_, off, n, r, scratch_, stream_);
+    if (!hipOk(hipMemcpyAsync(out, scratch_, 4, hipMemcpyDeviceToHost, stream_), "efree copy")) return false;
+    return hipOk(hipStreamSynchronize(stream_), "efree sync");
+}
+
+// FreeGrid::FreeGrid / SimulateFreeFieldEnergy (FreeGrid.cpp:6-34,71-94): a run on an EMPTY grid of the same
+// config, source at the centre cell, energy of the first nFree samples at the cell (int)(1/dx) to its +x side.
+// Only nFree samples are read, so by causality any sub-grid whose edges are more than nFree cells from both cells
+// gives bit-identical samples; large grids therefore simulate a window instead of the whole plane.
+bool Solver::computeEfree() {
+    const int lx0 = g_.gx / 2, ly0 = g_.gy / 2;         // FreeGrid.cpp:78-79
+    const int ex = lx0 + (int)(1.f / g_.dx), ey = ly0;  // FreeGrid.cpp:80-81
+    // the listener is passed in metres and truncated again by GenerateResponse (FreeGrid.cpp:84, FDTD.cpp:97-98)
+    int lcx, lcy;
+    listenerCell(g_, (float)lx0 * g_.dx, (float)ly0 * g_.dx, &lcx, &lcy);
+    const int n = g_.nFree;
+    const float r = (float)(ex - lx0) * g_.dx;  // FreeGrid.cpp:89
+    if (n > g_.T) return fail("free-field window longer than the impulse response");
+
+    const int margin = n + 8;
+    const int span = ex - lcx;
+    const bool window = (lcx - margin > 0) && (ex + margin < g_.gx) && (lcy - margin > 0) && (lcy + margin < g_.gy);
+    GridSpec fs;
+    int sx, sy, qx, qy;
+    if (window) {
+        fs = makeGridSpecCells(2 * margin + span + 1, 2 * margin + 1, g_.res);
+        sx = margin;
+        sy = margin;
+        qx = margin + span;
+        qy = margin;
+    } else {
+        fs = makeGridSpecCells(g_.gx, g_.gy, g_.res);
+        sx = lcx;
+        sy = lcy;
+        qx = ex;
+        qy = ey;
+    }
+    SolverOptions o;
+    o.K = K_;
+    o.rxi = rxi_;
+    o.withFreeGrid = false;
+    o.skipAnalysis = true;
+    o.numSteps = roundUp(n, K_);
+    std::string e;
+    Solver* f = Solver::create(fs, device_, o, &e);
+    if (!f) return fail("free grid: " + e);
+    bool ok = f->runCells(sx, sy, 0.f, 0.f, true) && f->freeFieldEnergyAt(qx, qy, n, r, &efree_);
+    if (!ok) err_ = "free grid: " + f->err_;
+    delete f;
+    hipSetDevice(device_);
+    return ok;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// run
+// ----------------------------------------------------------------------------------------------------------------
+
+bool Solver::prepareDyn(int lcx, int lcy, bool withPulse) {
+    DynParams d{};
+    const bool inside = withPulse && lcx >= 0 && lcx <= g_.gx && lcy >= 0 && lcy <= g_.gy;
+    d.lrow = inside ? lcx + geo_.G : -100000;
+    d.lcol = inside ? lcy + geo_.G : -100000;
+    // history window in tiles, centred on the listener and clamped to the grid
+    int tx0 = 0, ty0 = 0;
+    if (histTilesX_ < geo_.ntx) {
+        const int ltx = std::min(std::max(lcx, 0), g_.gx) / rxi_;
+        tx0 = std::min(std::max(ltx - histTilesX_ / 2, 0), geo_.ntx - histTilesX_);
+    }
+    if (histTilesY_ < geo_.nty) {
+        const int lty = std::min(std::max(lcy, 0), g_.gy) / wi_;
+        ty0 = std::min(std::max(lty - histTilesY_ / 2, 0), geo_.nty - histTilesY_);
+    }
+    d.histTileX0 = tx0;
+    d.histTileY0 = ty0;
+    d.histTilesX = histTilesX_;
+    d.histTilesY = histTilesY_;
+    d.histRow0 = geo_.G + tx0 * rxi_;
+    d.histCol0 = geo_.G + ty0 * wi_;
+    dynCur_ = d;
+    *dynHost_ = d;
+    if (!hipOk(hipMemcpyAsync(dynDev_, dynHost_, sizeof(DynParams), hipMemcpyHostToDevice, stream_), "dyn upload"))
+        return false;
+
+    // general-kernel work list = wall/edge tiles + every tile whose loaded region holds the listener
+    const int rowsT = rxi_ + 2 * K_;
+    int n = 0;
+    for (int t : wallTiles_) listHost_[n++] = t;
+    if (inside) {
+        const int a0 = d.lrow - (geo_.G - K_), b0 = d.lcol - (geo_.G - K_);
+        const int tiLo = std::max(0, floorDiv(a0 - rowsT, rxi_) + 1), tiHi = std::min(geo_.ntx - 1, floorDiv(a0, rxi_));
+        const int tjLo = std::max(0, floorDiv(b0 - 64, wi_) + 1), tjHi = std::min(geo_.nty - 1, floorDiv(b0, wi_));
+        for (int ti = tiLo; ti <= tiHi; ++ti)
+            for (int tj = tjLo; tj <= tjHi; ++tj) {
+                const int t = ti * geo_.nty + tj;
+                if (!tileClassHost_[(size_t)t]) listHost_[n++] = t;
+            }
+    }
+    numGeneral_ = n;
+    if (n > 0 && !hipOk(hipMemcpyAsync(generalList_, listHost_, sizeof(int) * (size_t)n, hipMemcpyHostToDevice,
+                                       stream_),
+                        "list upload"))
+        return false;
+    dynValid_ = true;
+    return true;
+}
+
+bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record) {
+    StepArgs a{};
+    a.codes = codes_;
+    a.lut = lutDev_;
+    a.pulse = pulseDev_;
+    a.hist = hist_;
+    a.tileFirst = tileFirst_;
+    a.tileClass = tileClass_;
+    a.generalList = generalList_;
+    a.numGeneral = numGeneral_;
+    a.dyn = dynDev_;
+    a.errFlag = errFlag_;
+    a.histPlane = histPlane_;
+    a.planeBytes = (long long)geo_.rows * geo_.pitch * 4;
+    a.histPitch = histPitch_;
+    a.pitch = geo_.pitch;
+    a.G = geo_.G;
+    a.ntx = geo_.ntx;
+    a.nty = geo_.nty;
+    a.ntiles = geo_.ntx * geo_.nty;
+    a.withPulse = withPulse ? 1 : 0;
+    a.record = record ? 1 : 0;
+    a.dense = opt_.denseHistory ? 1 : 0;
+    a.courant = g_.courant;
+    int done = 0;
+    while (done < nsteps) {
+        const int k = std::min(K_, nsteps - done);
+        a.prIn = pr_[cur_];
+        a.vxIn = vx_[cur_];
+        a.vyIn = vy_[cur_];
+        a.prOut = pr_[cur_ ^ 1];
+        a.vxOut = vx_[cur_ ^ 1];
+        a.vyOut = vy_[cur_ ^ 1];
+        a.t0 = firstStep + done;
+        a.nsteps = k;
+        launchStep(K_, rxi_, a, stream_);
+        cur_ ^= 1;
+        done += k;
+        ++tim_.stepLaunches;
+    }
+    return hipOk(hipGetLastError(), "step launch");
+}
+
+AnalyzeArgs Solver::analyzeArgs(float lx, float lz) const {
+    AnalyzeArgs a{};
+    a.hist = hist_;
+    a.codes = codes_;
+    a.lut = lutDev_;
+    a.tileFirst = tileFirst_;
+    a.dyn = dynDev_;
+    a.res8 = res8_;
+    a.delay = delay_;
+    a.histPlane = histPlane_;
+    a.histPitch = histPitch_;
+    a.pitch = geo_.pitch;
+    a.G = geo_.G;
+    a.gx = g_.gx;
+    a.gy = g_.gy;
+    a.rxi = rxi_;
+    a.wi = wi_;
+    a.nty = geo_.nty;
+    a.T = T_;
+    a.nDir = g_.nDir;
+    a.nDry = g_.nDry;
+    a.nWet = g_.nWet;
+    a.nCut = g_.nCut;
+    a.fs = g_.fs;
+    a.res = g_.res;
+    a.dx = g_.dx;
+    a.courant = g_.courant;
+    a.efree = efree_;
+    a.lx = lx;
+    a.lz = lz;
+    listenerCellRecip(g_, lx, lz, &a.lcx, &a.lcy);
+    return a;
+}
+
+bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
+    if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
+    if (!applyGeometry()) return false;
+    if (!prepareDyn(lcx, lcy, true)) return false;
+    lastLx_ = lx;
+    lastLz_ = lz;
+    const size_t planeBytes = (size_t)geo_.rows * geo_.pitch * 4;
+    tim_.stepLaunches = 0;
+    hipEventRecord(ev_[0], stream_);
+    // reset pr / vx / vy (FDTD.cpp:109-119); the other set is fully overwritten by the first launch
+    if (!hipOk(hipMemsetAsync(pr_[cur_], 0, planeBytes, stream_), "reset") ||
+        !hipOk(hipMemsetAsync(vx_[cur_], 0, planeBytes, stream_), "reset") ||
+        !hipOk(hipMemsetAsync(vy_[cur_], 0, planeBytes, stream_), "reset"))
+        return false;
+    // tileFirst = "never" (0x7f7f7f7f is treated as INT_MAX-like sentinel by memset; use exact INT_MAX fill)
+    {
+        const int ntiles = geo_.ntx * geo_.nty;
+        if (opt_.denseHistory) {
+            if (!hipOk(hipMemsetAsync(tileFirst_, 0, sizeof(int) * (size_t)ntiles, stream_), "tileFirst")) return false;
+        } else {
+            if (!hipOk(hipMemsetD32Async((hipDeviceptr_t)tileFirst_, INT_MAX, (size_t)ntiles, stream_), "tileFirst"))
+                return false;
+        }
+    }
+    if (!hipOk(hipMemsetAsync(errFlag_, 0, sizeof(int), stream_), "errFlag")) return false;
+    if (!enqueueSteps(0, T_, true, true)) return false;
+    hipEventRecord(ev_[1], stream_);
+    if (!opt_.skipAnalysis) launchAnalysis(analyzeArgs(lx, lz), stream_);
+    hipEventRecord(ev_[2], stream_);
+    pendingTimings_ = true;
+    return hipOk(hipGetLastError(), "run launch");
+}
+
+bool Solver::runCells(int lcx, int lcy, float lx, float lz, bool wait) {
+    if (!enqueueRun(lcx, lcy, lx, lz)) return false;
+    return wait ? sync() : true;
+}
+
+bool Solver::run(float lx, float ly, float lz, bool wait) {
+    (void)ly;  // world y is ignored: grid-x = world x, grid-y = world z (FDTD.cpp:97-98)
+    int lcx, lcy;
+    listenerCell(g_, lx, lz, &lcx, &lcy);
+    return runCells(lcx, lcy, lx, lz, wait);
+}
+
+bool Solver::sync() {
+    if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
+    if (!hipOk(hipStreamSynchronize(stream_), "stream sync")) return false;
+    if (pendingTimings_) {
+        pendingTimings_ = false;
+        hipEventElapsedTime(&tim_.fdtdMs, ev_[0], ev_[1]);
+        hipEventElapsedTime(&tim_.analysisMs, ev_[1], ev_[2]);
+        int flag = 0;
+        if (!hipOk(hipMemcpy(&flag, errFlag_, sizeof(int), hipMemcpyDeviceToHost), "errFlag copy")) return false;
+        if (flag) return fail("pressure history window overflow (a tile outside the window became non-zero)");
+    }
+    return true;
+}
+
+bool Solver::runSteps(int nsteps, bool withPulse, float lx, float lz) {
+    if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
+    if (!applyGeometry()) return false;
+    int lcx, lcy;
+    listenerCell(g_, lx, lz, &lcx, &lcy);
+    if (!prepareDyn(lcx, lcy, withPulse)) return false;
+    tim_.stepLaunches = 0;
+    hipEventRecord(ev_[0], stream_);
+    if (!enqueueSteps(0, nsteps, withPulse, false)) return false;
+    hipEventRecord(ev_[1], stream_);
+    hipEventRecord(ev_[2], stream_);
+    pendingTimings_ = true;
+    return sync();
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// read-back
+// ----------------------------------------------------------------------------------------------------------------
+
+bool Solver::getOutput(float ex, float ey, float ez, float out8[8], bool* valid) {
+    (void)ey;
+    int cx, cy;
+    *valid = resultCell(g_, ex, ez, &cx, &cy);
+    if (!*valid) return true;
+    if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
+    const size_t idx = (size_t)cx * g_.gy + cy;
+    if (!hipOk(hipMemcpyAsync(out8, res8_ + 8 * idx, 32, hipMemcpyDeviceToHost, stream_), "output copy")) return false;
+    return hipOk(hipStreamSynchronize(stream_), "output sync");
+}
+
+bool Solver::copyResults(float* res8, float* delay) {
+    if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
+    const size_t n = (size_t)g_.gx * g_.gy;
+    if (res8 && !hipOk(hipMemcpyAsync(res8, res8_, n * 32, hipMemcpyDeviceToHost, stream_), "results copy"))
+        return false;
+    if (delay && !hipOk(hipMemcpyAsync(delay, delay_, n * 4, hipMemcpyDeviceToHost, stream_), "delay copy"))
+        return false;
+    return hipOk(hipStreamSynchronize(stream_), "results sync");
+}
+
+bool Solver::copyResultsAsync(float* res8Host) {
+    const size_t n = (size_t)g_.gx * g_.gy;
+    return hipOk(hipMemcpyAsync(res8Host, res8_, n * 32, hipMemcpyDeviceToHost, stream_), "results copy");
+}
+
+bool Solver::impulseResponse(int cx, int cy, float* out3T) {
+    if (cx < 0 || cx > g_.gx || cy < 0 || cy > g_.gy) return fail("cell outside the grid");
+    if (!dynValid_) return fail("no simulation has run yet");
+    if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
+    launchIr(analyzeArgs(lastLx_, lastLz_), cx, cy, scratch_, stream_);
+    if (!hipOk(hipMemcpyAsync(out3T, scratch_, (size_t)3 * T_ * 4, hipMemcpyDeviceToHost, stream_), "ir copy"))
+        return false;
+    return hipOk(hipStreamSynchronize(stream_), "ir sync");
+}
+
+bool Solver::copyFields(float* pr, float* vx, float* vy) {
+    if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
+    const size_t n = (size_t)g_.NX * g_.NY;
+    const float* src[3] = {pr_[cur_], vx_[cur_], vy_[cur_]};
+    float* dst[3] = {pr, vx, vy};
+    for (int i = 0; i < 3; ++i) {
+        if (!dst[i]) continue;
+        launchUnpad(src[i], scratch_, geo_, stream_);
+        if (!hipOk(hipMemcpyAsync(dst[i], scratch_, n * 4, hipMemcpyDeviceToHost, stream_), "field copy")) return false;
+        if (!hipOk(hipStreamSynchronize(stream_), "field sync")) return false;
+    }
+    return true;
+}
+
+bool Solver::setFields(const float* pr, const float* vx, const float* vy) {
+    if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
+    const size_t n = (size_t)g_.NX * g_.NY;
+    const float* src[3] = {pr, vx, vy};
+    float* dst[3] = {pr_[cur_], vx_[cur_], vy_[cur_]};
+    const size_t planeBytes = (size_t)geo_.rows * geo_.pitch * 4;
+    for (int i = 0; i < 3; ++i) {
+        if (!hipOk(hipMemsetAsync(dst[i], 0, planeBytes, stream_), "field clear")) return false;
+        if (!src[i]) continue;
+        if (!hipOk(hipMemcpyAsync(scratch_, src[i], n * 4, hipMemcpyHostToDevice, stream_), "field upload")) return false;
+        launchPad(scratch_, dst[i], geo_, stream_);
+        if (!hipOk(hipStreamSynchronize(stream_), "field sync")) return false;
+    }
+    return true;
+}
+
+bool Solver::copyHistoryPlane(int t, float* pr) {
+    if (t < 0 || t >= T_) return fail("step outside the recorded range");
+    if (!dynValid_) return fail("no simulation has run yet");
+    if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
+    launchHistPlane(analyzeArgs(lastLx_, lastLz_), t, scratch_, g_.NX, g_.NY, histRows_, stream_);
+    if (!hipOk(hipMemcpyAsync(pr, scratch_, (size_t)g_.NX * g_.NY * 4, hipMemcpyDeviceToHost, stream_), "plane copy"))
+        return false;
+    return hipOk(hipStreamSynchronize(stream_), "plane sync");
+}
+
+bool Solver::copyPulse(float* out) {
+    std::memcpy(out, pulse_.data(), (size_t)g_.T * 4);
+    return true;
+}
+
+bool Solver::copyMaterial(uint8_t* beta, float* R) {
+    const size_t n = (size_t)g_.NX * g_.NY;
+    if (beta) std::memcpy(beta, mat_.beta().data(), n);
+    if (R) std::memcpy(R, mat_.R().data(), n * 4);
+    return true;
+}
+
+}  // namespace pva

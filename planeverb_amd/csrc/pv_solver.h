@@ -1,0 +1,159 @@
+// pv_solver.h -- host side of the MI355X solver: owns the HBM planes, the HIP stream and the launch schedule.
+//
+// One Solver = the reference's Grid + FreeGrid + Analyzer for one config on one GPU
+// (ProjectPlaneverb/src/FDTD/Grid.h:25-74, FreeGrid.h:7-24, DSP/Analyzer.h:24-50), without any thread: run()
+// enqueues  [geometry deltas] -> reset -> T/K fused step launches -> analysis  on the solver's stream, which is
+// what one iteration of Context's background loop does (Context/PvContext.cpp:74-93).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "pv_core.h"
+#include "pv_device.h"
+
+namespace pva {
+
+struct SolverOptions {
+    int K = 0;            // steps per launch (0 = default)
+    int rxi = 0;          // interior rows per tile (0 = default)
+    bool denseHistory = false;
+    int numSteps = 0;     // override T (0 = reference value)
+    bool skipAnalysis = false;
+    bool useGraph = false;
+    bool withFreeGrid = true;
+};
+
+struct SolverTimings {
+    float fdtdMs = 0, analysisMs = 0, geometryMs = 0;
+    int stepLaunches = 0;
+    long long histBytesWritten = 0;
+};
+
+class Solver {
+public:
+    static Solver* create(const GridSpec& spec, int device, const SolverOptions& opt, std::string* err);
+    ~Solver();
+
+    const GridSpec& spec() const { return g_; }
+    const Geometry& geometry() const { return geo_; }
+    int device() const { return device_; }
+    int K() const { return K_; }
+    float efree() const { return efree_; }
+    int T() const { return T_; }
+    long long deviceBytes() const { return deviceBytes_; }
+    int histRows() const { return histRows_; }
+    int histPitch() const { return histPitch_; }
+    const std::string& lastError() const { return err_; }
+    SolverOptions& options() { return opt_; }
+
+    // geometry table with the reference's id recycling (Geometry/GeometryManager.cpp:67-121)
+    int addBox(const Box& b);
+    bool updateBox(int id, const Box& b);
+    bool removeBox(int id);
+    int numBoxes() const;
+    std::vector<std::pair<int, Box>> boxes() const;
+    // raw rasteriser access (Grid::AddAABB / RemoveAABB), used by the live context's change queue
+    void rasterAdd(const Box& b) { mat_.add(b); }
+    void rasterRemove(const Box& b) { mat_.remove(b); }
+
+    bool run(float lx, float ly, float lz, bool wait);
+    bool runCells(int lcx, int lcy, float lx, float lz, bool wait);
+    bool sync();
+    bool runSteps(int nsteps, bool withPulse, float lx, float lz);
+    const SolverTimings& timings() const { return tim_; }
+
+    bool getOutput(float ex, float ey, float ez, float out8[8], bool* valid);
+    bool copyResults(float* res8, float* delay);
+    // device -> caller-provided (pinned) host buffers, asynchronously on the solver's stream
+    bool copyResultsAsync(float* res8Host);
+    bool impulseResponse(int cx, int cy, float* out3T);
+    bool copyFields(float* pr, float* vx, float* vy);
+    bool setFields(const float* pr, const float* vx, const float* vy);
+    bool copyHistoryPlane(int t, float* pr);
+    bool copyPulse(float* out);
+    bool copyMaterial(uint8_t* beta, float* R);
+    bool freeFieldEnergyAt(int cellX, int cellY, int n, float r, float* out);
+
+private:
+    Solver() = default;
+    bool init(const GridSpec& spec, int device, const SolverOptions& opt);
+    bool applyGeometry();
+    bool computeEfree();
+    bool enqueueRun(int lcx, int lcy, float lx, float lz);
+    bool enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record);
+    bool prepareDyn(int lcx, int lcy, bool withPulse);
+    AnalyzeArgs analyzeArgs(float lx, float lz) const;
+    bool fail(const std::string& what);
+    bool hipOk(hipError_t e, const char* what);
+    template <typename Tp>
+    bool dalloc(Tp** p, size_t count, bool zero);
+
+    GridSpec g_;
+    Geometry geo_{};
+    SolverOptions opt_;
+    int device_ = 0;
+    int K_ = 4, rxi_ = 32, wi_ = 56;
+    int T_ = 0;
+    hipStream_t stream_ = nullptr;
+    hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
+    long long deviceBytes_ = 0;
+    std::string err_;
+
+    // HBM
+    float* pr_[2] = {nullptr, nullptr};
+    float* vx_[2] = {nullptr, nullptr};
+    float* vy_[2] = {nullptr, nullptr};
+    int cur_ = 0;  // which set holds the current fields
+    uint16_t* codes_ = nullptr;
+    uint8_t* matDev_ = nullptr;
+    float* lutDev_ = nullptr;
+    float* pulseDev_ = nullptr;
+    float* hist_ = nullptr;
+    long long histPlane_ = 0;
+    int histRows_ = 0, histPitch_ = 0, histTilesX_ = 0, histTilesY_ = 0;
+    int* tileFirst_ = nullptr;
+    uint8_t* tileClass_ = nullptr;
+    int* generalList_ = nullptr;
+    int* generalCount_ = nullptr;
+    DynParams* dynDev_ = nullptr;
+    int* errFlag_ = nullptr;
+    float* res8_ = nullptr;
+    float* delay_ = nullptr;
+    float* scratch_ = nullptr;  // max(3T, NX*NY) floats
+    size_t scratchCount_ = 0;
+
+    // pinned host staging
+    DynParams* dynHost_ = nullptr;
+    int* listHost_ = nullptr;
+    int listCap_ = 0;
+
+    // host state
+    MaterialPlane mat_;
+    std::vector<uint8_t> matHost_;
+    std::vector<float> palette_;  // R values; [0] = 0
+    std::unordered_map<uint32_t, int> paletteIndex_;
+    std::vector<float> pulse_;
+    std::vector<int> wallTiles_;
+    std::vector<uint8_t> tileClassHost_;
+    int numGeneral_ = 0;
+    bool geometryDirty_ = true;
+    float efree_ = 0.f;
+    DynParams dynCur_{};
+    bool dynValid_ = false;
+    float lastLx_ = 0, lastLz_ = 0;
+
+    // geometry table (GeometryManager.cpp)
+    std::vector<Box> boxTable_;
+    std::vector<uint8_t> boxUsed_;
+    std::vector<int> boxFree_;
+
+    SolverTimings tim_;
+    bool pendingTimings_ = false;
+};
+
+}  // namespace pva

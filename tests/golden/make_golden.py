@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ from the UNMODIFIED reference.
+
+Runs only in the build container (needs /root/reference and `make -C oracle ref`).  The fixtures are data:
+inputs (scene boxes, positions) and the reference's outputs (pulse table, material planes, field snapshots,
+IR traces, result / delay maps).  No reference source text is stored.
+
+    python tests/golden/make_golden.py small      # 25 m @ 275 Hz scenes (seconds)
+    python tests/golden/make_golden.py modeA512   # Shoebox, 512^2 at 275 Hz   (~1 min, 4 GB)
+    python tests/golden/make_golden.py modeB512   # Shoebox, 25 m at res 2009  (~3 min, 27 GB)
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import pvref  # noqa: E402
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+SMALL = {
+    "smallroom": "DemoFiles/SmallRoomScene.pv",
+    "shoebox": "Shoebox.pv",
+    "bigroom": "BigRoom.pv",
+    "hugeroom": "HugeRoom.pv",
+    "floorplan": "DemoFiles/FloorPlanScene.pv",
+    "direction": "DirectionTester.pv",
+    "empty": None,
+}
+
+
+def probes(gx, gy, n, seed):
+    rng = np.random.default_rng(seed)
+    return np.stack([rng.integers(0, gx, n), rng.integers(0, gy, n)], 1).astype(np.int32)
+
+
+def run(name, scene, size, res, listener, emitters, snap_ts, nprobe, full_map, sample_cells=0):
+    boxes = pvref.load_pv(os.path.join(REF, scene)) if scene else np.zeros((0, 5), np.float32)
+    r = pvref.RefSolver(size, size, res, boxes)
+    t_f = r.generate(listener)
+    t_a = r.analyze(listener)
+    res8, delay = r.results()
+    b, R = r.material()
+    d = dict(
+        boxes=boxes, size=np.float32(size), res=np.int32(res), listener=np.array(listener, np.float32),
+        emitters=np.array(emitters, np.float32),
+        dims=np.array([r.gx, r.gy, r.T, r.fs], np.int32), dx=np.float32(r.dx), dt=np.float32(r.dt),
+        efree=np.float32(r.efree), pulse=r.pulse(),
+        emitter_out=np.stack([r.output(e) for e in emitters]),
+        ref_seconds=np.array([t_f, t_a, r.ctor_grid_s, r.ctor_free_s]),
+    )
+    if full_map:
+        d.update(beta=b.astype(np.uint8), R=R, results=res8, delay=delay)
+    else:
+        rng = np.random.default_rng(7)
+        cells = np.stack([rng.integers(0, r.gx, sample_cells), rng.integers(0, r.gy, sample_cells)], 1)
+        # bias half of the sample towards the region the wave reaches
+        lc = (int(listener[0] / r.dx), int(listener[2] / r.dx))
+        near = np.stack([np.clip(lc[0] + rng.integers(-60, 60, sample_cells), 0, r.gx - 1),
+                         np.clip(lc[1] + rng.integers(-60, 60, sample_cells), 0, r.gy - 1)], 1)
+        cells = np.concatenate([cells, near]).astype(np.int32)
+        d.update(cells=cells, cell_results=res8[cells[:, 0], cells[:, 1]],
+                 cell_delay=delay[cells[:, 0], cells[:, 1]])
+    if snap_ts:
+        snaps = [np.stack(r.snapshot(t)) for t in snap_ts]
+        d.update(snap_ts=np.array(snap_ts, np.int32), snaps=np.stack(snaps))
+    if nprobe:
+        pc = probes(r.gx, r.gy, nprobe, 3)
+        d.update(probe_cells=pc, probe_ir=np.stack([r.ir(x, y) for x, y in pc]))
+    r.close()
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **d)
+    print(name, "->", path, "%.1f kB" % (os.path.getsize(path) / 1e3), "fdtd %.2fs analysis %.2fs" % (t_f, t_a))
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "small"
+    if what == "small":
+        for name, scene in SMALL.items():
+            run("g71_" + name, scene, 25.0, 275, (5, 0, 4), [(5, 0, 6), (12, 0, 9), (20.5, 0, 3.2)],
+                [0, 1, 2, 9, 50, 200, 434], 16, True)
+        # a second listener position and the mid resolution preset
+        run("g71_smallroom_L2", SMALL["smallroom"], 25.0, 275, (9.3, 0, 8.1), [(5, 0, 6), (3, 0, 9)],
+            [10, 434], 8, True)
+        run("g96_smallroom_res375", SMALL["smallroom"], 25.0, 375, (5, 0, 4), [(5, 0, 6)], [100], 8, True)
+    elif what == "modeA512":
+        dx = pvref.RefSolver(1, 1, 275, None, False).dx
+        run("g512A_shoebox", "Shoebox.pv", 182.748, 275, (91, 0, 91), [(95, 0, 97)], None, 8, False, 256)
+    elif what == "modeB512":
+        run("g512B_shoebox", "Shoebox.pv", 25.0, 2009, (5, 0, 4), [(5, 0, 6)], None, 4, False, 256)
+
+
+if __name__ == "__main__":
+    main()
