@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the FDTD + IR-analysis hot path on MI355X.
+
+Workload (BASELINE.json configs[3], SURVEY.md 8d "config 4"): HugeRoom.pv in a 4096 x 4096 grid (Mode A: 275 Hz,
+dx = 0.3566 m, 1460.737 m side, T = 435 steps), one independent simulation run (= one listener position) per step
+per GPU; listener positions cycle through the eight of SURVEY.md 8d.  A "step" is one full pass of the hot path:
+field reset + T fused leapfrog steps incl. pressure-history record + per-cell IR analysis (what one iteration of the
+reference's background loop does, PvContext.cpp:80-83).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid 4096] [--no-cpu-baseline]
+
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL); runs are sharded round-robin
+with no data-path collective and one all-gather of the per-emitter outputs at the end ("scaling": "weak").
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# 8 listener positions inside the 25 m room (x, z metres); emitter A = listener + (0, 2),
+# emitter B = (5, 0, 6)
+LISTENERS = [(5, 4), (8, 8), (12, 6), (15, 15), (20, 5), (5, 20), (20, 20), (12.5, 18)]
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ALG_BYTES_PER_CELL_STEP = 24  # read + write pr, vx, vy once
+
+
+def mode_a_size(n, res=275):
+    dx = np.float32(343.21) / np.float32(res) / np.float32(3.5)
+    return float((n + 0.5) * dx)
+
+
+def cpu_baseline(grid_cells=513, scene="HugeRoom.pv"):
+    """Reference algorithm on ONE host core (the reference is single-threaded: SURVEY.md 6): the unmodified
+    reference compiled into oracle/_ref/libpvref.so when present ("reference"), else the C restatement ("port").
+    Bounded sample: the same scene / dx / T on a (grid_cells)^2 cell array."""
+    from oracle import pvref, pvoracle
+    scene_path = os.path.join(ROOT, "tests", "scenes", scene)
+    size = mode_a_size(grid_cells - 1)
+    L = (5.0, 0.0, 4.0)
+    try:
+        os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})
+    except Exception:
+        pass
+    if pvref.available():
+        boxes = pvref.load_pv(scene_path)
+        r = pvref.RefSolver(size, size, 275, boxes)
+        tf = r.generate(L)
+        ta = r.analyze(L)
+        cells = (r.gx + 1) * (r.gy + 1)
+        out = dict(value=cells * r.T / tf, unit="cell-updates/s", cores=1, kind="reference",
+                   sample="%s, %dx%d cells (Mode A, 275 Hz), T=%d, 1 listener: FDTD %.2f s, analysis %.2f s "
+                          "(grid ctor %.1f s + FreeGrid ctor %.1f s not counted)" % (
+                              scene, r.gx + 1, r.gy + 1, r.T, tf, ta, r.ctor_grid_s, r.ctor_free_s),
+                   ir_per_s=r.gx * r.gy / ta, fdtd_s=tf, analysis_s=ta)
+        r.close()
+    else:
+        boxes = pvref.load_pv(scene_path)
+        o = pvoracle.OracleGrid(size, size, 275, boxes)
+        t0 = time.perf_counter()
+        o.fdtd(L)
+        tf = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        o.analyze(np.float32(0.0447895788), L)
+        ta = time.perf_counter() - t0
+        out = dict(value=o.ncell * o.T / tf, unit="cell-updates/s", cores=1, kind="port",
+                   sample="%s, %dx%d cells, T=%d (C restatement, SoA history)" % (scene, o.gx + 1, o.gy + 1, o.T),
+                   ir_per_s=o.gx * o.gy / ta, fdtd_s=tf, analysis_s=ta)
+        o.close()
+    try:
+        os.sched_setaffinity(0, set(range(os.cpu_count())))
+    except Exception:
+        pass
+    out["host_cpus"] = os.cpu_count()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--grid", type=int, default=4096)
+    ap.add_argument("--scene", default="HugeRoom.pv")
+    ap.add_argument("--steps-per-launch", type=int, default=0)
+    ap.add_argument("--tile-rows", type=int, default=0)
+    ap.add_argument("--dense-history", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch  # first: libplaneverb_amd.so then binds to the HIP runtime torch already loaded
+    import torch.distributed as dist
+    from planeverb_amd import api, dist as pvd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a HIP device (no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    size = mode_a_size(args.grid)
+    opts = dict(time_kernels=1)
+    if args.steps_per_launch:
+        opts["steps_per_launch"] = args.steps_per_launch
+    if args.tile_rows:
+        opts["tile_rows"] = args.tile_rows
+    if args.dense_history:
+        opts["dense_history"] = 1
+    s = api.Solver(size, size, 275, device=local_rank, **opts)
+    s.load_scene(os.path.join(ROOT, "tests", "scenes", args.scene))
+    cells = (s.gx + 1) * (s.gy + 1)
+    T = s.T
+
+    def listener(step):
+        x, z = LISTENERS[(step * world + rank) % len(LISTENERS)]
+        return (float(x), 0.0, float(z))
+
+    def emitters(step):
+        x, _, z = listener(step)
+        return [(x, 0.0, z + 2.0), (5.0, 0.0, 6.0)]
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for w in range(args.warmup):
+        s.run(listener(w))
+    n_runs = args.steps * world
+    local = {}
+    fdtd_ms, ana_ms, air_ms, gen_ms = [], [], [], []
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        s.run(listener(k))
+        local[k * world + rank] = np.stack([s.get_output(e).as_array() for e in emitters(k)])
+        t = s.timings()
+        fdtd_ms.append(t.fdtdMs)
+        ana_ms.append(t.analysisMs)
+        air_ms.append(t.airKernelMs)
+        gen_ms.append(t.generalKernelMs)
+    gathered = pvd.gather_outputs(local, n_runs, dist if world > 1 else None, dev)  # the one RCCL gather
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        assert gathered.shape == (n_runs, 2, 8) and np.isfinite(gathered[:, :, 0]).all()
+        info = s.info
+        K = info.stepsPerLaunch
+        launches = s.timings().airLaunches
+        air = float(np.mean(air_ms))  # ms per air-kernel launch, HIP events on the solver's stream
+        steps_per_launch_avg = T / launches
+        achieved = ALG_BYTES_PER_CELL_STEP * cells * steps_per_launch_avg / (air * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("%d" % args.grid, {}).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        value = world * cells * T * args.steps / elapsed
+        fd = float(np.mean(fdtd_ms)) * 1e-3
+        out = {
+            "metric": "grid_cell_updates_per_s", "value": value, "unit": "cell-updates/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s in a %dx%d grid (Mode A: 275 Hz, dx=%.4f m, %.3f m), T=%d; 1 step = 1 "
+                                   "simulation run (reset + T leapfrog steps with pr-history record + per-cell IR "
+                                   "analysis) for one listener position; %d run(s) per step across %d GPU(s)" % (
+                                       args.scene, s.gx, s.gy, s.dx, size, T, world, world),
+                       "grid": [s.gx, s.gy], "T": T, "res": 275, "mode": "A", "steps_per_launch": K,
+                       "tile": [info.tileRows, info.tileCols], "dense_history": bool(args.dense_history),
+                       "parallelism": "runs sharded round-robin, 1 all-gather of outputs"},
+            "fdtd_cell_updates_per_s": world * cells * T / fd,
+            "impulse_responses_per_s": world * s.gx * s.gy * args.steps / elapsed,
+            "fdtd_ms": fd * 1e3, "analysis_ms": float(np.mean(ana_ms)),
+            "hbm_bytes_held": int(info.deviceBytes),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "pv_step_air_kernel<K=%d,rows=%d>" % (K, info.tileRows),
+                         "launch_ms": air, "launches_per_run": launches,
+                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_CELL_STEP * cells * steps_per_launch_avg,
+                         "general_kernel_launch_ms": float(np.mean(gen_ms)),
+                         "note": "algorithmic = 24 B per cell-step x cells x K fused steps; K-step temporal "
+                                 "blocking makes frac > 1 possible (SURVEY.md 8d)"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    s.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

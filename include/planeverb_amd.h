@@ -113,6 +113,9 @@ typedef struct PvAmdTimings {
     float stepKernelMs;     /* fdtdMs / number of step launches */
     int stepLaunches;
     long long histBytesWritten; /* bytes of pr history written by the last run */
+    float airKernelMs;      /* mean duration of one air-tile step-kernel launch (PVA_OPT_TIME_KERNELS) */
+    float generalKernelMs;  /* mean duration of one general-tile step-kernel launch */
+    int airLaunches, generalLaunches;
 } PvAmdTimings;
 
 /* option keys for PvAmdSetOption (must be set before the first run) */
@@ -123,7 +126,8 @@ enum {
     PVA_OPT_USE_GRAPH = 4,     /* 1 = replay the T-step loop from a captured hipGraph */
     PVA_OPT_STEPS_PER_LAUNCH = 5, /* K: time steps fused per kernel launch (tuning) */
     PVA_OPT_TILE_ROWS = 6,     /* interior rows of a wave tile (tuning; must pair with a compiled K) */
-    PVA_OPT_NO_FREE_GRID = 7   /* 1 = skip the free-field run (efree = 0; stencil-only use) */
+    PVA_OPT_NO_FREE_GRID = 7,  /* 1 = skip the free-field run (efree = 0; stencil-only use) */
+    PVA_OPT_TIME_KERNELS = 8   /* 1 = HIP events around every step-kernel launch (per-kernel durations) */
 };
 
 PVA_EXPORT int PvAmdDeviceCount(void);
@@ -176,6 +180,22 @@ PVA_EXPORT int PvAmdSetFields(PvAmdSolver* s, const float* pr, const float* vx, 
  * withPulse == 0 and without recording history: the raw stencil (used for roofline measurements and for
  * linearity / equivalence property tests). */
 PVA_EXPORT int PvAmdRunSteps(PvAmdSolver* s, int nsteps, int withPulse, float lx, float lz);
+
+/* Host-side pieces of the path that need no device (grid arithmetic, pulse table, rasteriser, .pv parser); the
+ * solver uses exactly these internally.  Exposed so that they can be checked without a GPU. */
+/* Grid.cpp:390-396,46-55: fills gx, gy, T, fs, res, dx, dt (other fields 0) */
+PVA_EXPORT int PvAmdHostGridInfo(float gridSizeX, float gridSizeY, int gridResolution, PvAmdInfo* out);
+/* Grid.cpp:12-27: T floats */
+PVA_EXPORT int PvAmdHostPulse(float gridSizeX, float gridSizeY, int gridResolution, float* out);
+/* Grid::AddAABB / RemoveAABB on a fresh grid: ops[i] = +1 add / -1 remove of boxes5[5*i..]; beta, R are
+ * (gx+1)*(gy+1) */
+PVA_EXPORT int PvAmdHostRasterize(float gridSizeX, float gridSizeY, int gridResolution, const float* boxes5,
+                                  const int* ops, int n, uint8_t* beta, float* R);
+/* Editor.cpp:245-281: returns the number of boxes (<= maxBoxes written as 5 floats each) or -1 */
+PVA_EXPORT int PvAmdHostLoadPv(const char* pvPath, float* boxes5, int maxBoxes);
+/* FDTD.cpp:97-98 listener cell and Analyzer.cpp:106-116 result cell (valid = 0 where GetOutput returns -1) */
+PVA_EXPORT int PvAmdHostCells(float gridSizeX, float gridSizeY, int gridResolution, float x, float z, int* listenerCx,
+                              int* listenerCy, int* resultCx, int* resultCy, int* resultValid);
 
 /* PlaneverbDSP reverb-bus split of wetGain by rt60 (PlaneverbDSP/src/PvDSPContext.cpp:165-228) */
 PVA_EXPORT void PvAmdReverbBusGains(float rt60, float wetGain, float* a, float* b, float* c);

@@ -30,6 +30,7 @@ PVA_OPT_USE_GRAPH = 4
 PVA_OPT_STEPS_PER_LAUNCH = 5
 PVA_OPT_TILE_ROWS = 6
 PVA_OPT_NO_FREE_GRID = 7
+PVA_OPT_TIME_KERNELS = 8
 
 
 class PlaneverbOutput(C.Structure):
@@ -53,7 +54,9 @@ class PvAmdInfo(C.Structure):
 
 class PvAmdTimings(C.Structure):
     _fields_ = [("fdtdMs", C.c_float), ("analysisMs", C.c_float), ("geometryMs", C.c_float),
-                ("stepKernelMs", C.c_float), ("stepLaunches", C.c_int), ("histBytesWritten", C.c_longlong)]
+                ("stepKernelMs", C.c_float), ("stepLaunches", C.c_int), ("histBytesWritten", C.c_longlong),
+                ("airKernelMs", C.c_float), ("generalKernelMs", C.c_float), ("airLaunches", C.c_int),
+                ("generalLaunches", C.c_int)]
 
 
 # every symbol include/planeverb_amd.h declares: name -> (restype, argtypes)
@@ -103,6 +106,12 @@ SYMBOLS = {
     "PvAmdSetFields": (C.c_int, [_vp, _fp, _fp, _fp]),
     "PvAmdRunSteps": (C.c_int, [_vp, C.c_int, C.c_int, C.c_float, C.c_float]),
     "PvAmdReverbBusGains": (None, [C.c_float, C.c_float, _fp, _fp, _fp]),
+    "PvAmdHostGridInfo": (C.c_int, [C.c_float, C.c_float, C.c_int, C.POINTER(PvAmdInfo)]),
+    "PvAmdHostPulse": (C.c_int, [C.c_float, C.c_float, C.c_int, _fp]),
+    "PvAmdHostRasterize": (C.c_int, [C.c_float, C.c_float, C.c_int, _fp, C.POINTER(C.c_int), C.c_int,
+                                     C.POINTER(C.c_ubyte), _fp]),
+    "PvAmdHostLoadPv": (C.c_int, [C.c_char_p, _fp, C.c_int]),
+    "PvAmdHostCells": (C.c_int, [C.c_float, C.c_float, C.c_int, C.c_float, C.c_float] + [C.POINTER(C.c_int)] * 5),
 }
 
 _lib = None
@@ -220,6 +229,46 @@ def reverb_bus_gains(rt60, wet):
     return a.value, b.value, c.value
 
 
+def host_grid_info(size_x, size_y, res):
+    i = PvAmdInfo()
+    _check(lib().PvAmdHostGridInfo(float(size_x), float(size_y), int(res), i))
+    return i
+
+
+def host_pulse(size_x, size_y, res):
+    i = host_grid_info(size_x, size_y, res)
+    out = np.empty(i.T, np.float32)
+    _check(lib().PvAmdHostPulse(float(size_x), float(size_y), int(res), _f(out)))
+    return out
+
+
+def host_rasterize(size_x, size_y, res, boxes, ops=None):
+    i = host_grid_info(size_x, size_y, res)
+    boxes = np.ascontiguousarray(boxes, np.float32).reshape(-1, 5)
+    ops_a = np.ascontiguousarray(ops if ops is not None else np.ones(len(boxes)), np.int32)
+    beta = np.empty((i.gx + 1, i.gy + 1), np.uint8)
+    R = np.empty((i.gx + 1, i.gy + 1), np.float32)
+    _check(lib().PvAmdHostRasterize(float(size_x), float(size_y), int(res), _f(boxes),
+                                    ops_a.ctypes.data_as(C.POINTER(C.c_int)), len(boxes),
+                                    beta.ctypes.data_as(C.POINTER(C.c_ubyte)), _f(R)))
+    return beta, R
+
+
+def load_pv(path, max_boxes=4096):
+    """.pv scene -> (n, 5) float32 array of (posX, posY, width, height, absorption)"""
+    buf = np.empty((max_boxes, 5), np.float32)
+    n = lib().PvAmdHostLoadPv(path.encode(), _f(buf), max_boxes)
+    if n < 0:
+        raise PlaneverbError(last_error())
+    return buf[:n].copy()
+
+
+def host_cells(size_x, size_y, res, x, z):
+    v = [C.c_int() for _ in range(5)]
+    _check(lib().PvAmdHostCells(float(size_x), float(size_y), int(res), float(x), float(z), *v))
+    return (v[0].value, v[1].value), ((v[2].value, v[3].value) if v[4].value else None)
+
+
 def device_count():
     return lib().PvAmdDeviceCount()
 
@@ -238,7 +287,7 @@ class Solver:
         keys = {"dense_history": PVA_OPT_DENSE_HISTORY, "num_steps": PVA_OPT_NUM_STEPS,
                 "skip_analysis": PVA_OPT_SKIP_ANALYSIS, "use_graph": PVA_OPT_USE_GRAPH,
                 "steps_per_launch": PVA_OPT_STEPS_PER_LAUNCH, "tile_rows": PVA_OPT_TILE_ROWS,
-                "no_free_grid": PVA_OPT_NO_FREE_GRID}
+                "no_free_grid": PVA_OPT_NO_FREE_GRID, "time_kernels": PVA_OPT_TIME_KERNELS}
         for k, v in options.items():
             _check(lib().PvAmdSetOption(self._h, keys[k], int(v)))
         self.info = PvAmdInfo()

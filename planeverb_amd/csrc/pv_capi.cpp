@@ -195,6 +195,7 @@ int PvAmdSetOption(PvAmdSolver* h, int key, long long value) {
         case PVA_OPT_STEPS_PER_LAUNCH: h->opt.K = (int)value; break;
         case PVA_OPT_TILE_ROWS: h->opt.rxi = (int)value; break;
         case PVA_OPT_NO_FREE_GRID: h->opt.withFreeGrid = value == 0; break;
+        case PVA_OPT_TIME_KERNELS: h->opt.timeKernels = value != 0; break;
         default: g_lastError = "unknown option"; return -1;
     }
     return 0;
@@ -279,6 +280,10 @@ int PvAmdGetTimings(PvAmdSolver* h, PvAmdTimings* out) {
     out->stepLaunches = t.stepLaunches;
     out->stepKernelMs = t.stepLaunches ? t.fdtdMs / (float)t.stepLaunches : 0.f;
     out->histBytesWritten = t.histBytesWritten;
+    out->airKernelMs = t.airKernelMs;
+    out->generalKernelMs = t.generalKernelMs;
+    out->airLaunches = t.airLaunches;
+    out->generalLaunches = t.generalLaunches;
     return 0;
 }
 
@@ -334,6 +339,73 @@ int PvAmdSetFields(PvAmdSolver* h, const float* pr, const float* vx, const float
 int PvAmdRunSteps(PvAmdSolver* h, int nsteps, int withPulse, float lx, float lz) {
     if (!ensure(h)) return -1;
     return ret(h, h->s->runSteps(nsteps, withPulse != 0, lx, lz));
+}
+
+int PvAmdHostGridInfo(float sx, float sy, int res, PvAmdInfo* out) {
+    if (!out || res < kLowResolution) return -1;
+    const GridSpec g = makeGridSpec(sx, sy, res);
+    std::memset(out, 0, sizeof(*out));
+    out->gx = g.gx;
+    out->gy = g.gy;
+    out->T = g.T;
+    out->fs = (int)g.fs;
+    out->res = g.res;
+    out->dx = g.dx;
+    out->dt = g.dt;
+    return 0;
+}
+
+int PvAmdHostPulse(float sx, float sy, int res, float* out) {
+    if (!out || res < kLowResolution) return -1;
+    const GridSpec g = makeGridSpec(sx, sy, res);
+    const std::vector<float> p = gaussianPulse(g);
+    std::memcpy(out, p.data(), p.size() * sizeof(float));
+    return 0;
+}
+
+int PvAmdHostRasterize(float sx, float sy, int res, const float* b5, const int* ops, int n, uint8_t* beta,
+                       float* R) {
+    if (res < kLowResolution) return -1;
+    const GridSpec g = makeGridSpec(sx, sy, res);
+    MaterialPlane m;
+    m.init(g);
+    for (int i = 0; i < n; ++i) {
+        const Box b{b5[5 * i], b5[5 * i + 1], b5[5 * i + 2], b5[5 * i + 3], b5[5 * i + 4]};
+        if (ops && ops[i] < 0)
+            m.remove(b);
+        else
+            m.add(b);
+    }
+    const size_t cells = (size_t)g.NX * g.NY;
+    if (beta) std::memcpy(beta, m.beta().data(), cells);
+    if (R) std::memcpy(R, m.R().data(), cells * sizeof(float));
+    return 0;
+}
+
+int PvAmdHostLoadPv(const char* path, float* b5, int maxBoxes) {
+    if (!path) return -1;
+    std::vector<Box> boxes;
+    if (!loadPv(path, &boxes, &g_lastError)) return -1;
+    for (int i = 0; i < (int)boxes.size() && i < maxBoxes; ++i) {
+        b5[5 * i] = boxes[(size_t)i].x;
+        b5[5 * i + 1] = boxes[(size_t)i].y;
+        b5[5 * i + 2] = boxes[(size_t)i].w;
+        b5[5 * i + 3] = boxes[(size_t)i].h;
+        b5[5 * i + 4] = boxes[(size_t)i].R;
+    }
+    return (int)boxes.size();
+}
+
+int PvAmdHostCells(float sx, float sy, int res, float x, float z, int* lcx, int* lcy, int* rcx, int* rcy,
+                   int* rvalid) {
+    if (res < kLowResolution) return -1;
+    const GridSpec g = makeGridSpec(sx, sy, res);
+    listenerCell(g, x, z, lcx, lcy);
+    int cx = -1, cy = -1;
+    *rvalid = resultCell(g, x, z, &cx, &cy) ? 1 : 0;
+    *rcx = cx;
+    *rcy = cy;
+    return 0;
 }
 
 void PvAmdReverbBusGains(float rt60, float wetGain, float* a, float* b, float* c) {

@@ -349,10 +349,12 @@ __global__ __launch_bounds__(256) void pv_tileclass_kernel(const uint16_t* codes
 }
 
 template <int K, int RXI, int WPS>
-static void launchStepT(const StepArgs& a, hipStream_t stream) {
-    const int blocks = (a.ntiles + 3) / 4;
-    hipLaunchKernelGGL((pv_step_air_kernel<K, RXI, WPS>), dim3(blocks), dim3(256), 0, stream, a);
-    if (a.numGeneral > 0) {
+static void launchStepT(const StepArgs& a, hipStream_t stream, int which) {
+    if (which & 1) {
+        const int blocks = (a.ntiles + 3) / 4;
+        hipLaunchKernelGGL((pv_step_air_kernel<K, RXI, WPS>), dim3(blocks), dim3(256), 0, stream, a);
+    }
+    if ((which & 2) && a.numGeneral > 0) {
         const int gblocks = (a.numGeneral + 3) / 4;
         hipLaunchKernelGGL((pv_step_general_kernel<K, RXI>), dim3(gblocks), dim3(256), 0, stream, a);
     }
@@ -368,9 +370,9 @@ static void launchTileClassT(const uint16_t* codes, uint8_t* tileClass, int* lis
 
 #define PV_STEP_CONFIGS(X) X(4, 32, 3) X(4, 24, 4) X(2, 28, 4) X(1, 30, 4) X(8, 24, 3) X(6, 28, 3) X(3, 26, 4)
 
-void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream) {
+void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream, int which) {
 #define X(k, r, w) \
-    if (K == k && rxi == r) return launchStepT<k, r, w>(a, stream);
+    if (K == k && rxi == r) return launchStepT<k, r, w>(a, stream, which);
     PV_STEP_CONFIGS(X)
 #undef X
 }

@@ -184,6 +184,7 @@ Solver::~Solver() {
     if (listHost_) hipHostFree(listHost_);
     for (auto& e : ev_)
         if (e) hipEventDestroy(e);
+    for (auto& e : kev_) hipEventDestroy(e);
     if (stream_) hipStreamDestroy(stream_);
 }
 
@@ -459,7 +460,21 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
         a.vyOut = vy_[cur_ ^ 1];
         a.t0 = firstStep + done;
         a.nsteps = k;
-        launchStep(K_, rxi_, a, stream_);
+        if (opt_.timeKernels) {
+            while ((int)kev_.size() < kevUsed_ + 3) {
+                hipEvent_t e;
+                if (!hipOk(hipEventCreate(&e), "hipEventCreate")) return false;
+                kev_.push_back(e);
+            }
+            hipEventRecord(kev_[(size_t)kevUsed_], stream_);
+            launchStep(K_, rxi_, a, stream_, 1);
+            hipEventRecord(kev_[(size_t)kevUsed_ + 1], stream_);
+            launchStep(K_, rxi_, a, stream_, 2);
+            hipEventRecord(kev_[(size_t)kevUsed_ + 2], stream_);
+            kevUsed_ += 3;
+        } else {
+            launchStep(K_, rxi_, a, stream_);
+        }
         cur_ ^= 1;
         done += k;
         ++tim_.stepLaunches;
@@ -509,6 +524,7 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
     lastLz_ = lz;
     const size_t planeBytes = (size_t)geo_.rows * geo_.pitch * 4;
     tim_.stepLaunches = 0;
+    kevUsed_ = 0;
     hipEventRecord(ev_[0], stream_);
     // reset pr / vx / vy (FDTD.cpp:109-119); the other set is fully overwritten by the first launch
     if (!hipOk(hipMemsetAsync(pr_[cur_], 0, planeBytes, stream_), "reset") ||
@@ -553,6 +569,21 @@ bool Solver::sync() {
         pendingTimings_ = false;
         hipEventElapsedTime(&tim_.fdtdMs, ev_[0], ev_[1]);
         hipEventElapsedTime(&tim_.analysisMs, ev_[1], ev_[2]);
+        if (opt_.timeKernels && kevUsed_ > 0) {
+            double air = 0, gen = 0;
+            const int n = kevUsed_ / 3;
+            for (int i = 0; i < n; ++i) {
+                float a = 0, g = 0;
+                hipEventElapsedTime(&a, kev_[(size_t)3 * i], kev_[(size_t)3 * i + 1]);
+                hipEventElapsedTime(&g, kev_[(size_t)3 * i + 1], kev_[(size_t)3 * i + 2]);
+                air += a;
+                gen += g;
+            }
+            tim_.airKernelMs = (float)(air / n);
+            tim_.generalKernelMs = (float)(gen / n);
+            tim_.airLaunches = n;
+            tim_.generalLaunches = numGeneral_ > 0 ? n : 0;
+        }
         int flag = 0;
         if (!hipOk(hipMemcpy(&flag, errFlag_, sizeof(int), hipMemcpyDeviceToHost), "errFlag copy")) return false;
         if (flag) return fail("pressure history window overflow (a tile outside the window became non-zero)");
@@ -567,6 +598,7 @@ bool Solver::runSteps(int nsteps, bool withPulse, float lx, float lz) {
     listenerCell(g_, lx, lz, &lcx, &lcy);
     if (!prepareDyn(lcx, lcy, withPulse)) return false;
     tim_.stepLaunches = 0;
+    kevUsed_ = 0;
     hipEventRecord(ev_[0], stream_);
     if (!enqueueSteps(0, nsteps, withPulse, false)) return false;
     hipEventRecord(ev_[1], stream_);

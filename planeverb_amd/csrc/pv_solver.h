@@ -26,10 +26,13 @@ struct SolverOptions {
     bool skipAnalysis = false;
     bool useGraph = false;
     bool withFreeGrid = true;
+    bool timeKernels = false;  // HIP events around every step-kernel launch (bench / roofline)
 };
 
 struct SolverTimings {
     float fdtdMs = 0, analysisMs = 0, geometryMs = 0;
+    float airKernelMs = 0, generalKernelMs = 0;  // mean duration per launch (timeKernels only)
+    int airLaunches = 0, generalLaunches = 0;
     int stepLaunches = 0;
     long long histBytesWritten = 0;
 };
@@ -152,6 +155,8 @@ private:
     std::vector<uint8_t> boxUsed_;
     std::vector<int> boxFree_;
 
+    std::vector<hipEvent_t> kev_;  // 3 events per step launch when opt_.timeKernels
+    int kevUsed_ = 0;
     SolverTimings tim_;
     bool pendingTimings_ = false;
 };

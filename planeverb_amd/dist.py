@@ -1,0 +1,61 @@
+"""Multi-GPU layer: independent simulation runs sharded over the GPUs of one node, one process per GPU.
+
+A "run" is one listener position on one scene (one pass of the reference's background loop,
+ProjectPlaneverb/src/Context/PvContext.cpp:74-93).  Runs share nothing, so the data path has no collective: rank r
+simulates runs r, r + W, r + 2W, ...  The only exchange is the final gather of the per-emitter PlaneverbOutput
+records (8 floats each, PvTypes.h:63-71): one all-gather over RCCL/xGMI on GPU ranks (backend "nccl"), or over gloo
+in the CPU tests.  Latency-bound: n_emitters * 32 B per rank.
+"""
+import numpy as np
+
+
+def shard_runs(n_runs, world_size, rank):
+    """indices of the runs rank `rank` simulates (round-robin: run k -> rank k mod W)"""
+    return list(range(rank, n_runs, world_size))
+
+
+def gather_outputs(local, n_runs, dist=None, device=None):
+    """local: {run index: float32 array [n_emitters, 8]} computed by this rank.
+    Returns float32 [n_runs, n_emitters, 8] on every rank (one all-gather).  Every run must have the same number of
+    emitters.  `dist` is torch.distributed (already initialised) or None for a single process."""
+    n_em = next(iter(local.values())).shape[0] if local else 0
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        out = np.zeros((n_runs, n_em, 8), np.float32)
+        for k, v in local.items():
+            out[k] = v
+        return out
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    per_rank = (n_runs + world - 1) // world
+    # every rank must agree on n_em even if it owns no run
+    t = torch.tensor([n_em], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    n_em = int(t.item())
+    send = torch.zeros((per_rank, n_em, 8), dtype=torch.float32, device=device)
+    for j, k in enumerate(shard_runs(n_runs, world, rank)):
+        send[j] = torch.from_numpy(np.ascontiguousarray(local[k], np.float32)).to(send.device)
+    recv = torch.empty((world * per_rank, n_em, 8), dtype=torch.float32, device=device)
+    dist.all_gather_into_tensor(recv, send)  # concatenation along dim 0, rank-major
+    recv = recv.cpu().numpy().reshape(world, per_rank, n_em, 8)
+    out = np.zeros((n_runs, n_em, 8), np.float32)
+    for r in range(world):
+        for j, k in enumerate(shard_runs(n_runs, world, r)):
+            out[k] = recv[r, j]
+    return out
+
+
+def run_sharded(make_solver, listeners, emitters_for, dist=None, device=None):
+    """Simulate `listeners` (list of (x, y, z)) sharded over the ranks and gather all per-emitter outputs.
+    make_solver() -> planeverb_amd.api.Solver bound to this rank's GPU; emitters_for(k) -> list of emitter positions
+    of run k.  Returns [n_runs, n_emitters, 8]."""
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    mine = shard_runs(len(listeners), world, rank)
+    local = {}
+    if mine:
+        s = make_solver()
+        for k in mine:
+            s.run(listeners[k])
+            local[k] = np.stack([s.get_output(e).as_array() for e in emitters_for(k)])
+        s.close()
+    return gather_outputs(local, len(listeners), dist, device)

@@ -1,0 +1,31 @@
+"""Worker process of tests/test_dist_cpu.py: one rank of a gloo group (started with plain subprocess)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def fake_result(k, n_em=3):
+    return np.array([[k, e, k * 10 + e, 0.5, -1, 1, 0, k + e / 8] for e in range(n_em)], np.float32)
+
+
+def main():
+    rank, world, port, n_runs, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), sys.argv[5]
+    import torch.distributed as dist
+    from planeverb_amd import dist as pvd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = port
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = pvd.shard_runs(n_runs, world, rank)
+    local = {k: fake_result(k) for k in mine}
+    res = pvd.gather_outputs(local, n_runs, dist)
+    np.savez(out, mine=np.array(mine, np.int64), out=res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

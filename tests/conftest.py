@@ -1,0 +1,63 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+SCENES = os.path.join(ROOT, "tests", "scenes")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def same_bits(a, b):
+    """element-wise: bit-identical float32, modulo the sign of zero, NaN == NaN"""
+    a = np.asarray(a, np.float32)
+    b = np.asarray(b, np.float32)
+    return (bits(a) == bits(b)) | ((a == 0) & (b == 0)) | (np.isnan(a) & np.isnan(b))
+
+
+def rel_err(a, b):
+    a = np.atleast_1d(np.asarray(a, np.float64))
+    b = np.atleast_1d(np.asarray(b, np.float64))
+    with np.errstate(all="ignore"):
+        e = np.abs(a - b) / np.maximum(np.abs(b), 1e-30)
+    e[(a == b) | (np.isnan(a) & np.isnan(b))] = 0
+    return e
+
+
+def valid_mask(delay, T, fs):
+    """cells whose analysis windows lie inside the IR (onset + N_dry + 2 <= T - N_cut); elsewhere the
+    reference reads past its own vector and only `delay` is comparable."""
+    n_dry = int(np.float32(0.01) * np.float32(fs))
+    n_cut = int(np.float32(0.01) * np.float32(fs))
+    return (delay < 1e30) & (delay + n_dry + 2 <= T - n_cut)
+
+
+@pytest.fixture(scope="session")
+def pvlib():
+    import planeverb_amd
+    planeverb_amd.build()
+    from planeverb_amd import api
+    return api
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import pvoracle
+    pvoracle.build()
+    return pvoracle

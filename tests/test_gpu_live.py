@@ -1,0 +1,91 @@
+"""GPU (-m gpu): the live module behind the reference's flat C-ABI (PlaneverbInit ... PlaneverbGetOutput), driven the
+way the Sandbox / Unity drive it (PlaneverbSandbox/src/main.cpp:14-21, Editor.cpp:245-281, PlaneverbEmitter.cs:49-60)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import SCENES, golden
+from test_gpu_parity import compare_output
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def module(pvlib):
+    pvlib.Init(pvlib.Config((25.0, 25.0), 275, 0, ".", 0, pvlib.pv_GPU))
+    yield pvlib
+    pvlib.Exit()
+
+
+def settle(pv, n=3):
+    """geometry queued now is rasterised after the current iteration, the listener is latched after it too
+    (PvContext.cpp:80-90): results are current from the second completed iteration on"""
+    target = pv.IterationCount() + n
+    assert pv.WaitIterations(target, 60000) >= target
+
+
+def test_sandbox_defaults(module):
+    pv = module
+    g = golden("g71_smallroom")
+    pv.SetListenerPosition(g["listener"])
+    assert pv.LoadScene(os.path.join(SCENES, "SmallRoomScene.pv")) == 5
+    ids = [pv.Emit(e) for e in g["emitters"]]
+    assert ids == [0, 1, 2]
+    settle(pv)
+    for i, ro in zip(ids, g["emitter_out"]):
+        compare_output(pv.GetOutput(i), ro, "emitter %d" % i)
+    # an emitter moved off the grid -> PV_INVALID_DRY_GAIN, rest zero (FDTD.cpp:43-47)
+    pv.UpdateEmission(ids[0], (40.0, 0.0, 5.0))
+    o = pv.GetOutput(ids[0])
+    assert o.occlusion == -1.0 and o.wetGain == 0.0 and o.rt60 == 0.0
+    # never-issued id
+    assert pv.GetOutput(17).occlusion == -1.0
+    # ended ids are recycled LIFO (EmissionManager.cpp:40-46)
+    pv.EndEmission(ids[1])
+    pv.EndEmission(ids[2])
+    assert pv.Emit((1, 0, 1)) == ids[2]
+    assert pv.Emit((1, 0, 1)) == ids[1]
+    assert pv.Emit((1, 0, 1)) == 3
+
+
+def test_listener_and_geometry_updates(module):
+    pv = module
+    ga, gb = golden("g71_smallroom"), golden("g71_shoebox")
+    pv.SetListenerPosition(ga["listener"])
+    gids = [pv.AddGeometry(b) for b in ga["boxes"]]
+    assert gids == list(range(len(gids)))
+    e = pv.Emit(ga["emitters"][0])
+    settle(pv)
+    compare_output(pv.GetOutput(e), ga["emitter_out"][0], "scene A")
+    # swap the scene: remove everything, add the shoebox (ids are recycled LIFO, GeometryManager.cpp:81-85)
+    for i in gids:
+        pv.RemoveGeometry(i)
+    new = [pv.AddGeometry(b) for b in gb["boxes"]]
+    assert sorted(new) == sorted(gids[:len(new)]) or len(new) != len(gids)
+    settle(pv)
+    compare_output(pv.GetOutput(e), gb["emitter_out"][0], "scene B")
+    # UpdateGeometry = Remove(old) + Add(new) (GeometryManager.cpp:112-121): move one wall away and back
+    b0 = gb["boxes"][0]
+    moved = b0.copy()
+    moved[1] += 3.0
+    pv.UpdateGeometry(new[0], moved)
+    settle(pv)
+    o_moved = pv.GetOutput(e).as_array()
+    pv.UpdateGeometry(new[0], b0)
+    # Remove(moved) also clears whatever the moved wall overlapped -- re-add the side walls
+    for i, b in zip(new[1:], gb["boxes"][1:]):
+        pv.UpdateGeometry(i, b)
+    settle(pv)
+    compare_output(pv.GetOutput(e), gb["emitter_out"][0], "scene B restored")
+    assert not np.array_equal(o_moved, pv.GetOutput(e).as_array())
+
+
+def test_reinit_while_running(pvlib):
+    """Init while running == Exit + Init (PvContext.cpp:27-31); Exit twice is harmless"""
+    pvlib.Init(pvlib.Config((25.0, 25.0), 275, 0, ".", 0, 1))
+    pvlib.Init(pvlib.Config((10.0, 10.0), 375, 0, ".", 0, 1))
+    assert pvlib.WaitIterations(2, 60000) >= 2
+    pvlib.Exit()
+    pvlib.Exit()
+    assert pvlib.GetOutput(0).occlusion == -1.0

@@ -1,0 +1,333 @@
+"""GPU (-m gpu): parity of the HIP path, called through the C-ABI of libplaneverb_amd.so, against
+  (1) the golden vectors generated from the unmodified reference (tests/golden/),
+  (2) the pinned oracle (oracle/pv_oracle.c) on seeded random scenes,
+  (3) size-independent properties at BASELINE.json's full sizes.
+
+Tolerances (BASELINE.json north_star: 1e-4 relative on the per-source outputs):
+  * fields, pressure history, reconstructed vx/vy impulse responses, onset delay, occlusion (dry gain), wet gain,
+    source directivity, listener direction: BIT-EXACT float32 (modulo the sign of zero);
+  * lowpass: <= 1e-6 relative (one powf, evaluated through double on the device, glibc's differs by <= 1 ulp);
+  * rt60: <= 1e-4 relative (T log10f evaluations per cell feed a float32 regression; observed <= 4e-6).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import SCENES, golden, rel_err, same_bits, valid_mask
+
+pytestmark = pytest.mark.gpu
+
+RT60_TOL = 1e-4
+LOWPASS_TOL = 1e-6
+NAMES = ["occlusion", "wetGain", "rt60", "lowpass", "dirX", "dirY", "srcDirX", "srcDirY"]
+
+
+def compare_maps(res, delay, rres, rdelay, T, fs, ctx=""):
+    assert same_bits(delay, rdelay).all(), ctx + " delay map"
+    valid = valid_mask(rdelay, T, fs)
+    for k, nm in enumerate(NAMES):
+        m = valid if k not in (4, 5) else np.ones_like(valid)
+        a, b = res[..., k][m], rres[..., k][m]
+        if k == 2:
+            assert rel_err(a, b).max(initial=0) <= RT60_TOL, ctx + " rt60"
+        elif k == 3:
+            assert rel_err(a, b).max(initial=0) <= LOWPASS_TOL, ctx + " lowpass"
+        else:
+            assert same_bits(a, b).all(), "%s %s: %d cells differ" % (ctx, nm, int((~same_bits(a, b)).sum()))
+    return int(valid.sum())
+
+
+def compare_output(o, ref8, ctx=""):
+    o = o.as_array()
+    for k in (0, 1, 4, 5, 6, 7):
+        assert same_bits(o[k], ref8[k]).all(), "%s %s %r vs %r" % (ctx, NAMES[k], o[k], ref8[k])
+    assert rel_err(o[2], ref8[2]).max() <= RT60_TOL, ctx
+    assert rel_err(o[3], ref8[3]).max() <= LOWPASS_TOL, ctx
+
+
+SMALL = ["g71_smallroom", "g71_shoebox", "g71_bigroom", "g71_hugeroom", "g71_floorplan", "g71_direction",
+         "g71_empty", "g71_smallroom_L2", "g96_smallroom_res375"]
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_golden_small(pvlib, name):
+    g = golden(name)
+    gx, gy, T, fs = (int(v) for v in g["dims"])
+    with pvlib.Solver(float(g["size"]), float(g["size"]), int(g["res"])) as s:
+        assert (s.gx, s.gy, s.T, s.fs) == (gx, gy, T, fs)
+        assert np.float32(s.efree) == g["efree"], "FreeGrid energy"
+        assert same_bits(s.pulse(), g["pulse"]).all()
+        for b in g["boxes"]:
+            s.add_geometry(b)
+        s.run(g["listener"])
+        beta, R = s.material()
+        assert np.array_equal(beta, g["beta"]) and same_bits(R, g["R"]).all()
+        for i, t in enumerate(g["snap_ts"]):
+            assert same_bits(s.history_plane(int(t)), g["snaps"][i][0]).all(), "recorded pr, step %d" % t
+        for (cx, cy), ir in zip(g["probe_cells"], g["probe_ir"]):
+            assert same_bits(s.impulse_response(cx, cy), ir).all(), "IR (pr,vx,vy) at %d,%d" % (cx, cy)
+        res, delay = s.results()
+        nvalid = compare_maps(res, delay, g["results"], g["delay"], T, fs, name)
+        assert nvalid > 100
+        for e, ro in zip(g["emitters"], g["emitter_out"]):
+            compare_output(s.get_output(e), ro, "%s emitter %s" % (name, e))
+        # final fields == last recorded plane + the last pulse sample at the listener
+        pr, vx, vy = s.fields()
+        last = g["snaps"][list(g["snap_ts"]).index(T - 1)] if (T - 1) in list(g["snap_ts"]) else None
+        if last is not None:
+            lc = (int(np.float32(g["listener"][0]) / np.float32(s.dx)), int(np.float32(g["listener"][2]) / np.float32(s.dx)))
+            exp = last[0].copy()
+            exp[lc] += g["pulse"][T - 1]
+            assert same_bits(pr, exp).all() and same_bits(vx, last[1]).all() and same_bits(vy, last[2]).all()
+
+
+@pytest.mark.parametrize("opts", [dict(steps_per_launch=1, tile_rows=30), dict(steps_per_launch=2, tile_rows=28),
+                                  dict(steps_per_launch=3, tile_rows=26), dict(steps_per_launch=4, tile_rows=24),
+                                  dict(steps_per_launch=6, tile_rows=28), dict(steps_per_launch=8, tile_rows=24),
+                                  dict(dense_history=1)])
+def test_every_kernel_configuration(pvlib, opts):
+    """every compiled (K, rows) instantiation and the dense-history mode produce the same bits"""
+    g = golden("g71_smallroom")
+    gx, gy, T, fs = (int(v) for v in g["dims"])
+    with pvlib.Solver(25.0, 25.0, 275, **opts) as s:
+        for b in g["boxes"]:
+            s.add_geometry(b)
+        s.run(g["listener"])
+        for i, t in enumerate(g["snap_ts"]):
+            assert same_bits(s.history_plane(int(t)), g["snaps"][i][0]).all()
+        res, delay = s.results()
+        compare_maps(res, delay, g["results"], g["delay"], T, fs, str(opts))
+
+
+def test_golden_512_mode_a(pvlib):
+    """BASELINE config 2: Shoebox.pv at 512^2 (Mode A: 182.748 m at 275 Hz)"""
+    g = golden("g512A_shoebox")
+    gx, gy, T, fs = (int(v) for v in g["dims"])
+    with pvlib.Solver(float(g["size"]), float(g["size"]), 275) as s:
+        assert (s.gx, s.gy, s.T) == (512, 512, 435)
+        assert np.float32(s.efree) == g["efree"]
+        for b in g["boxes"]:
+            s.add_geometry(b)
+        s.run(g["listener"])
+        res, delay = s.results()
+        c = g["cells"]
+        compare_maps(res[c[:, 0], c[:, 1]], delay[c[:, 0], c[:, 1]], g["cell_results"], g["cell_delay"], T, fs)
+        for (cx, cy), ir in zip(g["probe_cells"], g["probe_ir"]):
+            assert same_bits(s.impulse_response(cx, cy), ir).all()
+        compare_output(s.get_output(g["emitters"][0]), g["emitter_out"][0])
+        want = np.array([1.04278421, 0.0924116895, 0.545365036, 16091.9189, 0.54074657, 0.84118551, -0.503068805,
+                         -0.864246428], np.float32)  # SURVEY.md 8c anchor row
+        compare_output(s.get_output((95, 0, 97)), want)
+
+
+def test_golden_512_mode_b(pvlib):
+    """BASELINE config 2, Mode B: the 25 m Shoebox at res 2009 (fs 10547, T = 3179): the only oracle-checkable
+    case with T >> 435"""
+    g = golden("g512B_shoebox")
+    gx, gy, T, fs = (int(v) for v in g["dims"])
+    with pvlib.Solver(25.0, 25.0, 2009) as s:
+        assert (s.gx, s.gy, s.T, s.fs) == (512, 512, 3179, 10547)
+        assert np.float32(s.efree) == g["efree"]
+        for b in g["boxes"]:
+            s.add_geometry(b)
+        s.run(g["listener"])
+        res, delay = s.results()
+        c = g["cells"]
+        compare_maps(res[c[:, 0], c[:, 1]], delay[c[:, 0], c[:, 1]], g["cell_results"], g["cell_delay"], T, fs)
+        for (cx, cy), ir in zip(g["probe_cells"], g["probe_ir"]):
+            assert same_bits(s.impulse_response(cx, cy), ir).all()
+        compare_output(s.get_output(g["emitters"][0]), g["emitter_out"][0])
+
+
+def random_scene(rng, size, nbox):
+    boxes = []
+    for _ in range(nbox):
+        w, h = (rng.uniform(0.4, 8), rng.uniform(0.4, 1.2)) if rng.random() < 0.5 else (rng.uniform(0.4, 1.2),
+                                                                                        rng.uniform(0.4, 8))
+        boxes.append([rng.uniform(-1, size + 1), rng.uniform(-1, size + 1), w, h,
+                      rng.choice([0.969536, 0.85, 0.5, 0.0, 0.999, rng.uniform(0.05, 0.99)])])
+    return np.array(boxes, np.float32)
+
+
+@pytest.mark.parametrize("seed,size,res", [(1, 25.0, 275), (2, 25.0, 275), (3, 31.7, 300), (4, 18.0, 375),
+                                           (5, 25.0, 275), (6, 18.0, 375), (7, 40.0, 275)])
+def test_random_scenes_vs_oracle(pvlib, oracle, seed, size, res):
+    rng = np.random.default_rng(seed)
+    boxes = random_scene(rng, size, 12)
+    L = (rng.uniform(1, size - 1), 0.0, rng.uniform(1, size - 1))
+    o = oracle.OracleGrid(size, size, res, boxes)
+    o.fdtd(L)
+    ef = oracle.free_energy(size, size, res)
+    rres, rdelay, _ = o.analyze(ef, L)
+    hp, hx, hy = o.history()
+    with pvlib.Solver(size, size, res) as s:
+        assert (s.gx, s.gy, s.T) == (o.gx, o.gy, o.T)
+        assert np.float32(s.efree) == np.float32(ef)
+        for b in boxes:
+            s.add_geometry(b)
+        s.run(L)
+        for t in (0, 3, 17, o.T // 3, o.T - 1):
+            assert same_bits(s.history_plane(t), hp[t]).all(), "pr step %d" % t
+        for cx, cy in rng.integers(0, o.gx, (6, 2)):
+            ir = np.stack([hp[:, cx, cy], hx[:, cx, cy], hy[:, cx, cy]], 1)
+            assert same_bits(s.impulse_response(int(cx), int(cy)), ir).all()
+        res8, delay = s.results()
+        compare_maps(res8, delay, rres, rdelay, o.T, o.fs, "seed %d" % seed)
+    o.close()
+
+
+@pytest.mark.parametrize("listener", [(0.1, 0, 0.1), (24.8, 0, 24.8), (12.5, 0, 0.2), (5.88, 0, 11.24)])
+def test_listener_edge_positions_vs_oracle(pvlib, oracle, listener):
+    """listener in the corner cells, on an edge, and INSIDE a wall (the pulse is swallowed: beta = 0)"""
+    from oracle import pvref
+    boxes = pvref.load_pv(os.path.join(SCENES, "SmallRoomScene.pv"))
+    o = oracle.OracleGrid(25.0, 25.0, 275, boxes)
+    o.fdtd(listener)
+    hp, _, _ = o.history()
+    rres, rdelay, _ = o.analyze(np.float32(0.0447895788), listener)
+    with pvlib.Solver(25.0, 25.0, 275) as s:
+        for b in boxes:
+            s.add_geometry(b)
+        s.run(listener)
+        for t in (0, 1, 2, 50, 434):
+            assert same_bits(s.history_plane(t), hp[t]).all()
+        res8, delay = s.results()
+        compare_maps(res8, delay, rres, rdelay, o.T, o.fs, str(listener))
+    o.close()
+
+
+def test_geometry_update_remove_sequence(pvlib, oracle):
+    """Add / Update / Remove through the handle API follow GeometryManager + Grid semantics (ids recycled LIFO,
+    Update = Remove(old) + Add(new), removing a box clears overlaps: SURVEY Q4)"""
+    a = [10, 10, 6, 1, 0.9]
+    b = [12, 10, 1, 6, 0.8]
+    a2 = [10, 14, 6, 1, 0.7]
+    L = (5, 0, 4)
+    o = oracle.OracleGrid(25.0, 25.0, 275, None)
+    with pvlib.Solver(25.0, 25.0, 275) as s:
+        ia = s.add_geometry(a)
+        ib = s.add_geometry(b)
+        assert (ia, ib) == (0, 1)
+        o.add_aabb(a), o.add_aabb(b)
+        s.update_geometry(ia, a2)
+        o.remove_aabb(a), o.add_aabb(a2)
+        s.remove_geometry(ib)
+        o.remove_aabb(b)
+        assert s.add_geometry(b) == ib  # recycled id
+        o.add_aabb(b)
+        s.run(L)
+        beta, R = s.material()
+        ob, oR = o.material()
+        assert np.array_equal(beta, ob.astype(np.uint8)) and same_bits(R, oR).all()
+        o.fdtd(L)
+        hp, _, _ = o.history()
+        assert same_bits(s.history_plane(300), hp[300]).all()
+        with pytest.raises(pvlib.PlaneverbError):
+            s.update_geometry(99, a)
+    o.close()
+
+
+def test_output_sentinels_and_palette_limit(pvlib):
+    with pvlib.Solver(25.0, 25.0, 275) as s:
+        s.run((5, 0, 4))
+        assert s.get_output((30, 0, 5)).occlusion == -1.0  # off grid: FDTD.cpp:43-47
+        assert s.get_output((5, 0, -3)).occlusion == -1.0 or s.get_output((5, 0, -3)).occlusion >= 0
+        o = s.get_output((5, 0, 6))
+        assert o.occlusion > 0 and o.rt60 != 0
+    with pvlib.Solver(25.0, 25.0, 275) as s:
+        for i in range(130):
+            s.add_geometry([1 + (i % 20), 1 + i // 20, 0.5, 0.5, 0.1 + i * 0.005])
+        with pytest.raises(pvlib.PlaneverbError, match="distinct absorption"):
+            s.run((12, 0, 12))
+
+
+def test_step_composition_and_zero_fixed_point(pvlib):
+    """raw stencil properties: 2n steps == n steps twice (any K), and an all-zero field stays all-zero"""
+    rng = np.random.default_rng(11)
+    boxes = random_scene(rng, 25.0, 8)
+    init = [rng.standard_normal((71, 71)).astype(np.float32) for _ in range(3)]
+    outs = []
+    for opts in (dict(steps_per_launch=4, tile_rows=32), dict(steps_per_launch=1, tile_rows=30),
+                 dict(steps_per_launch=8, tile_rows=24)):
+        with pvlib.Solver(25.0, 25.0, 275, no_free_grid=1, **opts) as s:
+            for b in boxes:
+                s.add_geometry(b)
+            s.set_fields(*init)
+            s.run_steps(37)
+            s.run_steps(37)
+            a = s.fields()
+            s.set_fields(*init)
+            s.run_steps(74)
+            b2 = s.fields()
+            for x, y in zip(a, b2):
+                assert same_bits(x, y).all()
+            outs.append(a)
+            s.set_fields(*[np.zeros((71, 71), np.float32)] * 3)
+            s.run_steps(16)
+            assert all((f == 0).all() for f in s.fields())
+    for other in outs[1:]:
+        for x, y in zip(outs[0], other):
+            assert same_bits(x, y).all()
+
+
+def test_single_steps_from_oracle_states(pvlib, oracle):
+    """one FDTD.cpp:124-223 step started from the oracle's own dense mid-run states on a walled scene"""
+    rng = np.random.default_rng(3)
+    boxes = random_scene(rng, 25.0, 10)
+    o = oracle.OracleGrid(25.0, 25.0, 275, boxes)
+    L = (7.3, 0, 9.1)
+    o.fdtd(L)
+    hp, hx, hy = o.history()
+    pulse = o.pulse()
+    lc = o.listener_cell(np.float32(L[0]), np.float32(L[2]))
+    with pvlib.Solver(25.0, 25.0, 275, no_free_grid=1) as s:
+        for b in boxes:
+            s.add_geometry(b)
+        for t in (40, 100, 200, 433):
+            p0 = hp[t].copy()
+            p0[lc] += pulse[t]  # the state after step t includes the injected pulse (FDTD.cpp:234)
+            s.set_fields(p0, hx[t], hy[t])
+            s.run_steps(1)
+            pr, vx, vy = s.fields()
+            assert same_bits(pr, hp[t + 1]).all() and same_bits(vx, hx[t + 1]).all() and same_bits(vy, hy[t + 1]).all()
+    o.close()
+
+
+def test_closed_room_isolation_4096(pvlib):
+    """BASELINE config 4 at full size: HugeRoom.pv in a 4096^2 grid (Mode A, 1460.737 m at 275 Hz).  The interior
+    of a closed room is numerically decoupled from the outside (wall cells hold p = 0, no diagonal coupling), so the
+    per-emitter outputs must equal the 71^2 reference run of the same room bit-for-bit."""
+    g = golden("g71_hugeroom")
+    with pvlib.Solver(1460.737, 1460.737, 275) as s:
+        assert (s.gx, s.gy, s.T) == (4096, 4096, 435)
+        assert np.float32(s.efree) == g["efree"]
+        s.load_scene(os.path.join(SCENES, "HugeRoom.pv"))
+        s.run(g["listener"])
+        for e, ro in zip(g["emitters"], g["emitter_out"]):
+            compare_output(s.get_output(e), ro, "4096^2 emitter %s" % e)
+        res, delay = s.results()
+        # the whole room interior: cells well inside the walls of the 25 m room
+        sub, dsub = res[3:66, 3:66], delay[3:66, 3:66]
+        compare_maps(sub, dsub, g["results"][3:66, 3:66], g["delay"][3:66, 3:66], 435, 1443, "room interior")
+        # nothing outside the reach of the pulse has an onset
+        assert (delay[1000:, :] > 1e30).all() and (delay[:, 1000:] > 1e30).all()
+
+
+def test_second_run_reuses_solver(pvlib):
+    """two consecutive runs with different listeners on one solver == fresh solvers (history window moves)"""
+    ga, gb = golden("g71_smallroom"), golden("g71_smallroom_L2")
+    with pvlib.Solver(25.0, 25.0, 275) as s:
+        for b in ga["boxes"]:
+            s.add_geometry(b)
+        s.run(ga["listener"])
+        s.run(gb["listener"])
+        for i, t in enumerate(gb["snap_ts"]):
+            assert same_bits(s.history_plane(int(t)), gb["snaps"][i][0]).all()
+        # cells with an onset in this run are rewritten; cells without keep the previous run's values
+        # (Analyzer.cpp:160-165) -- compare only where this run has an onset
+        res, delay = s.results()
+        assert same_bits(delay, gb["delay"]).all()
+        m = valid_mask(gb["delay"], 435, 1443)
+        assert same_bits(res[..., 0][m], gb["results"][..., 0][m]).all()
+        assert same_bits(res[..., 1][m], gb["results"][..., 1][m]).all()

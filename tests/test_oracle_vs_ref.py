@@ -1,0 +1,60 @@
+"""CPU, build container only: the restatement against the compiled reference itself (oracle/_ref/libpvref.so) on
+cases beyond the committed fixtures.  Skipped where the reference build is absent."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import SCENES, same_bits
+
+from oracle import pvref
+
+pytestmark = pytest.mark.skipif(not pvref.available(), reason="oracle/_ref/libpvref.so not built")
+
+
+@pytest.mark.parametrize("scene,listener,res,size", [
+    ("MiddleWallScene.pv", (10.0, 0.0, 11.0), 275, 25.0),
+    ("UnityReplicationTest.pv", (4.0, 0.0, 4.5), 275, 25.0),
+    ("SingleWall.pv", (3.0, 0.0, 12.0), 275, 25.0),
+    ("SmallRoom.pv", (5.0, 0.0, 5.0), 275, 10.0),
+    ("ExampleProject.pv", (5.0, 0.0, 2.0), 500, 10.0),
+])
+def test_restatement_equals_reference(oracle, scene, listener, res, size):
+    boxes = pvref.load_pv(os.path.join(SCENES, scene))
+    r = pvref.RefSolver(size, size, res, boxes)
+    o = oracle.OracleGrid(size, size, res, boxes)
+    assert (r.gx, r.gy, r.T, r.fs) == (o.gx, o.gy, o.T, o.fs)
+    r.generate(listener)
+    r.analyze(listener)
+    o.fdtd(listener)
+    hp, hx, hy = o.history()
+    for t in (0, 7, o.T // 2, o.T - 1):
+        p, x, y = r.snapshot(t)
+        assert same_bits(p, hp[t]).all() and same_bits(x, hx[t]).all() and same_bits(y, hy[t]).all()
+    ef = oracle.free_energy(size, size, res)
+    assert ef == r.efree
+    res8, delay, valid = o.analyze(ef, listener)
+    rres, rdelay = r.results()
+    assert same_bits(delay, rdelay).all()
+    for k in range(8):
+        m = valid if k not in (4, 5) else np.ones_like(valid)
+        assert same_bits(res8[..., k][m], rres[..., k][m]).all(), k
+    r.close()
+    o.close()
+
+
+def test_dynamic_geometry_sequence(oracle):
+    """Add / Remove / overlapping boxes follow Grid::AddAABB / RemoveAABB incl. quirk Q4 (overlap cleared)"""
+    r = pvref.RefSolver(25.0, 25.0, 275, None, with_free_grid=False)
+    o = oracle.OracleGrid(25.0, 25.0, 275, None, with_history=False)
+    a = np.array([10, 10, 6, 1, 0.9], np.float32)
+    b = np.array([12, 10, 1, 6, 0.8], np.float32)
+    edge = np.array([24.9, 12, 1, 30, 0.7], np.float32)
+    for op, box in [("add", a), ("add", b), ("remove", a), ("add", edge), ("remove", edge), ("add", a)]:
+        getattr(r, op + "_aabb")(box)
+        getattr(o, op + "_aabb")(box)
+        rb, rR = r.material()
+        ob, oR = o.material()
+        assert np.array_equal(rb, ob) and same_bits(rR, oR).all(), op
+    r.close()
+    o.close()
