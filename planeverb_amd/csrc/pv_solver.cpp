@@ -339,16 +339,17 @@ bool Solver::computeEfree() {
     if (n > g_.T) return fail("free-field window longer than the impulse response");
 
     const int margin = n + 8;
-    const int span = ex - lcx;
-    const bool window = (lcx - margin > 0) && (ex + margin < g_.gx) && (lcy - margin > 0) && (lcy + margin < g_.gy);
+    const int spanX = ex - lcx, spanY = ey - lcy;  // >= 0; the re-truncation can move the source by one cell
+    const bool window = (lcx - margin > 0) && (ex + margin < g_.gx) && (lcy - margin > 0) && (ey + margin < g_.gy) &&
+                        spanX >= 0 && spanY >= 0;
     GridSpec fs;
     int sx, sy, qx, qy;
     if (window) {
-        fs = makeGridSpecCells(2 * margin + span + 1, 2 * margin + 1, g_.res);
+        fs = makeGridSpecCells(2 * margin + spanX + 1, 2 * margin + spanY + 1, g_.res);
         sx = margin;
         sy = margin;
-        qx = margin + span;
-        qy = margin;
+        qx = margin + spanX;
+        qy = margin + spanY;
     } else {
         fs = makeGridSpecCells(g_.gx, g_.gy, g_.res);
         sx = lcx;
