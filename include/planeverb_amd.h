@@ -127,7 +127,8 @@ enum {
     PVA_OPT_STEPS_PER_LAUNCH = 5, /* K: time steps fused per kernel launch (tuning) */
     PVA_OPT_TILE_ROWS = 6,     /* interior rows of a wave tile (tuning; must pair with a compiled K) */
     PVA_OPT_NO_FREE_GRID = 7,  /* 1 = skip the free-field run (efree = 0; stencil-only use) */
-    PVA_OPT_TIME_KERNELS = 8   /* 1 = HIP events around every step-kernel launch (per-kernel durations) */
+    PVA_OPT_TIME_KERNELS = 8,  /* 1 = HIP events around every step-kernel launch (per-kernel durations) */
+    PVA_OPT_TILE_ORDER = 9     /* air-kernel workgroup->tile map: 0 linear, 1 XCD band row-major, 2 band col-major */
 };
 
 PVA_EXPORT int PvAmdDeviceCount(void);

@@ -196,6 +196,7 @@ int PvAmdSetOption(PvAmdSolver* h, int key, long long value) {
         case PVA_OPT_TILE_ROWS: h->opt.rxi = (int)value; break;
         case PVA_OPT_NO_FREE_GRID: h->opt.withFreeGrid = value == 0; break;
         case PVA_OPT_TIME_KERNELS: h->opt.timeKernels = value != 0; break;
+        case PVA_OPT_TILE_ORDER: h->opt.tileOrder = (int)value; break;
         default: g_lastError = "unknown option"; return -1;
     }
     return 0;

@@ -184,13 +184,17 @@ __device__ __forceinline__ void bufStoreF(float v, rsrc_t r, int voff, int soff)
 // listener is not inside it -- no coefficient reads, no pulse.  GENERAL = true: walls / grid edges / listener.
 // They are separate kernels (not one kernel with a wave-uniform branch) so that each gets its own register
 // allocation: the air tile needs 3*ROWS VGPRs plus a handful and must not inherit the general path's pressure.
-template <int K, int RXI, bool GENERAL>
-__device__ __forceinline__ void stepTile(const StepArgs& a, const int tile, const int lane, const float* lut) {
-    constexpr int ROWS = RXI + 2 * K;
+// A wave advances SUB interior rows (+ K halo rows either side) of tile `tile`; `part` selects which SUB-row slice
+// of the tile's RXI rows (air tiles: SUB == RXI, part 0; general tiles are split over RXI/SUB waves to shorten the
+// latency of that small, VALU-heavier kernel).
+template <int K, int RXI, int SUB, bool GENERAL>
+__device__ __forceinline__ void stepTile(const StepArgs& a, const int tile, const int part, const int lane,
+                                         const float* lut) {
+    constexpr int ROWS = SUB + 2 * K;
     constexpr int WI = 64 - 2 * K;
     const int ti = tile / a.nty;
     const int tj = tile - ti * a.nty;
-    const int row0 = a.G - K + ti * RXI;  // first loaded row / column, padded coordinates
+    const int row0 = a.G - K + ti * RXI + part * SUB;  // first loaded row / column, padded coordinates
     const int col0 = a.G - K + tj * WI;
     const int voff = lane * 4;
     const int pitchB = a.pitch * 4;
@@ -237,18 +241,26 @@ __device__ __forceinline__ void stepTile(const StepArgs& a, const int tile, cons
 
     const int hti = ti - dyn.histTileX0, htj = tj - dyn.histTileY0;
     const bool inWin = hti >= 0 && hti < dyn.histTilesX && htj >= 0 && htj < dyn.histTilesY;
-    // once a tile has been active its history is recorded for the rest of the run
-    const bool wasActive = a.record && a.tileFirst[tile] != INT_MAX;
-    const bool rec = a.record && inWin && (active || wasActive || a.dense);
+    // tileFirst[tile] = first launch in which the tile was non-zero; the analysis reads its history from there on.
+    // Air tiles are recorded from that launch to the end of the run.  General tiles are recorded on every step:
+    // their slices are advanced by different waves, which could not otherwise agree on when recording starts.
+    bool rec;
+    if (GENERAL) {
+        rec = a.record && inWin;
+        if (a.record && active && lane == 0) atomicMin(&a.tileFirst[tile], a.t0);
+    } else {
+        const bool wasActive = a.record && a.tileFirst[tile] != INT_MAX;
+        rec = a.record && inWin && (active || wasActive || a.dense);
+        if (a.record && active && !wasActive && lane == 0) atomicMin(&a.tileFirst[tile], a.t0);
+    }
     if (a.record && active && !inWin && lane == 0) atomicExch(a.errFlag, 1);
-    if (a.record && active && !wasActive && lane == 0) atomicMin(&a.tileFirst[tile], a.t0);
 
     const float C = a.courant;
     const bool inCols = lane >= K && lane < 64 - K;
     const float* hplane = a.hist + (long long)a.t0 * a.histPlane;
     // history window addressing: soffset = row part (>= 0 for every stored row), voffset = column part
     const int hpitchB = a.histPitch * 4;
-    const int hsoff0 = (hti * RXI - K) * hpitchB;       // + r*hpitchB with r >= K
+    const int hsoff0 = (hti * RXI + part * SUB - K) * hpitchB;  // + r*hpitchB with r >= K
     const int hvoff = (htj * WI - K + lane) * 4;        // >= 0 for the stored lanes (lane >= K)
 
 #pragma unroll 1
@@ -297,34 +309,63 @@ __device__ __forceinline__ void stepTile(const StepArgs& a, const int tile, cons
     }
 }
 
-// air tiles: one wave per tile, 4 tiles per 256-thread block; tiles of the other class exit immediately
+// air tiles: one wave per tile, 4 tiles per 256-thread block; tiles of the other class exit immediately.
+// XCD-aware tile order: workgroup b is dispatched to XCD b % 8 (observed, speed only), and each XCD has a private
+// 4 MiB L2.  XCD x therefore owns a contiguous band of tile rows and walks it column by column, so the tiles that
+// share halo rows / columns are processed close together in time ON THE SAME L2 instead of being re-fetched
+// through the fabric by eight different L2s.
 template <int K, int RXI, int WPS>
 __global__ __launch_bounds__(256, WPS) void pv_step_air_kernel(const StepArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int tile = blockIdx.x * 4 + wave;
-    if (tile >= a.ntiles) return;
+    int ti, tj;
+    if (a.tileOrder == 0) {  // linear: block b = tiles 4b..4b+3 in row-major order
+        const int t = blockIdx.x * 4 + wave;
+        if (t >= a.ntiles) return;
+        ti = t / a.nty;
+        tj = t - ti * a.nty;
+    } else {
+        const int xcd = blockIdx.x & 7;
+        const int q = (blockIdx.x >> 3) * 4 + wave;  // index inside the XCD's band
+        const int ti0 = xcd * a.bandRows;
+        const int bandRows = min(a.bandRows, a.ntx - ti0);
+        if (bandRows <= 0) return;
+        if (a.tileOrder == 1) {  // band, row-major (a block = 4 horizontally adjacent tiles)
+            const int r = q / a.nty;
+            if (r >= bandRows) return;
+            ti = ti0 + r;
+            tj = q - r * a.nty;
+        } else {  // band, column-major
+            tj = q / bandRows;
+            if (tj >= a.nty) return;
+            ti = ti0 + (q - tj * bandRows);
+        }
+    }
+    const int tile = ti * a.nty + tj;
     if (a.tileClass[tile] != 0) return;
     if (a.withPulse) {  // the tile(s) holding the listener are on the general kernel's list
-        const int ti = tile / a.nty, tj = tile - ti * a.nty;
         const int lr = a.dyn->lrow - (a.G - K + ti * RXI), lc = a.dyn->lcol - (a.G - K + tj * (64 - 2 * K));
         if (lr >= 0 && lr < RXI + 2 * K && lc >= 0 && lc < 64) return;
     }
-    stepTile<K, RXI, false>(a, tile, lane, nullptr);
+    stepTile<K, RXI, RXI, false>(a, tile, 0, lane, nullptr);
 }
 
-// wall / edge / listener tiles, taken from a compact list
-template <int K, int RXI>
+// wall / edge / listener tiles, taken from a compact list; each tile is split over RXI/SUB waves
+template <int K, int RXI, int SUB>
 __global__ __launch_bounds__(256, 2) void pv_step_general_kernel(const StepArgs a) {
+    constexpr int S = RXI / SUB;
+    static_assert(S * SUB == RXI, "general-tile split must divide the tile");
     __shared__ float lut[256];
     lut[threadIdx.x] = a.lut[threadIdx.x];
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int idx = blockIdx.x * 4 + wave;
-    if (idx >= a.numGeneral) return;
-    const int tile = __builtin_amdgcn_readfirstlane(a.generalList[idx]);
-    stepTile<K, RXI, true>(a, tile, lane, lut);
+    if (idx >= a.numGeneral * S) return;
+    // few, long, latency-bound waves that run beside the air kernel: let them win VALU/issue arbitration
+    __builtin_amdgcn_s_setprio(3);
+    const int tile = __builtin_amdgcn_readfirstlane(a.generalList[idx / S]);
+    stepTile<K, RXI, SUB, true>(a, tile, idx % S, lane, lut);
 }
 
 // Per-tile class: 0 = every face code in the tile's loaded region is air|air, 1 = needs the general kernel.
@@ -348,15 +389,16 @@ __global__ __launch_bounds__(256) void pv_tileclass_kernel(const uint16_t* codes
     }
 }
 
-template <int K, int RXI, int WPS>
-static void launchStepT(const StepArgs& a, hipStream_t stream, int which) {
+template <int K, int RXI, int WPS, int SUB>
+static void launchStepT(const StepArgs& a, hipStream_t stream, int which, hipStream_t stream2) {
     if (which & 1) {
-        const int blocks = (a.ntiles + 3) / 4;
+        const int blocks = a.tileOrder == 0 ? (a.ntiles + 3) / 4 : 8 * ((a.bandRows * a.nty + 3) / 4);
         hipLaunchKernelGGL((pv_step_air_kernel<K, RXI, WPS>), dim3(blocks), dim3(256), 0, stream, a);
     }
     if ((which & 2) && a.numGeneral > 0) {
-        const int gblocks = (a.numGeneral + 3) / 4;
-        hipLaunchKernelGGL((pv_step_general_kernel<K, RXI>), dim3(gblocks), dim3(256), 0, stream, a);
+        const int gblocks = (a.numGeneral * (RXI / SUB) + 3) / 4;
+        hipLaunchKernelGGL((pv_step_general_kernel<K, RXI, SUB>), dim3(gblocks), dim3(256), 0,
+                           stream2 ? stream2 : stream, a);
     }
 }
 
@@ -368,25 +410,27 @@ static void launchTileClassT(const uint16_t* codes, uint8_t* tileClass, int* lis
                        count, g);
 }
 
-#define PV_STEP_CONFIGS(X) X(4, 32, 3) X(4, 24, 4) X(2, 28, 4) X(1, 30, 4) X(8, 24, 3) X(6, 28, 3) X(3, 26, 4)
+// (K steps per launch, interior rows per tile, waves/SIMD bound of the air kernel, rows per general-tile slice)
+#define PV_STEP_CONFIGS(X) \
+    X(4, 32, 3, 8) X(4, 24, 4, 6) X(2, 28, 4, 7) X(1, 30, 4, 15) X(8, 24, 3, 12) X(6, 28, 3, 14) X(3, 26, 4, 13)
 
-void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream, int which) {
-#define X(k, r, w) \
-    if (K == k && rxi == r) return launchStepT<k, r, w>(a, stream, which);
+void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream, int which, hipStream_t stream2) {
+#define X(k, r, w, sub) \
+    if (K == k && rxi == r) return launchStepT<k, r, w, sub>(a, stream, which, stream2);
     PV_STEP_CONFIGS(X)
 #undef X
 }
 
 void launchTileClass(int K, int rxi, const uint16_t* codes, uint8_t* tileClass, int* list, int* count,
                      const Geometry& g, hipStream_t stream) {
-#define X(k, r, w) \
+#define X(k, r, w, sub) \
     if (K == k && rxi == r) return launchTileClassT<k, r>(codes, tileClass, list, count, g, stream);
     PV_STEP_CONFIGS(X)
 #undef X
 }
 
 bool stepConfigSupported(int K, int rxi) {
-#define X(k, r, w) \
+#define X(k, r, w, sub) \
     if (K == k && rxi == r) return true;
     PV_STEP_CONFIGS(X)
 #undef X
@@ -439,13 +483,15 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
     const DynParams dyn = *a.dyn;
 
     const int tile = (X / a.rxi) * a.nty + (Y / a.wi);
-    const int tFirst = a.tileFirst[tile];
+    const int prow = X + a.G, pcol = Y + a.G;
+    const int hti = X / a.rxi - dyn.histTileX0, htj = Y / a.wi - dyn.histTileY0;
+    const bool inWin = hti >= 0 && hti < dyn.histTilesX && htj >= 0 && htj < dyn.histTilesY;
+    const int tFirst = inWin ? a.tileFirst[tile] : INT_MAX;
     if (tFirst == INT_MAX || tFirst >= a.T) {  // never reached by the pulse: no onset (Analyzer.cpp:160-165)
         a.delay[s] = FLT_MAX;
         return;
     }
     const int T = a.T;
-    const int prow = X + a.G, pcol = Y + a.G;
     const long long hoff = (long long)(prow - dyn.histRow0) * a.histPitch + (pcol - dyn.histCol0);
     CellHistory hc{a.hist + hoff, a.histPlane};
     // neighbours for the velocity recurrence; a neighbour tile that became active later (or never) has
@@ -648,7 +694,9 @@ __global__ void pv_ir_kernel(const AnalyzeArgs a, int X, int Y, float* out) {
     const DynParams dyn = *a.dyn;
     const int prow = X + a.G, pcol = Y + a.G;
     const int tj = (Y / a.wi), ti = (X / a.rxi);
-    const int tFirst = a.tileFirst[ti * a.nty + tj];
+    const int wti = ti - dyn.histTileX0, wtj = tj - dyn.histTileY0;
+    const bool inWin = wti >= 0 && wti < dyn.histTilesX && wtj >= 0 && wtj < dyn.histTilesY;
+    const int tFirst = inWin ? a.tileFirst[ti * a.nty + tj] : INT_MAX;
     const long long hoff = (long long)(prow - dyn.histRow0) * a.histPitch + (pcol - dyn.histCol0);
     int tFx = INT_MAX, tFy = INT_MAX;
     if (X > 0 && prow - 1 >= dyn.histRow0) tFx = a.tileFirst[((X - 1) / a.rxi) * a.nty + tj];

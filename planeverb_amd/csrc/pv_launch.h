@@ -12,7 +12,8 @@ namespace pva {
 // supported (K steps per launch, interior rows per tile) instantiations of the fused stencil
 bool stepConfigSupported(int K, int rxi);
 // which: bit 0 = air-tile kernel, bit 1 = general-tile kernel (both write disjoint tiles of the same planes)
-void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream, int which = 3);
+// The general kernel goes to stream2 when given (the caller orders the two streams with events).
+void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream, int which = 3, hipStream_t stream2 = nullptr);
 void launchTileClass(int K, int rxi, const uint16_t* codes, uint8_t* tileClass, int* list, int* count,
                      const Geometry& g, hipStream_t stream);
 void launchCodes(const uint8_t* mat, uint16_t* codes, const Geometry& g, hipStream_t stream);

@@ -60,11 +60,17 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     if (device < 0 || device >= ndev) return fail("HIP device index out of range");
     if (!hipOk(hipSetDevice(device), "hipSetDevice")) return false;
     if (!hipOk(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate")) return false;
+    {
+        int lo = 0, hi = 0;  // numerically lowest = highest priority
+        hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (!hipOk(hipStreamCreateWithPriority(&stream2_, hipStreamNonBlocking, hi), "hipStreamCreate")) return false;
+    }
+    if (!hipOk(hipEventCreateWithFlags(&forkEv_, hipEventDisableTiming), "hipEventCreate")) return false;
     for (auto& e : ev_)
         if (!hipOk(hipEventCreate(&e), "hipEventCreate")) return false;
 
-    K_ = opt.K > 0 ? opt.K : 4;
-    rxi_ = opt.rxi > 0 ? opt.rxi : 32;
+    K_ = opt.K > 0 ? opt.K : 8;  // defaults = fastest measured configuration on MI355X at 2048^2 .. 8192^2
+    rxi_ = opt.rxi > 0 ? opt.rxi : 24;
     if (!stepConfigSupported(K_, rxi_)) return fail("unsupported (stepsPerLaunch, tileRows) configuration");
     wi_ = 64 - 2 * K_;
     T_ = opt.numSteps > 0 ? opt.numSteps : g_.T;
@@ -171,6 +177,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
 
 Solver::~Solver() {
     if (stream_) hipStreamSynchronize(stream_);
+    if (stream2_) hipStreamSynchronize(stream2_);
     for (int i = 0; i < 2; ++i) {
         if (pr_[i]) hipFree(pr_[i]);
         if (vx_[i]) hipFree(vx_[i]);
@@ -185,6 +192,10 @@ Solver::~Solver() {
     for (auto& e : ev_)
         if (e) hipEventDestroy(e);
     for (auto& e : kev_) hipEventDestroy(e);
+    for (auto& e : airDone_) hipEventDestroy(e);
+    for (auto& e : genDone_) hipEventDestroy(e);
+    if (forkEv_) hipEventDestroy(forkEv_);
+    if (stream2_) hipStreamDestroy(stream2_);
     if (stream_) hipStreamDestroy(stream_);
 }
 
@@ -446,11 +457,32 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
     a.ntx = geo_.ntx;
     a.nty = geo_.nty;
     a.ntiles = geo_.ntx * geo_.nty;
+    a.bandRows = ceilDiv(geo_.ntx, 8);
+    a.tileOrder = opt_.tileOrder;
     a.withPulse = withPulse ? 1 : 0;
     a.record = record ? 1 : 0;
     a.dense = opt_.denseHistory ? 1 : 0;
     a.courant = g_.courant;
-    int done = 0;
+    // Two streams: the air-tile kernel (the bulk of the grid) on stream_, the general-tile kernel (walls, edges,
+    // listener: few tiles, latency-bound) concurrently on stream2_.  Both read buffer set `cur` and write disjoint
+    // tiles of the other set, so launch i+1 of EITHER kernel must wait for launch i of BOTH (RAW on the halos it
+    // reads, WAR on the tiles it overwrites): one event per kernel per launch.
+    const bool two = numGeneral_ > 0 && !opt_.timeKernels;
+    const int nl = ceilDiv(nsteps, K_);
+    if (two) {
+        auto grow = [&](std::vector<hipEvent_t>& v) {
+            while ((int)v.size() < nl) {
+                hipEvent_t e;
+                if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+                v.push_back(e);
+            }
+            return true;
+        };
+        if (!grow(airDone_) || !grow(genDone_)) return fail("hipEventCreate failed");
+        hipEventRecord(forkEv_, stream_);  // everything enqueued so far (reset, dyn upload, list upload)
+        hipStreamWaitEvent(stream2_, forkEv_, 0);
+    }
+    int done = 0, li = 0;
     while (done < nsteps) {
         const int k = std::min(K_, nsteps - done);
         a.prIn = pr_[cur_];
@@ -473,13 +505,24 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
             launchStep(K_, rxi_, a, stream_, 2);
             hipEventRecord(kev_[(size_t)kevUsed_ + 2], stream_);
             kevUsed_ += 3;
+        } else if (two) {
+            if (li > 0) {
+                hipStreamWaitEvent(stream_, genDone_[(size_t)li - 1], 0);
+                hipStreamWaitEvent(stream2_, airDone_[(size_t)li - 1], 0);
+            }
+            launchStep(K_, rxi_, a, stream_, 1);
+            hipEventRecord(airDone_[(size_t)li], stream_);
+            launchStep(K_, rxi_, a, stream_, 2, stream2_);
+            hipEventRecord(genDone_[(size_t)li], stream2_);
         } else {
             launchStep(K_, rxi_, a, stream_);
         }
         cur_ ^= 1;
         done += k;
+        ++li;
         ++tim_.stepLaunches;
     }
+    if (two) hipStreamWaitEvent(stream_, genDone_[(size_t)li - 1], 0);  // join
     return hipOk(hipGetLastError(), "step launch");
 }
 

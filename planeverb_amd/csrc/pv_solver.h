@@ -26,6 +26,7 @@ struct SolverOptions {
     bool skipAnalysis = false;
     bool useGraph = false;
     bool withFreeGrid = true;
+    int tileOrder = 0;
     bool timeKernels = false;  // HIP events around every step-kernel launch (bench / roofline)
 };
 
@@ -103,6 +104,9 @@ private:
     int K_ = 4, rxi_ = 32, wi_ = 56;
     int T_ = 0;
     hipStream_t stream_ = nullptr;
+    hipStream_t stream2_ = nullptr;        // general-tile kernels run here, concurrently with the air kernel
+    std::vector<hipEvent_t> airDone_, genDone_;  // per-launch cross-stream dependencies (no timing)
+    hipEvent_t forkEv_ = nullptr;
     hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
     long long deviceBytes_ = 0;
     std::string err_;

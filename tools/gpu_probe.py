@@ -140,8 +140,8 @@ if __name__ == "__main__":
     if "parityB" in what:
         check_scene("g512B_shoebox")
     if "perf" in what:
-        for (K, rows) in [(4, 32), (4, 24), (2, 28), (8, 24), (6, 28), (3, 26), (1, 30)]:
+        for (K, rows) in [(8, 24)]:
             perf(4096, K, rows)
-        perf(4096, 4, 32, dense=1)
-        perf(2048, 4, 32)
-        perf(8192, 4, 32)
+        perf(4096, 8, 24, dense=1)
+        perf(2048, 8, 24); perf(1024, 8, 24); perf(512, 8, 24)
+        perf(8192, 8, 24)
