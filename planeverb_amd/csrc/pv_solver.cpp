@@ -467,7 +467,7 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
     // listener: few tiles, latency-bound) concurrently on stream2_.  Both read buffer set `cur` and write disjoint
     // tiles of the other set, so launch i+1 of EITHER kernel must wait for launch i of BOTH (RAW on the halos it
     // reads, WAR on the tiles it overwrites): one event per kernel per launch.
-    const bool two = numGeneral_ > 0 && !opt_.timeKernels;
+    const bool two = numGeneral_ > 0;
     const int nl = ceilDiv(nsteps, K_);
     if (two) {
         auto grow = [&](std::vector<hipEvent_t>& v) {
@@ -493,30 +493,37 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
         a.vyOut = vy_[cur_ ^ 1];
         a.t0 = firstStep + done;
         a.nsteps = k;
-        if (opt_.timeKernels) {
-            while ((int)kev_.size() < kevUsed_ + 3) {
+        if (opt_.timeKernels) {  // 4 timing events per launch: air begin/end on stream_, general begin/end
+            while ((int)kev_.size() < kevUsed_ + 4) {
                 hipEvent_t e;
                 if (!hipOk(hipEventCreate(&e), "hipEventCreate")) return false;
                 kev_.push_back(e);
             }
-            hipEventRecord(kev_[(size_t)kevUsed_], stream_);
-            launchStep(K_, rxi_, a, stream_, 1);
-            hipEventRecord(kev_[(size_t)kevUsed_ + 1], stream_);
-            launchStep(K_, rxi_, a, stream_, 2);
-            hipEventRecord(kev_[(size_t)kevUsed_ + 2], stream_);
-            kevUsed_ += 3;
-        } else if (two) {
+        }
+        hipEvent_t* te = opt_.timeKernels ? &kev_[(size_t)kevUsed_] : nullptr;
+        if (two) {
             if (li > 0) {
                 hipStreamWaitEvent(stream_, genDone_[(size_t)li - 1], 0);
                 hipStreamWaitEvent(stream2_, airDone_[(size_t)li - 1], 0);
             }
+            if (te) hipEventRecord(te[0], stream_);
             launchStep(K_, rxi_, a, stream_, 1);
+            if (te) hipEventRecord(te[1], stream_);
             hipEventRecord(airDone_[(size_t)li], stream_);
+            if (te) hipEventRecord(te[2], stream2_);
             launchStep(K_, rxi_, a, stream_, 2, stream2_);
+            if (te) hipEventRecord(te[3], stream2_);
             hipEventRecord(genDone_[(size_t)li], stream2_);
         } else {
-            launchStep(K_, rxi_, a, stream_);
+            if (te) hipEventRecord(te[0], stream_);
+            launchStep(K_, rxi_, a, stream_, 1);
+            if (te) {
+                hipEventRecord(te[1], stream_);
+                hipEventRecord(te[2], stream_);
+                hipEventRecord(te[3], stream_);
+            }
         }
+        if (te) kevUsed_ += 4;
         cur_ ^= 1;
         done += k;
         ++li;
@@ -615,11 +622,11 @@ bool Solver::sync() {
         hipEventElapsedTime(&tim_.analysisMs, ev_[1], ev_[2]);
         if (opt_.timeKernels && kevUsed_ > 0) {
             double air = 0, gen = 0;
-            const int n = kevUsed_ / 3;
+            const int n = kevUsed_ / 4;
             for (int i = 0; i < n; ++i) {
                 float a = 0, g = 0;
-                hipEventElapsedTime(&a, kev_[(size_t)3 * i], kev_[(size_t)3 * i + 1]);
-                hipEventElapsedTime(&g, kev_[(size_t)3 * i + 1], kev_[(size_t)3 * i + 2]);
+                hipEventElapsedTime(&a, kev_[(size_t)4 * i], kev_[(size_t)4 * i + 1]);
+                hipEventElapsedTime(&g, kev_[(size_t)4 * i + 2], kev_[(size_t)4 * i + 3]);
                 air += a;
                 gen += g;
             }

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (through gpurun): rocprofv3 kernel trace + stats of the default bench command, the two
+# HBM PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs, as MI355X_MICROARCH.md prescribes), and the counter
+# calibration.  Everything lands in gpurun_out/; tools/summarize_profiles.py turns it into profiles/.
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+R=${1:-r01}
+O=gpurun_out/$R
+rm -rf $O && mkdir -p $O
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python bench.py --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2> $O/pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python bench.py --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2> $O/pmc_write.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch8k -o f -- python bench.py --no-cpu-baseline --grid 8192 --steps 2 --warmup 1 > /dev/null 2> $O/pmc_fetch8k.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write8k -o w -- python bench.py --no-cpu-baseline --grid 8192 --steps 2 --warmup 1 > /dev/null 2> $O/pmc_write8k.err
+hipcc --offload-arch=gfx950 -O3 tools/hbm_calib.hip -o /tmp/hbm_calib 2>/dev/null
+/tmp/hbm_calib > $O/hbm_calib.txt
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/calib_fetch -o c -- /tmp/hbm_calib > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/calib_write -o c -- /tmp/hbm_calib > /dev/null 2>&1
+# the un-profiled bench line, same box
+python bench.py > $O/bench.json 2> $O/bench.err
+python bench.py --grid 8192 --steps 4 --no-cpu-baseline > $O/bench_8192.json 2>> $O/bench.err
+python bench.py --grid 2048 --no-cpu-baseline > $O/bench_2048.json 2>> $O/bench.err
+python bench.py --dense-history 1 --no-cpu-baseline > $O/bench_dense.json 2>> $O/bench.err
+rm -f $O/trace/bench_kernel_trace.csv.bak
+ls -la $O

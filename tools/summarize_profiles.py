@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/<round>/ (written by tools/collect_profiles.sh on the GPU box) into the committed summaries under
+profiles/:  <round>_kernel_stats.csv (rocprofv3 --stats), <round>_hbm_pmc.md/json (FETCH_SIZE/WRITE_SIZE per launch
+with the gfx950 correction and its calibration), <round>_bench*.json, and profiles/hbm_traffic.json (read by bench.py
+for roofline.traffic)."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+SRC = os.path.join(ROOT, "gpurun_out", R)
+DST = os.path.join(ROOT, "profiles")
+os.makedirs(DST, exist_ok=True)
+
+
+def counters(path):
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        d[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return d
+
+
+def med(v):
+    v = sorted(v)
+    return v[len(v) // 2]
+
+
+def steady(v):
+    """per-launch values of the T-step loop: drop the short remainder launch and warm-up outliers -> median"""
+    return med(v)
+
+
+shutil.copy(os.path.join(SRC, "trace", "bench_kernel_stats.csv"), os.path.join(DST, R + "_kernel_stats.csv"))
+for f in ("bench.json", "bench_8192.json", "bench_2048.json", "bench_dense.json", "bench_under_rocprof.json",
+          "hbm_calib.txt"):
+    p = os.path.join(SRC, f)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(DST, R + "_" + f))
+
+# calibration: known 1 GiB per kernel
+cal_f = counters(os.path.join(SRC, "calib_fetch", "c_counter_collection.csv"))
+cal_w = counters(os.path.join(SRC, "calib_write", "c_counter_collection.csv"))
+GiB = float(1 << 30)
+cal = {}
+for k, v in cal_f.items():
+    if "calib_read_dword" in k:
+        cal["fetch_dword_read_ratio"] = med(v) * 1024 / GiB
+    if "calib_copy_x4" in k:
+        cal["fetch_dwordx4_copy_ratio"] = med(v) * 1024 / GiB
+for k, v in cal_w.items():
+    if "calib_write_dword" in k:
+        cal["write_dword_ratio"] = med(v) * 1024 / GiB
+fetch_corr = 1.0 / cal["fetch_dword_read_ratio"]
+write_corr = 1.0 / cal["write_dword_ratio"]
+
+out = {"calibration": cal, "fetch_correction": fetch_corr, "write_correction": write_corr, "grids": {}}
+traffic = {}
+lines = ["# HBM-side traffic per kernel launch (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes)", "",
+         "Counter units are KiB.  Calibration on this box with known 1 GiB streams in the same access pattern "
+         "(tools/hbm_calib.hip): FETCH_SIZE reads %.4f of the true bytes (dword-per-lane reads; %.4f for dwordx4), "
+         "WRITE_SIZE %.4f -> corrections x%.3f / x%.3f (MI355X_MICROARCH.md: FETCH_SIZE = 1/2 on gfx950)." % (
+             cal["fetch_dword_read_ratio"], cal.get("fetch_dwordx4_copy_ratio", float("nan")),
+             cal["write_dword_ratio"], fetch_corr, write_corr), ""]
+for tag, fd, wd in (("4096", "pmc_fetch", "pmc_write"), ("8192", "pmc_fetch8k", "pmc_write8k")):
+    fp = os.path.join(SRC, fd, "f_counter_collection.csv")
+    wp = os.path.join(SRC, wd, "w_counter_collection.csv")
+    if not (os.path.exists(fp) and os.path.exists(wp)):
+        continue
+    F, W = counters(fp), counters(wp)
+    lines += ["## grid %s^2" % tag, "", "| kernel | launches | FETCH_SIZE KiB (median) | corrected read MB | "
+              "WRITE_SIZE KiB (median) | corrected write MB | total MB |", "|---|---|---|---|---|---|---|"]
+    g = {}
+    for k in sorted(F):
+        if "pv_" not in k:
+            continue
+        f, w = steady(F[k]), steady(W.get(k, [0.0]))
+        rb, wb = f * 1024 * fetch_corr, w * 1024 * write_corr
+        short = k.split("(")[0].replace("void pva::", "").replace("pva::", "")
+        g[short] = {"launches_profiled": len(F[k]), "fetch_kib": f, "write_kib": w, "read_bytes": rb,
+                    "write_bytes": wb, "bytes_per_launch": rb + wb}
+        lines.append("| %s | %d | %.0f | %.1f | %.0f | %.1f | %.1f |" % (short, len(F[k]), f, rb / 1e6, w, wb / 1e6,
+                                                                         (rb + wb) / 1e6))
+        if "pv_step_air_kernel" in short:
+            traffic[tag] = {"bytes_per_launch": rb + wb, "read_bytes": rb, "write_bytes": wb, "kernel": short}
+    out["grids"][tag] = g
+    lines.append("")
+json.dump(out, open(os.path.join(DST, R + "_hbm_pmc.json"), "w"), indent=1)
+open(os.path.join(DST, R + "_hbm_pmc.md"), "w").write("\n".join(lines) + "\n")
+json.dump(traffic, open(os.path.join(DST, "hbm_traffic.json"), "w"), indent=1)
+print("\n".join(lines))
+print(open(os.path.join(DST, R + "_kernel_stats.csv")).read())
