@@ -101,14 +101,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a HIP device (no CPU path)")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("--gpus %d needs one rank per GPU: python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d ..." % (
+                             args.gpus, args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     size = mode_a_size(args.grid)
     opts = dict(time_kernels=1)
@@ -134,7 +138,7 @@ def main():
     def sync():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
 
     for w in range(args.warmup):
         s.run(listener(w))
@@ -207,7 +211,7 @@ def main():
         print(json.dumps(out))
     s.close()
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 

@@ -123,7 +123,7 @@ enum {
     PVA_OPT_DENSE_HISTORY = 1, /* 1 = record every tile every step (no zero-tile skipping) */
     PVA_OPT_NUM_STEPS = 2,     /* override T (extension); 0 = reference value */
     PVA_OPT_SKIP_ANALYSIS = 3, /* 1 = PvAmdRun does the FDTD loop only */
-    PVA_OPT_USE_GRAPH = 4,     /* 1 = replay the T-step loop from a captured hipGraph */
+    PVA_OPT_USE_GRAPH = 4,     /* replay a run from a captured hipGraph: 0 = auto (launch-bound small grids), 1 = always, 2 = never */
     PVA_OPT_STEPS_PER_LAUNCH = 5, /* K: time steps fused per kernel launch (tuning) */
     PVA_OPT_TILE_ROWS = 6,     /* interior rows of a wave tile (tuning; must pair with a compiled K) */
     PVA_OPT_NO_FREE_GRID = 7,  /* 1 = skip the free-field run (efree = 0; stencil-only use) */

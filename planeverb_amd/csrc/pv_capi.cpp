@@ -191,7 +191,7 @@ int PvAmdSetOption(PvAmdSolver* h, int key, long long value) {
         case PVA_OPT_DENSE_HISTORY: h->opt.denseHistory = value != 0; break;
         case PVA_OPT_NUM_STEPS: h->opt.numSteps = (int)value; break;
         case PVA_OPT_SKIP_ANALYSIS: h->opt.skipAnalysis = value != 0; break;
-        case PVA_OPT_USE_GRAPH: h->opt.useGraph = value != 0; break;
+        case PVA_OPT_USE_GRAPH: h->opt.useGraph = (int)value; break;
         case PVA_OPT_STEPS_PER_LAUNCH: h->opt.K = (int)value; break;
         case PVA_OPT_TILE_ROWS: h->opt.rxi = (int)value; break;
         case PVA_OPT_NO_FREE_GRID: h->opt.withFreeGrid = value == 0; break;

@@ -43,6 +43,7 @@ struct DynParams {
     int lrow, lcol;          // listener cell, padded coordinates
     int histRow0, histCol0;  // padded coordinates of the history window origin (tile aligned)
     int histTileX0, histTileY0, histTilesX, histTilesY;
+    int numGeneral;          // live entries of generalList (the launch grid is sized for its capacity)
 };
 
 struct StepArgs {
@@ -59,7 +60,7 @@ struct StepArgs {
     int* tileFirst;        // per tile: first step block in which the tile was non-zero (INT_MAX = never)
     const uint8_t* tileClass;   // per tile: 0 = all faces air|air (air kernel), 1 = general kernel
     const int* generalList;     // tiles for the general kernel: class-1 tiles + tiles holding the listener
-    int numGeneral;
+    int numGeneral;             // capacity of generalList used to size the grid; live count is dyn->numGeneral
     const DynParams* dyn;
     int* errFlag;
     long long histPlane;   // floats per recorded step

@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void pv_step_general_kernel(const StepArgs 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int idx = blockIdx.x * 4 + wave;
-    if (idx >= a.numGeneral * S) return;
+    if (idx >= a.dyn->numGeneral * S) return;
     // few, long, latency-bound waves that run beside the air kernel: let them win VALU/issue arbitration
     __builtin_amdgcn_s_setprio(3);
     const int tile = __builtin_amdgcn_readfirstlane(a.generalList[idx / S]);

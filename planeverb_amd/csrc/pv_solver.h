@@ -24,7 +24,7 @@ struct SolverOptions {
     bool denseHistory = false;
     int numSteps = 0;     // override T (0 = reference value)
     bool skipAnalysis = false;
-    bool useGraph = false;
+    int useGraph = 0;     // 0 = auto (small grids), 1 = always, 2 = never: replay the run from a captured hipGraph
     bool withFreeGrid = true;
     int tileOrder = 0;
     bool timeKernels = false;  // HIP events around every step-kernel launch (bench / roofline)
@@ -107,6 +107,13 @@ private:
     hipStream_t stream2_ = nullptr;        // general-tile kernels run here, concurrently with the air kernel
     std::vector<hipEvent_t> airDone_, genDone_;  // per-launch cross-stream dependencies (no timing)
     hipEvent_t forkEv_ = nullptr;
+    // captured launch schedule of one run (reset + all step launches on both streams), replayed per run
+    hipGraph_t graph_ = nullptr;
+    hipGraphExec_t graphExec_ = nullptr;
+    int graphCap_ = -1;  // general-list capacity the graph was captured with
+    bool buildGraph(int cap);
+    void dropGraph();
+    bool enqueueResetAndSteps();
     hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
     long long deviceBytes_ = 0;
     std::string err_;
@@ -148,6 +155,7 @@ private:
     std::vector<int> wallTiles_;
     std::vector<uint8_t> tileClassHost_;
     int numGeneral_ = 0;
+    int launchCap_ = 0;  // general-list entries the general kernel's grid is sized for
     bool geometryDirty_ = true;
     float efree_ = 0.f;
     DynParams dynCur_{};

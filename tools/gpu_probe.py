@@ -143,5 +143,5 @@ if __name__ == "__main__":
         for (K, rows) in [(8, 24)]:
             perf(4096, K, rows)
         perf(4096, 8, 24, dense=1)
-        perf(2048, 8, 24); perf(1024, 8, 24); perf(512, 8, 24)
+        perf(2048, 8, 24); perf(1024, 8, 24); perf(512, 8, 24); perf(70, 8, 24)
         perf(8192, 8, 24)
