@@ -109,8 +109,10 @@ def main():
                              args.gpus, args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("PV_BENCH_FORCE_DIST") == "1"  # the latter: 1-rank RCCL self-test
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -137,7 +139,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier(device_ids=[local_rank])
 
     for w in range(args.warmup):
@@ -155,10 +157,10 @@ def main():
         ana_ms.append(t.analysisMs)
         air_ms.append(t.airKernelMs)
         gen_ms.append(t.generalKernelMs)
-    gathered = pvd.gather_outputs(local, n_runs, dist if world > 1 else None, dev)  # the one RCCL gather
+    gathered = pvd.gather_outputs(local, n_runs, dist if use_dist else None, dev)  # the one RCCL gather
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -210,7 +212,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out))
     s.close()
-    if world > 1:
+    if use_dist:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 

@@ -197,6 +197,7 @@ int PvAmdSetOption(PvAmdSolver* h, int key, long long value) {
         case PVA_OPT_NO_FREE_GRID: h->opt.withFreeGrid = value == 0; break;
         case PVA_OPT_TIME_KERNELS: h->opt.timeKernels = value != 0; break;
         case PVA_OPT_TILE_ORDER: h->opt.tileOrder = (int)value; break;
+        case PVA_OPT_SMALL_GRID_KERNEL: h->opt.smallGrid = (int)value; break;
         default: g_lastError = "unknown option"; return -1;
     }
     return 0;

@@ -79,6 +79,25 @@ struct StepArgs {
     float courant;
 };
 
+// whole-grid-resident kernel for grids that fit one CU's LDS (pv_small_grid_kernel)
+struct SmallArgs {
+    float* prOut;
+    float* vxOut;
+    float* vyOut;
+    const uint16_t* codes;
+    const float* lut;
+    const float* pulse;
+    float* hist;
+    const DynParams* dyn;
+    long long histPlane;
+    int histPitch;
+    int pitch, G;
+    int NX, NY;
+    int T;
+    int record;
+    float courant;
+};
+
 struct AnalyzeArgs {
     const float* hist;
     const uint16_t* codes;

@@ -447,6 +447,120 @@ void launchLaneSelfTest(float* out, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// whole-grid-resident stencil for small grids
+// ---------------------------------------------------------------------------------------------------------------
+
+// Grids up to ~110^2 cells (the sandbox default is 71^2, the Unity demo 38^2) fit one CU: the three fields live in
+// LDS for the whole run (160 KiB per CU on MI355X), each of the 1024 threads owns up to CPT cells whose state and
+// face coefficients stay in registers, and ALL T time steps run inside one launch with two workgroup barriers per
+// step.  Per step a cell reads its four neighbour values from LDS (vx[x+1], vy[y+1] for the pressure update,
+// p[x-1], p[y-1] for the velocity update) and writes its three new values back; the pressure history row is stored
+// to HBM as it is produced.  This replaces ~110 launch-bound kernel launches per run by one.
+constexpr int kSmallThreads = 1024;
+constexpr int kSmallCpt = 12;
+constexpr int kSmallLdsBytes = 160 * 1024;
+
+__host__ __device__ inline int smallLdsFloats(int NX, int NY) { return 3 * ((NX + 2) * NY + 2); }
+
+bool smallGridFits(int NX, int NY) {
+    return NX * NY <= kSmallThreads * kSmallCpt && smallLdsFloats(NX, NY) * 4 <= kSmallLdsBytes;
+}
+
+__global__ __launch_bounds__(kSmallThreads) void pv_small_grid_kernel(const SmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int NX = a.NX, NY = a.NY;
+    const int cells = NX * NY;
+    const int plane = (NX + 2) * NY + 2;  // one guard row above and below, +2 slack for the y+1 read of the last cell
+    float* sp = smem + NY;                // cell (x, y) at sp[x*NY + y]; sp[-NY .. -1] is the zero guard row
+    float* sx = sp + plane;
+    float* sy = sx + plane;
+    for (int i = threadIdx.x; i < 3 * plane; i += kSmallThreads) smem[i] = 0.f;
+
+    const DynParams dyn = *a.dyn;
+    const float C = a.courant;
+    const int lcell = (dyn.lrow >= a.G && dyn.lcol >= a.G) ? (dyn.lrow - a.G) * NY + (dyn.lcol - a.G) : -1;
+
+    float p[kSmallCpt], vx[kSmallCpt], vy[kSmallCpt], kx[kSmallCpt], ky[kSmallCpt];
+    int hoff[kSmallCpt];
+    unsigned beta = 0;
+#pragma unroll
+    for (int j = 0; j < kSmallCpt; ++j) {
+        const int i = threadIdx.x + j * kSmallThreads;
+        p[j] = vx[j] = vy[j] = 0.f;
+        kx[j] = ky[j] = 0.f;
+        hoff[j] = 0;
+        if (i < cells) {
+            const int x = i / NY, y = i - x * NY;
+            const unsigned code = a.codes[(size_t)(x + a.G) * a.pitch + (y + a.G)];
+            kx[j] = a.lut[code & 0xffu];
+            ky[j] = a.lut[code >> 8];
+            if ((code & 0xffu) < (unsigned)kLutWall) beta |= 1u << j;
+            hoff[j] = (x + a.G - dyn.histRow0) * a.histPitch + (y + a.G - dyn.histCol0);
+        }
+    }
+    __syncthreads();
+
+    float* hplane = a.hist;
+#pragma unroll 1
+    for (int t = 0; t < a.T; ++t) {
+        // pressure, FDTD.cpp:124-141 (reads past the last row / element hit the zero guard and are times beta = 0)
+#pragma unroll
+        for (int j = 0; j < kSmallCpt; ++j) {
+            const int i = threadIdx.x + j * kSmallThreads;
+            if (i < cells) {
+                const float div = (sx[i + NY] - vx[j]) + (sy[i + 1] - vy[j]);
+                const float pn = p[j] - C * div;
+                p[j] = (beta >> j) & 1u ? pn : 0.f;
+                sp[i] = p[j];
+            }
+        }
+        __syncthreads();
+        // velocities, FDTD.cpp:143-223 through the face coefficients; record, FDTD.cpp:226-230
+#pragma unroll
+        for (int j = 0; j < kSmallCpt; ++j) {
+            const int i = threadIdx.x + j * kSmallThreads;
+            if (i < cells) {
+                const float pi = p[j];
+                const float pxn = sp[i - NY];
+                const float pyn = (i > 0) ? sp[i - 1] : 0.f;
+                const float ax = vx[j] - C * (pi - pxn), wx = kx[j] * (pi + pxn);
+                const float ay = vy[j] - C * (pi - pyn), wy = ky[j] * (pi + pyn);
+                vx[j] = (kx[j] != kx[j]) ? ax : wx;
+                vy[j] = (ky[j] != ky[j]) ? ay : wy;
+                sx[i] = vx[j];
+                sy[i] = vy[j];
+                if (a.record) hplane[hoff[j]] = pi;
+                if (i == lcell) p[j] = pi + a.pulse[t];  // soft source after the record, FDTD.cpp:234
+            }
+        }
+        hplane += a.histPlane;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < kSmallCpt; ++j) {
+        const int i = threadIdx.x + j * kSmallThreads;
+        if (i < cells) {
+            const int x = i / NY, y = i - x * NY;
+            const size_t o = (size_t)(x + a.G) * a.pitch + (y + a.G);
+            a.prOut[o] = p[j];
+            a.vxOut[o] = vx[j];
+            a.vyOut[o] = vy[j];
+        }
+    }
+}
+
+void launchSmallGrid(const SmallArgs& a, hipStream_t stream) {
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(pv_small_grid_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kSmallLdsBytes);
+        attr = true;
+    }
+    const size_t lds = (size_t)smallLdsFloats(a.NX, a.NY) * 4;
+    hipLaunchKernelGGL(pv_small_grid_kernel, dim3(1), dim3(kSmallThreads), lds, stream, a);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // impulse-response analysis
 // ---------------------------------------------------------------------------------------------------------------
 

@@ -16,6 +16,9 @@ bool stepConfigSupported(int K, int rxi);
 void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream, int which = 3, hipStream_t stream2 = nullptr);
 void launchTileClass(int K, int rxi, const uint16_t* codes, uint8_t* tileClass, int* list, int* count,
                      const Geometry& g, hipStream_t stream);
+// cells = NX*NY must satisfy smallGridFits()
+bool smallGridFits(int NX, int NY);
+void launchSmallGrid(const SmallArgs& a, hipStream_t stream);
 void launchCodes(const uint8_t* mat, uint16_t* codes, const Geometry& g, hipStream_t stream);
 void launchLaneSelfTest(float* out128, hipStream_t stream);
 void launchAnalysis(const AnalyzeArgs& a, hipStream_t stream);

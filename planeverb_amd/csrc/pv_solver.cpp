@@ -584,7 +584,33 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
     hipEventRecord(ev_[0], stream_);
     const int ntiles = geo_.ntx * geo_.nty;
     const bool graph = !opt_.timeKernels && (opt_.useGraph == 1 || (opt_.useGraph == 0 && ntiles <= 4096));
-    if (graph) {
+    const bool small = opt_.smallGrid != 2 && !opt_.timeKernels && opt_.useGraph != 1 && smallGridFits(g_.NX, g_.NY) &&
+                       histTilesX_ == geo_.ntx && histTilesY_ == geo_.nty;
+    if (small) {
+        // the whole grid lives in one CU's LDS for all T steps: one launch, every cell recorded from step 0
+        if (!hipOk(hipMemsetAsync(tileFirst_, 0, sizeof(int) * (size_t)ntiles, stream_), "tileFirst")) return false;
+        if (!hipOk(hipMemsetAsync(errFlag_, 0, sizeof(int), stream_), "errFlag")) return false;
+        SmallArgs sa{};
+        sa.prOut = pr_[0];
+        sa.vxOut = vx_[0];
+        sa.vyOut = vy_[0];
+        sa.codes = codes_;
+        sa.lut = lutDev_;
+        sa.pulse = pulseDev_;
+        sa.hist = hist_;
+        sa.dyn = dynDev_;
+        sa.histPlane = histPlane_;
+        sa.histPitch = histPitch_;
+        sa.pitch = geo_.pitch;
+        sa.G = geo_.G;
+        sa.NX = g_.NX;
+        sa.NY = g_.NY;
+        sa.T = T_;
+        sa.record = 1;
+        sa.courant = g_.courant;
+        launchSmallGrid(sa, stream_);
+        tim_.stepLaunches = 1;
+    } else if (graph) {
         // the grid of the general kernel is captured for a capacity; the live count is read from dyn on the device
         const int cap = (int)wallTiles_.size() + 4;
         if (!graphExec_ || graphCap_ != cap) {

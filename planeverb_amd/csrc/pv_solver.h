@@ -27,6 +27,7 @@ struct SolverOptions {
     int useGraph = 0;     // 0 = auto (small grids), 1 = always, 2 = never: replay the run from a captured hipGraph
     bool withFreeGrid = true;
     int tileOrder = 0;
+    int smallGrid = 0;    // 0 = auto: grids that fit one CU's LDS run in the whole-grid-resident kernel; 2 = never
     bool timeKernels = false;  // HIP events around every step-kernel launch (bench / roofline)
 };
 

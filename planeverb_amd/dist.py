@@ -19,7 +19,7 @@ def gather_outputs(local, n_runs, dist=None, device=None):
     Returns float32 [n_runs, n_emitters, 8] on every rank (one all-gather).  Every run must have the same number of
     emitters.  `dist` is torch.distributed (already initialised) or None for a single process."""
     n_em = next(iter(local.values())).shape[0] if local else 0
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         out = np.zeros((n_runs, n_em, 8), np.float32)
         for k, v in local.items():
             out[k] = v
