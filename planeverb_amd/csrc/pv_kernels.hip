@@ -621,31 +621,54 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
     const bool airX = kx != kx, airY = ky != ky;
     const float C = a.courant;
 
+    // Every loop below walks the history in chunks of CH samples: the CH loads are issued together (they do not
+    // depend on the running sums), then consumed strictly in sample order, so the float32 accumulation order is the
+    // reference's while the memory latency is paid once per chunk instead of once per sample.
+    constexpr int CH = 8;
+
     // onset + dry energy + flux, Analyzer.cpp:146-195 (sums run from sample 0; samples before tFirst are zero)
     int onset = -1, sourceDirEnd = INT_MAX, directEnd = INT_MAX;
     float Edry = 0.f, fluxX = 0.f, fluxY = 0.f, vx = 0.f, vy = 0.f;
-    for (int t = tFirst; t < T; ++t) {
-        if (t >= directEnd) break;
-        const float p = hc.at(t);
-        const bool needV = t < sourceDirEnd;
-        if (needV) {
-            const float pxn = (t >= tFx) ? hx.at(t) : 0.f;
-            const float pyn = (t >= tFy) ? hy.at(t) : 0.f;
-            const float ax = vx - C * (p - pxn), wx = kx * (p + pxn);
-            const float ay = vy - C * (p - pyn), wy = ky * (p + pyn);
-            vx = airX ? ax : wx;
-            vy = airY ? ay : wy;
+    bool done = false;
+    for (int t0 = tFirst; t0 < T && !done; t0 += CH) {
+        float pc[CH], pxc[CH], pyc[CH];
+        const bool needVChunk = t0 < sourceDirEnd;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int tt = min(t0 + k, T - 1);
+            pc[k] = hc.at(tt);
+            pxc[k] = (needVChunk && tt >= tFx) ? hx.at(tt) : 0.f;
+            pyc[k] = (needVChunk && tt >= tFy) ? hy.at(tt) : 0.f;
         }
-        if (onset < 0 && fabsf(p) > kAudibleThresholdDev) {
-            onset = t;
-            sourceDirEnd = t + a.nDir;
-            directEnd = t + a.nDry;
-            if (t >= directEnd) break;
-        }
-        Edry += p * p;
-        if (t < sourceDirEnd) {
-            fluxX += p * vx;
-            fluxY += p * vy;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int t = t0 + k;
+            if (done || t >= T || t >= directEnd) {
+                done = true;
+                continue;
+            }
+            const float p = pc[k];
+            if (t < sourceDirEnd) {
+                const float pxn = pxc[k], pyn = pyc[k];
+                const float ax = vx - C * (p - pxn), wx = kx * (p + pxn);
+                const float ay = vy - C * (p - pyn), wy = ky * (p + pyn);
+                vx = airX ? ax : wx;
+                vy = airY ? ay : wy;
+            }
+            if (onset < 0 && fabsf(p) > kAudibleThresholdDev) {
+                onset = t;
+                sourceDirEnd = t + a.nDir;
+                directEnd = t + a.nDry;
+                if (t >= directEnd) {
+                    done = true;
+                    continue;
+                }
+            }
+            Edry += p * p;
+            if (t < sourceDirEnd) {
+                fluxX += p * vx;
+                fluxY += p * vy;
+            }
         }
     }
     if (onset < 0) {
@@ -670,9 +693,13 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
     {
         int end = directEnd + 1 + a.nWet;
         if (T < end) end = T;
-        for (int j = directEnd + 1; j < end; ++j) {
-            const float p = hc.at(j);
-            wetEnergy += p * p;
+        for (int j0 = directEnd + 1; j0 < end; j0 += CH) {
+            float pc[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) pc[k] = hc.at(min(j0 + k, T - 1));
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+                if (j0 + k < end) wetEnergy += pc[k] * pc[k];
         }
     }
     const float wet = sqrtf(wetEnergy / a.efree);
@@ -688,16 +715,28 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
         const float xsum = rn * xmean;
         const float denominator = (1.0f / 12.0f) * rn * (rn * rn - 1.0f);
         float edc = 0.f, xysum = 0.f, ysum = 0.f;
-        for (int i = T - 1; i >= endPoint && i >= 0; --i) {
-            const float p = hc.at(i);
-            edc += p * p;
+        for (int i0 = T - 1; i0 >= endPoint && i0 >= 0; i0 -= CH) {
+            float pc[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) pc[k] = hc.at(max(i0 - k, 0));
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+                if (i0 - k >= endPoint && i0 - k >= 0) edc += pc[k] * pc[k];
         }
-        for (int i = endPoint - 1; i >= startingPoint; --i) {
-            const float p = hc.at(i);
-            edc += p * p;
-            const float y = 10.f * pvLog10f(edc);
-            xysum += y * (float)(i - startingPoint);
-            ysum += y;
+        for (int i0 = endPoint - 1; i0 >= startingPoint; i0 -= CH) {
+            float pc[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) pc[k] = hc.at(max(i0 - k, 0));
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const int i = i0 - k;
+                if (i >= startingPoint) {
+                    edc += pc[k] * pc[k];
+                    const float y = 10.f * pvLog10f(edc);
+                    xysum += y * (float)(i - startingPoint);
+                    ysum += y;
+                }
+            }
         }
         const float ymean = ysum / rn;
         const float numerator = xysum - ymean * xsum - xmean * ysum + rn * xmean * ymean;
