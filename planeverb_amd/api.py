@@ -33,6 +33,7 @@ PVA_OPT_NO_FREE_GRID = 7
 PVA_OPT_TIME_KERNELS = 8
 PVA_OPT_TILE_ORDER = 9
 PVA_OPT_SMALL_GRID_KERNEL = 10
+PVA_OPT_PACKED_MATH = 11
 
 
 class PlaneverbOutput(C.Structure):
@@ -290,7 +291,8 @@ class Solver:
                 "skip_analysis": PVA_OPT_SKIP_ANALYSIS, "use_graph": PVA_OPT_USE_GRAPH,
                 "steps_per_launch": PVA_OPT_STEPS_PER_LAUNCH, "tile_rows": PVA_OPT_TILE_ROWS,
                 "no_free_grid": PVA_OPT_NO_FREE_GRID, "time_kernels": PVA_OPT_TIME_KERNELS,
-                "tile_order": PVA_OPT_TILE_ORDER, "small_grid_kernel": PVA_OPT_SMALL_GRID_KERNEL}
+                "tile_order": PVA_OPT_TILE_ORDER, "small_grid_kernel": PVA_OPT_SMALL_GRID_KERNEL,
+                "packed_math": PVA_OPT_PACKED_MATH}
         for k, v in options.items():
             _check(lib().PvAmdSetOption(self._h, keys[k], int(v)))
         self.info = PvAmdInfo()

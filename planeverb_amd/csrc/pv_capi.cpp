@@ -198,6 +198,7 @@ int PvAmdSetOption(PvAmdSolver* h, int key, long long value) {
         case PVA_OPT_TIME_KERNELS: h->opt.timeKernels = value != 0; break;
         case PVA_OPT_TILE_ORDER: h->opt.tileOrder = (int)value; break;
         case PVA_OPT_SMALL_GRID_KERNEL: h->opt.smallGrid = (int)value; break;
+        case PVA_OPT_PACKED_MATH: h->opt.packed = value != 0; break;
         default: g_lastError = "unknown option"; return -1;
     }
     return 0;

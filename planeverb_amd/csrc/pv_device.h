@@ -70,6 +70,7 @@ struct StepArgs {
     int G;
     int ntx, nty, ntiles;
     int bandRows;          // tile rows per XCD band = ceil(ntx / 8)
+    int packed;            // air kernel: packed-f32 (v_pk_*) arithmetic variant
     int tileOrder;         // air-kernel block -> tile mapping (0 linear, 1 XCD band row-major, 2 band column-major)
     int t0;                // first global step of this launch
     int nsteps;            // steps in this launch (<= K)

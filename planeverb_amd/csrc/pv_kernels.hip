@@ -35,12 +35,13 @@ namespace pva {
 #define PV_USE_DPP 1
 #endif
 
+
 // value held by lane+1 (lane 63 receives an unspecified value; it is always a halo lane)
 __device__ __forceinline__ float laneNext(float v) {
 #if PV_USE_DPP
     // DPP wave_shl:1 -- dst[i] = src[i+1] across the whole 64-lane wavefront (gfx9 DPP_WF_SL1 = 0x130)
     return __builtin_bit_cast(
-        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
 #else
     return __shfl_down(v, 1);
 #endif
@@ -51,7 +52,7 @@ __device__ __forceinline__ float lanePrev(float v) {
 #if PV_USE_DPP
     // DPP wave_shr:1 -- dst[i] = src[i-1] (DPP_WF_SR1 = 0x138)
     return __builtin_bit_cast(
-        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 #else
     return __shfl_up(v, 1);
 #endif
@@ -309,12 +310,183 @@ __device__ __forceinline__ void stepTile(const StepArgs& a, const int tile, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// air tile with packed-f32 arithmetic
+// ---------------------------------------------------------------------------------------------------------------
+// PMC on the scalar form (SQ_ACTIVE_INST_VALU ~ 92 % of the SIMD issue slots at K = 8) shows the air kernel is bound
+// by VALU ISSUE, not by HBM: a CU issues one VALU instruction per SIMD every 4 cycles, and a plain wave64 f32 op
+// uses only half of the SIMD-32's lanes-per-slot; only packed ops (v_pk_add_f32 / v_pk_mul_f32, two floats per lane)
+// reach the full f32 rate.  Here two ADJACENT ROWS of a lane's column live in one 64-bit register pair, so every
+// y-direction difference and every multiply / subtract is one packed op per two cells; x-direction differences need
+// the row-shifted pair (p[r-1], p[r]), built with one v_pk_mov-style shuffle per pair.  Per-element arithmetic and
+// its order are unchanged (packed ops are IEEE per half), so the fields stay bit-identical.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// ILP: the three sweeps are written breadth-first over groups of G row pairs (all shuffles, then all differences,
+// then all multiplies ...) so that consecutive instructions of a wave are independent; written row by row the
+// compiler funnels every row through the same two temporaries and each instruction waits for its predecessor
+// (SQ_WAIT_INST_ANY 44 % of wave cycles).
+template <int NP, int G>
+__device__ __forceinline__ void leapfrogStepPacked(v2f (&pr)[NP], v2f (&vx)[NP], v2f (&vy)[NP], const float C) {
+    const v2f c2 = {C, C};
+    // pressure sweep, FDTD.cpp:124-141
+#pragma unroll
+    for (int i0 = 0; i0 < NP; i0 += G) {
+        v2f vxs[G], vyr[G], d[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int i = i0 + g;
+            if (i < NP) {
+                vxs[g] = (i + 1 < NP) ? __builtin_shufflevector(vx[i], vx[i + 1], 1, 2)
+                                      : __builtin_shufflevector(vx[i], vx[i], 1, 1);  // last row: halo garbage
+                vyr[g].x = laneNext(vy[i].x);
+                vyr[g].y = laneNext(vy[i].y);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (i0 + g < NP) vxs[g] = vxs[g] - vx[i0 + g];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (i0 + g < NP) vyr[g] = vyr[g] - vy[i0 + g];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (i0 + g < NP) d[g] = vxs[g] + vyr[g];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (i0 + g < NP) d[g] = c2 * d[g];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (i0 + g < NP) pr[i0 + g] = pr[i0 + g] - d[g];
+    }
+    // vx sweep, FDTD.cpp:143-170 (air|air faces only in this kernel); descending so that pr[i-1] is still needed
+#pragma unroll
+    for (int i0 = 0; i0 < NP; i0 += G) {
+        v2f t[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int i = i0 + g;
+            if (i < NP)
+                t[g] = (i > 0) ? __builtin_shufflevector(pr[i - 1], pr[i], 1, 2)
+                               : __builtin_shufflevector(pr[i], pr[i], 0, 0);  // first row: halo garbage
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (i0 + g < NP) t[g] = pr[i0 + g] - t[g];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (i0 + g < NP) t[g] = c2 * t[g];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (i0 + g < NP) vx[i0 + g] = vx[i0 + g] - t[g];
+    }
+    // vy sweep, FDTD.cpp:172-199
+#pragma unroll
+    for (int i0 = 0; i0 < NP; i0 += G) {
+        v2f t[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int i = i0 + g;
+            if (i < NP) {
+                t[g].x = lanePrev(pr[i].x);
+                t[g].y = lanePrev(pr[i].y);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (i0 + g < NP) t[g] = pr[i0 + g] - t[g];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (i0 + g < NP) t[g] = c2 * t[g];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (i0 + g < NP) vy[i0 + g] = vy[i0 + g] - t[g];
+    }
+}
+
+template <int K, int RXI>
+__device__ __forceinline__ void stepTileAirPacked(const StepArgs& a, const int tile, const int lane) {
+    constexpr int ROWS = RXI + 2 * K;
+    static_assert(ROWS % 2 == 0, "packed air tile needs an even number of rows");
+    constexpr int NP = ROWS / 2;
+    constexpr int WI = 64 - 2 * K;
+    const int ti = tile / a.nty;
+    const int tj = tile - ti * a.nty;
+    const int row0 = a.G - K + ti * RXI;
+    const int col0 = a.G - K + tj * WI;
+    const int voff = lane * 4;
+    const int pitchB = a.pitch * 4;
+    const int soff0 = (row0 * a.pitch + col0) * 4;
+
+    const rsrc_t rPrIn = makeRsrc(a.prIn, a.planeBytes), rVxIn = makeRsrc(a.vxIn, a.planeBytes),
+                 rVyIn = makeRsrc(a.vyIn, a.planeBytes);
+    v2f pr[NP], vx[NP], vy[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int so = soff0 + (2 * i) * pitchB;
+        pr[i].x = bufLoadF(rPrIn, voff, so);
+        pr[i].y = bufLoadF(rPrIn, voff, so + pitchB);
+        vx[i].x = bufLoadF(rVxIn, voff, so);
+        vx[i].y = bufLoadF(rVxIn, voff, so + pitchB);
+        vy[i].x = bufLoadF(rVyIn, voff, so);
+        vy[i].y = bufLoadF(rVyIn, voff, so + pitchB);
+    }
+    uint32_t nz = 0;
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+        nz |= (__float_as_uint(pr[i].x) | __float_as_uint(pr[i].y) | __float_as_uint(vx[i].x) |
+               __float_as_uint(vx[i].y) | __float_as_uint(vy[i].x) | __float_as_uint(vy[i].y)) &
+              0x7fffffffu;
+    const bool active = __ballot(nz != 0u) != 0ull;
+
+    const DynParams dyn = *a.dyn;
+    const int hti = ti - dyn.histTileX0, htj = tj - dyn.histTileY0;
+    const bool inWin = hti >= 0 && hti < dyn.histTilesX && htj >= 0 && htj < dyn.histTilesY;
+    const bool wasActive = a.record && a.tileFirst[tile] != INT_MAX;
+    const bool rec = a.record && inWin && (active || wasActive || a.dense);
+    if (a.record && active && !wasActive && lane == 0) atomicMin(&a.tileFirst[tile], a.t0);
+    if (a.record && active && !inWin && lane == 0) atomicExch(a.errFlag, 1);
+
+    const float C = a.courant;
+    const bool inCols = lane >= K && lane < 64 - K;
+    const float* hplane = a.hist + (long long)a.t0 * a.histPlane;
+    const int hpitchB = a.histPitch * 4;
+    const int hsoff0 = (hti * RXI - K) * hpitchB;
+    const int hvoff = (htj * WI - K + lane) * 4;
+
+#pragma unroll 1
+    for (int s = 0; s < a.nsteps; ++s) {
+        leapfrogStepPacked<NP, 4>(pr, vx, vy, C);
+        if (rec) {
+            const rsrc_t rH = makeRsrc(hplane, a.histPlane * 4);
+            if (inCols) {
+#pragma unroll
+                for (int r = K; r < ROWS - K; ++r)
+                    bufStoreF((r & 1) ? pr[r >> 1].y : pr[r >> 1].x, rH, hvoff, hsoff0 + r * hpitchB);
+            }
+        }
+        hplane += a.histPlane;
+    }
+
+    const rsrc_t rPrOut = makeRsrc(a.prOut, a.planeBytes), rVxOut = makeRsrc(a.vxOut, a.planeBytes),
+                 rVyOut = makeRsrc(a.vyOut, a.planeBytes);
+    if (inCols) {
+#pragma unroll
+        for (int r = K; r < ROWS - K; ++r) {
+            const int so = soff0 + r * pitchB;
+            bufStoreF((r & 1) ? pr[r >> 1].y : pr[r >> 1].x, rPrOut, voff, so);
+            bufStoreF((r & 1) ? vx[r >> 1].y : vx[r >> 1].x, rVxOut, voff, so);
+            bufStoreF((r & 1) ? vy[r >> 1].y : vy[r >> 1].x, rVyOut, voff, so);
+        }
+    }
+}
+
 // air tiles: one wave per tile, 4 tiles per 256-thread block; tiles of the other class exit immediately.
 // XCD-aware tile order: workgroup b is dispatched to XCD b % 8 (observed, speed only), and each XCD has a private
 // 4 MiB L2.  XCD x therefore owns a contiguous band of tile rows and walks it column by column, so the tiles that
 // share halo rows / columns are processed close together in time ON THE SAME L2 instead of being re-fetched
 // through the fabric by eight different L2s.
-template <int K, int RXI, int WPS>
+template <int K, int RXI, int WPS, bool PACKED>
 __global__ __launch_bounds__(256, WPS) void pv_step_air_kernel(const StepArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -347,7 +519,11 @@ __global__ __launch_bounds__(256, WPS) void pv_step_air_kernel(const StepArgs a)
         const int lr = a.dyn->lrow - (a.G - K + ti * RXI), lc = a.dyn->lcol - (a.G - K + tj * (64 - 2 * K));
         if (lr >= 0 && lr < RXI + 2 * K && lc >= 0 && lc < 64) return;
     }
-    stepTile<K, RXI, RXI, false>(a, tile, 0, lane, nullptr);
+    if constexpr (PACKED && (RXI + 2 * K) % 2 == 0) {
+        stepTileAirPacked<K, RXI>(a, tile, lane);
+    } else {
+        stepTile<K, RXI, RXI, false>(a, tile, 0, lane, nullptr);
+    }
 }
 
 // wall / edge / listener tiles, taken from a compact list; each tile is split over RXI/SUB waves
@@ -393,7 +569,10 @@ template <int K, int RXI, int WPS, int SUB>
 static void launchStepT(const StepArgs& a, hipStream_t stream, int which, hipStream_t stream2) {
     if (which & 1) {
         const int blocks = a.tileOrder == 0 ? (a.ntiles + 3) / 4 : 8 * ((a.bandRows * a.nty + 3) / 4);
-        hipLaunchKernelGGL((pv_step_air_kernel<K, RXI, WPS>), dim3(blocks), dim3(256), 0, stream, a);
+        if (a.packed)
+            hipLaunchKernelGGL((pv_step_air_kernel<K, RXI, WPS, true>), dim3(blocks), dim3(256), 0, stream, a);
+        else
+            hipLaunchKernelGGL((pv_step_air_kernel<K, RXI, WPS, false>), dim3(blocks), dim3(256), 0, stream, a);
     }
     if ((which & 2) && a.numGeneral > 0) {
         const int gblocks = (a.numGeneral * (RXI / SUB) + 3) / 4;

@@ -69,7 +69,6 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     for (auto& e : ev_)
         if (!hipOk(hipEventCreate(&e), "hipEventCreate")) return false;
 
-    if (opt_.tileOrder == 0) opt_.tileOrder = 1;  // XCD-band row-major: 1-5 % faster than linear (measured)
     K_ = opt.K > 0 ? opt.K : 8;  // defaults = fastest measured configuration on MI355X at 2048^2 .. 8192^2
     rxi_ = opt.rxi > 0 ? opt.rxi : 24;
     if (!stepConfigSupported(K_, rxi_)) return fail("unsupported (stepsPerLaunch, tileRows) configuration");
@@ -464,6 +463,7 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
     a.ntiles = geo_.ntx * geo_.nty;
     a.bandRows = ceilDiv(geo_.ntx, 8);
     a.tileOrder = opt_.tileOrder;
+    a.packed = opt_.packed ? 1 : 0;
     a.withPulse = withPulse ? 1 : 0;
     a.record = record ? 1 : 0;
     a.dense = opt_.denseHistory ? 1 : 0;

@@ -26,7 +26,8 @@ struct SolverOptions {
     bool skipAnalysis = false;
     int useGraph = 0;     // 0 = auto (small grids), 1 = always, 2 = never: replay the run from a captured hipGraph
     bool withFreeGrid = true;
-    int tileOrder = 0;
+    int tileOrder = 1;    // air-kernel block->tile map: 1 = XCD-band row-major (1-5 % faster than 0 = linear, measured)
+    bool packed = true;   // packed-f32 arithmetic in the air-tile kernel (VALU-issue bound otherwise)
     int smallGrid = 0;    // 0 = auto: grids that fit one CU's LDS run in the whole-grid-resident kernel; 2 = never
     bool timeKernels = false;  // HIP events around every step-kernel launch (bench / roofline)
 };
