@@ -196,6 +196,8 @@ PVA_EXPORT int PvAmdHostRasterize(float gridSizeX, float gridSizeY, int gridReso
                                   const int* ops, int n, uint8_t* beta, float* R);
 /* Editor.cpp:245-281: returns the number of boxes (<= maxBoxes written as 5 floats each) or -1 */
 PVA_EXPORT int PvAmdHostLoadPv(const char* pvPath, float* boxes5, int maxBoxes);
+/* Editor.cpp:219-243: writes `n` boxes (ids[i] or i when ids == NULL) in the .pv text format; 0 = ok */
+PVA_EXPORT int PvAmdHostSavePv(const char* pvPath, const float* boxes5, const int* ids, int n);
 /* FDTD.cpp:97-98 listener cell and Analyzer.cpp:106-116 result cell (valid = 0 where GetOutput returns -1) */
 PVA_EXPORT int PvAmdHostCells(float gridSizeX, float gridSizeY, int gridResolution, float x, float z, int* listenerCx,
                               int* listenerCy, int* resultCx, int* resultCy, int* resultValid);

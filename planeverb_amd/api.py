@@ -114,6 +114,7 @@ SYMBOLS = {
     "PvAmdHostRasterize": (C.c_int, [C.c_float, C.c_float, C.c_int, _fp, C.POINTER(C.c_int), C.c_int,
                                      C.POINTER(C.c_ubyte), _fp]),
     "PvAmdHostLoadPv": (C.c_int, [C.c_char_p, _fp, C.c_int]),
+    "PvAmdHostSavePv": (C.c_int, [C.c_char_p, _fp, C.POINTER(C.c_int), C.c_int]),
     "PvAmdHostCells": (C.c_int, [C.c_float, C.c_float, C.c_int, C.c_float, C.c_float] + [C.POINTER(C.c_int)] * 5),
 }
 
@@ -264,6 +265,14 @@ def load_pv(path, max_boxes=4096):
     if n < 0:
         raise PlaneverbError(last_error())
     return buf[:n].copy()
+
+
+def save_pv(path, boxes, ids=None):
+    """write boxes [(posX, posY, width, height, absorption), ...] as a .pv scene (Editor.cpp:219-243)"""
+    b = np.ascontiguousarray(boxes, np.float32).reshape(-1, 5)
+    ida = None if ids is None else np.ascontiguousarray(ids, np.int32)
+    _check(lib().PvAmdHostSavePv(path.encode(), _f(b), None if ida is None else ida.ctypes.data_as(C.POINTER(C.c_int)),
+                                 len(b)))
 
 
 def host_cells(size_x, size_y, res, x, z):

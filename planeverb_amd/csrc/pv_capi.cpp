@@ -399,6 +399,14 @@ int PvAmdHostLoadPv(const char* path, float* b5, int maxBoxes) {
     return (int)boxes.size();
 }
 
+int PvAmdHostSavePv(const char* path, const float* b5, const int* ids, int n) {
+    if (!path || (n > 0 && !b5)) return -1;
+    std::vector<std::pair<int, Box>> boxes;
+    for (int i = 0; i < n; ++i)
+        boxes.emplace_back(ids ? ids[i] : i, Box{b5[5 * i], b5[5 * i + 1], b5[5 * i + 2], b5[5 * i + 3], b5[5 * i + 4]});
+    return savePv(path, boxes, &g_lastError) ? 0 : -1;
+}
+
 int PvAmdHostCells(float sx, float sy, int res, float x, float z, int* lcx, int* lcy, int* rcx, int* rcy,
                    int* rvalid) {
     if (res < kLowResolution) return -1;

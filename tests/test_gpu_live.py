@@ -89,3 +89,22 @@ def test_reinit_while_running(pvlib):
     pvlib.Exit()
     pvlib.Exit()
     assert pvlib.GetOutput(0).occlusion == -1.0
+
+
+def test_headless_cli(pvlib):
+    """python -m planeverb_amd scene.pv ... prints the per-emitter parameters"""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    g = golden("g71_smallroom")
+    r = subprocess.run([sys.executable, "-m", "planeverb_amd", os.path.join(SCENES, "SmallRoomScene.pv"), "--listener",
+                        "5,0,4", "--emitter", "5,0,6", "--emitter", "12,0,9"], cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    assert out["grid"] == [70, 70] and out["T"] == 435
+    for e, ro in zip(out["emitters"], g["emitter_out"][:2]):
+        assert np.float32(e["occlusion"]) == ro[0] and np.float32(e["wetGain"]) == ro[1]
+        assert abs(e["rt60"] - ro[2]) <= 1e-4 * abs(ro[2])
+        assert np.float32(e["direction"][0]) == ro[4] and np.float32(e["sourceDirectivity"][1]) == ro[7]
+        assert len(e["reverbBusGains"]) == 3

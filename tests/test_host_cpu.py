@@ -129,3 +129,24 @@ def test_reverb_bus_gains_match_oracle(pvlib, oracle):
         for w in [0.0, 0.49, 1.73]:
             assert same_bits(np.array(pvlib.reverb_bus_gains(rt, w), np.float32),
                              np.array(oracle.find_gains(rt, w), np.float32)).all()
+
+
+def test_pv_save_load_round_trip(pvlib, tmp_path):
+    """Editor::SaveGeometry / LoadGeometry (Editor.cpp:219-281): what is written is read back unchanged"""
+    for f in sorted(os.listdir(SCENES)):
+        boxes = pvlib.load_pv(os.path.join(SCENES, f))
+        out = str(tmp_path / f)
+        pvlib.save_pv(out, boxes, ids=list(range(len(boxes) - 1, -1, -1)))
+        assert np.array_equal(pvlib.load_pv(out), boxes)
+        first = open(out).read().split()
+        assert int(first[0]) == len(boxes) and int(first[1]) == len(boxes) - 1  # count, then the first id
+
+
+def test_cli_save_without_gpu(pvlib, tmp_path):
+    import subprocess
+    import sys
+    out = str(tmp_path / "copy.pv")
+    r = subprocess.run([sys.executable, "-m", "planeverb_amd", os.path.join(SCENES, "Shoebox.pv"), "--save", out],
+                       cwd=ROOT, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(pvlib.load_pv(out), pvlib.load_pv(os.path.join(SCENES, "Shoebox.pv")))
