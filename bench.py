@@ -117,7 +117,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     size = mode_a_size(args.grid)
-    opts = dict(time_kernels=1)
+    opts = dict(time_kernels=3)  # HIP events around every 3rd step-kernel launch of the timed region
     if args.steps_per_launch:
         opts["steps_per_launch"] = args.steps_per_launch
     if args.tile_rows:
@@ -169,9 +169,9 @@ def main():
         assert gathered.shape == (n_runs, 2, 8) and np.isfinite(gathered[:, :, 0]).all()
         info = s.info
         K = info.stepsPerLaunch
-        launches = s.timings().airLaunches
-        air = float(np.mean(air_ms))  # ms per air-kernel launch, HIP events on the solver's stream
-        steps_per_launch_avg = T / launches
+        launches = s.timings().stepLaunches
+        air = float(np.mean(air_ms))  # ms per air-kernel launch, HIP events on the solver's stream (sampled launches)
+        steps_per_launch_avg = K  # every sampled launch advances K steps (the short remainder launch is the last one)
         achieved = ALG_BYTES_PER_CELL_STEP * cells * steps_per_launch_avg / (air * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")

@@ -195,7 +195,7 @@ int PvAmdSetOption(PvAmdSolver* h, int key, long long value) {
         case PVA_OPT_STEPS_PER_LAUNCH: h->opt.K = (int)value; break;
         case PVA_OPT_TILE_ROWS: h->opt.rxi = (int)value; break;
         case PVA_OPT_NO_FREE_GRID: h->opt.withFreeGrid = value == 0; break;
-        case PVA_OPT_TIME_KERNELS: h->opt.timeKernels = value != 0; break;
+        case PVA_OPT_TIME_KERNELS: h->opt.timeKernels = (int)value; break;
         case PVA_OPT_TILE_ORDER: h->opt.tileOrder = (int)value; break;
         case PVA_OPT_SMALL_GRID_KERNEL: h->opt.smallGrid = (int)value; break;
         case PVA_OPT_PACKED_MATH: h->opt.packed = value != 0; break;

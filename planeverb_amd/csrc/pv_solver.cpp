@@ -129,7 +129,8 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     // history window: the pulse moves at most one cell per step along each axis, so after T steps everything
     // farther than T cells from the listener is still exactly zero and needs no storage
     {
-        const int reach = T_ + 2;
+        // + K: a tile counts as active as soon as its K-cell halo is touched
+        const int reach = T_ + 2 + K_;
         int wtx = geo_.ntx, wty = geo_.nty;
         if (!opt.denseHistory) {
             wtx = std::min(geo_.ntx, ceilDiv(2 * reach + 1, rxi_) + 1);
@@ -396,15 +397,14 @@ bool Solver::prepareDyn(int lcx, int lcy, bool withPulse) {
     d.lrow = inside ? lcx + geo_.G : -100000;
     d.lcol = inside ? lcy + geo_.G : -100000;
     // history window in tiles, centred on the listener and clamped to the grid
+    // first window tile = the tile holding the lowest reachable row / column (init() sized the window so that
+    // histTiles * tile >= 2*reach + tile, i.e. it then also covers listener + reach), clamped into the grid
     int tx0 = 0, ty0 = 0;
-    if (histTilesX_ < geo_.ntx) {
-        const int ltx = std::min(std::max(lcx, 0), g_.gx) / rxi_;
-        tx0 = std::min(std::max(ltx - histTilesX_ / 2, 0), geo_.ntx - histTilesX_);
-    }
-    if (histTilesY_ < geo_.nty) {
-        const int lty = std::min(std::max(lcy, 0), g_.gy) / wi_;
-        ty0 = std::min(std::max(lty - histTilesY_ / 2, 0), geo_.nty - histTilesY_);
-    }
+    const int reach = T_ + 2 + K_;
+    if (histTilesX_ < geo_.ntx)
+        tx0 = std::min(std::max(floorDiv(std::min(std::max(lcx, 0), g_.gx) - reach, rxi_), 0), geo_.ntx - histTilesX_);
+    if (histTilesY_ < geo_.nty)
+        ty0 = std::min(std::max(floorDiv(std::min(std::max(lcy, 0), g_.gy) - reach, wi_), 0), geo_.nty - histTilesY_);
     d.histTileX0 = tx0;
     d.histTileY0 = ty0;
     d.histTilesX = histTilesX_;
@@ -498,14 +498,15 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
         a.vyOut = vy_[cur_ ^ 1];
         a.t0 = firstStep + done;
         a.nsteps = k;
-        if (opt_.timeKernels) {  // 4 timing events per launch: air begin/end on stream_, general begin/end
+        if (opt_.timeKernels > 0) {  // 4 timing events per sampled launch: air begin/end on stream_, general begin/end
             while ((int)kev_.size() < kevUsed_ + 4) {
                 hipEvent_t e;
                 if (!hipOk(hipEventCreate(&e), "hipEventCreate")) return false;
                 kev_.push_back(e);
             }
         }
-        hipEvent_t* te = opt_.timeKernels ? &kev_[(size_t)kevUsed_] : nullptr;
+        // only full K-step launches are sampled, so that duration and algorithmic bytes refer to the same work
+        hipEvent_t* te = (opt_.timeKernels > 0 && k == K_ && li % opt_.timeKernels == 0) ? &kev_[(size_t)kevUsed_] : nullptr;
         if (two) {
             if (li > 0) {
                 hipStreamWaitEvent(stream_, genDone_[(size_t)li - 1], 0);

@@ -29,7 +29,7 @@ struct SolverOptions {
     int tileOrder = 1;    // air-kernel block->tile map: 1 = XCD-band row-major (1-5 % faster than 0 = linear, measured)
     bool packed = true;   // packed-f32 arithmetic in the air-tile kernel (VALU-issue bound otherwise)
     int smallGrid = 0;    // 0 = auto: grids that fit one CU's LDS run in the whole-grid-resident kernel; 2 = never
-    bool timeKernels = false;  // HIP events around every step-kernel launch (bench / roofline)
+    int timeKernels = 0;  // N > 0: HIP events around every Nth step-kernel launch (bench / roofline)
 };
 
 struct SolverTimings {

@@ -349,3 +349,58 @@ def test_free_grid_energy(pvlib, size, res, want):
     large grids; values are the unmodified reference's (tests/test_oracle_vs_ref.py)"""
     with pvlib.Solver(size, size, res) as s:
         assert np.float32(s.efree) == np.float32(want)
+
+
+def test_open_field_8192_vs_oracle_window(pvlib, oracle):
+    """BASELINE config 5 at full size (8192^2 open grid, Mode A): in the open field the pressure history and the onset
+    map around the listener do not depend on where the listener sits, and -- inside the region the grid edges cannot
+    have influenced within T steps -- they equal the oracle's on a 513^2 grid with the listener at its centre."""
+    n_small = 512
+    dx = np.float32(343.21) / np.float32(275) / np.float32(3.5)
+    size_small = float((n_small + 0.5) * dx)
+    c = 256
+    Ls = ((c + 0.5) * float(dx), 0.0, (c + 0.5) * float(dx))
+    o = oracle.OracleGrid(size_small, size_small, 275, None)
+    assert o.listener_cell(np.float32(Ls[0]), np.float32(Ls[2])) == (c, c)
+    o.fdtd(Ls)
+    hp, _, _ = o.history()
+    _, odelay, _ = o.analyze(np.float32(0.0447895788), Ls)
+    R = 70  # edge effects of the 513^2 grid need 256 + (256 - R) > 434 steps to get back within R cells
+    rng = np.random.default_rng(0)
+    cells = rng.integers(1024, 7168, size=(64, 2))  # SURVEY.md 8d config 5 listener cells
+    with pvlib.Solver(2921.297, 2921.297, 275) as s:
+        assert (s.gx, s.gy, s.T) == (8192, 8192, 435)
+        for lx, ly in (cells[0], cells[37]):
+            L = ((lx + 0.5) * float(dx), 0.0, (ly + 0.5) * float(dx))
+            s.run(L)
+            for t in (0, 1, 2, 40, 150, 300, 434):
+                plane = s.history_plane(t)
+                assert same_bits(plane[lx - R:lx + R + 1, ly - R:ly + R + 1], hp[t][c - R:c + R + 1, c - R:c + R + 1]).all(), t
+                far = plane.copy()
+                far[max(lx - t - 2, 0):lx + t + 3, max(ly - t - 2, 0):ly + t + 3] = 0
+                assert not far.any(), "pressure outside the causal reach of the pulse at step %d" % t
+            _, delay = s.results()
+            assert same_bits(delay[lx - R:lx + R + 1, ly - R:ly + R + 1], odelay[c - R:c + R + 1, c - R:c + R + 1]).all()
+            # mirror symmetry of the onset map about the listener row and column (open field)
+            w = delay[lx - 200:lx + 201, ly - 200:ly + 201]
+            assert np.array_equal(w, w[::-1, :]) and np.array_equal(w, w[:, ::-1])
+    o.close()
+
+
+@pytest.mark.parametrize("cell", [(479, 1000), (1000, 479 + 48 * 3 - 1), (2030, 2040), (3, 5), (1007, 2047), (960, 960)])
+def test_history_window_placement_2048(pvlib, cell):
+    """listener at tile ends / grid corners: the (2T+3)-cell history window must hold everything the pulse reaches
+    (a run fails loudly with 'history window overflow' otherwise) and results must not depend on the placement"""
+    dx = np.float32(343.21) / np.float32(275) / np.float32(3.5)
+    lx, ly = cell
+    L = ((lx + 0.5) * float(dx), 0.0, (ly + 0.5) * float(dx))
+    size = float((2048 + 0.5) * dx)
+    with pvlib.Solver(size, size, 275) as s, pvlib.Solver(size, size, 275, dense_history=1) as d:
+        s.run(L)
+        d.run(L)
+        for t in (0, 100, 434):
+            assert same_bits(s.history_plane(t), d.history_plane(t)).all()
+        rs, ds = s.results()
+        rd, dd = d.results()
+        assert same_bits(ds, dd).all() and same_bits(rs, rd).all()
+        assert (ds < 1e30).sum() > 1000
