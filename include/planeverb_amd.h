@@ -130,7 +130,8 @@ enum {
     PVA_OPT_TIME_KERNELS = 8,  /* N > 0: HIP events around every Nth step-kernel launch (per-kernel durations) */
     PVA_OPT_TILE_ORDER = 9,    /* air-kernel workgroup->tile map: 0 linear, 1 XCD band row-major, 2 band col-major */
     PVA_OPT_SMALL_GRID_KERNEL = 10, /* 0 = auto (grids that fit one CU's LDS run in one resident kernel), 2 = never */
-    PVA_OPT_PACKED_MATH = 11   /* air-tile kernel arithmetic: 1 = packed f32 (default), 0 = scalar f32 */
+    PVA_OPT_PACKED_MATH = 11,  /* air-tile kernel arithmetic: 1 = packed f32 (default), 0 = scalar f32 */
+    PVA_OPT_STREAMING_ANALYSIS = 12 /* 1 = sparse-emitter mode: ring history + incremental analysis (see PvAmdSetEmitters) */
 };
 
 PVA_EXPORT int PvAmdDeviceCount(void);
@@ -163,6 +164,11 @@ PVA_EXPORT int PvAmdRunAsync(PvAmdSolver* s, float lx, float ly, float lz);
 PVA_EXPORT int PvAmdSync(PvAmdSolver* s);
 PVA_EXPORT int PvAmdGetTimings(PvAmdSolver* s, PvAmdTimings* out);
 
+/* Streaming-analysis (sparse-emitter) mode only -- SURVEY.md 8f N3.  Registers the emitter positions (n x {x,y,z})
+ * whose wet gain and RT60 the next runs compute; onset, occlusion, lowpass, source directivity and listener direction
+ * are still produced for EVERY cell, wet gain / RT60 only at these cells (0 elsewhere).  This removes the
+ * T x cells pressure history, which is what makes T ~ 25 000 (a 25 m scene at 4096^2) possible at all. */
+PVA_EXPORT int PvAmdSetEmitters(PvAmdSolver* s, const float* xyz, int n);
 /* Analyzer::GetResponseResult + Planeverb::GetOutput (Analyzer.cpp:106-116, FDTD.cpp:16-58) */
 PVA_EXPORT int PvAmdGetOutput(PvAmdSolver* s, float ex, float ey, float ez, PlaneverbOutput* out);
 /* Whole result map: res8 = gx*gy*8 floats in AnalyzerResult order (Analyzer.h:13-21), delay = gx*gy */

@@ -34,6 +34,7 @@ PVA_OPT_TIME_KERNELS = 8
 PVA_OPT_TILE_ORDER = 9
 PVA_OPT_SMALL_GRID_KERNEL = 10
 PVA_OPT_PACKED_MATH = 11
+PVA_OPT_STREAMING_ANALYSIS = 12
 
 
 class PlaneverbOutput(C.Structure):
@@ -99,6 +100,7 @@ SYMBOLS = {
     "PvAmdRunAsync": (C.c_int, [_vp] + [C.c_float] * 3),
     "PvAmdSync": (C.c_int, [_vp]),
     "PvAmdGetTimings": (C.c_int, [_vp, C.POINTER(PvAmdTimings)]),
+    "PvAmdSetEmitters": (C.c_int, [_vp, _fp, C.c_int]),
     "PvAmdGetOutput": (C.c_int, [_vp] + [C.c_float] * 3 + [C.POINTER(PlaneverbOutput)]),
     "PvAmdCopyResults": (C.c_int, [_vp, _fp, _fp]),
     "PvAmdGetImpulseResponse": (C.c_int, [_vp, C.c_int, C.c_int, _fp]),
@@ -301,7 +303,7 @@ class Solver:
                 "steps_per_launch": PVA_OPT_STEPS_PER_LAUNCH, "tile_rows": PVA_OPT_TILE_ROWS,
                 "no_free_grid": PVA_OPT_NO_FREE_GRID, "time_kernels": PVA_OPT_TIME_KERNELS,
                 "tile_order": PVA_OPT_TILE_ORDER, "small_grid_kernel": PVA_OPT_SMALL_GRID_KERNEL,
-                "packed_math": PVA_OPT_PACKED_MATH}
+                "packed_math": PVA_OPT_PACKED_MATH, "streaming_analysis": PVA_OPT_STREAMING_ANALYSIS}
         for k, v in options.items():
             _check(lib().PvAmdSetOption(self._h, keys[k], int(v)))
         self.info = PvAmdInfo()
@@ -360,6 +362,11 @@ class Solver:
         t = PvAmdTimings()
         _check(lib().PvAmdGetTimings(self._h, t))
         return t
+
+    def set_emitters(self, emitters):
+        """streaming-analysis mode: the emitter positions whose wet gain / RT60 are computed"""
+        e = np.ascontiguousarray(emitters, np.float32).reshape(-1, 3)
+        _check(lib().PvAmdSetEmitters(self._h, _f(e), len(e)))
 
     def get_output(self, emitter):
         o = PlaneverbOutput()

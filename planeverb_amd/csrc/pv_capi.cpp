@@ -199,6 +199,7 @@ int PvAmdSetOption(PvAmdSolver* h, int key, long long value) {
         case PVA_OPT_TILE_ORDER: h->opt.tileOrder = (int)value; break;
         case PVA_OPT_SMALL_GRID_KERNEL: h->opt.smallGrid = (int)value; break;
         case PVA_OPT_PACKED_MATH: h->opt.packed = value != 0; break;
+        case PVA_OPT_STREAMING_ANALYSIS: h->opt.streaming = value != 0; break;
         default: g_lastError = "unknown option"; return -1;
     }
     return 0;
@@ -288,6 +289,11 @@ int PvAmdGetTimings(PvAmdSolver* h, PvAmdTimings* out) {
     out->airLaunches = t.airLaunches;
     out->generalLaunches = t.generalLaunches;
     return 0;
+}
+
+int PvAmdSetEmitters(PvAmdSolver* h, const float* xyz, int n) {
+    if (!ensure(h) || (n > 0 && !xyz)) return -1;
+    return ret(h, h->s->setEmitters(xyz, n));
 }
 
 int PvAmdGetOutput(PvAmdSolver* h, float ex, float ey, float ez, PlaneverbOutput* out) {

@@ -73,6 +73,7 @@ struct StepArgs {
     int packed;            // air kernel: packed-f32 (v_pk_*) arithmetic variant
     int tileOrder;         // air-kernel block -> tile mapping (0 linear, 1 XCD band row-major, 2 band column-major)
     int t0;                // first global step of this launch
+    int histSlot;          // history plane index of step t0 (= t0, or t0 % ring length in streaming mode)
     int nsteps;            // steps in this launch (<= K)
     int withPulse;
     int record;            // write pr history
@@ -121,6 +122,19 @@ struct AnalyzeArgs {
     float efree;
     float lx, lz;        // listener, metres
     int lcx, lcy;        // listener cell by reciprocal multiply (Analyzer.cpp:200-201)
+    // streaming analysis (sparse-emitter mode): the history is a ring of `ring` planes and the forward sums of
+    // every cell are carried in per-cell state planes between passes
+    int ring;            // 0 = full history (plane index = t), else plane index = t % ring
+    int tA, tB;          // step range of this accumulate pass
+    int* sOnset;
+    float* sEdry;
+    float* sFx;
+    float* sFy;
+    float* sVx;
+    float* sVy;
+    const int* emCells;  // registered emitter cells: X*gy + Y
+    float* emTrace;      // numEmitters x T pressure traces
+    int numEmitters;
 };
 
 }  // namespace pva

@@ -258,7 +258,7 @@ __device__ __forceinline__ void stepTile(const StepArgs& a, const int tile, cons
 
     const float C = a.courant;
     const bool inCols = lane >= K && lane < 64 - K;
-    const float* hplane = a.hist + (long long)a.t0 * a.histPlane;
+    const float* hplane = a.hist + (long long)a.histSlot * a.histPlane;
     // history window addressing: soffset = row part (>= 0 for every stored row), voffset = column part
     const int hpitchB = a.histPitch * 4;
     const int hsoff0 = (hti * RXI + part * SUB - K) * hpitchB;  // + r*hpitchB with r >= K
@@ -449,7 +449,7 @@ __device__ __forceinline__ void stepTileAirPacked(const StepArgs& a, const int t
 
     const float C = a.courant;
     const bool inCols = lane >= K && lane < 64 - K;
-    const float* hplane = a.hist + (long long)a.t0 * a.histPlane;
+    const float* hplane = a.hist + (long long)a.histSlot * a.histPlane;
     const int hpitchB = a.histPitch * 4;
     const int hsoff0 = (hti * RXI - K) * hpitchB;
     const int hvoff = (htj * WI - K + lane) * 4;
@@ -998,6 +998,195 @@ void launchAnalysis(const AnalyzeArgs& a, hipStream_t stream) {
     const int n = a.gx * a.gy;
     hipLaunchKernelGGL(pv_fill_delay_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a.delay, n);
     hipLaunchKernelGGL(pv_encode_kernel, grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(pv_direction_kernel, grid, dim3(256), 0, stream, a);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// streaming analysis (sparse-emitter mode)
+// ---------------------------------------------------------------------------------------------------------------
+// With T in the tens of thousands (a 25 m scene at a 4096^2 grid: T = 25432) the full pressure history cannot be
+// kept.  What needs ALL of a cell's samples is only the wet gain and the RT60 regression; onset, dry energy and
+// flux are forward sums that close N_dry samples after the onset.  So the history becomes a ring of `ring` planes;
+// after every `ring` steps pv_stream_accum_kernel advances the forward sums of every open cell in the reference's
+// sample order (state carried in per-cell planes), and the pressure of the REGISTERED emitter cells is copied to
+// per-emitter traces, from which wet gain and RT60 are computed at the end exactly as pv_encode_kernel does.
+
+__global__ __launch_bounds__(256) void pv_stream_accum_kernel(const AnalyzeArgs a) {
+    const int Y = blockIdx.x * blockDim.x + threadIdx.x;
+    const int X = blockIdx.y;
+    if (Y >= a.gy || X >= a.gx) return;
+    const int s = X * a.gy + Y;
+    const DynParams dyn = *a.dyn;
+    const int tile = (X / a.rxi) * a.nty + (Y / a.wi);
+    const int tFirst = a.tileFirst[tile];
+    if (tFirst == INT_MAX || tFirst >= a.tB) return;
+    int onset = a.sOnset[s];
+    int sourceDirEnd = onset >= 0 ? onset + a.nDir : INT_MAX;
+    int directEnd = onset >= 0 ? onset + a.nDry : INT_MAX;
+    if (a.tA >= directEnd) return;  // this cell's dry window is closed
+
+    const int prow = X + a.G, pcol = Y + a.G;
+    const long long hoff = (long long)(prow - dyn.histRow0) * a.histPitch + (pcol - dyn.histCol0);
+    int tFx = INT_MAX, tFy = INT_MAX;
+    if (X > 0 && prow - 1 >= dyn.histRow0) tFx = a.tileFirst[((X - 1) / a.rxi) * a.nty + (Y / a.wi)];
+    if (Y > 0 && pcol - 1 >= dyn.histCol0) tFy = a.tileFirst[(X / a.rxi) * a.nty + ((Y - 1) / a.wi)];
+    const float* hc = a.hist + hoff;
+    const float* hx = hc - a.histPitch;
+    const float* hy = hc - 1;
+    const uint32_t code = a.codes[(size_t)prow * a.pitch + pcol];
+    const float kx = a.lut[code & 0xffu], ky = a.lut[code >> 8];
+    const bool airX = kx != kx, airY = ky != ky;
+    const float C = a.courant;
+
+    float Edry = a.sEdry[s], fluxX = a.sFx[s], fluxY = a.sFy[s], vx = a.sVx[s], vy = a.sVy[s];
+    constexpr int CH = 8;
+    bool done = false;
+    const int tEnd = min(a.tB, a.T);
+    for (int t0 = max(a.tA, tFirst); t0 < tEnd && !done; t0 += CH) {
+        float pc[CH], pxc[CH], pyc[CH];
+        const bool needVChunk = t0 < sourceDirEnd;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int tt = min(t0 + k, tEnd - 1);
+            const long long o = (long long)(tt % a.ring) * a.histPlane;
+            pc[k] = hc[o];
+            pxc[k] = (needVChunk && tt >= tFx) ? hx[o] : 0.f;
+            pyc[k] = (needVChunk && tt >= tFy) ? hy[o] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int t = t0 + k;
+            if (done || t >= tEnd || t >= directEnd) {
+                done = done || t >= directEnd;
+                continue;
+            }
+            const float p = pc[k];
+            if (t < sourceDirEnd) {
+                const float pxn = pxc[k], pyn = pyc[k];
+                const float ax = vx - C * (p - pxn), wx = kx * (p + pxn);
+                const float ay = vy - C * (p - pyn), wy = ky * (p + pyn);
+                vx = airX ? ax : wx;
+                vy = airY ? ay : wy;
+            }
+            if (onset < 0 && fabsf(p) > kAudibleThresholdDev) {
+                onset = t;
+                sourceDirEnd = t + a.nDir;
+                directEnd = t + a.nDry;
+                if (t >= directEnd) {
+                    done = true;
+                    continue;
+                }
+            }
+            Edry += p * p;
+            if (t < sourceDirEnd) {
+                fluxX += p * vx;
+                fluxY += p * vy;
+            }
+        }
+    }
+    a.sOnset[s] = onset;
+    a.sEdry[s] = Edry;
+    a.sFx[s] = fluxX;
+    a.sFy[s] = fluxY;
+    a.sVx[s] = vx;
+    a.sVy[s] = vy;
+}
+
+// pressure of the registered emitter cells for steps [tA, tB): ring -> per-emitter trace
+__global__ void pv_stream_trace_kernel(const AnalyzeArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = a.tB - a.tA;
+    if (i >= a.numEmitters * n) return;
+    const int e = i / n, t = a.tA + (i - e * n);
+    if (t >= a.T) return;
+    const DynParams dyn = *a.dyn;
+    const int cell = a.emCells[e];
+    const int X = cell / a.gy, Y = cell - X * a.gy;
+    const int tFirst = a.tileFirst[(X / a.rxi) * a.nty + (Y / a.wi)];
+    float v = 0.f;
+    if (t >= tFirst)
+        v = a.hist[(long long)(t % a.ring) * a.histPlane +
+                   (long long)(X + a.G - dyn.histRow0) * a.histPitch + (Y + a.G - dyn.histCol0)];
+    a.emTrace[(size_t)e * a.T + t] = v;
+}
+
+// end of run: onset map + the outputs that come from the forward sums (Analyzer.cpp:197-230), every cell
+__global__ __launch_bounds__(256) void pv_stream_finalize_kernel(const AnalyzeArgs a) {
+    const int Y = blockIdx.x * blockDim.x + threadIdx.x;
+    const int X = blockIdx.y;
+    if (Y >= a.gy || X >= a.gx) return;
+    const int s = X * a.gy + Y;
+    const int onset = a.sOnset[s];
+    if (onset < 0) {
+        a.delay[s] = FLT_MAX;
+        return;
+    }
+    a.delay[s] = (float)onset;
+    const float Edry = a.sEdry[s], fluxX = a.sFx[s], fluxY = a.sFy[s];
+    const float EfreePr = efreePerR(a.efree, a.dx, a.lcx, a.lcy, X, Y);
+    const float occ = sqrtf(Edry / EfreePr);
+    float norm = sqrtf(fluxX * fluxX + fluxY * fluxY);
+    norm = -1.0f / (norm > 0.0f ? norm : 1.0f);
+    const float rr = 1.0f / ((0.001f < occ) ? occ : 0.001f);
+    float* o = a.res8 + 8 * (size_t)s;
+    o[0] = occ;
+    o[3] = -147.f + (18390.f) / (1.f + pvPowf(rr / 12.f, 0.8f));
+    o[6] = norm * fluxX;
+    o[7] = norm * fluxY;
+}
+
+// wet gain + RT60 of the registered emitter cells from their traces (Analyzer.cpp:235-327); one thread each
+__global__ void pv_stream_emitter_kernel(const AnalyzeArgs a) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= a.numEmitters) return;
+    const int s = a.emCells[e];
+    const int onset = a.sOnset[s];
+    if (onset < 0) return;
+    const float* tr = a.emTrace + (size_t)e * a.T;
+    const int T = a.T;
+    const int directEnd = onset + a.nDry;
+    float wetEnergy = 0.f;
+    {
+        int end = directEnd + 1 + a.nWet;
+        if (T < end) end = T;
+        for (int j = directEnd + 1; j < end; ++j) wetEnergy += tr[j] * tr[j];
+    }
+    const int startingPoint = directEnd + 1;
+    const int endPoint = T - a.nCut;
+    const float rn = (float)(endPoint - startingPoint);
+    const float xmean = (rn - 1.0f) * 0.5f;
+    const float xsum = rn * xmean;
+    const float denominator = (1.0f / 12.0f) * rn * (rn * rn - 1.0f);
+    float edc = 0.f, xysum = 0.f, ysum = 0.f;
+    for (int i = T - 1; i >= endPoint && i >= 0; --i) edc += tr[i] * tr[i];
+    for (int i = endPoint - 1; i >= startingPoint; --i) {
+        edc += tr[i] * tr[i];
+        const float y = 10.f * pvLog10f(edc);
+        xysum += y * (float)(i - startingPoint);
+        ysum += y;
+    }
+    const float ymean = ysum / rn;
+    const float numerator = xysum - ymean * xsum - xmean * ysum + rn * xmean * ymean;
+    const float slopePerSec = (numerator / denominator) * (float)a.fs;
+    float* o = a.res8 + 8 * (size_t)s;
+    o[1] = sqrtf(wetEnergy / a.efree);
+    o[2] = -60.f / slopePerSec;
+}
+
+void launchStreamAccum(const AnalyzeArgs& a, hipStream_t stream) {
+    dim3 grid((a.gy + 255) / 256, a.gx);
+    hipLaunchKernelGGL(pv_stream_accum_kernel, grid, dim3(256), 0, stream, a);
+    const int n = a.numEmitters * (a.tB - a.tA);
+    if (n > 0) hipLaunchKernelGGL(pv_stream_trace_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a);
+}
+
+void launchStreamFinalize(const AnalyzeArgs& a, hipStream_t stream) {
+    dim3 grid((a.gy + 255) / 256, a.gx);
+    const int n = a.gx * a.gy;
+    hipLaunchKernelGGL(pv_fill_delay_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a.delay, n);
+    hipLaunchKernelGGL(pv_stream_finalize_kernel, grid, dim3(256), 0, stream, a);
+    if (a.numEmitters > 0)
+        hipLaunchKernelGGL(pv_stream_emitter_kernel, dim3((a.numEmitters + 63) / 64), dim3(64), 0, stream, a);
     hipLaunchKernelGGL(pv_direction_kernel, grid, dim3(256), 0, stream, a);
 }
 

@@ -132,7 +132,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         // + K: a tile counts as active as soon as its K-cell halo is touched
         const int reach = T_ + 2 + K_;
         int wtx = geo_.ntx, wty = geo_.nty;
-        if (!opt.denseHistory) {
+        if (!opt.denseHistory && !opt.streaming) {
             wtx = std::min(geo_.ntx, ceilDiv(2 * reach + 1, rxi_) + 1);
             wty = std::min(geo_.nty, ceilDiv(2 * reach + 1, wi_) + 1);
         }
@@ -141,7 +141,9 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         histRows_ = wtx * rxi_;
         histPitch_ = roundUp(wty * wi_, 64);
         histPlane_ = (long long)histRows_ * histPitch_;
-        const long long bytes = histPlane_ * 4 * (long long)T_;
+        // streaming mode keeps a ring of 8 launches' worth of planes instead of all T
+        ring_ = opt.streaming ? std::min(roundUp(T_, K_), 8 * K_) : T_;
+        const long long bytes = histPlane_ * 4 * (long long)ring_;
         if (histPlane_ * 4 > (long long)INT_MAX) return fail("history plane too large for 32-bit offsets");
         size_t freeB = 0, totalB = 0;
         hipMemGetInfo(&freeB, &totalB);
@@ -151,6 +153,12 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         deviceBytes_ += bytes;
     }
 
+    if (opt.streaming) {
+        const size_t nres = (size_t)g_.gx * g_.gy;
+        if (!dalloc(&sOnset_, nres, true)) return false;
+        for (auto& p : sState_)
+            if (!dalloc(&p, nres, true)) return false;
+    }
     if (!hipOk(hipHostMalloc((void**)&dynHost_, sizeof(DynParams)), "hipHostMalloc")) return false;
     if (!hipOk(hipHostMalloc((void**)&listHost_, sizeof(int) * (size_t)listCap_), "hipHostMalloc")) return false;
 
@@ -184,6 +192,11 @@ Solver::~Solver() {
         if (vx_[i]) hipFree(vx_[i]);
         if (vy_[i]) hipFree(vy_[i]);
     }
+    for (float* p : sState_)
+        if (p) hipFree(p);
+    if (sOnset_) hipFree(sOnset_);
+    if (emCells_) hipFree(emCells_);
+    if (emTrace_) hipFree(emTrace_);
     void* ptrs[] = {codes_,     matDev_, lutDev_, pulseDev_, hist_,  tileFirst_, tileClass_, generalList_,
                     generalCount_, dynDev_, errFlag_, res8_,     delay_, scratch_};
     for (void* p : ptrs)
@@ -497,6 +510,7 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
         a.vxOut = vx_[cur_ ^ 1];
         a.vyOut = vy_[cur_ ^ 1];
         a.t0 = firstStep + done;
+        a.histSlot = opt_.streaming ? a.t0 % ring_ : a.t0;
         a.nsteps = k;
         if (opt_.timeKernels > 0) {  // 4 timing events per sampled launch: air begin/end on stream_, general begin/end
             while ((int)kev_.size() < kevUsed_ + 4) {
@@ -570,6 +584,16 @@ AnalyzeArgs Solver::analyzeArgs(float lx, float lz) const {
     a.lx = lx;
     a.lz = lz;
     listenerCellRecip(g_, lx, lz, &a.lcx, &a.lcy);
+    a.ring = opt_.streaming ? ring_ : 0;
+    a.sOnset = sOnset_;
+    a.sEdry = sState_[0];
+    a.sFx = sState_[1];
+    a.sFy = sState_[2];
+    a.sVx = sState_[3];
+    a.sVy = sState_[4];
+    a.emCells = emCells_;
+    a.emTrace = emTrace_;
+    a.numEmitters = numEmitters_;
     return a;
 }
 
@@ -584,9 +608,43 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
     cur_ = 0;  // the reset clears set 0; a run never depends on the previous run's fields
     hipEventRecord(ev_[0], stream_);
     const int ntiles = geo_.ntx * geo_.nty;
-    const bool graph = !opt_.timeKernels && (opt_.useGraph == 1 || (opt_.useGraph == 0 && ntiles <= 4096));
-    const bool small = opt_.smallGrid != 2 && !opt_.timeKernels && opt_.useGraph != 1 && smallGridFits(g_.NX, g_.NY) &&
+    const bool graph = !opt_.timeKernels && !opt_.streaming &&
+                       (opt_.useGraph == 1 || (opt_.useGraph == 0 && ntiles <= 4096));
+    const bool small = opt_.smallGrid != 2 && !opt_.timeKernels && opt_.useGraph != 1 && !opt_.streaming &&
+                       smallGridFits(g_.NX, g_.NY) &&
                        histTilesX_ == geo_.ntx && histTilesY_ == geo_.nty;
+    if (opt_.streaming) {
+        // sparse-emitter mode: ring history; forward sums advanced after every `ring_` steps
+        const size_t nres = (size_t)g_.gx * g_.gy;
+        if (!hipOk(hipMemsetAsync(sOnset_, 0xff, nres * 4, stream_), "state reset")) return false;  // onset = -1
+        for (float* p : sState_)
+            if (!hipOk(hipMemsetAsync(p, 0, nres * 4, stream_), "state reset")) return false;
+        if (numEmitters_ > 0 &&
+            !hipOk(hipMemsetAsync(emTrace_, 0, (size_t)numEmitters_ * T_ * 4, stream_), "trace reset"))
+            return false;
+        launchCap_ = numGeneral_;
+        const size_t planeBytes = (size_t)geo_.rows * geo_.pitch * 4;
+        if (!hipOk(hipMemsetAsync(pr_[cur_], 0, planeBytes, stream_), "reset") ||
+            !hipOk(hipMemsetAsync(vx_[cur_], 0, planeBytes, stream_), "reset") ||
+            !hipOk(hipMemsetAsync(vy_[cur_], 0, planeBytes, stream_), "reset"))
+            return false;
+        if (!hipOk(hipMemsetD32Async((hipDeviceptr_t)tileFirst_, INT_MAX, (size_t)ntiles, stream_), "tileFirst"))
+            return false;
+        if (!hipOk(hipMemsetAsync(errFlag_, 0, sizeof(int), stream_), "errFlag")) return false;
+        AnalyzeArgs aa = analyzeArgs(lx, lz);
+        for (int tA = 0; tA < T_; tA += ring_) {
+            const int n = std::min(ring_, T_ - tA);
+            if (!enqueueSteps(tA, n, true, true)) return false;
+            aa.tA = tA;
+            aa.tB = tA + n;
+            launchStreamAccum(aa, stream_);
+        }
+        hipEventRecord(ev_[1], stream_);
+        launchStreamFinalize(aa, stream_);
+        hipEventRecord(ev_[2], stream_);
+        pendingTimings_ = true;
+        return hipOk(hipGetLastError(), "run launch");
+    }
     if (small) {
         // the whole grid lives in one CU's LDS for all T steps: one launch, every cell recorded from step 0
         if (!hipOk(hipMemsetAsync(tileFirst_, 0, sizeof(int) * (size_t)ntiles, stream_), "tileFirst")) return false;
@@ -768,7 +826,31 @@ bool Solver::copyResultsAsync(float* res8Host) {
     return hipOk(hipMemcpyAsync(res8Host, res8_, n * 32, hipMemcpyDeviceToHost, stream_), "results copy");
 }
 
+bool Solver::setEmitters(const float* xyz, int n) {
+    if (!opt_.streaming) return fail("emitters are registered only in streaming-analysis mode");
+    if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
+    std::vector<int> cells;
+    for (int i = 0; i < n; ++i) {
+        int cx, cy;
+        if (resultCell(g_, xyz[3 * i], xyz[3 * i + 2], &cx, &cy)) cells.push_back(cx * g_.gy + cy);
+    }
+    if (!hipOk(hipStreamSynchronize(stream_), "sync")) return false;
+    if ((int)cells.size() > emCap_) {
+        if (emCells_) hipFree(emCells_);
+        if (emTrace_) hipFree(emTrace_);
+        emCells_ = nullptr;
+        emTrace_ = nullptr;
+        emCap_ = (int)cells.size();
+        if (!dalloc(&emCells_, (size_t)emCap_, true) || !dalloc(&emTrace_, (size_t)emCap_ * T_, true)) return false;
+    }
+    numEmitters_ = (int)cells.size();
+    if (numEmitters_ > 0 && !hipOk(hipMemcpy(emCells_, cells.data(), cells.size() * 4, hipMemcpyHostToDevice), "emitters"))
+        return false;
+    return true;
+}
+
 bool Solver::impulseResponse(int cx, int cy, float* out3T) {
+    if (opt_.streaming) return fail("the full pressure history is not kept in streaming-analysis mode");
     if (cx < 0 || cx > g_.gx || cy < 0 || cy > g_.gy) return fail("cell outside the grid");
     if (!dynValid_) return fail("no simulation has run yet");
     if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
@@ -809,6 +891,7 @@ bool Solver::setFields(const float* pr, const float* vx, const float* vy) {
 }
 
 bool Solver::copyHistoryPlane(int t, float* pr) {
+    if (opt_.streaming) return fail("the full pressure history is not kept in streaming-analysis mode");
     if (t < 0 || t >= T_) return fail("step outside the recorded range");
     if (!dynValid_) return fail("no simulation has run yet");
     if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;

@@ -27,6 +27,7 @@ struct SolverOptions {
     int useGraph = 0;     // 0 = auto (small grids), 1 = always, 2 = never: replay the run from a captured hipGraph
     bool withFreeGrid = true;
     int tileOrder = 1;    // air-kernel block->tile map: 1 = XCD-band row-major (1-5 % faster than 0 = linear, measured)
+    bool streaming = false;  // sparse-emitter mode: ring history + incremental forward analysis
     bool packed = true;   // packed-f32 arithmetic in the air-tile kernel (VALU-issue bound otherwise)
     int smallGrid = 0;    // 0 = auto: grids that fit one CU's LDS run in the whole-grid-resident kernel; 2 = never
     int timeKernels = 0;  // N > 0: HIP events around every Nth step-kernel launch (bench / roofline)
@@ -84,6 +85,8 @@ public:
     bool copyPulse(float* out);
     bool copyMaterial(uint8_t* beta, float* R);
     bool freeFieldEnergyAt(int cellX, int cellY, int n, float r, float* out);
+    // streaming mode: the cells whose wet gain / RT60 are wanted (world positions -> result cells)
+    bool setEmitters(const float* xyz, int n);
 
 private:
     Solver() = default;
@@ -140,6 +143,13 @@ private:
     int* errFlag_ = nullptr;
     float* res8_ = nullptr;
     float* delay_ = nullptr;
+    // streaming analysis state
+    int ring_ = 0;             // history planes allocated (T_ when not streaming)
+    int* sOnset_ = nullptr;
+    float* sState_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // Edry, fluxX, fluxY, vx, vy
+    int* emCells_ = nullptr;
+    float* emTrace_ = nullptr;
+    int numEmitters_ = 0, emCap_ = 0;
     float* scratch_ = nullptr;  // max(3T, NX*NY) floats
     size_t scratchCount_ = 0;
 

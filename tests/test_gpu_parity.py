@@ -404,3 +404,88 @@ def test_history_window_placement_2048(pvlib, cell):
         rd, dd = d.results()
         assert same_bits(ds, dd).all() and same_bits(rs, rd).all()
         assert (ds < 1e30).sum() > 1000
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# streaming analysis (sparse-emitter mode)
+# ----------------------------------------------------------------------------------------------------------------
+
+def check_streaming_against(res, delay, rres, rdelay, T, fs, emitter_cells, ctx=""):
+    """every cell: delay, occlusion, lowpass, source directivity, listener direction; emitter cells: all 8"""
+    assert same_bits(delay, rdelay).all(), ctx + " delay"
+    valid = valid_mask(rdelay, T, fs)
+    for k in (0, 6, 7):
+        assert same_bits(res[..., k][valid], rres[..., k][valid]).all(), ctx + " " + NAMES[k]
+    assert rel_err(res[..., 3][valid], rres[..., 3][valid]).max(initial=0) <= LOWPASS_TOL
+    for k in (4, 5):
+        assert same_bits(res[..., k], rres[..., k]).all(), ctx + " " + NAMES[k]
+    em = np.zeros_like(valid)
+    for cx, cy in emitter_cells:
+        em[cx, cy] = True
+    # wet gain / RT60 exist only at the registered cells
+    assert (res[..., 1][~em] == 0).all() and (res[..., 2][~em] == 0).all()
+    for cx, cy in emitter_cells:
+        if valid[cx, cy]:
+            assert same_bits(res[cx, cy, 1], rres[cx, cy, 1]).all(), ctx + " wet at emitter"
+            assert rel_err(res[cx, cy, 2], rres[cx, cy, 2]).max() <= RT60_TOL, ctx + " rt60 at emitter"
+
+
+@pytest.mark.parametrize("name", ["g71_smallroom", "g71_hugeroom", "g71_floorplan", "g96_smallroom_res375"])
+def test_streaming_mode_small(pvlib, name):
+    g = golden(name)
+    gx, gy, T, fs = (int(v) for v in g["dims"])
+    size, res = float(g["size"]), int(g["res"])
+    rng = np.random.default_rng(1)
+    extra = rng.uniform(0.5, size - 0.5, (12, 3)).astype(np.float32)
+    emitters = np.concatenate([g["emitters"], extra])
+    with pvlib.Solver(size, size, res, streaming_analysis=1) as s:
+        for b in g["boxes"]:
+            s.add_geometry(b)
+        s.set_emitters(emitters)
+        s.run(g["listener"])
+        res8, delay = s.results()
+        cells = [pvlib.host_cells(size, size, res, e[0], e[2])[1] for e in emitters]
+        check_streaming_against(res8, delay, g["results"], g["delay"], T, fs, [c for c in cells if c], name)
+        for e, ro in zip(g["emitters"], g["emitter_out"]):
+            compare_output(s.get_output(e), ro, name)
+        with pytest.raises(pvlib.PlaneverbError):
+            s.impulse_response(3, 3)
+        # a second run with another emitter set on the same solver
+        s.set_emitters(g["emitters"][:1])
+        s.run(g["listener"])
+        compare_output(s.get_output(g["emitters"][0]), g["emitter_out"][0], name + " rerun")
+
+
+def test_streaming_mode_512_mode_b(pvlib):
+    """T = 3179: 50 ring passes; checked against the reference vectors of BASELINE config 2 / Mode B"""
+    g = golden("g512B_shoebox")
+    gx, gy, T, fs = (int(v) for v in g["dims"])
+    c = g["cells"]
+    dx = np.float32(343.21) / np.float32(2009) / np.float32(3.5)
+    em_pos = np.stack([(c[:, 0] + 0.5) * float(dx), np.zeros(len(c)), (c[:, 1] + 0.5) * float(dx)], 1)
+    with pvlib.Solver(25.0, 25.0, 2009, streaming_analysis=1) as s:
+        for b in g["boxes"]:
+            s.add_geometry(b)
+        s.set_emitters(np.concatenate([g["emitters"], em_pos]))
+        s.run(g["listener"])
+        res, delay = s.results()
+        compare_maps(res[c[:, 0], c[:, 1]], delay[c[:, 0], c[:, 1]], g["cell_results"], g["cell_delay"], T, fs, "512B")
+        compare_output(s.get_output(g["emitters"][0]), g["emitter_out"][0])
+
+
+def test_streaming_equals_full_history_1024(pvlib):
+    dx = np.float32(343.21) / np.float32(275) / np.float32(3.5)
+    size = float((1024 + 0.5) * dx)
+    L, E = (91.0, 0.0, 91.0), [(95.0, 0.0, 97.0), (100.0, 0.0, 80.0), (60.3, 0.0, 110.9)]
+    with pvlib.Solver(size, size, 275) as full, pvlib.Solver(size, size, 275, streaming_analysis=1) as st:
+        for s in (full, st):
+            s.load_scene(os.path.join(SCENES, "Shoebox.pv"))
+        st.set_emitters(E)
+        full.run(L)
+        st.run(L)
+        rf, df = full.results()
+        rs, ds = st.results()
+        cells = [pvlib.host_cells(size, size, 275, e[0], e[2])[1] for e in E]
+        check_streaming_against(rs, ds, rf, df, 435, 1443, cells, "1024")
+        for e in E:
+            assert same_bits(st.get_output(e).as_array(), full.get_output(e).as_array()).all()
