@@ -489,3 +489,80 @@ def test_streaming_equals_full_history_1024(pvlib):
         check_streaming_against(rs, ds, rf, df, 435, 1443, cells, "1024")
         for e in E:
             assert same_bits(st.get_output(e).as_array(), full.get_output(e).as_array()).all()
+
+
+@pytest.mark.parametrize("size,res,scene", [(10.0, 500, "ExampleProject.pv"), (10.0, 750, "SmallRoom.pv"),
+                                            (3.0, 275, None), (6.5, 375, "SmallRoom.pv")])
+def test_resolution_presets_and_tiny_grids_vs_oracle(pvlib, oracle, size, res, scene):
+    """pv_HighResolution / pv_ExtremeResolution (PvTypes.h:22-30) and grids of a few cells"""
+    from oracle import pvref
+    boxes = pvref.load_pv(os.path.join(SCENES, scene)) if scene else np.zeros((0, 5), np.float32)
+    L = (size * 0.45, 0.0, size * 0.3)
+    o = oracle.OracleGrid(size, size, res, boxes)
+    o.fdtd(L)
+    ef = oracle.free_energy(size, size, res)
+    rres, rdelay, _ = o.analyze(ef, L)
+    hp, _, _ = o.history()
+    with pvlib.Solver(size, size, res) as s:
+        assert (s.gx, s.gy, s.T, s.fs) == (o.gx, o.gy, o.T, o.fs)
+        assert np.float32(s.efree) == np.float32(ef)
+        for b in boxes:
+            s.add_geometry(b)
+        s.run(L)
+        for t in (0, 5, o.T // 2, o.T - 1):
+            assert same_bits(s.history_plane(t), hp[t]).all()
+        res8, delay = s.results()
+        compare_maps(res8, delay, rres, rdelay, o.T, o.fs, "%g m @ %d" % (size, res))
+    o.close()
+
+
+def test_non_square_grid_closed_room(pvlib):
+    """Non-square grids are inconsistent in the reference and are implemented here with stride gy+1
+    throughout.  Property: a closed room is decoupled from the outside, so the same room gives identical per-emitter
+    outputs on a 25 x 25 m and on a 25 x 14.6 m / 14.6 x 25 m grid."""
+    room = golden("g71_bigroom")  # 10 m closed room in the corner of the 25 m grid
+    outs = []
+    for sx, sy in ((25.0, 25.0), (25.0, 14.6), (14.6, 25.0)):
+        with pvlib.Solver(sx, sy, 275) as s:
+            assert s.gx == int(np.float32(sx) * (np.float32(1) / np.float32(s.dx)))
+            for b in room["boxes"]:
+                s.add_geometry(b)
+            s.run(room["listener"])
+            outs.append(np.stack([s.get_output(e).as_array() for e in room["emitters"][:1]]))
+            res, delay = s.results()
+            assert res.shape == (s.gx, s.gy, 8)
+    compare_output_arrays = lambda a, b: [same_bits(a[:, k], b[:, k]).all() for k in (0, 1, 4, 5, 6, 7)]
+    assert all(compare_output_arrays(outs[0], outs[1])) and all(compare_output_arrays(outs[0], outs[2]))
+    assert rel_err(outs[0][:, 2], outs[1][:, 2]).max() <= RT60_TOL
+    compare_output(type("O", (), {"as_array": lambda self: outs[0][0]})(), room["emitter_out"][0], "square")
+
+
+def test_listener_outside_grid_and_api_misc(pvlib):
+    """a listener off the grid injects nothing (the reference would write outside its array); RunAsync/Sync;
+    PlaneverbCreateGrid alias; scene save through the handle API"""
+    import ctypes as C
+    import tempfile
+    with pvlib.Solver(25.0, 25.0, 275) as s:
+        s.load_scene(os.path.join(SCENES, "SmallRoomScene.pv"))
+        s.run((5, 0, 4))
+        before, d0 = s.results()
+        s.run_async((-7.0, 0.0, 300.0))
+        s.sync()
+        after, d1 = s.results()
+        assert (d1 > 1e30).all()                      # no onset anywhere
+        keep = [0, 1, 2, 3, 6, 7]                     # results untouched (Analyzer.cpp:160-165) ...
+        assert same_bits(before[..., keep], after[..., keep]).all()
+        assert not same_bits(before[..., 4:6], after[..., 4:6]).all()  # ... but direction is re-encoded for every cell
+        assert (s.history_plane(400) == 0).all()
+        with tempfile.TemporaryDirectory() as td:
+            p = os.path.join(td, "scene.pv")
+            s.save_scene(p)
+            assert np.array_equal(pvlib.load_pv(p), pvlib.load_pv(os.path.join(SCENES, "SmallRoomScene.pv")))
+    L = pvlib.lib()
+    h = L.PlaneverbCreateGrid(25.0, 25.0, 275, 0)
+    assert h
+    info = pvlib.PvAmdInfo()
+    assert L.PvAmdGetInfo(h, info) == 0 and (info.gx, info.T) == (70, 435)
+    assert L.PvAmdSetOption(h, pvlib.PVA_OPT_DENSE_HISTORY, 1) != 0  # options only before first use
+    L.PvAmdDestroy(h)
+    assert L.PvAmdCreate(25.0, 25.0, 275, 99) is None and "device" in pvlib.last_error()
