@@ -601,6 +601,8 @@ AnalyzeArgs Solver::analyzeArgs(float lx, float lz) const {
 
 bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
     if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
+    // one run in flight at a time: the pinned staging of the per-run parameters is reused
+    if (pendingTimings_ && !sync()) return false;
     if (!applyGeometry()) return false;
     if (!prepareDyn(lcx, lcy, true)) return false;
     lastLx_ = lx;

@@ -6,11 +6,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import planeverb_amd.api as pv
 
+SCENE = os.environ.get("SCENE", "HugeRoom.pv")
 for res in [int(a) for a in sys.argv[1:]] or [2009, 4017, 8034, 16067]:
     t0 = time.time()
     s = pv.Solver(25.0, 25.0, res, streaming_analysis=1)
     t_init = time.time() - t0
-    s.load_scene(os.path.join(ROOT, "tests", "scenes", "HugeRoom.pv"))
+    s.load_scene(os.path.join(ROOT, "tests", "scenes", SCENE))
     E = [(5.0, 0.0, 6.0), (12.0, 0.0, 9.0), (20.5, 0.0, 3.2), (7.0, 0.0, 4.0)]
     s.set_emitters(E)
     L = (5.0, 0.0, 4.0)
