@@ -35,6 +35,7 @@ PVA_OPT_TILE_ORDER = 9
 PVA_OPT_SMALL_GRID_KERNEL = 10
 PVA_OPT_PACKED_MATH = 11
 PVA_OPT_STREAMING_ANALYSIS = 12
+PVA_OPT_STREAM_ROWS = 13
 
 
 class PlaneverbOutput(C.Structure):
@@ -303,7 +304,8 @@ class Solver:
                 "steps_per_launch": PVA_OPT_STEPS_PER_LAUNCH, "tile_rows": PVA_OPT_TILE_ROWS,
                 "no_free_grid": PVA_OPT_NO_FREE_GRID, "time_kernels": PVA_OPT_TIME_KERNELS,
                 "tile_order": PVA_OPT_TILE_ORDER, "small_grid_kernel": PVA_OPT_SMALL_GRID_KERNEL,
-                "packed_math": PVA_OPT_PACKED_MATH, "streaming_analysis": PVA_OPT_STREAMING_ANALYSIS}
+                "packed_math": PVA_OPT_PACKED_MATH, "streaming_analysis": PVA_OPT_STREAMING_ANALYSIS,
+                "stream_rows": PVA_OPT_STREAM_ROWS}
         for k, v in options.items():
             _check(lib().PvAmdSetOption(self._h, keys[k], int(v)))
         self.info = PvAmdInfo()

@@ -71,6 +71,9 @@ struct StepArgs {
     int ntx, nty, ntiles;
     int bandRows;          // tile rows per XCD band = ceil(ntx / 8)
     int packed;            // air kernel: packed-f32 (v_pk_*) arithmetic variant
+    int streamM;           // > 0: all-air chunks of streamM vertically adjacent tiles go to the row-streaming kernel
+    const uint8_t* nzIn;   // per tile: non-zero at the end of the previous launch (conservative)
+    uint8_t* nzOut;        // per tile: non-zero at the end of this launch
     int tileOrder;         // air-kernel block -> tile mapping (0 linear, 1 XCD band row-major, 2 band column-major)
     int t0;                // first global step of this launch
     int histSlot;          // history plane index of step t0 (= t0, or t0 % ring length in streaming mode)

@@ -239,6 +239,9 @@ __device__ __forceinline__ void stepTile(const StepArgs& a, const int tile, cons
     const int lc = dyn.lcol - col0;
     const bool hasL = GENERAL && a.withPulse && lr >= 0 && lr < ROWS && lc >= 0 && lc < 64;
     active = active || hasL;
+    // non-zero flag for the row-streaming kernel's recording decision in the next launch (conservative: general
+    // tiles, whose slices are advanced by several waves, always count as non-zero)
+    if (lane == 0 && (GENERAL || part == 0)) a.nzOut[tile] = (GENERAL || active) ? 1 : 0;
 
     const int hti = ti - dyn.histTileX0, htj = tj - dyn.histTileY0;
     const bool inWin = hti >= 0 && hti < dyn.histTilesX && htj >= 0 && htj < dyn.histTilesY;
@@ -438,6 +441,7 @@ __device__ __forceinline__ void stepTileAirPacked(const StepArgs& a, const int t
                __float_as_uint(vx[i].y) | __float_as_uint(vy[i].x) | __float_as_uint(vy[i].y)) &
               0x7fffffffu;
     const bool active = __ballot(nz != 0u) != 0ull;
+    if (lane == 0) a.nzOut[tile] = active ? 1 : 0;
 
     const DynParams dyn = *a.dyn;
     const int hti = ti - dyn.histTileX0, htj = tj - dyn.histTileY0;
@@ -481,6 +485,177 @@ __device__ __forceinline__ void stepTileAirPacked(const StepArgs& a, const int t
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// row-streaming air kernel
+// ---------------------------------------------------------------------------------------------------------------
+// The tile kernels sit on their load/store floor: a (RXI+2K) x 64 tile re-reads a K-row halo above and below its RXI
+// interior rows, so the CUs move 2.2x the unique state at K = 8.  Here a wave owns a 64-lane column strip and STREAMS
+// down a chunk of M tiles: every iteration loads one new row (time level 0) and advances all K time levels by one
+// row each -- level s+1 row q needs level s rows q, q+1 and level s+1 row q-1 -- keeping only the two newest rows of
+// every level in registers (6*(K+1) VGPRs, independent of the chunk height).  The x halo is paid once per chunk
+// ((CH+2K)/CH instead of (RXI+2K)/RXI) and every level's update inside an iteration uses the previous iteration's
+// rows, so the K updates are independent instruction streams.  Same arithmetic per cell as the tile kernels.
+
+// does the stream kernel own chunk `ci` of tile column `tj`?  (all its tiles air, listener not in its loaded region)
+template <int K, int RXI>
+__device__ __forceinline__ bool streamOwnsChunk(const StepArgs& a, int ci, int tj) {
+    const int M = a.streamM;
+    const int ti0 = ci * M, ti1 = min(ti0 + M, a.ntx);
+    for (int ti = ti0; ti < ti1; ++ti)
+        if (a.tileClass[ti * a.nty + tj] != 0) return false;
+    if (a.withPulse) {
+        const int lr = a.dyn->lrow - (a.G - K + ti0 * RXI), lc = a.dyn->lcol - (a.G - K + tj * (64 - 2 * K));
+        if (lr >= 0 && lr < (ti1 - ti0) * RXI + 2 * K && lc >= 0 && lc < 64) return false;
+    }
+    return true;
+}
+
+template <int K, int RXI, int WPS>
+__global__ __launch_bounds__(256, WPS) void pv_step_stream_kernel(const StepArgs a) {
+    constexpr int WI = 64 - 2 * K;
+    constexpr int PF = 4;  // input rows in flight (ring of PF register rows, loop unrolled by PF)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int unit = blockIdx.x * 4 + wave;
+    const int nchunks = (a.ntx + a.streamM - 1) / a.streamM;
+    if (unit >= nchunks * a.nty) return;
+    // consecutive units walk down a tile column band by band is not needed: chunks of one column are far apart in
+    // memory anyway; neighbouring columns share their y halo, so units are ordered column-fastest
+    const int ci = unit / a.nty;
+    const int tj = unit - ci * a.nty;
+    if (!streamOwnsChunk<K, RXI>(a, ci, tj)) return;
+    const int ti0 = ci * a.streamM;
+    const int ntile = min(a.streamM, a.ntx - ti0);
+    const int CH = ntile * RXI;            // interior rows of this chunk
+    const int nin = CH + 2 * K;            // input rows
+    const int row0 = a.G - K + ti0 * RXI;  // first loaded row / column, padded coordinates
+    const int col0 = a.G - K + tj * WI;
+    const int voff = lane * 4;
+    const int pitchB = a.pitch * 4;
+    const int soff0 = (row0 * a.pitch + col0) * 4;
+    const rsrc_t rPrIn = makeRsrc(a.prIn, a.planeBytes), rVxIn = makeRsrc(a.vxIn, a.planeBytes),
+                 rVyIn = makeRsrc(a.vyIn, a.planeBytes);
+    const rsrc_t rPrOut = makeRsrc(a.prOut, a.planeBytes), rVxOut = makeRsrc(a.vxOut, a.planeBytes),
+                 rVyOut = makeRsrc(a.vyOut, a.planeBytes);
+
+    const DynParams dyn = *a.dyn;
+    // recording decision per tile of the chunk, from the previous launch's non-zero flags of the tile and its 8
+    // neighbours: one launch moves the field by at most K < tile cells, so a tile whose 3x3 block was zero stays zero
+    unsigned recMask = 0;  // bit i: tile ti0+i is recorded in this launch
+    unsigned winMask = 0;  // bit i: tile ti0+i lies inside the history window
+    if (a.record) {
+        for (int i = 0; i < ntile; ++i) {
+            const int ti = ti0 + i;
+            const int tile = ti * a.nty + tj;
+            const int hti = ti - dyn.histTileX0, htj = tj - dyn.histTileY0;
+            const bool inWin = hti >= 0 && hti < dyn.histTilesX && htj >= 0 && htj < dyn.histTilesY;
+            bool on = a.dense || a.tileFirst[tile] != INT_MAX;
+            if (!on) {
+                for (int di = -1; di <= 1 && !on; ++di)
+                    for (int dj = -1; dj <= 1; ++dj) {
+                        const int u = ti + di, v = tj + dj;
+                        if (u >= 0 && u < a.ntx && v >= 0 && v < a.nty && a.nzIn[u * a.nty + v]) on = true;
+                    }
+            }
+            if (inWin) winMask |= 1u << i;
+            if (on && inWin) {
+                recMask |= 1u << i;
+                if (lane == 0 && !a.dense) atomicMin(&a.tileFirst[tile], a.t0);
+            }
+        }
+    }
+    const float C = a.courant;
+    const bool inCols = lane >= K && lane < 64 - K;
+    const int hpitchB = a.histPitch * 4;
+    const int hvoff = ((tj - dyn.histTileY0) * WI - K + lane) * 4;
+    const int hrow0 = (ti0 - dyn.histTileX0) * RXI - K;  // history row of relative row 0
+
+    // S[par][level]: the two newest rows of every time level; in an iteration of parity par, [par] is the older row
+    float Sp[2][K + 1], Sx[2][K + 1], Sy[2][K + 1];
+#pragma unroll
+    for (int s = 0; s <= K; ++s) {
+        Sp[0][s] = Sp[1][s] = 0.f;
+        Sx[0][s] = Sx[1][s] = 0.f;
+        Sy[0][s] = Sy[1][s] = 0.f;
+    }
+    float inP[PF], inX[PF], inY[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+        const int so = soff0 + min(k, nin - 1) * pitchB;
+        inP[k] = bufLoadF(rPrIn, voff, so);
+        inX[k] = bufLoadF(rVxIn, voff, so);
+        inY[k] = bufLoadF(rVyIn, voff, so);
+    }
+    unsigned nzAcc = 0;     // OR of the final-level outputs of the current tile
+    unsigned nzMask = 0;    // bit i: tile ti0+i has a non-zero output
+    const int niter = nin + 2 * K;  // level K row o leaves at iteration o + 2K
+#pragma unroll 1
+    for (int n0 = 0; n0 < niter; n0 += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int n = n0 + k;
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int par = k & 1;  // PF is even, so the parity of n is the parity of k
+            // take this iteration's input row and refill its slot with row n + PF
+            const float p0 = (n < nin) ? inP[k] : 0.f;
+            const float x0 = (n < nin) ? inX[k] : 0.f;
+            const float y0 = (n < nin) ? inY[k] : 0.f;
+            if (n + PF < nin) {
+                const int so = soff0 + (n + PF) * pitchB;
+                inP[k] = bufLoadF(rPrIn, voff, so);
+                inX[k] = bufLoadF(rVxIn, voff, so);
+                inY[k] = bufLoadF(rVyIn, voff, so);
+            }
+            // advance every level by one row, highest level first (each uses the rows of the previous iteration)
+#pragma unroll
+            for (int s = K - 1; s >= 0; --s) {
+                const float ap = Sp[par][s], ax = Sx[par][s], ay = Sy[par][s];  // level s, row q
+                const float bx = Sx[par ^ 1][s];                                // level s, row q+1
+                const float div = (bx - ax) + (laneNext(ay) - ay);
+                const float pn = ap - C * div;                                  // FDTD.cpp:124-141
+                const float xn = ax - C * (pn - Sp[par ^ 1][s + 1]);            // FDTD.cpp:143-170
+                const float yn = ay - C * (pn - lanePrev(pn));                  // FDTD.cpp:172-199
+                const int q = n - 2 * (s + 1);                                  // relative row of the new row
+                if (recMask) {  // pressure after step t0+s, before any pulse (none in an air chunk)
+                    const int ql = q - K;
+                    if (ql >= 0 && ql < CH && ((recMask >> (ql / RXI)) & 1u) && inCols) {
+                        const rsrc_t rH = makeRsrc(a.hist + (long long)(a.histSlot + s) * a.histPlane, a.histPlane * 4);
+                        bufStoreF(pn, rH, hvoff, (hrow0 + q) * hpitchB);
+                    }
+                }
+                if (s + 1 == K) {
+                    const int ql = q - K;
+                    if (ql >= 0 && ql < CH) {
+                        if (inCols) {
+                            const int so = soff0 + q * pitchB;
+                            bufStoreF(pn, rPrOut, voff, so);
+                            bufStoreF(xn, rVxOut, voff, so);
+                            bufStoreF(yn, rVyOut, voff, so);
+                            nzAcc |= (__float_as_uint(pn) | __float_as_uint(xn) | __float_as_uint(yn)) & 0x7fffffffu;
+                        }
+                        if ((ql + 1) % RXI == 0) {  // last row of a tile
+                            if (__ballot(nzAcc != 0u) != 0ull) nzMask |= 1u << (ql / RXI);
+                            nzAcc = 0;
+                        }
+                    }
+                }
+                Sp[par][s + 1] = pn;
+                Sx[par][s + 1] = xn;
+                Sy[par][s + 1] = yn;
+            }
+            Sp[par][0] = p0;
+            Sx[par][0] = x0;
+            Sy[par][0] = y0;
+        }
+    }
+    if (lane == 0) {
+        for (int i = 0; i < ntile; ++i) a.nzOut[(ti0 + i) * a.nty + tj] = (nzMask >> i) & 1u;
+        // a tile outside the history window must never become non-zero (the window covers the pulse's reach)
+        if (a.record && (nzMask & ~winMask)) atomicExch(a.errFlag, 1);
+    }
+}
+
 // air tiles: one wave per tile, 4 tiles per 256-thread block; tiles of the other class exit immediately.
 // XCD-aware tile order: workgroup b is dispatched to XCD b % 8 (observed, speed only), and each XCD has a private
 // 4 MiB L2.  XCD x therefore owns a contiguous band of tile rows and walks it column by column, so the tiles that
@@ -515,6 +690,7 @@ __global__ __launch_bounds__(256, WPS) void pv_step_air_kernel(const StepArgs a)
     }
     const int tile = ti * a.nty + tj;
     if (a.tileClass[tile] != 0) return;
+    if (a.streamM > 0 && streamOwnsChunk<K, RXI>(a, ti / a.streamM, tj)) return;  // row-streaming kernel's
     if (a.withPulse) {  // the tile(s) holding the listener are on the general kernel's list
         const int lr = a.dyn->lrow - (a.G - K + ti * RXI), lc = a.dyn->lcol - (a.G - K + tj * (64 - 2 * K));
         if (lr >= 0 && lr < RXI + 2 * K && lc >= 0 && lc < 64) return;
@@ -567,6 +743,10 @@ __global__ __launch_bounds__(256) void pv_tileclass_kernel(const uint16_t* codes
 
 template <int K, int RXI, int WPS, int SUB>
 static void launchStepT(const StepArgs& a, hipStream_t stream, int which, hipStream_t stream2) {
+    if ((which & 1) && a.streamM > 0) {
+        const int units = ((a.ntx + a.streamM - 1) / a.streamM) * a.nty;
+        hipLaunchKernelGGL((pv_step_stream_kernel<K, RXI, 4>), dim3((units + 3) / 4), dim3(256), 0, stream, a);
+    }
     if (which & 1) {
         const int blocks = a.tileOrder == 0 ? (a.ntiles + 3) / 4 : 8 * ((a.bandRows * a.nty + 3) / 4);
         if (a.packed)

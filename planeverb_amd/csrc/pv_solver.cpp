@@ -117,6 +117,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     if (!dalloc(&pulseDev_, (size_t)std::max(T_, g_.T), true)) return false;
     if (!dalloc(&tileFirst_, (size_t)ntiles, true)) return false;
     if (!dalloc(&tileClass_, (size_t)ntiles, true)) return false;
+    if (!dalloc(&nz_[0], (size_t)ntiles, true) || !dalloc(&nz_[1], (size_t)ntiles, true)) return false;
     listCap_ = ntiles;
     if (!dalloc(&generalList_, (size_t)listCap_, true)) return false;
     if (!dalloc(&generalCount_, 1, true)) return false;
@@ -193,6 +194,8 @@ Solver::~Solver() {
         if (vx_[i]) hipFree(vx_[i]);
         if (vy_[i]) hipFree(vy_[i]);
     }
+    for (uint8_t* p : nz_)
+        if (p) hipFree(p);
     for (float* p : sState_)
         if (p) hipFree(p);
     if (sOnset_) hipFree(sOnset_);
@@ -513,6 +516,9 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
         a.t0 = firstStep + done;
         a.histSlot = opt_.streaming ? a.t0 % ring_ : a.t0;
         a.nsteps = k;
+        a.streamM = (k == K_) ? opt_.streamRows : 0;  // the streaming kernel always advances exactly K levels
+        a.nzIn = nz_[li & 1];
+        a.nzOut = nz_[(li & 1) ^ 1];
         if (opt_.timeKernels > 0) {  // 4 timing events per sampled launch: air begin/end on stream_, general begin/end
             while ((int)kev_.size() < kevUsed_ + 4) {
                 hipEvent_t e;
@@ -709,6 +715,9 @@ bool Solver::enqueueResetAndSteps() {
             return false;
     }
     if (!hipOk(hipMemsetAsync(errFlag_, 0, sizeof(int), stream_), "errFlag")) return false;
+    if (!hipOk(hipMemsetAsync(nz_[0], 0, (size_t)ntiles, stream_), "nz") ||
+        !hipOk(hipMemsetAsync(nz_[1], 0, (size_t)ntiles, stream_), "nz"))
+        return false;
     return enqueueSteps(0, T_, true, true);
 }
 

@@ -27,6 +27,7 @@ struct SolverOptions {
     int useGraph = 0;     // 0 = auto (small grids), 1 = always, 2 = never: replay the run from a captured hipGraph
     bool withFreeGrid = true;
     int tileOrder = 1;    // air-kernel block->tile map: 1 = XCD-band row-major (1-5 % faster than 0 = linear, measured)
+    int streamRows = 0;   // M > 0: all-air chunks of M stacked tiles run in the row-streaming kernel
     bool streaming = false;  // sparse-emitter mode: ring history + incremental forward analysis
     bool packed = true;   // packed-f32 arithmetic in the air-tile kernel (VALU-issue bound otherwise)
     int smallGrid = 0;    // 0 = auto: grids that fit one CU's LDS run in the whole-grid-resident kernel; 2 = never
@@ -135,6 +136,7 @@ private:
     float* hist_ = nullptr;
     long long histPlane_ = 0;
     int histRows_ = 0, histPitch_ = 0, histTilesX_ = 0, histTilesY_ = 0;
+    uint8_t* nz_[2] = {nullptr, nullptr};  // per-tile non-zero flags, ping-pong per launch
     int* tileFirst_ = nullptr;
     uint8_t* tileClass_ = nullptr;
     int* generalList_ = nullptr;

@@ -566,3 +566,33 @@ def test_listener_outside_grid_and_api_misc(pvlib):
     assert L.PvAmdSetOption(h, pvlib.PVA_OPT_DENSE_HISTORY, 1) != 0  # options only before first use
     L.PvAmdDestroy(h)
     assert L.PvAmdCreate(25.0, 25.0, 275, 99) is None and "device" in pvlib.last_error()
+
+
+@pytest.mark.parametrize("M", [1, 3, 4])
+def test_row_streaming_kernel_equivalence(pvlib, M):
+    """PVA_OPT_STREAM_ROWS (experimental row-streaming stencil for all-air chunks): same bits as the tile kernels,
+    raw stencil from dense random fields and a full run (history, activity flags, analysis)"""
+    dx = np.float32(343.21) / np.float32(275) / np.float32(3.5)
+    n = 600
+    size = float((n + 0.5) * dx)
+    rng = np.random.default_rng(0)
+    init = [rng.standard_normal((n + 1, n + 1)).astype(np.float32) for _ in range(3)]
+    walls = [[60, 70, 20, 1, 0.9], [120, 40, 1, 30, 0.7]]
+    outs = []
+    for m in (0, M):
+        with pvlib.Solver(size, size, 275, no_free_grid=1, stream_rows=m) as s:
+            for w in walls:
+                s.add_geometry(w)
+            s.set_fields(*init)
+            s.run_steps(37)
+            outs.append(s.fields())
+    assert all(same_bits(a, b).all() for a, b in zip(*outs))
+    res = []
+    for m in (0, M):
+        with pvlib.Solver(size, size, 275, stream_rows=m) as s:
+            s.load_scene(os.path.join(SCENES, "HugeRoom.pv"))
+            s.run((100.0, 0.0, 90.0))
+            res.append((s.results(), [s.history_plane(t) for t in (3, 100, 434)]))
+    (r0, h0), (r1, h1) = res
+    assert same_bits(r0[0], r1[0]).all() and same_bits(r0[1], r1[1]).all()
+    assert all(same_bits(a, b).all() for a, b in zip(h0, h1))
