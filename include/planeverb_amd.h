@@ -132,7 +132,8 @@ enum {
     PVA_OPT_SMALL_GRID_KERNEL = 10, /* 0 = auto (grids that fit one CU's LDS run in one resident kernel), 2 = never */
     PVA_OPT_PACKED_MATH = 11,  /* air-tile kernel arithmetic: 1 = packed f32 (default), 0 = scalar f32 */
     PVA_OPT_STREAMING_ANALYSIS = 12, /* 1 = sparse-emitter mode: ring history + incremental analysis (see PvAmdSetEmitters) */
-    PVA_OPT_STREAM_ROWS = 13   /* M > 0: all-air chunks of M stacked tiles run in the row-streaming stencil kernel */
+    PVA_OPT_STREAM_ROWS = 13,  /* M > 0: all-air chunks of M stacked tiles run in the row-streaming stencil kernel */
+    PVA_OPT_MERGED_LAUNCH = 14 /* 1 (default) = general + air tiles in one launch per K steps; 0 = two kernels, two streams */
 };
 
 PVA_EXPORT int PvAmdDeviceCount(void);

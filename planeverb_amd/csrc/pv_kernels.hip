@@ -720,6 +720,53 @@ __global__ __launch_bounds__(256, 2) void pv_step_general_kernel(const StepArgs 
     stepTile<K, RXI, SUB, true>(a, tile, idx % S, lane, lut);
 }
 
+// Merged form: ONE launch per K steps.  The first blocks advance the general tiles (listed, split into SUB-row
+// slices), the rest the air tiles.  Versus the two-kernel / two-stream form this removes the cross-stream event
+// hand-shake between every pair of launches; it needs the general path to fit the air path's register budget, hence
+// the smaller slices.
+template <int K, int RXI, int WPS, int SUB>
+__global__ __launch_bounds__(256, WPS) void pv_step_merged_kernel(const StepArgs a) {
+    __shared__ float lut[256];
+    constexpr int S = RXI / SUB;
+    static_assert(S * SUB == RXI, "general-tile split must divide the tile");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int gblocks = (a.numGeneral * S + 3) / 4;
+    if ((int)blockIdx.x < gblocks) {
+        lut[threadIdx.x] = a.lut[threadIdx.x];
+        __syncthreads();
+        const int idx = blockIdx.x * 4 + wave;
+        if (idx >= a.dyn->numGeneral * S) return;
+        const int tile = __builtin_amdgcn_readfirstlane(a.generalList[idx / S]);
+        stepTile<K, RXI, SUB, true>(a, tile, idx % S, lane, lut);
+        return;
+    }
+    const int b = blockIdx.x - gblocks;
+    int ti, tj;
+    {
+        const int xcd = b & 7;
+        const int q = (b >> 3) * 4 + wave;  // index inside the XCD's band
+        const int ti0 = xcd * a.bandRows;
+        const int bandRows = min(a.bandRows, a.ntx - ti0);
+        if (bandRows <= 0) return;
+        const int r = q / a.nty;
+        if (r >= bandRows) return;
+        ti = ti0 + r;
+        tj = q - r * a.nty;
+    }
+    const int tile = ti * a.nty + tj;
+    if (a.tileClass[tile] != 0) return;
+    if (a.withPulse) {
+        const int lr = a.dyn->lrow - (a.G - K + ti * RXI), lc = a.dyn->lcol - (a.G - K + tj * (64 - 2 * K));
+        if (lr >= 0 && lr < RXI + 2 * K && lc >= 0 && lc < 64) return;
+    }
+    if constexpr ((RXI + 2 * K) % 2 == 0) {
+        stepTileAirPacked<K, RXI>(a, tile, lane);
+    } else {
+        stepTile<K, RXI, RXI, false>(a, tile, 0, lane, nullptr);
+    }
+}
+
 // Per-tile class: 0 = every face code in the tile's loaded region is air|air, 1 = needs the general kernel.
 // One wave per tile.  Tiles of class 1 are also appended to generalList (order irrelevant).
 template <int K, int RXI>
@@ -743,6 +790,13 @@ __global__ __launch_bounds__(256) void pv_tileclass_kernel(const uint16_t* codes
 
 template <int K, int RXI, int WPS, int SUB>
 static void launchStepT(const StepArgs& a, hipStream_t stream, int which, hipStream_t stream2) {
+    if (which == 4) {  // merged single launch
+        constexpr int MS = (RXI % 4 == 0) ? RXI / 4 : SUB;
+        const int gblocks = (a.numGeneral * (RXI / MS) + 3) / 4;
+        const int blocks = gblocks + 8 * ((a.bandRows * a.nty + 3) / 4);
+        hipLaunchKernelGGL((pv_step_merged_kernel<K, RXI, WPS, MS>), dim3(blocks), dim3(256), 0, stream, a);
+        return;
+    }
     if ((which & 1) && a.streamM > 0) {
         const int units = ((a.ntx + a.streamM - 1) / a.streamM) * a.nty;
         hipLaunchKernelGGL((pv_step_stream_kernel<K, RXI, 4>), dim3((units + 3) / 4), dim3(256), 0, stream, a);
@@ -787,6 +841,9 @@ void launchTileClass(int K, int rxi, const uint16_t* codes, uint8_t* tileClass, 
     PV_STEP_CONFIGS(X)
 #undef X
 }
+
+// configurations whose merged (single-launch) kernel allocates without spills
+bool mergedConfigOk(int K, int rxi) { return (K == 8 && rxi == 24) || (K == 4 && rxi == 32) || (K == 6 && rxi == 28); }
 
 bool stepConfigSupported(int K, int rxi) {
 #define X(k, r, w, sub) \

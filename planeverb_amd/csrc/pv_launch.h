@@ -11,7 +11,9 @@ namespace pva {
 
 // supported (K steps per launch, interior rows per tile) instantiations of the fused stencil
 bool stepConfigSupported(int K, int rxi);
-// which: bit 0 = air-tile kernel, bit 1 = general-tile kernel (both write disjoint tiles of the same planes)
+bool mergedConfigOk(int K, int rxi);
+// which: bit 0 = air-tile kernel, bit 1 = general-tile kernel (both write disjoint tiles of the same planes);
+// 4 = both in ONE merged launch (general slices first, then the air tiles)
 // The general kernel goes to stream2 when given (the caller orders the two streams with events).
 void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream, int which = 3, hipStream_t stream2 = nullptr);
 void launchTileClass(int K, int rxi, const uint16_t* codes, uint8_t* tileClass, int* list, int* count,

@@ -489,7 +489,9 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
     // listener: few tiles, latency-bound) concurrently on stream2_.  Both read buffer set `cur` and write disjoint
     // tiles of the other set, so launch i+1 of EITHER kernel must wait for launch i of BOTH (RAW on the halos it
     // reads, WAR on the tiles it overwrites): one event per kernel per launch.
-    const bool two = launchCap_ > 0;
+    // merged: one launch per K steps on one stream (no cross-stream hand-shake); not with the streaming kernel
+    const bool mergedLaunch = opt_.merged == 1 && mergedConfigOk(K_, rxi_) && opt_.streamRows == 0;
+    const bool two = launchCap_ > 0 && !mergedLaunch;
     const int nl = ceilDiv(nsteps, K_);
     if (two) {
         auto grow = [&](std::vector<hipEvent_t>& v) {
@@ -528,7 +530,15 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
         }
         // only full K-step launches are sampled, so that duration and algorithmic bytes refer to the same work
         hipEvent_t* te = (opt_.timeKernels > 0 && k == K_ && li % opt_.timeKernels == 0) ? &kev_[(size_t)kevUsed_] : nullptr;
-        if (two) {
+        if (mergedLaunch) {
+            if (te) hipEventRecord(te[0], stream_);
+            launchStep(K_, rxi_, a, stream_, 4);
+            if (te) {
+                hipEventRecord(te[1], stream_);
+                hipEventRecord(te[2], stream_);
+                hipEventRecord(te[3], stream_);
+            }
+        } else if (two) {
             if (li > 0) {
                 hipStreamWaitEvent(stream_, genDone_[(size_t)li - 1], 0);
                 hipStreamWaitEvent(stream2_, airDone_[(size_t)li - 1], 0);

@@ -27,6 +27,7 @@ struct SolverOptions {
     int useGraph = 0;     // 0 = auto (small grids), 1 = always, 2 = never: replay the run from a captured hipGraph
     bool withFreeGrid = true;
     int tileOrder = 1;    // air-kernel block->tile map: 1 = XCD-band row-major (1-5 % faster than 0 = linear, measured)
+    int merged = 1;       // 1 = general + air tiles in one launch per K steps (where it compiles spill-free), 0 = two kernels on two streams
     int streamRows = 0;   // M > 0: all-air chunks of M stacked tiles run in the row-streaming kernel
     bool streaming = false;  // sparse-emitter mode: ring history + incremental forward analysis
     bool packed = true;   // packed-f32 arithmetic in the air-tile kernel (VALU-issue bound otherwise)

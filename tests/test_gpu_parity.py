@@ -86,7 +86,8 @@ def test_golden_small(pvlib, name):
                                   dict(steps_per_launch=3, tile_rows=26), dict(steps_per_launch=4, tile_rows=24), dict(steps_per_launch=4, tile_rows=32),
                                   dict(steps_per_launch=6, tile_rows=28), dict(steps_per_launch=8, tile_rows=24),
                                   dict(dense_history=1), dict(use_graph=1), dict(use_graph=2),
-                                  dict(small_grid_kernel=2), dict(small_grid_kernel=2, use_graph=2), dict(small_grid_kernel=2, packed_math=0)])
+                                  dict(small_grid_kernel=2), dict(small_grid_kernel=2, use_graph=2), dict(small_grid_kernel=2, packed_math=0), dict(small_grid_kernel=2, merged_launch=0),
+                                  dict(small_grid_kernel=2, merged_launch=0, use_graph=2)])
 def test_every_kernel_configuration(pvlib, opts):
     """every compiled (K, rows) instantiation and the dense-history mode produce the same bits"""
     g = golden("g71_smallroom")
