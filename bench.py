@@ -199,7 +199,8 @@ def main():
             "hbm_bytes_held": int(info.deviceBytes),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "pv_step_air_kernel<K=%d,rows=%d>" % (K, info.tileRows),
+                         "kernel": "pv_step_merged_kernel<K=%d,rows=%d> (air tiles + general slices, one launch per K "
+                                   "steps)" % (K, info.tileRows),
                          "launch_ms": air, "launches_per_run": launches,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_CELL_STEP * cells * steps_per_launch_avg,
                          "general_kernel_launch_ms": float(np.mean(gen_ms)),
