@@ -112,7 +112,6 @@ typedef struct PvAmdTimings {
     float geometryMs;       /* material upload + face-code build, last time it ran */
     float stepKernelMs;     /* fdtdMs / number of step launches */
     int stepLaunches;
-    long long histBytesWritten; /* bytes of pr history written by the last run */
     float airKernelMs;      /* mean duration of one air-tile step-kernel launch (PVA_OPT_TIME_KERNELS) */
     float generalKernelMs;  /* mean duration of one general-tile step-kernel launch */
     int airLaunches, generalLaunches;

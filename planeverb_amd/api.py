@@ -60,8 +60,7 @@ class PvAmdInfo(C.Structure):
 
 class PvAmdTimings(C.Structure):
     _fields_ = [("fdtdMs", C.c_float), ("analysisMs", C.c_float), ("geometryMs", C.c_float),
-                ("stepKernelMs", C.c_float), ("stepLaunches", C.c_int), ("histBytesWritten", C.c_longlong),
-                ("airKernelMs", C.c_float), ("generalKernelMs", C.c_float), ("airLaunches", C.c_int),
+                ("stepKernelMs", C.c_float), ("stepLaunches", C.c_int), ("airKernelMs", C.c_float), ("generalKernelMs", C.c_float), ("airLaunches", C.c_int),
                 ("generalLaunches", C.c_int)]
 
 

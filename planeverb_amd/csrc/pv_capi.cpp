@@ -18,7 +18,6 @@ struct PvAmdSolver {
     SolverOptions opt;
     GridSpec spec;
     int device = 0;
-    std::string createErr;
 };
 
 static bool ensure(PvAmdSolver* h) {
@@ -285,7 +284,6 @@ int PvAmdGetTimings(PvAmdSolver* h, PvAmdTimings* out) {
     out->geometryMs = t.geometryMs;
     out->stepLaunches = t.stepLaunches;
     out->stepKernelMs = t.stepLaunches ? t.fdtdMs / (float)t.stepLaunches : 0.f;
-    out->histBytesWritten = t.histBytesWritten;
     out->airKernelMs = t.airKernelMs;
     out->generalKernelMs = t.generalKernelMs;
     out->airLaunches = t.airLaunches;

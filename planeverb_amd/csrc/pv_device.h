@@ -111,6 +111,7 @@ struct AnalyzeArgs {
     const DynParams* dyn;
     float* res8;   // gx*gy*8
     float* delay;  // gx*gy
+    float* occ;    // gx*gy: occlusion again as its own plane (coalesced neighbour reads in the direction kernel)
     long long histPlane;
     int histPitch;
     int pitch, G;

@@ -1163,6 +1163,7 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
 
     float* o = a.res8 + 8 * (size_t)s;
     o[0] = occ;
+    a.occ[s] = occ;  // SoA copy of the occlusion map for the direction kernel's neighbour reads
     o[1] = wet;
     o[2] = rt60;
     o[3] = lowpass;
@@ -1180,7 +1181,7 @@ __global__ __launch_bounds__(256) void pv_direction_kernel(const AnalyzeArgs a) 
     const int X = blockIdx.y;
     if (Y >= a.gy || X >= a.gx) return;
     const int index = X * a.gy + Y;
-    float loudness = a.res8[8 * (size_t)index];
+    float loudness = a.occ[index];
     int cur = index;
     float delay = FLT_MAX;
     const float samplingRate = (float)a.fs;
@@ -1194,7 +1195,7 @@ __global__ __launch_bounds__(256) void pv_direction_kernel(const AnalyzeArgs a) 
             const int nr = r + kNeighbors[i][0], nc = c + kNeighbors[i][1];
             if (nr < 0 || nc < 0 || nr >= a.gx || nc >= a.gy) continue;
             const int ni = nr * a.gy + nc;
-            const float occ = a.res8[8 * (size_t)ni];
+            const float occ = a.occ[ni];
             const float d = a.delay[ni];
             if (occ == 0.f) continue;               // Analyzer.cpp:372 (the (unsigned)delay test never fires)
             if (d < bestDelay && occ > 0.f) {       // strict <: first neighbour wins ties
@@ -1367,6 +1368,7 @@ __global__ __launch_bounds__(256) void pv_stream_finalize_kernel(const AnalyzeAr
     const float rr = 1.0f / ((0.001f < occ) ? occ : 0.001f);
     float* o = a.res8 + 8 * (size_t)s;
     o[0] = occ;
+    a.occ[s] = occ;  // SoA copy of the occlusion map for the direction kernel's neighbour reads
     o[3] = -147.f + (18390.f) / (1.f + pvPowf(rr / 12.f, 0.8f));
     o[6] = norm * fluxX;
     o[7] = norm * fluxY;

@@ -125,6 +125,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     if (!dalloc(&errFlag_, 1, true)) return false;
     if (!dalloc(&res8_, (size_t)g_.gx * g_.gy * 8, true)) return false;  // zeroed pool: PvContext.cpp:132
     if (!dalloc(&delay_, (size_t)g_.gx * g_.gy, true)) return false;
+    if (!dalloc(&occ_, (size_t)g_.gx * g_.gy, true)) return false;
     scratchCount_ = std::max<size_t>((size_t)3 * std::max(T_, g_.T), (size_t)g_.NX * g_.NY * 3);
     if (!dalloc(&scratch_, scratchCount_, true)) return false;
 
@@ -202,7 +203,7 @@ Solver::~Solver() {
     if (emCells_) hipFree(emCells_);
     if (emTrace_) hipFree(emTrace_);
     void* ptrs[] = {codes_,     matDev_, lutDev_, pulseDev_, hist_,  tileFirst_, tileClass_, generalList_,
-                    generalCount_, dynDev_, errFlag_, res8_,     delay_, scratch_};
+                    generalCount_, dynDev_, errFlag_, res8_,     delay_, scratch_, occ_};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (dynHost_) hipHostFree(dynHost_);
@@ -580,6 +581,7 @@ AnalyzeArgs Solver::analyzeArgs(float lx, float lz) const {
     a.dyn = dynDev_;
     a.res8 = res8_;
     a.delay = delay_;
+    a.occ = occ_;
     a.histPlane = histPlane_;
     a.histPitch = histPitch_;
     a.pitch = geo_.pitch;

@@ -40,7 +40,6 @@ struct SolverTimings {
     float airKernelMs = 0, generalKernelMs = 0;  // mean duration per launch (timeKernels only)
     int airLaunches = 0, generalLaunches = 0;
     int stepLaunches = 0;
-    long long histBytesWritten = 0;
 };
 
 class Solver {
@@ -146,6 +145,7 @@ private:
     int* errFlag_ = nullptr;
     float* res8_ = nullptr;
     float* delay_ = nullptr;
+    float* occ_ = nullptr;
     // streaming analysis state
     int ring_ = 0;             // history planes allocated (T_ when not streaming)
     int* sOnset_ = nullptr;
