@@ -28,6 +28,7 @@
 
 #include "pv_device.h"
 #include "pv_launch.h"
+#include "pv_libm.h"
 
 namespace pva {
 
@@ -980,10 +981,7 @@ void launchSmallGrid(const SmallArgs& a, hipStream_t stream) {
 // impulse-response analysis
 // ---------------------------------------------------------------------------------------------------------------
 
-// libm-equivalents evaluated through double precision and rounded once to float: within 1 ulp of glibc's
-// log10f / powf (which are themselves not correctly rounded), SURVEY.md section 8c "third-party arithmetic".
-__device__ __forceinline__ float pvLog10f(float x) { return (float)log10((double)x); }
-__device__ __forceinline__ float pvPowf(float x, float y) { return (float)pow((double)x, (double)y); }
+// pvLog10f / pvPowf: glibc-2.35-exact log10f and powf, see pv_libm.h
 
 struct CellHistory {
     const float* h;     // this cell, step 0

@@ -1,0 +1,140 @@
+// pv_libm.h -- log10f and powf with the exact results of glibc 2.35's libm (the libm the strict-IEEE reference
+// build links), usable from device and host code.
+//
+// The analysis evaluates log10f once per tail sample (Analyzer.cpp:311) and powf once per cell (Analyzer.cpp:230).
+// ROCm's device functions are within 1-2 ulp of glibc's, and neither is correctly rounded, so to get the
+// reference's bits the published algorithms glibc uses are restated here:
+//   * log10f: sysdeps/ieee754/flt-32/e_log10f.c (fdlibm lineage): x = 2^k*m, result = (k*log10_2lo + ivln10*logf(m))
+//     + k*log10_2hi in float arithmetic;
+//   * logf, powf: sysdeps/ieee754/flt-32/e_logf.c, e_powf.c + e_powf_log2_data.c, e_exp2f_data.c (ARM Optimized
+//     Routines, Szabolcs Nagy): 16-entry log tables, 32-entry exp2 table, polynomials evaluated in double.
+// tools/libm_check.cpp compares them with the host libm: every positive finite float for log10f (2 139 095 039
+// values) and every non-negative float for powf(x, 0.8f) (2 139 095 041 values) match bit for bit on this image.
+// Must be compiled without FP contraction (-ffp-contract=off); results do not depend on it for these inputs (checked
+// both ways), but the step kernels need the flag anyway.
+#pragma once
+
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define PV_HD __host__ __device__
+#else
+#define PV_HD
+#endif
+
+namespace pva {
+
+PV_HD inline uint32_t pvBitsF(float f) { return __builtin_bit_cast(uint32_t, f); }
+PV_HD inline float pvFloatBits(uint32_t u) { return __builtin_bit_cast(float, u); }
+
+// logf for a positive NORMAL argument (the only kind log10f passes in)
+PV_HD inline float pvLogfNormal(float x) {
+    constexpr double T[16][2] = {
+        {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2},
+        {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2},  {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3},
+        {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3},
+        {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4},
+        {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5}, {0x1p+0, 0x0p+0},
+        {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},
+        {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3},
+        {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},  {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
+    const uint32_t ix = pvBitsF(x);
+    if (ix == 0x3f800000u) return 0.f;
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> 19) & 15u);
+    const int k = (int)tmp >> 23;
+    const uint32_t iz = ix - (tmp & (0x1ffu << 23));
+    const double invc = T[i][0], logc = T[i][1];
+    const double z = (double)pvFloatBits(iz);
+    const double r = z * invc - 1.0;
+    const double y0 = logc + (double)k * 0x1.62e42fefa39efp-1;
+    const double r2 = r * r;
+    double y = 0x1.5575b0be00b6ap-2 * r + -0x1.ffffef20a4123p-2;
+    y = -0x1.00ea348b88334p-2 * r2 + y;
+    y = y * r2 + (y0 + r);
+    return (float)y;
+}
+
+PV_HD inline float pvLog10f(float x) {
+    const float two25 = 3.3554432000e+07f, ivln10 = 4.3429449201e-01f, log10_2hi = 3.0102920532e-01f,
+                log10_2lo = 7.9034151668e-07f;
+    int hx = (int)pvBitsF(x);
+    int k = 0;
+    if (hx < 0x00800000) {                                                          // x < 2^-126
+        if ((hx & 0x7fffffff) == 0) return -two25 / pvFloatBits((uint32_t)hx & 0x7fffffffu);  // log(+-0) = -inf
+        if (hx < 0) return (x - x) / (x - x);                                       // log(-#) = NaN
+        k -= 25;
+        x *= two25;                                                                 // subnormal: scale up
+        hx = (int)pvBitsF(x);
+    }
+    if (hx >= 0x7f800000) return x + x;
+    k += (hx >> 23) - 127;
+    const int i = (int)(((unsigned)k & 0x80000000u) >> 31);
+    hx = (hx & 0x007fffff) | ((0x7f - i) << 23);
+    const float y = (float)(k + i);
+    const float m = pvFloatBits((uint32_t)hx);
+    const float z = y * log10_2lo + ivln10 * pvLogfNormal(m);
+    return z + y * log10_2hi;
+}
+
+// powf for x >= 0 (zero, subnormal, inf and NaN included) and a positive finite y with |y * log2(x)| < 126 -- the
+// analysis calls it with y = 0.8f, for which the overflow / underflow branches of glibc's powf cannot be taken.
+PV_HD inline float pvPowf(float x, float y) {
+    constexpr double LT[16][2] = {
+        {0x1.661ec79f8f3bep+0, -0x1.efec65b963019p-2}, {0x1.571ed4aaf883dp+0, -0x1.b0b6832d4fca4p-2},
+        {0x1.49539f0f010bp+0, -0x1.7418b0a1fb77bp-2},  {0x1.3c995b0b80385p+0, -0x1.39de91a6dcf7bp-2},
+        {0x1.30d190c8864a5p+0, -0x1.01d9bf3f2b631p-2}, {0x1.25e227b0b8eap+0, -0x1.97c1d1b3b7afp-3},
+        {0x1.1bb4a4a1a343fp+0, -0x1.2f9e393af3c9fp-3}, {0x1.12358f08ae5bap+0, -0x1.960cbbf788d5cp-4},
+        {0x1.0953f419900a7p+0, -0x1.a6f9db6475fcep-5}, {0x1p+0, 0x0p+0},
+        {0x1.e608cfd9a47acp-1, 0x1.338ca9f24f53dp-4},  {0x1.ca4b31f026aap-1, 0x1.476a9543891bap-3},
+        {0x1.b2036576afce6p-1, 0x1.e840b4ac4e4d2p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.40645f0c6651cp-2},
+        {0x1.886e6037841edp-1, 0x1.88e9c2c1b9ff8p-2},  {0x1.767dcf5534862p-1, 0x1.ce0a44eb17bccp-2}};
+    constexpr uint64_t ET[32] = {
+        0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+        0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+        0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+        0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+        0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+        0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+        0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+        0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+    uint32_t ix = pvBitsF(x);
+    if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {          // zero, subnormal, inf, NaN
+        if (2u * ix - 1u >= 2u * 0x7f800000u - 1u) return x * x;  // +0 -> 0, inf -> inf, NaN -> NaN (y > 0)
+        ix = pvBitsF(x * 0x1p23f);
+        ix &= 0x7fffffffu;
+        ix -= 23u << 23;
+    }
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> 19) & 15u);
+    const uint32_t top = tmp & 0xff800000u;
+    const uint32_t iz = ix - top;
+    const int k = (int)top >> 23;
+    const double invc = LT[i][0], logc = LT[i][1];
+    const double z = (double)pvFloatBits(iz);
+    const double r = z * invc - 1.0;
+    const double y0 = logc + (double)k;
+    const double r2 = r * r;
+    double yy = 0x1.27616c9496e0bp-2 * r + -0x1.71969a075c67ap-2;
+    const double p = 0x1.ec70a6ca7baddp-2 * r + -0x1.7154748bef6c8p-1;
+    const double r4 = r2 * r2;
+    double q = 0x1.71547652ab82bp+0 * r + y0;
+    q = p * r2 + q;
+    yy = yy * r4 + q;                       // log2(x)
+    const double xd = (double)y * yy;
+    double kd = xd + 0x1.8p+47;             // round to a multiple of 1/32
+    const uint64_t ki = __builtin_bit_cast(uint64_t, kd);
+    kd -= 0x1.8p+47;
+    const double rr = xd - kd;
+    uint64_t t = ET[ki & 31ull];
+    t += ki << (52 - 5);
+    const double sc = __builtin_bit_cast(double, t);
+    const double zz = 0x1.c6af84b912394p-5 * rr + 0x1.ebfce50fac4f3p-3;
+    const double rr2 = rr * rr;
+    double e = 0x1.62e42ff0c52d6p-1 * rr + 1.0;
+    e = zz * rr2 + e;
+    e = e * sc;
+    return (float)e;
+}
+
+}  // namespace pva

@@ -3,11 +3,12 @@
   (2) the pinned oracle (oracle/pv_oracle.c) on seeded random scenes,
   (3) size-independent properties at BASELINE.json's full sizes.
 
-Tolerances (BASELINE.json north_star: 1e-4 relative on the per-source outputs):
-  * fields, pressure history, reconstructed vx/vy impulse responses, onset delay, occlusion (dry gain), wet gain,
-    source directivity, listener direction: BIT-EXACT float32 (modulo the sign of zero);
-  * lowpass: <= 1e-6 relative (one powf, evaluated through double on the device, glibc's differs by <= 1 ulp);
-  * rt60: <= 1e-4 relative (T log10f evaluations per cell feed a float32 regression; observed <= 4e-6).
+Tolerance: BASELINE.json's north_star allows 1e-4 relative on the per-source outputs; the bar here is BIT-EXACT
+float32 (modulo the sign of zero, NaN == NaN) for everything -- fields, pressure history, reconstructed vx/vy impulse
+responses, onset delay, occlusion, wet gain, rt60, lowpass, source directivity, listener direction.  rt60 and lowpass
+go through log10f / powf, which the device evaluates with glibc 2.35's own algorithms (planeverb_amd/csrc/pv_libm.h,
+checked against the host libm for every float by tools/libm_check.cpp); RT60_TOL / LOWPASS_TOL stay as knobs for a
+host whose libm is not glibc 2.35.
 """
 import os
 
@@ -18,8 +19,8 @@ from conftest import SCENES, golden, rel_err, same_bits, valid_mask
 
 pytestmark = pytest.mark.gpu
 
-RT60_TOL = 1e-4
-LOWPASS_TOL = 1e-6
+RT60_TOL = 0.0
+LOWPASS_TOL = 0.0
 NAMES = ["occlusion", "wetGain", "rt60", "lowpass", "dirX", "dirY", "srcDirX", "srcDirY"]
 
 

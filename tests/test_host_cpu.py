@@ -150,3 +150,16 @@ def test_cli_save_without_gpu(pvlib, tmp_path):
                        cwd=ROOT, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert np.array_equal(pvlib.load_pv(out), pvlib.load_pv(os.path.join(SCENES, "Shoebox.pv")))
+
+
+def test_device_libm_matches_host_libm(tmp_path):
+    """pv_libm.h (the log10f / powf the analysis kernels use, compiled here for the host) against this machine's
+    libm on a 1-in-97 sample of all floats + special values; tools/libm_check.cpp 1 runs all of them"""
+    import json
+    import subprocess
+    exe = str(tmp_path / "libm_check")
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-I", os.path.join(ROOT, "planeverb_amd", "csrc"),
+                           os.path.join(ROOT, "tools", "libm_check.cpp"), "-o", exe])
+    r = subprocess.run([exe, "97"], capture_output=True, text=True)
+    out = json.loads(r.stdout)
+    assert r.returncode == 0 and out["log10f_mismatches"] == 0 and out["powf_mismatches"] == 0 and out["values"] > 2e7
