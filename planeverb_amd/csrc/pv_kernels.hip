@@ -1224,6 +1224,93 @@ __global__ __launch_bounds__(256) void pv_direction_kernel(const AnalyzeArgs a) 
     a.res8[8 * (size_t)index + 5] = oy;
 }
 
+// ---- the same descent by pointer jumping (used when T is large: streaming / Mode B) -------------------------------
+// After its first move the walk's state is a function of the cell it stands on (delay = delay[cell], loudness =
+// occ[cell]), so "where does the walk end" is a functional graph: hop(p) = stop here | stop at neighbour n | continue
+// from n, and delays strictly decrease along "continue" edges.  ceil(log2 T) rounds of J[p] = J[J[p]] resolve every
+// cell; the per-cell cost no longer grows with the path length (a 4096-cell-wide room: 191 ms -> a few ms).
+constexpr int kDirFinal = (int)0x80000000;
+
+__device__ __forceinline__ int dirBestNeighbour(const AnalyzeArgs& a, int cell, float* bestDelay) {
+    const int r = cell / a.gy, c = cell - r * a.gy;
+    int best = -1;
+    float bd = FLT_MAX;
+    for (int i = 0; i < 8; ++i) {
+        const int nr = r + kNeighbors[i][0], nc = c + kNeighbors[i][1];
+        if (nr < 0 || nc < 0 || nr >= a.gx || nc >= a.gy) continue;
+        const int ni = nr * a.gy + nc;
+        const float occ = a.occ[ni];
+        const float d = a.delay[ni];
+        if (occ == 0.f) continue;
+        if (d < bd && occ > 0.f) {
+            best = ni;
+            bd = d;
+        }
+    }
+    *bestDelay = bd;
+    return best;
+}
+
+__device__ __forceinline__ bool dirLineOfSight(const AnalyzeArgs& a, int cell, float d) {
+    const float geodesic = kCDev * d / (float)a.fs;
+    const int r = cell / a.gy, c = cell - r * a.gy;
+    const float tx = (float)r * a.dx - a.lx, ty = (float)c * a.dx - a.lz;
+    const float euclid = sqrtf((tx * tx) + (ty * ty));
+    return fabsf(geodesic - euclid) < 0.3f * (kCDev / (float)a.res);
+}
+
+__global__ __launch_bounds__(256) void pv_dir_init_kernel(const AnalyzeArgs a, int* J) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.gx * a.gy) return;
+    const float d = a.delay[p], o = a.occ[p];
+    int hop = p | kDirFinal;
+    if (d > kDelayCloseDev && o < kDistanceGainDev) {
+        float nd;
+        const int n = dirBestNeighbour(a, p, &nd);
+        if (n >= 0) hop = (nd >= d || dirLineOfSight(a, n, nd)) ? (n | kDirFinal) : n;
+    }
+    J[p] = hop;
+}
+
+__global__ __launch_bounds__(256) void pv_dir_jump_kernel(int* J, int n) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const int h = J[p];
+    if (h < 0) return;  // final
+    J[p] = J[h];        // either the old or an already-updated entry of h: both describe the same walk
+}
+
+__global__ __launch_bounds__(256) void pv_dir_final_kernel(const AnalyzeArgs a, const int* J) {
+    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= a.gx * a.gy) return;
+    int fin = index;
+    if (a.occ[index] < kDistanceGainDev) {  // first iteration: delay = FLT_MAX, so only the loudness test applies
+        float nd;
+        const int n = dirBestNeighbour(a, index, &nd);
+        if (n >= 0) fin = dirLineOfSight(a, n, nd) ? n : (J[n] & ~kDirFinal);
+    }
+    const int r = fin / a.gy, c = fin - r * a.gy;
+    float ox = (float)r * a.dx - a.lx, oy = (float)c * a.dx - a.lz;
+    float len = (ox * ox) + (oy * oy);
+    if (len != 0.f) {
+        len = sqrtf(len);
+        ox /= len;
+        oy /= len;
+    }
+    a.res8[8 * (size_t)index + 4] = ox;
+    a.res8[8 * (size_t)index + 5] = oy;
+}
+
+static void launchDirectionJump(const AnalyzeArgs& a, int* J, hipStream_t stream) {
+    const int n = a.gx * a.gy;
+    const dim3 grid((n + 255) / 256), block(256);
+    hipLaunchKernelGGL(pv_dir_init_kernel, grid, block, 0, stream, a, J);
+    int rounds = 1;
+    while ((1 << rounds) < a.T + 2) ++rounds;  // chains are shorter than T (delays are distinct integers < T)
+    for (int i = 0; i < rounds + 1; ++i) hipLaunchKernelGGL(pv_dir_jump_kernel, grid, block, 0, stream, J, n);
+    hipLaunchKernelGGL(pv_dir_final_kernel, grid, block, 0, stream, a, J);
+}
+
 __global__ void pv_fill_delay_kernel(float* delay, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) delay[i] = FLT_MAX;  // Analyzer.cpp:64-68
@@ -1424,7 +1511,8 @@ void launchStreamFinalize(const AnalyzeArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(pv_stream_finalize_kernel, grid, dim3(256), 0, stream, a);
     if (a.numEmitters > 0)
         hipLaunchKernelGGL(pv_stream_emitter_kernel, dim3((a.numEmitters + 63) / 64), dim3(64), 0, stream, a);
-    hipLaunchKernelGGL(pv_direction_kernel, grid, dim3(256), 0, stream, a);
+    // T is large in this mode: resolve the delay-map descent by pointer jumping (the vx state plane is free now)
+    launchDirectionJump(a, reinterpret_cast<int*>(a.sVx), stream);
 }
 
 // FreeGrid::CalculateEFree + SimulateFreeFieldEnergy tail, FreeGrid.cpp:86-110: sequential float sum of p^2 over
