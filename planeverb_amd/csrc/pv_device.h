@@ -72,6 +72,8 @@ struct StepArgs {
     int bandRows;          // tile rows per XCD band = ceil(ntx / 8)
     int packed;            // air kernel: packed-f32 (v_pk_*) arithmetic variant
     int streamM;           // > 0: all-air chunks of streamM vertically adjacent tiles go to the row-streaming kernel
+    const uint8_t* tileOpen;    // streaming analysis only (else NULL): per tile, 1 while any of its cells still has an
+                                // open forward-analysis window, or the tile holds a registered emitter
     const uint8_t* nzIn;   // per tile: non-zero at the end of the previous launch (conservative)
     uint8_t* nzOut;        // per tile: non-zero at the end of this launch
     int tileOrder;         // air-kernel block -> tile mapping (0 linear, 1 XCD band row-major, 2 band column-major)
@@ -136,6 +138,7 @@ struct AnalyzeArgs {
     float* sFy;
     float* sVx;
     float* sVy;
+    uint8_t* tileOpenOut; // per tile: set to 1 by any cell whose window is still open after this pass
     const int* emCells;  // registered emitter cells: X*gy + Y
     float* emTrace;      // numEmitters x T pressure traces
     int numEmitters;

@@ -186,6 +186,20 @@ __device__ __forceinline__ void bufStoreF(float v, rsrc_t r, int voff, int soff)
 // listener is not inside it -- no coefficient reads, no pulse.  GENERAL = true: walls / grid edges / listener.
 // They are separate kernels (not one kernel with a wave-uniform branch) so that each gets its own register
 // allocation: the air tile needs 3*ROWS VGPRs plus a handful and must not inherit the general path's pressure.
+// Streaming-analysis mode: a tile's pressure history is only consumed while one of its cells -- or a cell of the
+// tile below / to the right, whose velocity reconstruction reads this tile's last row / column -- still has an open
+// forward-analysis window, or while it holds a registered emitter.  Once all of that is closed (N_dry samples after
+// the wave front passed), the tile stops writing history planes: in a 25 m scene at 4096^2 that is most tiles for
+// most of the 25 432 steps.
+__device__ __forceinline__ bool historyWanted(const StepArgs& a, int ti, int tj) {
+    if (!a.tileOpen) return true;
+    const int t = ti * a.nty + tj;
+    if (a.tileOpen[t]) return true;
+    if (ti + 1 < a.ntx && a.tileOpen[t + a.nty]) return true;
+    if (tj + 1 < a.nty && a.tileOpen[t + 1]) return true;
+    return false;
+}
+
 // A wave advances SUB interior rows (+ K halo rows either side) of tile `tile`; `part` selects which SUB-row slice
 // of the tile's RXI rows (air tiles: SUB == RXI, part 0; general tiles are split over RXI/SUB waves to shorten the
 // latency of that small, VALU-heavier kernel).
@@ -251,11 +265,11 @@ __device__ __forceinline__ void stepTile(const StepArgs& a, const int tile, cons
     // their slices are advanced by different waves, which could not otherwise agree on when recording starts.
     bool rec;
     if (GENERAL) {
-        rec = a.record && inWin;
+        rec = a.record && inWin && historyWanted(a, ti, tj);
         if (a.record && active && lane == 0) atomicMin(&a.tileFirst[tile], a.t0);
     } else {
         const bool wasActive = a.record && a.tileFirst[tile] != INT_MAX;
-        rec = a.record && inWin && (active || wasActive || a.dense);
+        rec = a.record && inWin && (active || wasActive || a.dense) && historyWanted(a, ti, tj);
         if (a.record && active && !wasActive && lane == 0) atomicMin(&a.tileFirst[tile], a.t0);
     }
     if (a.record && active && !inWin && lane == 0) atomicExch(a.errFlag, 1);
@@ -448,7 +462,7 @@ __device__ __forceinline__ void stepTileAirPacked(const StepArgs& a, const int t
     const int hti = ti - dyn.histTileX0, htj = tj - dyn.histTileY0;
     const bool inWin = hti >= 0 && hti < dyn.histTilesX && htj >= 0 && htj < dyn.histTilesY;
     const bool wasActive = a.record && a.tileFirst[tile] != INT_MAX;
-    const bool rec = a.record && inWin && (active || wasActive || a.dense);
+    const bool rec = a.record && inWin && (active || wasActive || a.dense) && historyWanted(a, ti, tj);
     if (a.record && active && !wasActive && lane == 0) atomicMin(&a.tileFirst[tile], a.t0);
     if (a.record && active && !inWin && lane == 0) atomicExch(a.errFlag, 1);
 
@@ -1347,6 +1361,8 @@ __global__ __launch_bounds__(256) void pv_stream_accum_kernel(const AnalyzeArgs 
     int sourceDirEnd = onset >= 0 ? onset + a.nDir : INT_MAX;
     int directEnd = onset >= 0 ? onset + a.nDry : INT_MAX;
     if (a.tA >= directEnd) return;  // this cell's dry window is closed
+    // a wall cell's pressure is identically zero: it never has an onset and must not keep its tile recording
+    if ((a.codes[(size_t)(X + a.G) * a.pitch + (Y + a.G)] & 0xffu) >= (unsigned)kLutWall) return;
 
     const int prow = X + a.G, pcol = Y + a.G;
     const long long hoff = (long long)(prow - dyn.histRow0) * a.histPitch + (pcol - dyn.histCol0);
@@ -1407,6 +1423,8 @@ __global__ __launch_bounds__(256) void pv_stream_accum_kernel(const AnalyzeArgs 
             }
         }
     }
+    // still open after this pass?  (no onset yet, or the dry window reaches past tB) -> keep the tile recording
+    if (onset < 0 || a.tB < directEnd) a.tileOpenOut[tile] = 1;
     a.sOnset[s] = onset;
     a.sEdry[s] = Edry;
     a.sFx[s] = fluxX;
@@ -1497,9 +1515,21 @@ __global__ void pv_stream_emitter_kernel(const AnalyzeArgs a) {
     o[2] = -60.f / slopePerSec;
 }
 
-void launchStreamAccum(const AnalyzeArgs& a, hipStream_t stream) {
+// tileOpen[tile] for the next launches: some cell marked it open in this pass, or the wave has not reached it yet,
+// or it holds a registered emitter (its whole trace is needed)
+__global__ void pv_stream_tilegate_kernel(const uint8_t* marks, const uint8_t* hasEmitter, const int* tileFirst, int tB,
+                                          uint8_t* tileOpen, int ntiles) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < ntiles) tileOpen[t] = (marks[t] || hasEmitter[t] || tileFirst[t] >= tB) ? 1 : 0;
+}
+
+void launchStreamAccum(const AnalyzeArgs& a, const uint8_t* hasEmitter, uint8_t* tileOpen, int ntiles,
+                       hipStream_t stream) {
     dim3 grid((a.gy + 255) / 256, a.gx);
+    hipMemsetAsync(a.tileOpenOut, 0, (size_t)ntiles, stream);
     hipLaunchKernelGGL(pv_stream_accum_kernel, grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(pv_stream_tilegate_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, stream, a.tileOpenOut,
+                       hasEmitter, a.tileFirst, a.tB, tileOpen, ntiles);
     const int n = a.numEmitters * (a.tB - a.tA);
     if (n > 0) hipLaunchKernelGGL(pv_stream_trace_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a);
 }

@@ -24,7 +24,8 @@ void launchSmallGrid(const SmallArgs& a, hipStream_t stream);
 void launchCodes(const uint8_t* mat, uint16_t* codes, const Geometry& g, hipStream_t stream);
 void launchLaneSelfTest(float* out128, hipStream_t stream);
 void launchAnalysis(const AnalyzeArgs& a, hipStream_t stream);
-void launchStreamAccum(const AnalyzeArgs& a, hipStream_t stream);
+void launchStreamAccum(const AnalyzeArgs& a, const uint8_t* hasEmitter, uint8_t* tileOpen, int ntiles,
+                       hipStream_t stream);
 void launchStreamFinalize(const AnalyzeArgs& a, hipStream_t stream);
 void launchEfree(const float* hist, long long plane, long long cellOff, int n, float r, float* out,
                  hipStream_t stream);

@@ -161,6 +161,9 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         if (!dalloc(&sOnset_, nres, true)) return false;
         for (auto& p : sState_)
             if (!dalloc(&p, nres, true)) return false;
+        if (!dalloc(&tileOpen_, (size_t)ntiles, true) || !dalloc(&tileMarks_, (size_t)ntiles, true) ||
+            !dalloc(&tileEmit_, (size_t)ntiles, true))
+            return false;
     }
     if (!hipOk(hipHostMalloc((void**)&dynHost_, sizeof(DynParams)), "hipHostMalloc")) return false;
     if (!hipOk(hipHostMalloc((void**)&listHost_, sizeof(int) * (size_t)listCap_), "hipHostMalloc")) return false;
@@ -200,6 +203,9 @@ Solver::~Solver() {
     for (float* p : sState_)
         if (p) hipFree(p);
     if (sOnset_) hipFree(sOnset_);
+    if (tileOpen_) hipFree(tileOpen_);
+    if (tileMarks_) hipFree(tileMarks_);
+    if (tileEmit_) hipFree(tileEmit_);
     if (emCells_) hipFree(emCells_);
     if (emTrace_) hipFree(emTrace_);
     void* ptrs[] = {codes_,     matDev_, lutDev_, pulseDev_, hist_,  tileFirst_, tileClass_, generalList_,
@@ -470,6 +476,7 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
     a.generalList = generalList_;
     a.numGeneral = launchCap_;
     a.dyn = dynDev_;
+    a.tileOpen = opt_.streaming ? tileOpen_ : nullptr;
     a.errFlag = errFlag_;
     a.histPlane = histPlane_;
     a.planeBytes = (long long)geo_.rows * geo_.pitch * 4;
@@ -614,6 +621,7 @@ AnalyzeArgs Solver::analyzeArgs(float lx, float lz) const {
     a.emCells = emCells_;
     a.emTrace = emTrace_;
     a.numEmitters = numEmitters_;
+    a.tileOpenOut = tileMarks_;
     return a;
 }
 
@@ -653,13 +661,17 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
         if (!hipOk(hipMemsetD32Async((hipDeviceptr_t)tileFirst_, INT_MAX, (size_t)ntiles, stream_), "tileFirst"))
             return false;
         if (!hipOk(hipMemsetAsync(errFlag_, 0, sizeof(int), stream_), "errFlag")) return false;
+        if (!hipOk(hipMemsetAsync(tileOpen_, 1, (size_t)ntiles, stream_), "tileOpen")) return false;
+        if (!hipOk(hipMemsetAsync(nz_[0], 0, (size_t)ntiles, stream_), "nz") ||
+            !hipOk(hipMemsetAsync(nz_[1], 0, (size_t)ntiles, stream_), "nz"))
+            return false;
         AnalyzeArgs aa = analyzeArgs(lx, lz);
         for (int tA = 0; tA < T_; tA += ring_) {
             const int n = std::min(ring_, T_ - tA);
             if (!enqueueSteps(tA, n, true, true)) return false;
             aa.tA = tA;
             aa.tB = tA + n;
-            launchStreamAccum(aa, stream_);
+            launchStreamAccum(aa, tileEmit_, tileOpen_, ntiles, stream_);
         }
         hipEventRecord(ev_[1], stream_);
         launchStreamFinalize(aa, stream_);
@@ -869,6 +881,11 @@ bool Solver::setEmitters(const float* xyz, int n) {
         if (!dalloc(&emCells_, (size_t)emCap_, true) || !dalloc(&emTrace_, (size_t)emCap_ * T_, true)) return false;
     }
     numEmitters_ = (int)cells.size();
+    {
+        std::vector<uint8_t> te((size_t)geo_.ntx * geo_.nty, 0);
+        for (int c : cells) te[(size_t)((c / g_.gy) / rxi_) * geo_.nty + (c % g_.gy) / wi_] = 1;
+        if (!hipOk(hipMemcpy(tileEmit_, te.data(), te.size(), hipMemcpyHostToDevice), "emitter tiles")) return false;
+    }
     if (numEmitters_ > 0 && !hipOk(hipMemcpy(emCells_, cells.data(), cells.size() * 4, hipMemcpyHostToDevice), "emitters"))
         return false;
     return true;

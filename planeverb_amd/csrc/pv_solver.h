@@ -150,6 +150,9 @@ private:
     int ring_ = 0;             // history planes allocated (T_ when not streaming)
     int* sOnset_ = nullptr;
     float* sState_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // Edry, fluxX, fluxY, vx, vy
+    uint8_t* tileOpen_ = nullptr;   // per tile: history still wanted (streaming mode)
+    uint8_t* tileMarks_ = nullptr;  // scratch of one accumulate pass
+    uint8_t* tileEmit_ = nullptr;   // per tile: holds a registered emitter
     int* emCells_ = nullptr;
     float* emTrace_ = nullptr;
     int numEmitters_ = 0, emCap_ = 0;
