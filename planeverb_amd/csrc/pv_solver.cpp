@@ -151,7 +151,9 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         size_t freeB = 0, totalB = 0;
         hipMemGetInfo(&freeB, &totalB);
         if ((unsigned long long)bytes + (1ull << 30) > freeB)
-            return fail("not enough HBM for the pressure history (" + std::to_string(bytes >> 20) + " MiB)");
+            return fail("not enough HBM for the pressure history (" + std::to_string(bytes >> 20) +
+                        " MiB for " + std::to_string(ring_) + " steps): use the sparse-emitter mode "
+                        "(PVA_OPT_STREAMING_ANALYSIS + PvAmdSetEmitters), which keeps a 64-step ring instead");
         if (!hipOk(hipMalloc((void**)&hist_, (size_t)bytes), "hipMalloc history")) return false;
         deviceBytes_ += bytes;
     }

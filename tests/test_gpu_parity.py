@@ -598,3 +598,9 @@ def test_row_streaming_kernel_equivalence(pvlib, M):
     (r0, h0), (r1, h1) = res
     assert same_bits(r0[0], r1[0]).all() and same_bits(r0[1], r1[1]).all()
     assert all(same_bits(a, b).all() for a, b in zip(h0, h1))
+
+
+def test_history_that_cannot_fit_fails_loudly(pvlib):
+    """a 25 m scene at 4096^2 needs T = 25 432 history planes (1.7 TB): refused with a pointer to the streaming mode"""
+    with pytest.raises(pvlib.PlaneverbError, match="sparse-emitter mode"):
+        pvlib.Solver(25.0, 25.0, 16067)
