@@ -92,6 +92,10 @@ def main():
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--dense-history", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--use-graph", type=int, default=0, help="0 auto (grids of <= 4096 tiles), 1 always, 2 never")
+    ap.add_argument("--time-kernels", type=int, default=0,
+                    help="N > 0: HIP events around every Nth step-kernel launch instead of around the whole launch loop "
+                         "(the extra events cost 0.2-0.5 ms per run)")
     args = ap.parse_args()
 
     import torch  # first: libplaneverb_amd.so then binds to the HIP runtime torch already loaded
@@ -117,7 +121,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     size = mode_a_size(args.grid)
-    opts = dict(time_kernels=3)  # HIP events around every 3rd step-kernel launch of the timed region
+    # roofline launch duration: HIP events on the solver's stream around the back-to-back step launches of every timed
+    # run (PvAmdTimings.stepLoopMs), or around every Nth single launch with --time-kernels N
+    opts = dict(time_kernels=args.time_kernels, use_graph=args.use_graph)
     if args.steps_per_launch:
         opts["steps_per_launch"] = args.steps_per_launch
     if args.tile_rows:
@@ -146,7 +152,7 @@ def main():
         s.run(listener(w))
     n_runs = args.steps * world
     local = {}
-    fdtd_ms, ana_ms, air_ms, gen_ms = [], [], [], []
+    fdtd_ms, ana_ms, air_ms, gen_ms, loop_ms = [], [], [], [], []
     sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -157,6 +163,7 @@ def main():
         ana_ms.append(t.analysisMs)
         air_ms.append(t.airKernelMs)
         gen_ms.append(t.generalKernelMs)
+        loop_ms.append(t.stepLoopMs)
     gathered = pvd.gather_outputs(local, n_runs, dist if use_dist else None, dev)  # the one RCCL gather
     sync()
     elapsed = time.perf_counter() - t0
@@ -170,8 +177,19 @@ def main():
         info = s.info
         K = info.stepsPerLaunch
         launches = s.timings().stepLaunches
-        air = float(np.mean(air_ms))  # ms per air-kernel launch, HIP events on the solver's stream (sampled launches)
-        steps_per_launch_avg = K  # every sampled launch advances K steps (the short remainder launch is the last one)
+        steps_per_launch_avg = K
+        if args.time_kernels > 0:
+            # sampled single launches (only full K-step launches are sampled)
+            air = float(np.mean(air_ms))
+            how = "HIP events around every %d. launch" % args.time_kernels
+        else:
+            # mean over the timed runs of (launch-loop time) / (T / K): the duration of one full K-step launch with
+            # the short remainder launch counted by its share of steps
+            air = float(np.mean(loop_ms)) * K / T
+            how = "HIP events around the %d back-to-back launches of each timed run, x K/T" % launches
+            if air == 0.0:  # the run was replayed from a hipGraph (<= 4096 tiles): events sit around the whole graph
+                air = float(np.mean(fdtd_ms)) * K / T
+                how = "HIP events around the graph replay (field reset + %d launches), x K/T" % launches
         achieved = ALG_BYTES_PER_CELL_STEP * cells * steps_per_launch_avg / (air * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -201,9 +219,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "pv_step_merged_kernel<K=%d,rows=%d> (air tiles + general slices, one launch per K "
                                    "steps)" % (K, info.tileRows),
-                         "launch_ms": air, "launches_per_run": launches,
+                         "launch_ms": air, "launch_ms_from": how, "launches_per_run": launches,
                          "algorithmic_bytes_per_launch": ALG_BYTES_PER_CELL_STEP * cells * steps_per_launch_avg,
-                         "general_kernel_launch_ms": float(np.mean(gen_ms)),
                          "note": "algorithmic = 24 B per cell-step x cells x K fused steps; K-step temporal "
                                  "blocking makes frac > 1 possible (SURVEY.md 8d)"},
         }

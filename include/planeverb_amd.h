@@ -115,6 +115,8 @@ typedef struct PvAmdTimings {
     float airKernelMs;      /* mean duration of one air-tile step-kernel launch (PVA_OPT_TIME_KERNELS) */
     float generalKernelMs;  /* mean duration of one general-tile step-kernel launch */
     int airLaunches, generalLaunches;
+    float stepLoopMs;       /* HIP-event time of the back-to-back step launches alone (fdtdMs minus the field reset);
+                               0 when the run was replayed from a hipGraph */
 } PvAmdTimings;
 
 /* option keys for PvAmdSetOption (must be set before the first run) */

@@ -61,7 +61,7 @@ class PvAmdInfo(C.Structure):
 class PvAmdTimings(C.Structure):
     _fields_ = [("fdtdMs", C.c_float), ("analysisMs", C.c_float), ("geometryMs", C.c_float),
                 ("stepKernelMs", C.c_float), ("stepLaunches", C.c_int), ("airKernelMs", C.c_float), ("generalKernelMs", C.c_float), ("airLaunches", C.c_int),
-                ("generalLaunches", C.c_int)]
+                ("generalLaunches", C.c_int), ("stepLoopMs", C.c_float)]
 
 
 # every symbol include/planeverb_amd.h declares: name -> (restype, argtypes)

@@ -288,6 +288,7 @@ int PvAmdGetTimings(PvAmdSolver* h, PvAmdTimings* out) {
     out->generalKernelMs = t.generalKernelMs;
     out->airLaunches = t.airLaunches;
     out->generalLaunches = t.generalLaunches;
+    out->stepLoopMs = t.stepLoopMs;
     return 0;
 }
 

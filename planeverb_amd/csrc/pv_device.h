@@ -84,6 +84,26 @@ struct StepArgs {
     int record;            // write pr history
     int dense;             // record even all-zero tiles
     float courant;
+    int inBytes;           // extent of the INPUT planes' buffer descriptors: planeBytes, or 0 for the first launch of a
+                           // run -- every field load is then out of range and returns 0 without touching memory,
+                           // which is the run's zero initial state (no reset pass over the planes)
+};
+
+// pv_begin_run_kernel: the per-run parameters travel from pinned host memory to HBM inside a kernel (a node of the
+// captured run graph like every other launch) together with the per-tile bookkeeping resets
+struct BeginArgs {
+    const DynParams* dynHost;  // pinned, device-visible
+    DynParams* dyn;
+    const int* listHost;       // pinned, dynHost->numGeneral live entries
+    int* list;
+    int* tileFirst;            // NULL = leave the per-tile state alone (stencil-only stepping)
+    uint8_t* nz0;
+    uint8_t* nz1;
+    uint8_t* tileOpen;         // streaming analysis only (else NULL): all tiles start open
+    int* errFlag;
+    int ntiles;
+    int tileFirstInit;         // INT_MAX (recorded from the first non-zero launch) or 0 (dense history)
+    int listCap;
 };
 
 // whole-grid-resident kernel for grids that fit one CU's LDS (pv_small_grid_kernel)

@@ -216,8 +216,8 @@ __device__ __forceinline__ void stepTile(const StepArgs& a, const int tile, cons
     const int pitchB = a.pitch * 4;
     const int soff0 = (row0 * a.pitch + col0) * 4;
 
-    const rsrc_t rPrIn = makeRsrc(a.prIn, a.planeBytes), rVxIn = makeRsrc(a.vxIn, a.planeBytes),
-                 rVyIn = makeRsrc(a.vyIn, a.planeBytes);
+    const rsrc_t rPrIn = makeRsrc(a.prIn, a.inBytes), rVxIn = makeRsrc(a.vxIn, a.inBytes),
+                 rVyIn = makeRsrc(a.vyIn, a.inBytes);
 
     float pr[ROWS], vx[ROWS], vy[ROWS];
     uint32_t cd[(ROWS + 1) / 2];
@@ -436,8 +436,8 @@ __device__ __forceinline__ void stepTileAirPacked(const StepArgs& a, const int t
     const int pitchB = a.pitch * 4;
     const int soff0 = (row0 * a.pitch + col0) * 4;
 
-    const rsrc_t rPrIn = makeRsrc(a.prIn, a.planeBytes), rVxIn = makeRsrc(a.vxIn, a.planeBytes),
-                 rVyIn = makeRsrc(a.vyIn, a.planeBytes);
+    const rsrc_t rPrIn = makeRsrc(a.prIn, a.inBytes), rVxIn = makeRsrc(a.vxIn, a.inBytes),
+                 rVyIn = makeRsrc(a.vyIn, a.inBytes);
     v2f pr[NP], vx[NP], vy[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -548,8 +548,8 @@ __global__ __launch_bounds__(256, WPS) void pv_step_stream_kernel(const StepArgs
     const int voff = lane * 4;
     const int pitchB = a.pitch * 4;
     const int soff0 = (row0 * a.pitch + col0) * 4;
-    const rsrc_t rPrIn = makeRsrc(a.prIn, a.planeBytes), rVxIn = makeRsrc(a.vxIn, a.planeBytes),
-                 rVyIn = makeRsrc(a.vyIn, a.planeBytes);
+    const rsrc_t rPrIn = makeRsrc(a.prIn, a.inBytes), rVxIn = makeRsrc(a.vxIn, a.inBytes),
+                 rVyIn = makeRsrc(a.vyIn, a.inBytes);
     const rsrc_t rPrOut = makeRsrc(a.prOut, a.planeBytes), rVxOut = makeRsrc(a.vxOut, a.planeBytes),
                  rVyOut = makeRsrc(a.vyOut, a.planeBytes);
 
@@ -857,7 +857,8 @@ void launchTileClass(int K, int rxi, const uint16_t* codes, uint8_t* tileClass, 
 #undef X
 }
 
-// configurations whose merged (single-launch) kernel allocates without spills
+// configurations whose merged (single-launch) kernel allocates without spills in the air-tile path (K = 8 keeps one
+// 4-byte spill in the general-slice path, outside the air tiles' code; measured: no effect on the launch time)
 bool mergedConfigOk(int K, int rxi) { return (K == 8 && rxi == 24) || (K == 4 && rxi == 32) || (K == 6 && rxi == 28); }
 
 bool stepConfigSupported(int K, int rxi) {
@@ -866,6 +867,39 @@ bool stepConfigSupported(int K, int rxi) {
     PV_STEP_CONFIGS(X)
 #undef X
     return false;
+}
+
+// First node of every run: per-run parameters (listener cell, history window, general-tile list) from pinned host
+// memory into HBM, per-tile bookkeeping back to "never non-zero".  Doing this in a kernel keeps the whole run a
+// chain of kernel nodes (no DMA copy or memset node whose ordering against a graph replay would matter).
+__global__ void pv_begin_run_kernel(BeginArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = min(a.dynHost->numGeneral, a.listCap);
+    if (i < n) a.list[i] = a.listHost[i];
+    if (i == 0) {
+        *a.dyn = *a.dynHost;
+        *a.errFlag = 0;
+    }
+    if (a.tileFirst && i < a.ntiles) {
+        a.tileFirst[i] = a.tileFirstInit;
+        a.nz0[i] = 0;
+        a.nz1[i] = 0;
+        if (a.tileOpen) a.tileOpen[i] = 1;
+    }
+}
+
+__global__ void pv_zero_kernel(float4* p, long long n4) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n4) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+void launchZero(float* p, long long n, hipStream_t stream) {
+    const long long n4 = n / 4;
+    hipLaunchKernelGGL(pv_zero_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, (float4*)p, n4);
+}
+
+void launchBeginRun(const BeginArgs& a, hipStream_t stream) {
+    const int n = a.ntiles > a.listCap ? a.ntiles : a.listCap;
+    hipLaunchKernelGGL(pv_begin_run_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a);
 }
 
 void launchCodes(const uint8_t* mat, uint16_t* codes, const Geometry& g, hipStream_t stream) {

@@ -21,6 +21,8 @@ void launchTileClass(int K, int rxi, const uint16_t* codes, uint8_t* tileClass, 
 // cells = NX*NY must satisfy smallGridFits()
 bool smallGridFits(int NX, int NY);
 void launchSmallGrid(const SmallArgs& a, hipStream_t stream);
+void launchZero(float* p, long long n, hipStream_t stream);
+void launchBeginRun(const BeginArgs& a, hipStream_t stream);
 void launchCodes(const uint8_t* mat, uint16_t* codes, const Geometry& g, hipStream_t stream);
 void launchLaneSelfTest(float* out128, hipStream_t stream);
 void launchAnalysis(const AnalyzeArgs& a, hipStream_t stream);

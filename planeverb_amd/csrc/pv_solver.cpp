@@ -457,17 +457,30 @@ bool Solver::prepareDyn(int lcx, int lcy, bool withPulse) {
     numGeneral_ = n;
     dynCur_.numGeneral = n;
     dynHost_->numGeneral = n;
-    if (n > 0 && !hipOk(hipMemcpyAsync(generalList_, listHost_, sizeof(int) * (size_t)n, hipMemcpyHostToDevice,
-                                       stream_),
-                        "list upload"))
-        return false;
-    if (!hipOk(hipMemcpyAsync(dynDev_, dynHost_, sizeof(DynParams), hipMemcpyHostToDevice, stream_), "dyn upload"))
-        return false;
     dynValid_ = true;
     return true;
 }
 
-bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record) {
+// prepareDyn() left the run's parameters in pinned host memory; this launch moves them to HBM and resets the
+// per-tile bookkeeping (see pv_begin_run_kernel).  It is captured into the run graph with the step launches.
+void Solver::enqueueBeginRun(bool resetTiles) {
+    BeginArgs b{};
+    b.dynHost = dynHost_;
+    b.dyn = dynDev_;
+    b.listHost = listHost_;
+    b.list = generalList_;
+    b.tileFirst = resetTiles ? tileFirst_ : nullptr;
+    b.nz0 = nz_[0];
+    b.nz1 = nz_[1];
+    b.tileOpen = opt_.streaming ? tileOpen_ : nullptr;
+    b.errFlag = errFlag_;
+    b.ntiles = geo_.ntx * geo_.nty;
+    b.tileFirstInit = opt_.denseHistory ? 0 : INT_MAX;
+    b.listCap = listCap_;
+    launchBeginRun(b, stream_);
+}
+
+bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record, bool fromZero) {
     StepArgs a{};
     a.codes = codes_;
     a.lut = lutDev_;
@@ -516,6 +529,16 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
         hipEventRecord(forkEv_, stream_);  // everything enqueued so far (reset, dyn upload, list upload)
         hipStreamWaitEvent(stream2_, forkEv_, 0);
     }
+    // A run starts from zero fields.  The first launch gets zero-extent input descriptors (its loads return 0) and
+    // overwrites the other buffer set completely, so no reset pass over the planes exists; only the experimental
+    // row-streaming kernel still wants real zeros.  (No hipMemsetAsync here on purpose: as nodes of a replayed graph the three large plane
+    // memsets were observed to be skipped after a hipDeviceSynchronize on ROCm 7.0's runtime.)
+    if (fromZero && opt_.streamRows > 0) {
+        const long long n = (long long)geo_.rows * geo_.pitch;
+        launchZero(pr_[cur_], n, stream_);
+        launchZero(vx_[cur_], n, stream_);
+        launchZero(vy_[cur_], n, stream_);
+    }
     int done = 0, li = 0;
     while (done < nsteps) {
         const int k = std::min(K_, nsteps - done);
@@ -528,6 +551,7 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
         a.t0 = firstStep + done;
         a.histSlot = opt_.streaming ? a.t0 % ring_ : a.t0;
         a.nsteps = k;
+        a.inBytes = (fromZero && done == 0 && opt_.streamRows == 0) ? 0 : (int)a.planeBytes;
         a.streamM = (k == K_) ? opt_.streamRows : 0;  // the streaming kernel always advances exactly K levels
         a.nzIn = nz_[li & 1];
         a.nzOut = nz_[(li & 1) ^ 1];
@@ -637,6 +661,7 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
     lastLz_ = lz;
     tim_.stepLaunches = 0;
     kevUsed_ = 0;
+    loopTimed_ = false;
     cur_ = 0;  // the reset clears set 0; a run never depends on the previous run's fields
     hipEventRecord(ev_[0], stream_);
     const int ntiles = geo_.ntx * geo_.nty;
@@ -655,22 +680,11 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
             !hipOk(hipMemsetAsync(emTrace_, 0, (size_t)numEmitters_ * T_ * 4, stream_), "trace reset"))
             return false;
         launchCap_ = numGeneral_;
-        const size_t planeBytes = (size_t)geo_.rows * geo_.pitch * 4;
-        if (!hipOk(hipMemsetAsync(pr_[cur_], 0, planeBytes, stream_), "reset") ||
-            !hipOk(hipMemsetAsync(vx_[cur_], 0, planeBytes, stream_), "reset") ||
-            !hipOk(hipMemsetAsync(vy_[cur_], 0, planeBytes, stream_), "reset"))
-            return false;
-        if (!hipOk(hipMemsetD32Async((hipDeviceptr_t)tileFirst_, INT_MAX, (size_t)ntiles, stream_), "tileFirst"))
-            return false;
-        if (!hipOk(hipMemsetAsync(errFlag_, 0, sizeof(int), stream_), "errFlag")) return false;
-        if (!hipOk(hipMemsetAsync(tileOpen_, 1, (size_t)ntiles, stream_), "tileOpen")) return false;
-        if (!hipOk(hipMemsetAsync(nz_[0], 0, (size_t)ntiles, stream_), "nz") ||
-            !hipOk(hipMemsetAsync(nz_[1], 0, (size_t)ntiles, stream_), "nz"))
-            return false;
+        enqueueBeginRun(true);
         AnalyzeArgs aa = analyzeArgs(lx, lz);
         for (int tA = 0; tA < T_; tA += ring_) {
             const int n = std::min(ring_, T_ - tA);
-            if (!enqueueSteps(tA, n, true, true)) return false;
+            if (!enqueueSteps(tA, n, true, true, tA == 0)) return false;
             aa.tA = tA;
             aa.tB = tA + n;
             launchStreamAccum(aa, tileEmit_, tileOpen_, ntiles, stream_);
@@ -683,8 +697,8 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
     }
     if (small) {
         // the whole grid lives in one CU's LDS for all T steps: one launch, every cell recorded from step 0
+        enqueueBeginRun(false);
         if (!hipOk(hipMemsetAsync(tileFirst_, 0, sizeof(int) * (size_t)ntiles, stream_), "tileFirst")) return false;
-        if (!hipOk(hipMemsetAsync(errFlag_, 0, sizeof(int), stream_), "errFlag")) return false;
         SmallArgs sa{};
         sa.prOut = pr_[0];
         sa.vxOut = vx_[0];
@@ -727,24 +741,15 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
 
 // reset pr / vx / vy (FDTD.cpp:109-119) + the T-step loop; this is what a captured graph contains
 bool Solver::enqueueResetAndSteps() {
-    const size_t planeBytes = (size_t)geo_.rows * geo_.pitch * 4;
-    // the other set is fully overwritten by the first launch
-    if (!hipOk(hipMemsetAsync(pr_[cur_], 0, planeBytes, stream_), "reset") ||
-        !hipOk(hipMemsetAsync(vx_[cur_], 0, planeBytes, stream_), "reset") ||
-        !hipOk(hipMemsetAsync(vy_[cur_], 0, planeBytes, stream_), "reset"))
-        return false;
-    const int ntiles = geo_.ntx * geo_.nty;
-    if (opt_.denseHistory) {
-        if (!hipOk(hipMemsetAsync(tileFirst_, 0, sizeof(int) * (size_t)ntiles, stream_), "tileFirst")) return false;
-    } else {
-        if (!hipOk(hipMemsetD32Async((hipDeviceptr_t)tileFirst_, INT_MAX, (size_t)ntiles, stream_), "tileFirst"))
-            return false;
+    enqueueBeginRun(true);
+    // graph capture cannot hold timing events; plain launches get one more event so that the launch loop is timed alone
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    hipStreamIsCapturing(stream_, &cs);
+    if (cs == hipStreamCaptureStatusNone) {
+        hipEventRecord(ev_[3], stream_);
+        loopTimed_ = true;
     }
-    if (!hipOk(hipMemsetAsync(errFlag_, 0, sizeof(int), stream_), "errFlag")) return false;
-    if (!hipOk(hipMemsetAsync(nz_[0], 0, (size_t)ntiles, stream_), "nz") ||
-        !hipOk(hipMemsetAsync(nz_[1], 0, (size_t)ntiles, stream_), "nz"))
-        return false;
-    return enqueueSteps(0, T_, true, true);
+    return enqueueSteps(0, T_, true, true, true);
 }
 
 void Solver::dropGraph() {
@@ -796,6 +801,8 @@ bool Solver::sync() {
         pendingTimings_ = false;
         hipEventElapsedTime(&tim_.fdtdMs, ev_[0], ev_[1]);
         hipEventElapsedTime(&tim_.analysisMs, ev_[1], ev_[2]);
+        tim_.stepLoopMs = 0.f;
+        if (loopTimed_) hipEventElapsedTime(&tim_.stepLoopMs, ev_[3], ev_[1]);
         if (opt_.timeKernels && kevUsed_ > 0) {
             double air = 0, gen = 0;
             const int n = kevUsed_ / 4;
@@ -826,7 +833,9 @@ bool Solver::runSteps(int nsteps, bool withPulse, float lx, float lz) {
     if (!prepareDyn(lcx, lcy, withPulse)) return false;
     tim_.stepLaunches = 0;
     kevUsed_ = 0;
+    loopTimed_ = false;
     launchCap_ = numGeneral_;
+    enqueueBeginRun(false);
     hipEventRecord(ev_[0], stream_);
     if (!enqueueSteps(0, nsteps, withPulse, false)) return false;
     hipEventRecord(ev_[1], stream_);

@@ -37,6 +37,7 @@ struct SolverOptions {
 
 struct SolverTimings {
     float fdtdMs = 0, analysisMs = 0, geometryMs = 0;
+    float stepLoopMs = 0;  // the back-to-back step launches alone (fdtdMs minus the field reset); 0 when replayed from a graph
     float airKernelMs = 0, generalKernelMs = 0;  // mean duration per launch (timeKernels only)
     int airLaunches = 0, generalLaunches = 0;
     int stepLaunches = 0;
@@ -95,8 +96,9 @@ private:
     bool applyGeometry();
     bool computeEfree();
     bool enqueueRun(int lcx, int lcy, float lx, float lz);
-    bool enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record);
+    bool enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record, bool fromZero = false);
     bool prepareDyn(int lcx, int lcy, bool withPulse);
+    void enqueueBeginRun(bool resetTiles);
     AnalyzeArgs analyzeArgs(float lx, float lz) const;
     bool fail(const std::string& what);
     bool hipOk(hipError_t e, const char* what);
@@ -189,6 +191,7 @@ private:
     int kevUsed_ = 0;
     SolverTimings tim_;
     bool pendingTimings_ = false;
+    bool loopTimed_ = false;  // ev_[3] was recorded between the reset and the first step launch of this run
 };
 
 }  // namespace pva

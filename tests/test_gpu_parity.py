@@ -604,3 +604,44 @@ def test_history_that_cannot_fit_fails_loudly(pvlib):
     """a 25 m scene at 4096^2 needs T = 25 432 history planes (1.7 TB): refused with a pointer to the streaming mode"""
     with pytest.raises(pvlib.PlaneverbError, match="sparse-emitter mode"):
         pvlib.Solver(25.0, 25.0, 16067)
+
+
+_GRAPH_SYNC_SCRIPT = r"""
+import os, sys
+import numpy as np
+import torch                      # first, as in bench.py: the library then binds to torch's bundled HIP runtime
+torch.cuda.set_device(0)
+sys.path.insert(0, sys.argv[1])
+import planeverb_amd.api as pv
+dx = 343.21 / 275 / 3.5
+size = (2048 + 0.5) * dx
+listeners = [(5, 4), (8, 8), (5, 4), (8, 8), (12, 6), (15, 15), (20, 5), (5, 20)]
+outs = {}
+for name, ug in (("graph", 1), ("plain", 2)):
+    with pv.Solver(size, size, 275, use_graph=ug) as s:
+        s.load_scene(os.path.join(sys.argv[1], "tests", "scenes", "HugeRoom.pv"))
+        o = []
+        for n, (x, z) in enumerate(listeners):
+            if n == 2:
+                torch.cuda.synchronize()
+            s.run((float(x), 0.0, float(z)))
+            o.append(np.stack([s.get_output(e).as_array() for e in [(x, 0.0, z + 2.0), (5.0, 0.0, 6.0)]]))
+        outs[name] = np.stack(o).view(np.uint32)
+assert (outs["graph"] == outs["plain"]).all()
+print("REPLAY-OK")
+"""
+
+
+def test_graph_replay_survives_device_sync(pvlib):
+    """Regression: a run replayed from the captured hipGraph must start from zero fields every time.  The reset used
+    to be three hipMemsetAsync nodes; after a device-wide synchronize (which torch.cuda.synchronize() issues in
+    bench.py, on torch's bundled ROCm 7.0 runtime) later replays skipped them, the previous run's wave kept spreading
+    and left the history window.  The run now has no memset / copy nodes at all (zero-extent input descriptors on
+    the first launch, parameters uploaded by a kernel); graph replays must equal plain launches for a moving
+    listener.  Own process: torch has to be imported before the library, as bench.py does."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _GRAPH_SYNC_SCRIPT, root], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "REPLAY-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
