@@ -840,7 +840,9 @@ static void launchTileClassT(const uint16_t* codes, uint8_t* tileClass, int* lis
 
 // (K steps per launch, interior rows per tile, waves/SIMD bound of the air kernel, rows per general-tile slice)
 #define PV_STEP_CONFIGS(X) \
-    X(4, 32, 3, 8) X(4, 24, 4, 6) X(2, 28, 4, 7) X(1, 30, 4, 15) X(8, 24, 3, 12) X(6, 28, 3, 14) X(3, 26, 4, 13)
+    X(4, 32, 3, 8) X(4, 24, 4, 6) X(2, 28, 4, 7) X(1, 30, 4, 15) X(8, 24, 3, 12) X(6, 28, 3, 14) X(3, 26, 4, 13) \
+    X(8, 48, 2, 12) X(12, 40, 2, 10) X(8, 40, 2, 10) X(12, 32, 2, 8) X(10, 36, 2, 9) X(8, 44, 2, 11) X(10, 40, 2, 10) X(12, 36, 2, 9) \
+    X(9, 42, 2, 14) X(11, 36, 2, 9) X(9, 40, 2, 10)
 
 void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream, int which, hipStream_t stream2) {
 #define X(k, r, w, sub) \
@@ -859,7 +861,9 @@ void launchTileClass(int K, int rxi, const uint16_t* codes, uint8_t* tileClass, 
 
 // configurations whose merged (single-launch) kernel allocates without spills in the air-tile path (K = 8 keeps one
 // 4-byte spill in the general-slice path, outside the air tiles' code; measured: no effect on the launch time)
-bool mergedConfigOk(int K, int rxi) { return (K == 8 && rxi == 24) || (K == 4 && rxi == 32) || (K == 6 && rxi == 28); }
+bool mergedConfigOk(int K, int rxi) {
+    return (K == 8 && rxi == 24) || (K == 4 && rxi == 32) || (K == 6 && rxi == 28) || K >= 10 || rxi >= 40;
+}
 
 bool stepConfigSupported(int K, int rxi) {
 #define X(k, r, w, sub) \

@@ -14,7 +14,7 @@
 namespace pva {
 
 namespace {
-constexpr int kGuard = 8;  // >= the largest K instantiated in pv_kernels.hip
+constexpr int kMinGuard = 8;  // guard width = max(this, K): a tile's halo never leaves the allocation
 inline int roundUp(int v, int m) { return (v + m - 1) / m * m; }
 inline int ceilDiv(int a, int b) { return (a + b - 1) / b; }
 inline int floorDiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
@@ -70,8 +70,23 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     for (auto& e : ev_)
         if (!hipOk(hipEventCreate(&e), "hipEventCreate")) return false;
 
-    K_ = opt.K > 0 ? opt.K : 8;  // defaults = fastest measured configuration on MI355X at 2048^2 .. 8192^2
-    rxi_ = opt.rxi > 0 ? opt.rxi : 24;
+    // Default tile = fastest measured on MI355X for the grid's size class (tools/gpu_tune.py).  Large grids take the
+    // 60-row tile at 2 waves/SIMD (K = 10: 40 x 44 interior cells of 60 x 64 loaded, 2.2x less halo traffic per step
+    // than the 40-row tile); it needs >= 4096 tiles to fill 256 CUs x 8 waves twice over.  Small grids are bound by
+    // launch latency and prefer many small tiles.
+    if (opt.K > 0 || opt.rxi > 0) {
+        K_ = opt.K > 0 ? opt.K : 8;
+        rxi_ = opt.rxi > 0 ? opt.rxi : 24;
+    } else if ((long long)ceilDiv(g_.NX, 40) * ceilDiv(g_.NY, 44) >= 4096) {
+        K_ = 10;
+        rxi_ = 40;
+    } else if ((long long)ceilDiv(g_.NX, 40) * ceilDiv(g_.NY, 48) >= 2048) {
+        K_ = 8;
+        rxi_ = 40;
+    } else {
+        K_ = 8;
+        rxi_ = 24;
+    }
     if (!stepConfigSupported(K_, rxi_)) return fail("unsupported (stepsPerLaunch, tileRows) configuration");
     wi_ = 64 - 2 * K_;
     T_ = opt.numSteps > 0 ? opt.numSteps : g_.T;
@@ -80,6 +95,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     geo_.gy = g_.gy;
     geo_.NX = g_.NX;
     geo_.NY = g_.NY;
+    const int kGuard = std::max(kMinGuard, K_);
     geo_.G = kGuard;
     geo_.rxi = rxi_;
     geo_.wi = wi_;
@@ -398,11 +414,9 @@ bool Solver::computeEfree() {
         qy = ey;
     }
     SolverOptions o;
-    o.K = K_;
-    o.rxi = rxi_;
-    o.withFreeGrid = false;
+    o.withFreeGrid = false;  // (tile configuration: the child's own default for its size)
     o.skipAnalysis = true;
-    o.numSteps = roundUp(n, K_);
+    o.numSteps = roundUp(n, 8);
     std::string e;
     Solver* f = Solver::create(fs, device_, o, &e);
     if (!f) return fail("free grid: " + e);
@@ -667,8 +681,9 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
     const int ntiles = geo_.ntx * geo_.nty;
     const bool graph = !opt_.timeKernels && !opt_.streaming &&
                        (opt_.useGraph == 1 || (opt_.useGraph == 0 && ntiles <= 4096));
-    const bool small = opt_.smallGrid != 2 && !opt_.timeKernels && opt_.useGraph != 1 && !opt_.streaming &&
-                       smallGridFits(g_.NX, g_.NY) &&
+    // (an explicit tile configuration means "use the tile kernels")
+    const bool small = opt_.smallGrid != 2 && opt_.K == 0 && opt_.rxi == 0 && !opt_.timeKernels &&
+                       opt_.useGraph != 1 && !opt_.streaming && smallGridFits(g_.NX, g_.NY) &&
                        histTilesX_ == geo_.ntx && histTilesY_ == geo_.nty;
     if (opt_.streaming) {
         // sparse-emitter mode: ring history; forward sums advanced after every `ring_` steps

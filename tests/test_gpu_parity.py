@@ -86,6 +86,13 @@ def test_golden_small(pvlib, name):
 @pytest.mark.parametrize("opts", [dict(steps_per_launch=1, tile_rows=30), dict(steps_per_launch=2, tile_rows=28),
                                   dict(steps_per_launch=3, tile_rows=26), dict(steps_per_launch=4, tile_rows=24), dict(steps_per_launch=4, tile_rows=32),
                                   dict(steps_per_launch=6, tile_rows=28), dict(steps_per_launch=8, tile_rows=24),
+                                  dict(steps_per_launch=8, tile_rows=40), dict(steps_per_launch=10, tile_rows=40),
+                                  dict(steps_per_launch=10, tile_rows=36), dict(steps_per_launch=12, tile_rows=32),
+                                  dict(steps_per_launch=8, tile_rows=44), dict(steps_per_launch=12, tile_rows=36),
+                                  dict(steps_per_launch=9, tile_rows=42), dict(steps_per_launch=11, tile_rows=36),
+                                  dict(steps_per_launch=9, tile_rows=40), dict(steps_per_launch=8, tile_rows=48),
+                                  dict(steps_per_launch=12, tile_rows=40), dict(steps_per_launch=10, tile_rows=40, packed_math=0),
+                                  dict(steps_per_launch=10, tile_rows=40, merged_launch=0),
                                   dict(dense_history=1), dict(use_graph=1), dict(use_graph=2),
                                   dict(small_grid_kernel=2), dict(small_grid_kernel=2, use_graph=2), dict(small_grid_kernel=2, packed_math=0), dict(small_grid_kernel=2, merged_launch=0),
                                   dict(small_grid_kernel=2, merged_launch=0, use_graph=2)])

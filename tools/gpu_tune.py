@@ -26,8 +26,10 @@ def run(n, reps=4, **opts):
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-    for order in (0, 1, 2):
-        for K, rows in ((4, 32), (8, 24), (6, 28)):
-            run(n, steps_per_launch=K, tile_rows=rows, tile_order=order)
-    run(n, steps_per_launch=4, tile_rows=32, tile_order=0, time_kernels=1)
-    run(n, steps_per_launch=8, tile_rows=24, tile_order=0, time_kernels=1)
+    cfgs = [tuple(int(v) for v in c.split(",")) for c in sys.argv[2:]] or [(4, 32), (8, 24), (6, 28)]
+    for rep in range(2):
+        for K, rows in cfgs:
+            try:
+                run(n, steps_per_launch=K, tile_rows=rows)
+            except pv.PlaneverbError as e:
+                print("K=%d rows=%d: %s" % (K, rows, e))
