@@ -37,6 +37,8 @@ namespace pva {
 #endif
 
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 // value held by lane+1 (lane 63 receives an unspecified value; it is always a halo lane)
 __device__ __forceinline__ float laneNext(float v) {
 #if PV_USE_DPP
@@ -56,6 +58,29 @@ __device__ __forceinline__ float lanePrev(float v) {
         float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
 #else
     return __shfl_up(v, 1);
+#endif
+}
+
+// t = v - (value held by lane-1) for two row pairs (4 floats) in 4 instructions: v_subrev_f32_dpp computes
+// src1 - dpp(src0), the lane shift rides on the subtract.  The compiler folds laneNext(v) - v like this by itself
+// but leaves this operand order as shift + subtract, hence the asm.  gfx9-family ISAs need 2 wait states between a
+// VALU write of a VGPR and a DPP read of it, and the compiler's hazard recogniser cannot see into inline asm: the
+// leading s_nop 1 covers the inputs, and the outputs are early-clobber so they never alias a later input.
+__device__ __forceinline__ void subLanePrev2(const v2f a, const v2f b, v2f& ta, v2f& tb) {
+#if PV_USE_DPP
+    float t0, t1, t2, t3;
+    asm("s_nop 1\n\t"
+        "v_subrev_f32_dpp %0, %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_subrev_f32_dpp %1, %5, %5 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_subrev_f32_dpp %2, %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_subrev_f32_dpp %3, %7, %7 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y));
+    ta = v2f{t0, t1};
+    tb = v2f{t2, t3};
+#else
+    ta = v2f{a.x - lanePrev(a.x), a.y - lanePrev(a.y)};
+    tb = v2f{b.x - lanePrev(b.x), b.y - lanePrev(b.y)};
 #endif
 }
 
@@ -338,7 +363,6 @@ __device__ __forceinline__ void stepTile(const StepArgs& a, const int tile, cons
 // y-direction difference and every multiply / subtract is one packed op per two cells; x-direction differences need
 // the row-shifted pair (p[r-1], p[r]), built with one v_pk_mov-style shuffle per pair.  Per-element arithmetic and
 // its order are unchanged (packed ops are IEEE per half), so the fields stay bit-identical.
-typedef float v2f __attribute__((ext_vector_type(2)));
 
 // ILP: the three sweeps are written breadth-first over groups of G row pairs (all shuffles, then all differences,
 // then all multiplies ...) so that consecutive instructions of a wave are independent; written row by row the
@@ -357,16 +381,15 @@ __device__ __forceinline__ void leapfrogStepPacked(v2f (&pr)[NP], v2f (&vx)[NP],
             if (i < NP) {
                 vxs[g] = (i + 1 < NP) ? __builtin_shufflevector(vx[i], vx[i + 1], 1, 2)
                                       : __builtin_shufflevector(vx[i], vx[i], 1, 1);  // last row: halo garbage
-                vyr[g].x = laneNext(vy[i].x);
-                vyr[g].y = laneNext(vy[i].y);
+                // y-differences as two scalar subtracts: the lane shift folds into the subtract (v_sub_f32_dpp), one
+                // instruction per cell pair less than shift + shift + packed subtract
+                vyr[g].x = laneNext(vy[i].x) - vy[i].x;
+                vyr[g].y = laneNext(vy[i].y) - vy[i].y;
             }
         }
 #pragma unroll
         for (int g = 0; g < G; ++g)
             if (i0 + g < NP) vxs[g] = vxs[g] - vx[i0 + g];
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-            if (i0 + g < NP) vyr[g] = vyr[g] - vy[i0 + g];
 #pragma unroll
         for (int g = 0; g < G; ++g)
             if (i0 + g < NP) d[g] = vxs[g] + vyr[g];
@@ -403,16 +426,15 @@ __device__ __forceinline__ void leapfrogStepPacked(v2f (&pr)[NP], v2f (&vx)[NP],
     for (int i0 = 0; i0 < NP; i0 += G) {
         v2f t[G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
+        for (int g = 0; g < G; g += 2) {
             const int i = i0 + g;
-            if (i < NP) {
-                t[g].x = lanePrev(pr[i].x);
-                t[g].y = lanePrev(pr[i].y);
+            if (i + 1 < NP) {
+                subLanePrev2(pr[i], pr[i + 1], t[g], t[g + 1]);
+            } else if (i < NP) {
+                v2f unused;
+                subLanePrev2(pr[i], pr[i], t[g], unused);
             }
         }
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-            if (i0 + g < NP) t[g] = pr[i0 + g] - t[g];
 #pragma unroll
         for (int g = 0; g < G; ++g)
             if (i0 + g < NP) t[g] = c2 * t[g];

@@ -163,3 +163,22 @@ def test_device_libm_matches_host_libm(tmp_path):
     r = subprocess.run([exe, "97"], capture_output=True, text=True)
     out = json.loads(r.stdout)
     assert r.returncode == 0 and out["log10f_mismatches"] == 0 and out["powf_mismatches"] == 0 and out["values"] > 2e7
+
+
+def test_inline_asm_dpp_has_no_pipeline_hazard(tmp_path):
+    """the packed air-tile kernel subtracts a lane-shifted operand with an inline-asm v_subrev_f32_dpp; gfx9-family
+    ISAs need 2 wait states between a VALU write of a VGPR and a DPP read of it and the compiler cannot see into
+    inline asm -- scan the generated gfx950 assembly of every instantiation (tools/check_dpp_hazard.py)"""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    asm = str(tmp_path / "pv_kernels.s")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
+                           "-std=c++17", "-S", "--cuda-device-only", "-w",
+                           os.path.join(ROOT, "planeverb_amd", "csrc", "pv_kernels.hip"), "-o", asm])
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dpp_hazard.py"), asm],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
