@@ -71,18 +71,16 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         if (!hipOk(hipEventCreate(&e), "hipEventCreate")) return false;
 
     // Default tile = fastest measured on MI355X for the grid's size class (tools/gpu_tune.py).  Large grids take the
-    // 60-row tile at 2 waves/SIMD (K = 10: 40 x 44 interior cells of 60 x 64 loaded, 2.2x less halo traffic per step
-    // than the 40-row tile); it needs >= 4096 tiles to fill 256 CUs x 8 waves twice over.  Small grids are bound by
-    // launch latency and prefer many small tiles.
+    // 60-row tile at 2 waves/SIMD with K = 12 (36 x 40 interior cells of the 60 x 64 loaded: 3.7 B of CU-level
+    // traffic per cell-step instead of 4.8 for the 40-row tile at K = 8); it needs several thousand tiles to fill
+    // 256 CUs x 8 waves a few times over.  Smaller grids are bound by launch latency and wave quantisation and
+    // prefer many small tiles.
     if (opt.K > 0 || opt.rxi > 0) {
         K_ = opt.K > 0 ? opt.K : 8;
         rxi_ = opt.rxi > 0 ? opt.rxi : 24;
-    } else if ((long long)ceilDiv(g_.NX, 40) * ceilDiv(g_.NY, 44) >= 4096) {
-        K_ = 10;
-        rxi_ = 40;
-    } else if ((long long)ceilDiv(g_.NX, 40) * ceilDiv(g_.NY, 48) >= 2048) {
-        K_ = 8;
-        rxi_ = 40;
+    } else if ((long long)ceilDiv(g_.NX, 36) * ceilDiv(g_.NY, 40) >= 8192) {
+        K_ = 12;
+        rxi_ = 36;
     } else {
         K_ = 8;
         rxi_ = 24;
