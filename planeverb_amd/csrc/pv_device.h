@@ -131,9 +131,11 @@ struct AnalyzeArgs {
     const float* lut;
     const int* tileFirst;
     const DynParams* dyn;
-    float* res8;   // gx*gy*8
+    float* out;    // 8 planes of gx*gy floats (SoA): occlusion, wet gain, RT60, lowpass, direction x/y, source
+                   // direction x/y -- plane k of cell s at out[k*resN + s].  The AoS view the C-ABI hands out
+                   // (PlaneverbOutput per cell) is packed on demand (pv_pack_results_kernel)
     float* delay;  // gx*gy
-    float* occ;    // gx*gy: occlusion again as its own plane (coalesced neighbour reads in the direction kernel)
+    long long resN;  // gx*gy
     long long histPlane;
     int histPitch;
     int pitch, G;

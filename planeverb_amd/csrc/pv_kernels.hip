@@ -1249,14 +1249,12 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
         rt60 = -60.f / slopePerSec;
     }
 
-    float* o = a.res8 + 8 * (size_t)s;
-    o[0] = occ;
-    a.occ[s] = occ;  // SoA copy of the occlusion map for the direction kernel's neighbour reads
-    o[1] = wet;
-    o[2] = rt60;
-    o[3] = lowpass;
-    o[6] = sdx;
-    o[7] = sdy;
+    a.out[s] = occ;
+    a.out[a.resN + s] = wet;
+    a.out[2 * a.resN + s] = rt60;
+    a.out[3 * a.resN + s] = lowpass;
+    a.out[6 * a.resN + s] = sdx;
+    a.out[7 * a.resN + s] = sdy;
 }
 
 // Analyzer.cpp:332-337
@@ -1269,7 +1267,7 @@ __global__ __launch_bounds__(256) void pv_direction_kernel(const AnalyzeArgs a) 
     const int X = blockIdx.y;
     if (Y >= a.gy || X >= a.gx) return;
     const int index = X * a.gy + Y;
-    float loudness = a.occ[index];
+    float loudness = a.out[index];
     int cur = index;
     float delay = FLT_MAX;
     const float samplingRate = (float)a.fs;
@@ -1283,7 +1281,7 @@ __global__ __launch_bounds__(256) void pv_direction_kernel(const AnalyzeArgs a) 
             const int nr = r + kNeighbors[i][0], nc = c + kNeighbors[i][1];
             if (nr < 0 || nc < 0 || nr >= a.gx || nc >= a.gy) continue;
             const int ni = nr * a.gy + nc;
-            const float occ = a.occ[ni];
+            const float occ = a.out[ni];
             const float d = a.delay[ni];
             if (occ == 0.f) continue;               // Analyzer.cpp:372 (the (unsigned)delay test never fires)
             if (d < bestDelay && occ > 0.f) {       // strict <: first neighbour wins ties
@@ -1310,8 +1308,8 @@ __global__ __launch_bounds__(256) void pv_direction_kernel(const AnalyzeArgs a) 
         ox /= len;
         oy /= len;
     }
-    a.res8[8 * (size_t)index + 4] = ox;
-    a.res8[8 * (size_t)index + 5] = oy;
+    a.out[4 * a.resN + index] = ox;
+    a.out[5 * a.resN + index] = oy;
 }
 
 // ---- the same descent by pointer jumping (used when T is large: streaming / Mode B) -------------------------------
@@ -1329,7 +1327,7 @@ __device__ __forceinline__ int dirBestNeighbour(const AnalyzeArgs& a, int cell, 
         const int nr = r + kNeighbors[i][0], nc = c + kNeighbors[i][1];
         if (nr < 0 || nc < 0 || nr >= a.gx || nc >= a.gy) continue;
         const int ni = nr * a.gy + nc;
-        const float occ = a.occ[ni];
+        const float occ = a.out[ni];
         const float d = a.delay[ni];
         if (occ == 0.f) continue;
         if (d < bd && occ > 0.f) {
@@ -1352,7 +1350,7 @@ __device__ __forceinline__ bool dirLineOfSight(const AnalyzeArgs& a, int cell, f
 __global__ __launch_bounds__(256) void pv_dir_init_kernel(const AnalyzeArgs a, int* J) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= a.gx * a.gy) return;
-    const float d = a.delay[p], o = a.occ[p];
+    const float d = a.delay[p], o = a.out[p];
     int hop = p | kDirFinal;
     if (d > kDelayCloseDev && o < kDistanceGainDev) {
         float nd;
@@ -1374,7 +1372,7 @@ __global__ __launch_bounds__(256) void pv_dir_final_kernel(const AnalyzeArgs a, 
     const int index = blockIdx.x * blockDim.x + threadIdx.x;
     if (index >= a.gx * a.gy) return;
     int fin = index;
-    if (a.occ[index] < kDistanceGainDev) {  // first iteration: delay = FLT_MAX, so only the loudness test applies
+    if (a.out[index] < kDistanceGainDev) {  // first iteration: delay = FLT_MAX, so only the loudness test applies
         float nd;
         const int n = dirBestNeighbour(a, index, &nd);
         if (n >= 0) fin = dirLineOfSight(a, n, nd) ? n : (J[n] & ~kDirFinal);
@@ -1387,8 +1385,8 @@ __global__ __launch_bounds__(256) void pv_dir_final_kernel(const AnalyzeArgs a, 
         ox /= len;
         oy /= len;
     }
-    a.res8[8 * (size_t)index + 4] = ox;
-    a.res8[8 * (size_t)index + 5] = oy;
+    a.out[4 * a.resN + index] = ox;
+    a.out[5 * a.resN + index] = oy;
 }
 
 static void launchDirectionJump(const AnalyzeArgs& a, int* J, hipStream_t stream) {
@@ -1406,10 +1404,32 @@ __global__ void pv_fill_delay_kernel(float* delay, int n) {
     if (i < n) delay[i] = FLT_MAX;  // Analyzer.cpp:64-68
 }
 
+// SoA result planes -> the reference's array of PlaneverbOutput structs (AnalyzerResult, Analyzer.h:11-22)
+__global__ void pv_pack_results_kernel(const float* __restrict__ res, long long n, float* __restrict__ res8) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 lo = make_float4(res[i], res[n + i], res[2 * n + i], res[3 * n + i]);
+    float4 hi = make_float4(res[4 * n + i], res[5 * n + i], res[6 * n + i], res[7 * n + i]);
+    reinterpret_cast<float4*>(res8)[2 * i] = lo;
+    reinterpret_cast<float4*>(res8)[2 * i + 1] = hi;
+}
+
+// one cell of the result map -> 8 floats in pinned host memory (Analyzer::GetResponseResult, Analyzer.cpp:106-116)
+__global__ void pv_gather_output_kernel(const float* __restrict__ res, long long n, long long cell, float* out8) {
+    if (threadIdx.x < 8) out8[threadIdx.x] = res[threadIdx.x * n + cell];
+}
+
+void launchGatherOutput(const float* res, long long n, long long cell, float* out8Host, hipStream_t stream) {
+    hipLaunchKernelGGL(pv_gather_output_kernel, dim3(1), dim3(64), 0, stream, res, n, cell, out8Host);
+}
+
+void launchPackResults(const float* res, long long n, float* res8, hipStream_t stream) {
+    hipLaunchKernelGGL(pv_pack_results_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, res, n, res8);
+}
+
 void launchAnalysis(const AnalyzeArgs& a, hipStream_t stream) {
     dim3 grid((a.gy + 255) / 256, a.gx);
-    const int n = a.gx * a.gy;
-    hipLaunchKernelGGL(pv_fill_delay_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a.delay, n);
+    // (pv_encode_kernel writes the delay of EVERY cell, FLT_MAX where there is no onset: Analyzer.cpp:64-68,160-165)
     hipLaunchKernelGGL(pv_encode_kernel, grid, dim3(256), 0, stream, a);
     hipLaunchKernelGGL(pv_direction_kernel, grid, dim3(256), 0, stream, a);
 }
@@ -1545,12 +1565,10 @@ __global__ __launch_bounds__(256) void pv_stream_finalize_kernel(const AnalyzeAr
     float norm = sqrtf(fluxX * fluxX + fluxY * fluxY);
     norm = -1.0f / (norm > 0.0f ? norm : 1.0f);
     const float rr = 1.0f / ((0.001f < occ) ? occ : 0.001f);
-    float* o = a.res8 + 8 * (size_t)s;
-    o[0] = occ;
-    a.occ[s] = occ;  // SoA copy of the occlusion map for the direction kernel's neighbour reads
-    o[3] = -147.f + (18390.f) / (1.f + pvPowf(rr / 12.f, 0.8f));
-    o[6] = norm * fluxX;
-    o[7] = norm * fluxY;
+    a.out[s] = occ;
+    a.out[3 * a.resN + s] = -147.f + (18390.f) / (1.f + pvPowf(rr / 12.f, 0.8f));
+    a.out[6 * a.resN + s] = norm * fluxX;
+    a.out[7 * a.resN + s] = norm * fluxY;
 }
 
 // wet gain + RT60 of the registered emitter cells from their traces (Analyzer.cpp:235-327); one thread each
@@ -1586,9 +1604,8 @@ __global__ void pv_stream_emitter_kernel(const AnalyzeArgs a) {
     const float ymean = ysum / rn;
     const float numerator = xysum - ymean * xsum - xmean * ysum + rn * xmean * ymean;
     const float slopePerSec = (numerator / denominator) * (float)a.fs;
-    float* o = a.res8 + 8 * (size_t)s;
-    o[1] = sqrtf(wetEnergy / a.efree);
-    o[2] = -60.f / slopePerSec;
+    a.out[a.resN + s] = sqrtf(wetEnergy / a.efree);
+    a.out[2 * a.resN + s] = -60.f / slopePerSec;
 }
 
 // tileOpen[tile] for the next launches: some cell marked it open in this pass, or the wave has not reached it yet,

@@ -26,6 +26,8 @@ void launchBeginRun(const BeginArgs& a, hipStream_t stream);
 void launchCodes(const uint8_t* mat, uint16_t* codes, const Geometry& g, hipStream_t stream);
 void launchLaneSelfTest(float* out128, hipStream_t stream);
 void launchAnalysis(const AnalyzeArgs& a, hipStream_t stream);
+void launchGatherOutput(const float* res, long long n, long long cell, float* out8Host, hipStream_t stream);
+void launchPackResults(const float* res, long long n, float* res8, hipStream_t stream);
 void launchStreamAccum(const AnalyzeArgs& a, const uint8_t* hasEmitter, uint8_t* tileOpen, int ntiles,
                        hipStream_t stream);
 void launchStreamFinalize(const AnalyzeArgs& a, hipStream_t stream);

@@ -137,9 +137,8 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     if (!dalloc(&generalCount_, 1, true)) return false;
     if (!dalloc(&dynDev_, 1, true)) return false;
     if (!dalloc(&errFlag_, 1, true)) return false;
-    if (!dalloc(&res8_, (size_t)g_.gx * g_.gy * 8, true)) return false;  // zeroed pool: PvContext.cpp:132
+    if (!dalloc(&res_, (size_t)g_.gx * g_.gy * 8, true)) return false;  // zeroed pool: PvContext.cpp:132
     if (!dalloc(&delay_, (size_t)g_.gx * g_.gy, true)) return false;
-    if (!dalloc(&occ_, (size_t)g_.gx * g_.gy, true)) return false;
     scratchCount_ = std::max<size_t>((size_t)3 * std::max(T_, g_.T), (size_t)g_.NX * g_.NY * 3);
     if (!dalloc(&scratch_, scratchCount_, true)) return false;
 
@@ -182,6 +181,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
             return false;
     }
     if (!hipOk(hipHostMalloc((void**)&dynHost_, sizeof(DynParams)), "hipHostMalloc")) return false;
+    if (!hipOk(hipHostMalloc((void**)&outHost_, 8 * sizeof(float)), "hipHostMalloc")) return false;
     if (!hipOk(hipHostMalloc((void**)&listHost_, sizeof(int) * (size_t)listCap_), "hipHostMalloc")) return false;
 
     pulse_ = gaussianPulse(g_);
@@ -225,10 +225,11 @@ Solver::~Solver() {
     if (emCells_) hipFree(emCells_);
     if (emTrace_) hipFree(emTrace_);
     void* ptrs[] = {codes_,     matDev_, lutDev_, pulseDev_, hist_,  tileFirst_, tileClass_, generalList_,
-                    generalCount_, dynDev_, errFlag_, res8_,     delay_, scratch_, occ_};
+                    generalCount_, dynDev_, errFlag_, res8_,     delay_, scratch_, res_};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (dynHost_) hipHostFree(dynHost_);
+    if (outHost_) hipHostFree(outHost_);
     if (listHost_) hipHostFree(listHost_);
     for (auto& e : ev_)
         if (e) hipEventDestroy(e);
@@ -624,9 +625,9 @@ AnalyzeArgs Solver::analyzeArgs(float lx, float lz) const {
     a.lut = lutDev_;
     a.tileFirst = tileFirst_;
     a.dyn = dynDev_;
-    a.res8 = res8_;
+    a.out = res_;
+    a.resN = (long long)g_.gx * g_.gy;
     a.delay = delay_;
-    a.occ = occ_;
     a.histPlane = histPlane_;
     a.histPitch = histPitch_;
     a.pitch = geo_.pitch;
@@ -868,13 +869,29 @@ bool Solver::getOutput(float ex, float ey, float ez, float out8[8], bool* valid)
     if (!*valid) return true;
     if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
     const size_t idx = (size_t)cx * g_.gy + cy;
-    if (!hipOk(hipMemcpyAsync(out8, res8_ + 8 * idx, 32, hipMemcpyDeviceToHost, stream_), "output copy")) return false;
-    return hipOk(hipStreamSynchronize(stream_), "output sync");
+    // 8 planes -> 8 floats: a one-wave kernel writes them straight into pinned host memory (a strided
+    // hipMemcpy2DAsync of 8 x 4 bytes costs 0.4 ms on this runtime)
+    launchGatherOutput(res_, (long long)g_.gx * g_.gy, (long long)idx, outHost_, stream_);
+    if (!hipOk(hipStreamSynchronize(stream_), "output sync")) return false;
+    for (int k = 0; k < 8; ++k) out8[k] = outHost_[k];
+    return true;
+}
+
+// the reference's result map is an array of 8-float structs; ours is 8 planes.  Whole-map read-backs (tests, the live
+// module's host copy) get the AoS form from a pack kernel into a buffer that exists only once somebody asked.
+bool Solver::packResults() {
+    const size_t n = (size_t)g_.gx * g_.gy;
+    if (!res8_) {
+        if (!dalloc(&res8_, n * 8, false)) return false;
+    }
+    launchPackResults(res_, (long long)n, res8_, stream_);
+    return hipOk(hipGetLastError(), "pack results");
 }
 
 bool Solver::copyResults(float* res8, float* delay) {
     if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
     const size_t n = (size_t)g_.gx * g_.gy;
+    if (res8 && !packResults()) return false;
     if (res8 && !hipOk(hipMemcpyAsync(res8, res8_, n * 32, hipMemcpyDeviceToHost, stream_), "results copy"))
         return false;
     if (delay && !hipOk(hipMemcpyAsync(delay, delay_, n * 4, hipMemcpyDeviceToHost, stream_), "delay copy"))
@@ -884,6 +901,7 @@ bool Solver::copyResults(float* res8, float* delay) {
 
 bool Solver::copyResultsAsync(float* res8Host) {
     const size_t n = (size_t)g_.gx * g_.gy;
+    if (!packResults()) return false;
     return hipOk(hipMemcpyAsync(res8Host, res8_, n * 32, hipMemcpyDeviceToHost, stream_), "results copy");
 }
 

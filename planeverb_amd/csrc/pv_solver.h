@@ -145,9 +145,10 @@ private:
     int* generalCount_ = nullptr;
     DynParams* dynDev_ = nullptr;
     int* errFlag_ = nullptr;
-    float* res8_ = nullptr;
+    float* res_ = nullptr;   // 8 SoA result planes (see AnalyzeArgs::res)
+    float* res8_ = nullptr;  // AoS copy for whole-map read-backs, allocated and packed on demand
+    bool packResults();
     float* delay_ = nullptr;
-    float* occ_ = nullptr;
     // streaming analysis state
     int ring_ = 0;             // history planes allocated (T_ when not streaming)
     int* sOnset_ = nullptr;
@@ -163,6 +164,7 @@ private:
 
     // pinned host staging
     DynParams* dynHost_ = nullptr;
+    float* outHost_ = nullptr;  // 8 floats the output-gather kernel writes straight into host memory
     int* listHost_ = nullptr;
     int listCap_ = 0;
 
