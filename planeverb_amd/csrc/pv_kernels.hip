@@ -709,6 +709,36 @@ __global__ __launch_bounds__(256, WPS) void pv_step_stream_kernel(const StepArgs
     }
 }
 
+// Position q inside an XCD's band of `bandRows` tile rows -> (row in band, tile column).
+//   order 1      : row-major over the whole band
+//   order 2      : column-major over the whole band
+//   order H >= 4 : the band is cut into sub-bands of H tile rows, each walked column by column.  The ~256 tiles an
+//                  XCD has in flight then form a compact H x (256/H) patch: a tile's vertical AND horizontal halo
+//                  neighbours are in flight with it or a few tiles away, instead of a whole tile row (13 MB of
+//                  traffic at 8192^2, three times the 4 MiB L2) away.
+__device__ __forceinline__ bool bandPosition(const StepArgs& a, int q, int bandRows, int* r, int* tj) {
+    if (a.tileOrder <= 1) {
+        *r = q / a.nty;
+        *tj = q - *r * a.nty;
+        return *r < bandRows;
+    }
+    if (a.tileOrder == 2) {
+        *tj = q / bandRows;
+        *r = q - *tj * bandRows;
+        return *tj < a.nty;
+    }
+    const int H = max(a.tileOrder, 4);
+    const int per = H * a.nty;
+    const int sb = q / per;
+    const int r0 = sb * H;
+    if (r0 >= bandRows) return false;
+    const int h = min(H, bandRows - r0);
+    const int qq = q - sb * per;
+    *tj = qq / h;
+    *r = r0 + (qq - *tj * h);
+    return *tj < a.nty;
+}
+
 // air tiles: one wave per tile, 4 tiles per 256-thread block; tiles of the other class exit immediately.
 // XCD-aware tile order: workgroup b is dispatched to XCD b % 8 (observed, speed only), and each XCD has a private
 // 4 MiB L2.  XCD x therefore owns a contiguous band of tile rows and walks it column by column, so the tiles that
@@ -730,16 +760,9 @@ __global__ __launch_bounds__(256, WPS) void pv_step_air_kernel(const StepArgs a)
         const int ti0 = xcd * a.bandRows;
         const int bandRows = min(a.bandRows, a.ntx - ti0);
         if (bandRows <= 0) return;
-        if (a.tileOrder == 1) {  // band, row-major (a block = 4 horizontally adjacent tiles)
-            const int r = q / a.nty;
-            if (r >= bandRows) return;
-            ti = ti0 + r;
-            tj = q - r * a.nty;
-        } else {  // band, column-major
-            tj = q / bandRows;
-            if (tj >= a.nty) return;
-            ti = ti0 + (q - tj * bandRows);
-        }
+        int r;
+        if (!bandPosition(a, q, bandRows, &r, &tj)) return;
+        ti = ti0 + r;
     }
     const int tile = ti * a.nty + tj;
     if (a.tileClass[tile] != 0) return;
@@ -802,10 +825,9 @@ __global__ __launch_bounds__(256, WPS) void pv_step_merged_kernel(const StepArgs
         const int ti0 = xcd * a.bandRows;
         const int bandRows = min(a.bandRows, a.ntx - ti0);
         if (bandRows <= 0) return;
-        const int r = q / a.nty;
-        if (r >= bandRows) return;
+        int r;
+        if (!bandPosition(a, q, bandRows, &r, &tj)) return;
         ti = ti0 + r;
-        tj = q - r * a.nty;
     }
     const int tile = ti * a.nty + tj;
     if (a.tileClass[tile] != 0) return;
@@ -841,12 +863,19 @@ __global__ __launch_bounds__(256) void pv_tileclass_kernel(const uint16_t* codes
     }
 }
 
+// positions an XCD's band needs under the chosen order (sub-bands are padded to whole multiples of H rows)
+static int bandPositions(const StepArgs& a) {
+    if (a.tileOrder < 4) return a.bandRows * a.nty;
+    const int H = a.tileOrder;
+    return ((a.bandRows + H - 1) / H) * H * a.nty;
+}
+
 template <int K, int RXI, int WPS, int SUB>
 static void launchStepT(const StepArgs& a, hipStream_t stream, int which, hipStream_t stream2) {
     if (which == 4) {  // merged single launch
         constexpr int MS = (RXI % 4 == 0) ? RXI / 4 : SUB;
         const int gblocks = (a.numGeneral * (RXI / MS) + 3) / 4;
-        const int blocks = gblocks + 8 * ((a.bandRows * a.nty + 3) / 4);
+        const int blocks = gblocks + 8 * ((bandPositions(a) + 3) / 4);
         hipLaunchKernelGGL((pv_step_merged_kernel<K, RXI, WPS, MS>), dim3(blocks), dim3(256), 0, stream, a);
         return;
     }
@@ -855,7 +884,7 @@ static void launchStepT(const StepArgs& a, hipStream_t stream, int which, hipStr
         hipLaunchKernelGGL((pv_step_stream_kernel<K, RXI, 4>), dim3((units + 3) / 4), dim3(256), 0, stream, a);
     }
     if (which & 1) {
-        const int blocks = a.tileOrder == 0 ? (a.ntiles + 3) / 4 : 8 * ((a.bandRows * a.nty + 3) / 4);
+        const int blocks = a.tileOrder == 0 ? (a.ntiles + 3) / 4 : 8 * ((bandPositions(a) + 3) / 4);
         if (a.packed)
             hipLaunchKernelGGL((pv_step_air_kernel<K, RXI, WPS, true>), dim3(blocks), dim3(256), 0, stream, a);
         else

@@ -91,7 +91,9 @@ def check_scene(name, **opts):
 def perf(n, K, rows, dense=0, steps=None):
     dx = 343.21 / 275 / 3.5
     size = (n + 0.5) * dx
-    opts = dict(steps_per_launch=K, tile_rows=rows, dense_history=dense)
+    opts = dict(dense_history=dense)
+    if K:
+        opts.update(steps_per_launch=K, tile_rows=rows)  # 0 = the solver's own choice for the grid size
     if steps:
         opts["num_steps"] = steps
     try:
@@ -110,6 +112,7 @@ def perf(n, K, rows, dense=0, steps=None):
             best = t
     cells = (s.gx + 1) * (s.gy + 1)
     ups = cells * s.T / (best.fdtdMs * 1e-3)
+    K, rows = s.info.stepsPerLaunch, s.info.tileRows
     print("perf n=%d K=%d rows=%d dense=%d T=%d: fdtd %.2f ms  analysis %.2f ms  %.3e upd/s  algorithmic %.2f TB/s "
           "(%.0f%% of 8 TB/s)  MB=%d" % (n, K, rows, dense, s.T, best.fdtdMs, best.analysisMs, ups, ups * 24 / 1e12,
                                          ups * 24 / 8e12 * 100, s.info.deviceBytes >> 20))
@@ -140,8 +143,8 @@ if __name__ == "__main__":
     if "parityB" in what:
         check_scene("g512B_shoebox")
     if "perf" in what:
-        for (K, rows) in [(8, 24)]:
-            perf(4096, K, rows)
-        perf(4096, 8, 24, dense=1)
-        perf(2048, 8, 24); perf(1024, 8, 24); perf(512, 8, 24); perf(70, 8, 24)
-        perf(8192, 8, 24)
+        perf(4096, 0, 0)
+        perf(4096, 0, 0, dense=1)
+        perf(2048, 0, 0); perf(1024, 0, 0); perf(512, 0, 0); perf(70, 0, 0)
+        perf(8192, 0, 0)
+        perf(4096, 8, 24)

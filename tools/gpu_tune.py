@@ -25,11 +25,15 @@ def run(n, reps=4, **opts):
     s.close()
 
 if __name__ == "__main__":
+    # usage: gpu_tune.py N K,rows[,tile_order] ...
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     cfgs = [tuple(int(v) for v in c.split(",")) for c in sys.argv[2:]] or [(4, 32), (8, 24), (6, 28)]
     for rep in range(2):
-        for K, rows in cfgs:
+        for c in cfgs:
+            opts = dict(steps_per_launch=c[0], tile_rows=c[1])
+            if len(c) > 2:
+                opts["tile_order"] = c[2]
             try:
-                run(n, steps_per_launch=K, tile_rows=rows)
+                run(n, **opts)
             except pv.PlaneverbError as e:
-                print("K=%d rows=%d: %s" % (K, rows, e))
+                print("%s: %s" % (opts, e))
