@@ -739,6 +739,28 @@ __device__ __forceinline__ bool bandPosition(const StepArgs& a, int q, int bandR
     return *tj < a.nty;
 }
 
+// block b (of the air part of a launch), wave w -> tile.  XCD x = b % 8 owns a contiguous span of the row-major tile
+// sequence: ntiles/8 tiles each (order 1, balanced to one tile), or a band of whole tile rows (orders 2, >= 4).
+__device__ __forceinline__ bool xcdTile(const StepArgs& a, int b, int wave, int* ti, int* tj) {
+    const int xcd = b & 7;
+    const int q = (b >> 3) * 4 + wave;  // position inside the XCD's share
+    if (a.tileOrder <= 1) {
+        const int per = (a.ntiles + 7) >> 3;
+        const int t = xcd * per + q;
+        if (q >= per || t >= a.ntiles) return false;
+        *ti = t / a.nty;
+        *tj = t - *ti * a.nty;
+        return true;
+    }
+    const int ti0 = xcd * a.bandRows;
+    const int bandRows = min(a.bandRows, a.ntx - ti0);
+    if (bandRows <= 0) return false;
+    int r;
+    if (!bandPosition(a, q, bandRows, &r, tj)) return false;
+    *ti = ti0 + r;
+    return true;
+}
+
 // air tiles: one wave per tile, 4 tiles per 256-thread block; tiles of the other class exit immediately.
 // XCD-aware tile order: workgroup b is dispatched to XCD b % 8 (observed, speed only), and each XCD has a private
 // 4 MiB L2.  XCD x therefore owns a contiguous band of tile rows and walks it column by column, so the tiles that
@@ -755,14 +777,7 @@ __global__ __launch_bounds__(256, WPS) void pv_step_air_kernel(const StepArgs a)
         ti = t / a.nty;
         tj = t - ti * a.nty;
     } else {
-        const int xcd = blockIdx.x & 7;
-        const int q = (blockIdx.x >> 3) * 4 + wave;  // index inside the XCD's band
-        const int ti0 = xcd * a.bandRows;
-        const int bandRows = min(a.bandRows, a.ntx - ti0);
-        if (bandRows <= 0) return;
-        int r;
-        if (!bandPosition(a, q, bandRows, &r, &tj)) return;
-        ti = ti0 + r;
+        if (!xcdTile(a, blockIdx.x, wave, &ti, &tj)) return;
     }
     const int tile = ti * a.nty + tj;
     if (a.tileClass[tile] != 0) return;
@@ -819,16 +834,7 @@ __global__ __launch_bounds__(256, WPS) void pv_step_merged_kernel(const StepArgs
     }
     const int b = blockIdx.x - gblocks;
     int ti, tj;
-    {
-        const int xcd = b & 7;
-        const int q = (b >> 3) * 4 + wave;  // index inside the XCD's band
-        const int ti0 = xcd * a.bandRows;
-        const int bandRows = min(a.bandRows, a.ntx - ti0);
-        if (bandRows <= 0) return;
-        int r;
-        if (!bandPosition(a, q, bandRows, &r, &tj)) return;
-        ti = ti0 + r;
-    }
+    if (!xcdTile(a, b, wave, &ti, &tj)) return;
     const int tile = ti * a.nty + tj;
     if (a.tileClass[tile] != 0) return;
     if (a.withPulse) {
@@ -865,6 +871,7 @@ __global__ __launch_bounds__(256) void pv_tileclass_kernel(const uint16_t* codes
 
 // positions an XCD's band needs under the chosen order (sub-bands are padded to whole multiples of H rows)
 static int bandPositions(const StepArgs& a) {
+    if (a.tileOrder <= 1) return (a.ntiles + 7) / 8;
     if (a.tileOrder < 4) return a.bandRows * a.nty;
     const int H = a.tileOrder;
     return ((a.bandRows + H - 1) / H) * H * a.nty;
