@@ -4,7 +4,8 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
-LIB_PATH = os.path.join(PKG_DIR, "libplaneverb_amd.so")
+# PLANEVERB_AMD_LIB: development aid for A/B runs of two builds on one GPU box (tools/gpu_tune.py)
+LIB_PATH = os.environ.get("PLANEVERB_AMD_LIB") or os.path.join(PKG_DIR, "libplaneverb_amd.so")
 
 
 def build(force=False, jobs=4):

@@ -25,6 +25,7 @@
 #include <cfloat>
 #include <climits>
 #include <cstdint>
+#include <cstdlib>
 
 #include "pv_device.h"
 #include "pv_launch.h"
@@ -193,6 +194,40 @@ __device__ __forceinline__ void leapfrogStep(float (&pr)[ROWS], float (&vx)[ROWS
     }
 }
 
+// General tiles, coefficients in registers.  kx[r] / ky[r] are the face coefficients of this lane's cell in row r
+// (NaN = air|air face, else v = k * (p_i + p_n), which covers walls, wall|wall (k = 0) and the absorbing grid edges),
+// bt[r] = beta of the cell as 0.f / 1.f -- all looked up ONCE per launch.  The first version re-read the two LUT
+// entries of every cell on every step (41 instructions per row and step, 6x an air row); with the coefficients
+// resident a row costs 20.  pr = beta * (...) is the reference's own expression (FDTD.cpp:139).
+template <int ROWS>
+__device__ __forceinline__ void leapfrogStepCoef(float (&pr)[ROWS], float (&vx)[ROWS], float (&vy)[ROWS],
+                                                 const float (&kx)[ROWS], const float (&ky)[ROWS],
+                                                 const float (&bt)[ROWS], const float C) {
+    // pressure sweep, FDTD.cpp:124-141
+#pragma unroll
+    for (int r = 0; r < ROWS - 1; ++r) {
+        const float vyR = laneNext(vy[r]);
+        const float div = (vx[r + 1] - vx[r]) + (vyR - vy[r]);
+        pr[r] = bt[r] * (pr[r] - C * div);
+    }
+    // velocity sweeps, FDTD.cpp:143-199 (+ edges :201-223 through the coefficients)
+#pragma unroll
+    for (int r = ROWS - 1; r >= 1; --r) {
+        const float pi = pr[r], pn = pr[r - 1];
+        const float air = vx[r] - C * (pi - pn);
+        const float wall = kx[r] * (pi + pn);
+        vx[r] = (kx[r] != kx[r]) ? air : wall;
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const float pi = pr[r];
+        const float pn = lanePrev(pi);
+        const float air = vy[r] - C * (pi - pn);
+        const float wall = ky[r] * (pi + pn);
+        vy[r] = (ky[r] != ky[r]) ? air : wall;
+    }
+}
+
 // Buffer (SRSRC) addressing: every plane is reached through a 128-bit descriptor built from kernel arguments;
 // the per-lane part of an address is the constant lane*4 in voffset and everything wave-uniform (tile origin,
 // row) goes into the scalar soffset, so the 3*ROWS loads / stores of a tile cost no address VGPRs.
@@ -245,6 +280,8 @@ __device__ __forceinline__ void stepTile(const StepArgs& a, const int tile, cons
                  rVyIn = makeRsrc(a.vyIn, a.inBytes);
 
     float pr[ROWS], vx[ROWS], vy[ROWS];
+    constexpr int CR = GENERAL ? ROWS : 1;
+    float kx[CR], ky[CR], bt[CR];
     uint32_t cd[(ROWS + 1) / 2];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
@@ -256,14 +293,12 @@ __device__ __forceinline__ void stepTile(const StepArgs& a, const int tile, cons
     if (GENERAL) {
         const rsrc_t rCodes = makeRsrc(a.codes, a.planeBytes / 2);
 #pragma unroll
-        for (int i = 0; i < (ROWS + 1) / 2; ++i) {
-            const int so = (soff0 >> 1) + (2 * i) * (pitchB >> 1);
-            uint32_t lo = __builtin_amdgcn_raw_buffer_load_b16(rCodes, lane * 2, so, 0);
-            uint32_t hi =
-                (2 * i + 1 < ROWS)
-                    ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rCodes, lane * 2, so + (pitchB >> 1), 0)
-                    : 0u;
-            cd[i] = lo | (hi << 16);
+        for (int r = 0; r < ROWS; ++r) {
+            const uint32_t c =
+                __builtin_amdgcn_raw_buffer_load_b16(rCodes, lane * 2, (soff0 >> 1) + r * (pitchB >> 1), 0);
+            kx[r] = lut[c & 0xffu];
+            ky[r] = lut[(c >> 8) & 0xffu];
+            bt[r] = (c & 0xffu) < (uint32_t)kLutWall ? 1.f : 0.f;
         }
     }
 
@@ -309,16 +344,10 @@ __device__ __forceinline__ void stepTile(const StepArgs& a, const int tile, cons
 
 #pragma unroll 1
     for (int s = 0; s < a.nsteps; ++s) {
-        if (!GENERAL) {
+        if constexpr (!GENERAL) {
             leapfrogStep<ROWS, true>(pr, vx, vy, cd, lut, C);
         } else {
-            // The face codes and LUT are loop-invariant; left alone, LICM hoists the 2*ROWS coefficient reads out
-            // of the time loop and spills them.  Re-materialise them every step instead (empty asm = opaque).
-            const float* lutS = lut;
-            asm volatile("" : "+v"(lutS));
-#pragma unroll
-            for (int i = 0; i < (ROWS + 1) / 2; ++i) asm volatile("" : "+v"(cd[i]));
-            leapfrogStep<ROWS, false>(pr, vx, vy, cd, lutS, C);
+            leapfrogStepCoef<ROWS>(pr, vx, vy, kx, ky, bt, C);
         }
 
         // record the pressure of this step before the pulse is injected (FDTD.cpp:226-234)
@@ -539,6 +568,536 @@ __device__ __forceinline__ void stepTileAirPacked(const StepArgs& a, const int t
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// air tile, MIRROR-packed
+// ---------------------------------------------------------------------------------------------------------------
+// The row-pair packing above spends 2 of its 15 VALU instructions per cell pair and step on v_pk_mov shuffles: the
+// x-differences vx[r+1]-vx[r] and pr[r]-pr[r-1] straddle register pairs.  Here a pair holds row i of the tile's TOP
+// half in .x and the MIRRORED row ROWS-1-i of its BOTTOM half in .y, and the bottom half's vx is stored negated and
+// shifted by one face (vx[i].y = -vx_row[ROWS-i]).  Reflecting the staggered grid about the tile's centre line maps
+// the leapfrog update onto itself when vx changes sign, so both halves of every pair obey the SAME recurrence with
+// the SAME neighbour pair (i+1 for the pressure sweep, i-1 for the vx sweep): every x-difference is one packed
+// subtract of two whole register pairs, no shuffles -- 13 VALU instructions per cell pair and step.  IEEE negation,
+// a-b = -(b-a) and round-to-nearest are sign-symmetric, so the fields keep the reference's bits (sign of zero
+// aside, as everywhere in this file).  The two halves meet at face vx_row[NP], kept in one extra register per lane
+// (`vxS`) and advanced by three scalar ops per step.  The trapezoid of still-valid rows is [s, ROWS-s-1) = pairs
+// [s, NP) (.y of pair s is scratch), the same number of pairs per step as in the row-pair form.
+template <int NP, int G, int LO>
+__device__ __forceinline__ void mirrorPressureSweep(v2f (&pr)[NP], const v2f (&vx)[NP], const v2f (&vy)[NP],
+                                                    const float vxS, const float C) {
+    const v2f c2 = {C, C};
+    // FDTD.cpp:124-141
+#pragma unroll
+    for (int i0 = LO; i0 < NP; i0 += G) {
+        v2f xd[G], yd[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int i = i0 + g;
+            if (i < NP) {
+                const v2f nxt = (i + 1 < NP) ? vx[i + 1] : v2f{vxS, -vxS};
+                xd[g] = nxt - vx[i];
+                yd[g].x = laneNext(vy[i].x) - vy[i].x;
+                yd[g].y = laneNext(vy[i].y) - vy[i].y;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (i0 + g < NP) xd[g] = xd[g] + yd[g];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (i0 + g < NP) xd[g] = c2 * xd[g];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (i0 + g < NP) pr[i0 + g] = pr[i0 + g] - xd[g];
+    }
+}
+
+// FDTD.cpp:143-170 (air|air faces only); the seam face between the halves first
+template <int NP, int G, int LO>
+__device__ __forceinline__ void mirrorVxSweep(const v2f (&pr)[NP], v2f (&vx)[NP], float& vxS, const float C) {
+    const v2f c2 = {C, C};
+    {
+        const float t = C * (pr[NP - 1].y - pr[NP - 1].x);
+        vxS = vxS - t;
+    }
+#pragma unroll
+    for (int i0 = LO; i0 < NP; i0 += G) {
+        v2f t[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int i = i0 + g;
+            if (i < NP) t[g] = pr[i] - pr[i > 0 ? i - 1 : 0];  // pair 0: tile-edge rows, never valid
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (i0 + g < NP) t[g] = c2 * t[g];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (i0 + g < NP) vx[i0 + g] = vx[i0 + g] - t[g];
+    }
+}
+
+// FDTD.cpp:172-199
+template <int NP, int G, int LO>
+__device__ __forceinline__ void mirrorVySweep(const v2f (&pr)[NP], v2f (&vy)[NP], const float C) {
+    const v2f c2 = {C, C};
+#pragma unroll
+    for (int i0 = LO; i0 < NP; i0 += G) {
+        v2f t[G];
+#pragma unroll
+        for (int g = 0; g < G; g += 2) {
+            const int i = i0 + g;
+            if (i + 1 < NP) {
+                subLanePrev2(pr[i], pr[i + 1], t[g], t[g + 1]);
+            } else if (i < NP) {
+                v2f unused;
+                subLanePrev2(pr[i], pr[i], t[g], unused);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (i0 + g < NP) t[g] = c2 * t[g];
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (i0 + g < NP) vy[i0 + g] = vy[i0 + g] - t[g];
+    }
+}
+
+template <int NP, int G, int LO>
+__device__ __forceinline__ void leapfrogStepMirror(v2f (&pr)[NP], v2f (&vx)[NP], v2f (&vy)[NP], float& vxS,
+                                                   const float C) {
+    mirrorPressureSweep<NP, G, LO>(pr, vx, vy, vxS, C);
+    mirrorVxSweep<NP, G, LO>(pr, vx, vxS, C);
+    mirrorVySweep<NP, G, LO>(pr, vy, C);
+}
+
+template <int K, int RXI, int S>
+struct MirrorSteps {
+    static constexpr int ROWS = RXI + 2 * K;
+    static constexpr int NP = ROWS / 2;
+    static __device__ __forceinline__ void run(v2f (&pr)[NP], v2f (&vx)[NP], v2f (&vy)[NP], float& vxS,
+                                               const float C, const StepArgs& a, const bool recLane,
+                                               const float* hplane, const int hvoff, const int hsoff0,
+                                               const int hpitchB) {
+        if constexpr (S < K) {
+            if (S < a.nsteps) {
+                leapfrogStepMirror<NP, 4, S>(pr, vx, vy, vxS, C);
+                if (recLane) {  // pressure of this step, interior rows (air tiles never hold the listener)
+                    const rsrc_t rH = makeRsrc(hplane, a.histPlane * 4);
+#pragma unroll
+                    for (int r = K; r < ROWS - K; ++r)
+                        bufStoreF(r < NP ? pr[r].x : pr[ROWS - 1 - r].y, rH, hvoff, hsoff0 + r * hpitchB);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // keep the steps apart: interleaving them only costs registers
+                MirrorSteps<K, RXI, S + 1>::run(pr, vx, vy, vxS, C, a, recLane, hplane + a.histPlane, hvoff,
+                                                hsoff0, hpitchB);
+            }
+        }
+    }
+};
+
+template <int K, int RXI>
+__device__ __forceinline__ void stepTileAirMirror(const StepArgs& a, const int tile, const int lane) {
+    constexpr int ROWS = RXI + 2 * K;
+    static_assert(ROWS % 2 == 0, "packed air tile needs an even number of rows");
+    constexpr int NP = ROWS / 2;
+    constexpr int WI = 64 - 2 * K;
+    const int ti = tile / a.nty;
+    const int tj = tile - ti * a.nty;
+    const int row0 = a.G - K + ti * RXI;
+    const int col0 = a.G - K + tj * WI;
+    const int voff = lane * 4;
+    const int pitchB = a.pitch * 4;
+    const int soff0 = (row0 * a.pitch + col0) * 4;
+
+    const rsrc_t rPrIn = makeRsrc(a.prIn, a.inBytes), rVxIn = makeRsrc(a.vxIn, a.inBytes),
+                 rVyIn = makeRsrc(a.vyIn, a.inBytes);
+    v2f pr[NP], vx[NP], vy[NP];
+    float vxS = bufLoadF(rVxIn, voff, soff0 + NP * pitchB);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int soT = soff0 + i * pitchB, soB = soff0 + (ROWS - 1 - i) * pitchB;
+        pr[i].x = bufLoadF(rPrIn, voff, soT);
+        pr[i].y = bufLoadF(rPrIn, voff, soB);
+        vy[i].x = bufLoadF(rVyIn, voff, soT);
+        vy[i].y = bufLoadF(rVyIn, voff, soB);
+        vx[i].x = bufLoadF(rVxIn, voff, soT);
+        vx[i].y = (i > 0) ? -bufLoadF(rVxIn, voff, soB + pitchB) : 0.f;  // face ROWS-i; face ROWS is not in the tile
+    }
+    uint32_t nz = __float_as_uint(vxS);
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+        nz |= __float_as_uint(pr[i].x) | __float_as_uint(pr[i].y) | __float_as_uint(vx[i].x) |
+              __float_as_uint(vx[i].y) | __float_as_uint(vy[i].x) | __float_as_uint(vy[i].y);
+    const bool active = __ballot((nz & 0x7fffffffu) != 0u) != 0ull;
+    if (lane == 0) a.nzOut[tile] = active ? 1 : 0;
+
+    const DynParams dyn = *a.dyn;
+    const int hti = ti - dyn.histTileX0, htj = tj - dyn.histTileY0;
+    const bool inWin = hti >= 0 && hti < dyn.histTilesX && htj >= 0 && htj < dyn.histTilesY;
+    const bool wasActive = a.record && a.tileFirst[tile] != INT_MAX;
+    const bool rec = a.record && inWin && (active || wasActive || a.dense) && historyWanted(a, ti, tj);
+    if (a.record && active && !wasActive && lane == 0) atomicMin(&a.tileFirst[tile], a.t0);
+    if (a.record && active && !inWin && lane == 0) atomicExch(a.errFlag, 1);
+
+    const float C = a.courant;
+    const bool inCols = lane >= K && lane < 64 - K;
+    const float* hplane = a.hist + (long long)a.histSlot * a.histPlane;
+    const int hpitchB = a.histPitch * 4;
+    const int hsoff0 = (hti * RXI - K) * hpitchB;
+    const int hvoff = (htj * WI - K + lane) * 4;
+
+    MirrorSteps<K, RXI, 0>::run(pr, vx, vy, vxS, C, a, rec && inCols, hplane, hvoff, hsoff0, hpitchB);
+
+    const rsrc_t rPrOut = makeRsrc(a.prOut, a.planeBytes), rVxOut = makeRsrc(a.vxOut, a.planeBytes),
+                 rVyOut = makeRsrc(a.vyOut, a.planeBytes);
+    if (inCols) {
+#pragma unroll
+        for (int r = K; r < ROWS - K; ++r) {
+            const int so = soff0 + r * pitchB;
+            bufStoreF(r < NP ? pr[r].x : pr[ROWS - 1 - r].y, rPrOut, voff, so);
+            bufStoreF(r < NP ? vx[r].x : (r == NP ? vxS : -vx[ROWS - r].y), rVxOut, voff, so);
+            bufStoreF(r < NP ? vy[r].x : vy[ROWS - 1 - r].y, rVyOut, voff, so);
+        }
+    }
+}
+
+// Which packed form a configuration uses: the mirror pairs win on the tall tiles that run at 2 waves/SIMD (-1..2 %
+// at 4096^2 / 8192^2 with the 60-row tile) and lose 1-2 % on the 40-row tiles at 3 waves/SIMD (measured, K = 8).
+// -DPV_AIR_MIRROR=0 / =2 force one form for A/B builds.
+#ifndef PV_AIR_MIRROR
+#define PV_AIR_MIRROR 1
+#endif
+template <int K, int RXI>
+__device__ __forceinline__ void airTilePacked(const StepArgs& a, const int tile, const int lane) {
+    if constexpr (PV_AIR_MIRROR == 2 || (PV_AIR_MIRROR == 1 && RXI + 2 * K >= 48))
+        stepTileAirMirror<K, RXI>(a, tile, lane);
+    else
+        stepTileAirPacked<K, RXI>(a, tile, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// general tile: 4 waves share the tile's rows, boundary faces exchanged through LDS
+// ---------------------------------------------------------------------------------------------------------------
+// Walls, grid edges, listener.  A general row needs its two face coefficients and beta beside the three fields
+// (6 registers per row instead of 3) and 20 instructions per step instead of 6.5, so a whole (RXI+2K)-row tile does
+// not fit one wave.  The first design cut the tile into RXI/4-row slices advanced by independent waves, each
+// recomputing its own 2K-row halo: 4 x 33 rows for a 60-row tile, and the ~4 % of tiles on the border of an open
+// 4096^2 grid took 22 % of the run.  Here the block's 4 waves own CONSECUTIVE windows of the tile's rows and keep
+// each other's boundary faces current through LDS (the scheme of the stacked air tile below, scalar layout):
+//   wave w holds rows [w(R-2), w(R-2)+R) of the loaded tile; row 0 of its window is the previous wave's last owned
+//   row, whose pr and vy it advances redundantly; rows 1..R-2 are its own; of row R-1 it only needs vx.
+//   Every step it publishes vx[1] (the wave above's vx[R-1]) and vx[R-2] (the wave below's vx[0]) and receives
+//   the two counterparts: one 8-byte LDS write per lane, one workgroup barrier, two LDS reads.
+// 4 x 17 rows for the 60-row tile, no halo recomputed between the waves.
+template <int K, int RXI>
+struct GenStackGeom {
+    static constexpr int L0 = RXI + 2 * K;
+    static constexpr int R = (L0 + 6 + 3) / 4;   // 4 windows of R rows, stride R-2, cover 4R-6 >= L0 rows
+    static constexpr int L = 4 * R - 6;           // rows the block loads
+    static constexpr int D = L - L0;              // rows beyond the tile's own K-row halo at the bottom (0..3)
+};
+
+struct GenShared {
+    float xch[2][4][2][64];  // [step parity][wave][0: vx[1] for the wave above, 1: vx[R-2] for the wave below][lane]
+};
+
+template <int K, int RXI>
+__device__ __forceinline__ void stepTileGeneral4(const StepArgs& a, const int tile, const int wave, const int lane,
+                                                 const float* lut, GenShared& sh) {
+    using Gm = GenStackGeom<K, RXI>;
+    constexpr int R = Gm::R;
+    constexpr int WI = 64 - 2 * K;
+    const int ti = tile / a.nty;
+    const int tj = tile - ti * a.nty;
+    const int ws = wave * (R - 2);                   // first row of this wave's window, in loaded-tile rows
+    const int row0 = a.G - K + ti * RXI + ws;
+    const int col0 = a.G - K + tj * WI;
+    const int voff = lane * 4;
+    const int pitchB = a.pitch * 4;
+    const int soff0 = (row0 * a.pitch + col0) * 4;
+    const bool first = wave == 0, last = wave == 3;
+
+    const rsrc_t rPrIn = makeRsrc(a.prIn, a.inBytes), rVxIn = makeRsrc(a.vxIn, a.inBytes),
+                 rVyIn = makeRsrc(a.vyIn, a.inBytes);
+    const rsrc_t rCodes = makeRsrc(a.codes, a.planeBytes / 2);
+    float pr[R], vx[R], vy[R], kx[R], ky[R], bt[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int so = soff0 + r * pitchB;
+        pr[r] = bufLoadF(rPrIn, voff, so);
+        vx[r] = bufLoadF(rVxIn, voff, so);
+        vy[r] = bufLoadF(rVyIn, voff, so);
+        const uint32_t c = __builtin_amdgcn_raw_buffer_load_b16(rCodes, lane * 2, so >> 1, 0);
+        kx[r] = lut[c & 0xffu];
+        ky[r] = lut[(c >> 8) & 0xffu];
+        bt[r] = (c & 0xffu) < (uint32_t)kLutWall ? 1.f : 0.f;
+    }
+
+    const DynParams dyn = *a.dyn;
+    // listener row inside this wave's window: rows 0..R-2 hold a live pressure (row 0 = the copy of the previous
+    // wave's last row), row R-1 does not
+    const int lr = dyn.lrow - row0;
+    const int lc = dyn.lcol - col0;
+    const bool hasL = a.withPulse && lr >= 0 && lr <= R - 2 && lc >= 0 && lc < 64;
+    const int lrT = dyn.lrow - (row0 - ws);  // listener row in loaded-tile rows: is it anywhere in the block?
+    const bool tileHasL = a.withPulse && lrT >= 0 && lrT < Gm::L && lc >= 0 && lc < 64;
+    // general tiles always count as non-zero and are recorded on every step
+    if (first && lane == 0) a.nzOut[tile] = 1;
+    const int hti = ti - dyn.histTileX0, htj = tj - dyn.histTileY0;
+    const bool inWin = hti >= 0 && hti < dyn.histTilesX && htj >= 0 && htj < dyn.histTilesY;
+    const bool rec = a.record && inWin && historyWanted(a, ti, tj);
+    if (a.record) {
+        uint32_t nz = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            nz |= (__float_as_uint(pr[r]) | __float_as_uint(vx[r]) | __float_as_uint(vy[r])) & 0x7fffffffu;
+        const bool active = tileHasL || __ballot(nz != 0u) != 0ull;
+        if (active && lane == 0) {
+            atomicMin(&a.tileFirst[tile], a.t0);
+            if (!inWin) atomicExch(a.errFlag, 1);
+        }
+    }
+
+    // rows this wave stores: its own rows 1..R-2 that lie in the tile's interior
+    const int rLo = max(1, K - ws), rHi = min(R - 1, K + RXI - ws);
+    const float C = a.courant;
+    const bool inCols = lane >= K && lane < 64 - K;
+    const float* hplane = a.hist + (long long)a.histSlot * a.histPlane;
+    const int hpitchB = a.histPitch * 4;
+    const int hsoff0 = (hti * RXI - K + ws) * hpitchB;
+    const int hvoff = (htj * WI - K + lane) * 4;
+
+#pragma unroll 1
+    for (int s = 0; s < a.nsteps; ++s) {
+        // pressure sweep, FDTD.cpp:124-141 (row R-1 holds no live pressure)
+#pragma unroll
+        for (int r = 0; r < R - 1; ++r) {
+            const float vyR = laneNext(vy[r]);
+            const float div = (vx[r + 1] - vx[r]) + (vyR - vy[r]);
+            pr[r] = bt[r] * (pr[r] - C * div);
+        }
+        // vx sweep, FDTD.cpp:143-170 (+ edges :201-223 through the coefficients): own rows only
+#pragma unroll
+        for (int r = R - 2; r >= 1; --r) {
+            const float pi = pr[r], pn = pr[r - 1];
+            const float air = vx[r] - C * (pi - pn);
+            const float wall = kx[r] * (pi + pn);
+            vx[r] = (kx[r] != kx[r]) ? air : wall;
+        }
+        sh.xch[s & 1][wave][0][lane] = vx[1];
+        sh.xch[s & 1][wave][1][lane] = vx[R - 2];
+        // vy sweep, FDTD.cpp:172-199
+#pragma unroll
+        for (int r = 0; r < R - 1; ++r) {
+            const float pi = pr[r];
+            const float pn = lanePrev(pi);
+            const float air = vy[r] - C * (pi - pn);
+            const float wall = ky[r] * (pi + pn);
+            vy[r] = (ky[r] != ky[r]) ? air : wall;
+        }
+        // LDS only: the history stores of earlier steps stay in flight across the barrier
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (!first) vx[0] = sh.xch[s & 1][wave - 1][1][lane];
+        if (!last) vx[R - 1] = sh.xch[s & 1][wave + 1][0][lane];
+
+        // record the pressure of this step before the pulse is injected (FDTD.cpp:226-234)
+        if (rec && inCols) {
+            const rsrc_t rH = makeRsrc(hplane, a.histPlane * 4);
+#pragma unroll
+            for (int r = 1; r < R - 1; ++r)
+                if (r >= rLo && r < rHi) bufStoreF(pr[r], rH, hvoff, hsoff0 + r * hpitchB);
+        }
+        hplane += a.histPlane;
+
+        if (hasL) {  // soft source: p[listener] += pulse[t], FDTD.cpp:234
+            const float pv = (lane == lc) ? a.pulse[a.t0 + s] : 0.f;
+#pragma unroll
+            for (int r = 0; r < R - 1; ++r) pr[r] += (r == lr) ? pv : 0.f;
+        }
+    }
+
+    const rsrc_t rPrOut = makeRsrc(a.prOut, a.planeBytes), rVxOut = makeRsrc(a.vxOut, a.planeBytes),
+                 rVyOut = makeRsrc(a.vyOut, a.planeBytes);
+    if (inCols) {
+#pragma unroll
+        for (int r = 1; r < R - 1; ++r) {
+            if (r >= rLo && r < rHi) {
+                const int so = soff0 + r * pitchB;
+                bufStoreF(pr[r], rPrOut, voff, so);
+                bufStoreF(vx[r], rVxOut, voff, so);
+                bufStoreF(vy[r], rVyOut, voff, so);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// stacked air tile: W waves share one tall tile, x halo paid once per block
+// ---------------------------------------------------------------------------------------------------------------
+// The single-wave tile re-loads and re-computes a K-row halo above and below its RXI interior rows (36 of 60 rows are
+// interior at K = 12), and the kernel is bound by the bytes its CUs move.  Here the W waves of a block
+// own CONSECUTIVE row windows of one X-row tile and keep each other's boundary faces current through LDS, so the K-row
+// x halo is loaded once per block (X = 189 of 213 rows interior at K = 12, NP = 27, W = 4): 2.8 B of CU-level traffic
+// per cell-step instead of 3.7.
+//
+// Rows of the block, counted from the first loaded row (tile interior = rows [K, K+X)): wave w holds the R = 2*NP
+// rows [w(R-1), w(R-1)+R) in the mirror-pair layout above, plus face vx_row[R] in the spare slot vx[0].y.  Its first
+// row is the previous wave's last one: pr and vy of that row are advanced redundantly by both waves, so that the ONLY
+// values a wave needs from its neighbours each step are two faces of vx --
+//     vx_row[0]  (from the wave above: its vx_row[R-1])    and    vx_row[R]  (from the wave below: its vx_row[1]),
+// both of which live in the sender's pair vx[1] and both of which land in the receiver's pair vx[0].  Per step and
+// wave: one 8-byte LDS write, one workgroup barrier, two 4-byte LDS reads (slots double-buffered by step parity).
+// The first wave's top K rows and the last wave's bottom K (+D) rows are the tile's x halo; what they hold decays
+// one row per step exactly as in the single-wave tile.  Every wave advances all of its rows on every step (no
+// trapezoid), so the waves of a block stay balanced and the time loop is a real loop: the kernel is a tenth of the
+// unrolled tile kernel's code.
+template <int K, int NP, int W, int X>
+struct StackGeom {
+    static constexpr int R = 2 * NP;
+    static constexpr int L = W * (R - 1) + 1;   // rows loaded by the block
+    static constexpr int D = L - X - 2 * K;     // halo rows beyond K at the bottom (X need not use every row)
+    static constexpr int WI = 64 - 2 * K;
+    static_assert(D >= 0, "tile taller than the block's windows");
+    static_assert(R - 1 >= K + D + 1, "halo must fit the end waves");
+};
+
+// row r of a wave's window (LO <= r < HI, compile-time) -> register
+template <int NP>
+__device__ __forceinline__ float mirrorRow(const v2f (&f)[NP], int r) {
+    return r < NP ? f[r].x : f[2 * NP - 1 - r].y;
+}
+template <int NP>
+__device__ __forceinline__ float mirrorVxRow(const v2f (&vx)[NP], float vxS, int r) {
+    return r < NP ? vx[r].x : (r == NP ? vxS : -vx[2 * NP - r].y);
+}
+
+template <int NP, int LO, int HI>
+__device__ __forceinline__ void stackRecord(const v2f (&pr)[NP], rsrc_t rH, int hvoff, int hsoff, int hpitchB) {
+#pragma unroll
+    for (int r = LO; r < HI; ++r) bufStoreF(mirrorRow<NP>(pr, r), rH, hvoff, hsoff + r * hpitchB);
+}
+
+template <int NP, int LO, int HI>
+__device__ __forceinline__ void stackStore(const v2f (&pr)[NP], const v2f (&vx)[NP], const v2f (&vy)[NP],
+                                           float vxS, rsrc_t rPr, rsrc_t rVx, rsrc_t rVy, int voff, int soff,
+                                           int pitchB) {
+#pragma unroll
+    for (int r = LO; r < HI; ++r) {
+        const int so = soff + r * pitchB;
+        bufStoreF(mirrorRow<NP>(pr, r), rPr, voff, so);
+        bufStoreF(mirrorVxRow<NP>(vx, vxS, r), rVx, voff, so);
+        bufStoreF(mirrorRow<NP>(vy, r), rVy, voff, so);
+    }
+}
+
+// LDS of one block: exchange slots [parity][wave][lane] + one activity flag per wave
+template <int W>
+struct StackShared {
+    v2f xch[2][W][64];
+    int nz[W];
+};
+
+template <int K, int NP, int W, int X>
+__device__ __forceinline__ void stepTileStack(const StepArgs& a, const int tile, const int wave, const int lane,
+                                              StackShared<W>& sh) {
+    using Gm = StackGeom<K, NP, W, X>;
+    constexpr int R = Gm::R, D = Gm::D, WI = Gm::WI;
+    const int ti = tile / a.nty;
+    const int tj = tile - ti * a.nty;
+    const int row0 = a.G - K + ti * X;
+    const int col0 = a.G - K + tj * WI;
+    const int ws = wave * (R - 1);  // first row of this wave's window
+    const int voff = lane * 4;
+    const int pitchB = a.pitch * 4;
+    const int soffW = ((row0 + ws) * a.pitch + col0) * 4;
+    const bool first = wave == 0, last = wave == W - 1;
+
+    const rsrc_t rPrIn = makeRsrc(a.prIn, a.inBytes), rVxIn = makeRsrc(a.vxIn, a.inBytes),
+                 rVyIn = makeRsrc(a.vyIn, a.inBytes);
+    v2f pr[NP], vx[NP], vy[NP];
+    float vxS = bufLoadF(rVxIn, voff, soffW + NP * pitchB);
+    float faceR = 0.f;  // vx_row[R]: the next wave's vx_row[1]; below the last wave it is outside the block
+    if (!last) faceR = bufLoadF(rVxIn, voff, soffW + R * pitchB);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int soT = soffW + i * pitchB, soB = soffW + (R - 1 - i) * pitchB;
+        pr[i].x = bufLoadF(rPrIn, voff, soT);
+        pr[i].y = bufLoadF(rPrIn, voff, soB);
+        vy[i].x = bufLoadF(rVyIn, voff, soT);
+        vy[i].y = bufLoadF(rVyIn, voff, soB);
+        vx[i].x = bufLoadF(rVxIn, voff, soT);
+        if (i > 0) vx[i].y = -bufLoadF(rVxIn, voff, soB + pitchB);
+    }
+    vx[0].y = -faceR;
+
+    uint32_t nz = __float_as_uint(vxS) | __float_as_uint(faceR);
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+        nz |= __float_as_uint(pr[i].x) | __float_as_uint(pr[i].y) | __float_as_uint(vx[i].x) |
+              __float_as_uint(vx[i].y) | __float_as_uint(vy[i].x) | __float_as_uint(vy[i].y);
+    const bool activeW = __ballot((nz & 0x7fffffffu) != 0u) != 0ull;
+    if (lane == 0) sh.nz[wave] = activeW ? 1 : 0;
+    __syncthreads();
+    bool active = false;
+#pragma unroll
+    for (int w = 0; w < W; ++w) active = active || sh.nz[w] != 0;
+    const bool writer = first && lane == 0;
+    if (writer) a.nzOut[tile] = active ? 1 : 0;
+
+    const DynParams dyn = *a.dyn;
+    const int hti = ti - dyn.histTileX0, htj = tj - dyn.histTileY0;
+    const bool inWin = hti >= 0 && hti < dyn.histTilesX && htj >= 0 && htj < dyn.histTilesY;
+    const bool wasActive = a.record && a.tileFirst[tile] != INT_MAX;
+    const bool rec = a.record && inWin && (active || wasActive || a.dense) && historyWanted(a, ti, tj);
+    // tileFirst is read by every wave above and written here: the barrier inside the first step separates the two
+    const bool setFirst = a.record && active && !wasActive && writer;
+    if (a.record && active && !inWin && writer) atomicExch(a.errFlag, 1);
+
+    const float C = a.courant;
+    const bool inCols = lane >= K && lane < 64 - K;
+    const bool recLane = rec && inCols;
+    const float* hplane = a.hist + (long long)a.histSlot * a.histPlane;
+    const int hpitchB = a.histPitch * 4;
+    const int hsoffW = (hti * X - K + ws) * hpitchB;  // + r*hpitchB; stored rows have -K + ws + r >= 0
+    const int hvoff = (htj * WI - K + lane) * 4;
+
+#pragma unroll 1
+    for (int s = 0; s < a.nsteps; ++s) {
+        mirrorPressureSweep<NP, 4, 0>(pr, vx, vy, vxS, C);
+        mirrorVxSweep<NP, 4, 1>(pr, vx, vxS, C);  // pair 0 of vx is received, not computed
+        sh.xch[s & 1][wave][lane] = vx[1];
+        mirrorVySweep<NP, 4, 0>(pr, vy, C);
+        // LDS only: the history stores of earlier steps stay in flight across the barrier
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (s == 0 && setFirst) atomicMin(&a.tileFirst[tile], a.t0);
+        const float up = first ? 0.f : sh.xch[s & 1][first ? 0 : wave - 1][lane].y;
+        const float dn = last ? 0.f : sh.xch[s & 1][last ? 0 : wave + 1][lane].x;
+        vx[0] = v2f{-up, -dn};
+        if (recLane) {  // pressure of this step, interior rows (air tiles never hold the listener)
+            const rsrc_t rH = makeRsrc(hplane, a.histPlane * 4);
+            if (first)
+                stackRecord<NP, K, R>(pr, rH, hvoff, hsoffW, hpitchB);
+            else if (last)
+                stackRecord<NP, 1, R - K - D>(pr, rH, hvoff, hsoffW, hpitchB);
+            else
+                stackRecord<NP, 1, R>(pr, rH, hvoff, hsoffW, hpitchB);
+        }
+        hplane += a.histPlane;
+    }
+
+    const rsrc_t rPrOut = makeRsrc(a.prOut, a.planeBytes), rVxOut = makeRsrc(a.vxOut, a.planeBytes),
+                 rVyOut = makeRsrc(a.vyOut, a.planeBytes);
+    if (inCols) {
+        if (first)
+            stackStore<NP, K, R>(pr, vx, vy, vxS, rPrOut, rVxOut, rVyOut, voff, soffW, pitchB);
+        else if (last)
+            stackStore<NP, 1, R - K - D>(pr, vx, vy, vxS, rPrOut, rVxOut, rVyOut, voff, soffW, pitchB);
+        else
+            stackStore<NP, 1, R>(pr, vx, vy, vxS, rPrOut, rVxOut, rVyOut, voff, soffW, pitchB);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // row-streaming air kernel
 // ---------------------------------------------------------------------------------------------------------------
 // The tile kernels sit on their load/store floor: a (RXI+2K) x 64 tile re-reads a K-row halo above and below its RXI
@@ -741,9 +1300,7 @@ __device__ __forceinline__ bool bandPosition(const StepArgs& a, int q, int bandR
 
 // block b (of the air part of a launch), wave w -> tile.  XCD x = b % 8 owns a contiguous span of the row-major tile
 // sequence: ntiles/8 tiles each (order 1, balanced to one tile), or a band of whole tile rows (orders 2, >= 4).
-__device__ __forceinline__ bool xcdTile(const StepArgs& a, int b, int wave, int* ti, int* tj) {
-    const int xcd = b & 7;
-    const int q = (b >> 3) * 4 + wave;  // position inside the XCD's share
+__device__ __forceinline__ bool xcdTileAt(const StepArgs& a, int xcd, int q, int* ti, int* tj) {
     if (a.tileOrder <= 1) {
         const int per = (a.ntiles + 7) >> 3;
         const int t = xcd * per + q;
@@ -759,6 +1316,9 @@ __device__ __forceinline__ bool xcdTile(const StepArgs& a, int b, int wave, int*
     if (!bandPosition(a, q, bandRows, &r, tj)) return false;
     *ti = ti0 + r;
     return true;
+}
+__device__ __forceinline__ bool xcdTile(const StepArgs& a, int b, int wave, int* ti, int* tj) {
+    return xcdTileAt(a, b & 7, (b >> 3) * 4 + wave, ti, tj);  // position inside the XCD's share
 }
 
 // air tiles: one wave per tile, 4 tiles per 256-thread block; tiles of the other class exit immediately.
@@ -787,7 +1347,7 @@ __global__ __launch_bounds__(256, WPS) void pv_step_air_kernel(const StepArgs a)
         if (lr >= 0 && lr < RXI + 2 * K && lc >= 0 && lc < 64) return;
     }
     if constexpr (PACKED && (RXI + 2 * K) % 2 == 0) {
-        stepTileAirPacked<K, RXI>(a, tile, lane);
+        airTilePacked<K, RXI>(a, tile, lane);
     } else {
         stepTile<K, RXI, RXI, false>(a, tile, 0, lane, nullptr);
     }
@@ -818,18 +1378,16 @@ __global__ __launch_bounds__(256, 2) void pv_step_general_kernel(const StepArgs 
 template <int K, int RXI, int WPS, int SUB>
 __global__ __launch_bounds__(256, WPS) void pv_step_merged_kernel(const StepArgs a) {
     __shared__ float lut[256];
-    constexpr int S = RXI / SUB;
-    static_assert(S * SUB == RXI, "general-tile split must divide the tile");
+    __shared__ GenShared gsh;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int gblocks = (a.numGeneral * S + 3) / 4;
+    const int gblocks = a.numGeneral;  // one block per general tile
     if ((int)blockIdx.x < gblocks) {
+        if ((int)blockIdx.x >= a.dyn->numGeneral) return;
         lut[threadIdx.x] = a.lut[threadIdx.x];
         __syncthreads();
-        const int idx = blockIdx.x * 4 + wave;
-        if (idx >= a.dyn->numGeneral * S) return;
-        const int tile = __builtin_amdgcn_readfirstlane(a.generalList[idx / S]);
-        stepTile<K, RXI, SUB, true>(a, tile, idx % S, lane, lut);
+        const int tile = __builtin_amdgcn_readfirstlane(a.generalList[blockIdx.x]);
+        stepTileGeneral4<K, RXI>(a, tile, wave, lane, lut, gsh);
         return;
     }
     const int b = blockIdx.x - gblocks;
@@ -842,18 +1400,51 @@ __global__ __launch_bounds__(256, WPS) void pv_step_merged_kernel(const StepArgs
         if (lr >= 0 && lr < RXI + 2 * K && lc >= 0 && lc < 64) return;
     }
     if constexpr ((RXI + 2 * K) % 2 == 0) {
-        stepTileAirPacked<K, RXI>(a, tile, lane);
+        airTilePacked<K, RXI>(a, tile, lane);
     } else {
         stepTile<K, RXI, RXI, false>(a, tile, 0, lane, nullptr);
     }
 }
 
+// Stacked form of the merged launch: the first blocks advance the general tiles in SUB-row slices (one wave each,
+// as above), every other block advances ONE air tile of X rows with its W = 4 waves (stepTileStack).
+template <int K, int NP, int X, int SUB>
+__global__ __launch_bounds__(256, 2) void pv_step_stack_kernel(const StepArgs a) {
+    constexpr int W = 4;
+    using Gm = StackGeom<K, NP, W, X>;
+    __shared__ float lut[256];
+    __shared__ StackShared<W> sh;
+    constexpr int S = X / SUB;
+    static_assert(S * SUB == X, "general-tile split must divide the tile");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int gblocks = (a.numGeneral * S + 3) / 4;
+    if ((int)blockIdx.x < gblocks) {
+        lut[threadIdx.x] = a.lut[threadIdx.x];
+        __syncthreads();
+        const int idx = blockIdx.x * 4 + wave;
+        if (idx >= a.dyn->numGeneral * S) return;
+        const int tile = __builtin_amdgcn_readfirstlane(a.generalList[idx / S]);
+        stepTile<K, X, SUB, true>(a, tile, idx % S, lane, lut);
+        return;
+    }
+    const int b = blockIdx.x - gblocks;
+    int ti, tj;
+    if (!xcdTileAt(a, b & 7, b >> 3, &ti, &tj)) return;
+    const int tile = ti * a.nty + tj;
+    if (a.tileClass[tile] != 0) return;
+    if (a.withPulse) {  // the tile(s) holding the listener are on the general list
+        const int lr = a.dyn->lrow - (a.G - K + ti * X), lc = a.dyn->lcol - (a.G - K + tj * Gm::WI);
+        if (lr >= 0 && lr < Gm::L && lc >= 0 && lc < 64) return;
+    }
+    stepTileStack<K, NP, W, X>(a, tile, wave, lane, sh);
+}
+
 // Per-tile class: 0 = every face code in the tile's loaded region is air|air, 1 = needs the general kernel.
 // One wave per tile.  Tiles of class 1 are also appended to generalList (order irrelevant).
-template <int K, int RXI>
+template <int K, int RXI, int ROWS = RXI + 2 * K>
 __global__ __launch_bounds__(256) void pv_tileclass_kernel(const uint16_t* codes, uint8_t* tileClass,
                                                            int* generalList, int* generalCount, Geometry g) {
-    constexpr int ROWS = RXI + 2 * K;
     constexpr int WI = 64 - 2 * K;
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -879,11 +1470,10 @@ static int bandPositions(const StepArgs& a) {
 
 template <int K, int RXI, int WPS, int SUB>
 static void launchStepT(const StepArgs& a, hipStream_t stream, int which, hipStream_t stream2) {
-    if (which == 4) {  // merged single launch
-        constexpr int MS = (RXI % 4 == 0) ? RXI / 4 : SUB;
-        const int gblocks = (a.numGeneral * (RXI / MS) + 3) / 4;
-        const int blocks = gblocks + 8 * ((bandPositions(a) + 3) / 4);
-        hipLaunchKernelGGL((pv_step_merged_kernel<K, RXI, WPS, MS>), dim3(blocks), dim3(256), 0, stream, a);
+    if (which == 4) {  // merged single launch: one block per general tile, then 4 air tiles per block
+        if (getenv("PVA_DEBUG_SKIP_GENERAL")) const_cast<StepArgs&>(a).numGeneral = 0;
+        const int blocks = a.numGeneral + 8 * ((bandPositions(a) + 3) / 4);
+        hipLaunchKernelGGL((pv_step_merged_kernel<K, RXI, WPS, SUB>), dim3(blocks), dim3(256), 0, stream, a);
         return;
     }
     if ((which & 1) && a.streamM > 0) {
@@ -904,12 +1494,21 @@ static void launchStepT(const StepArgs& a, hipStream_t stream, int which, hipStr
     }
 }
 
-template <int K, int RXI>
+template <int K, int RXI, int ROWS = RXI + 2 * K>
 static void launchTileClassT(const uint16_t* codes, uint8_t* tileClass, int* list, int* count, const Geometry& g,
                              hipStream_t stream) {
     const int blocks = (g.ntx * g.nty + 3) / 4;
-    hipLaunchKernelGGL((pv_tileclass_kernel<K, RXI>), dim3(blocks), dim3(256), 0, stream, codes, tileClass, list,
-                       count, g);
+    hipLaunchKernelGGL((pv_tileclass_kernel<K, RXI, ROWS>), dim3(blocks), dim3(256), 0, stream, codes, tileClass,
+                       list, count, g);
+}
+
+template <int K, int NP, int X, int SUB>
+static void launchStackT(const StepArgs& a0, hipStream_t stream) {
+    StepArgs a = a0;
+    if (getenv("PVA_DEBUG_SKIP_GENERAL")) a.numGeneral = 0;
+    const int gblocks = (a.numGeneral * (X / SUB) + 3) / 4;
+    const int blocks = gblocks + 8 * bandPositions(a);  // one block per air tile
+    hipLaunchKernelGGL((pv_step_stack_kernel<K, NP, X, SUB>), dim3(blocks), dim3(256), 0, stream, a);
 }
 
 // (K steps per launch, interior rows per tile, waves/SIMD bound of the air kernel, rows per general-tile slice)
@@ -918,7 +1517,16 @@ static void launchTileClassT(const uint16_t* codes, uint8_t* tileClass, int* lis
     X(8, 48, 2, 12) X(12, 40, 2, 10) X(8, 40, 2, 10) X(12, 32, 2, 8) X(10, 36, 2, 9) X(8, 44, 2, 11) X(10, 40, 2, 10) X(12, 36, 2, 9) \
     X(9, 42, 2, 14) X(11, 36, 2, 9) X(9, 40, 2, 10)
 
+// stacked tiles (K steps per launch, row pairs per wave, interior rows per tile, rows per general-tile slice); the
+// tile's interior height doubles as the configuration's `rxi`
+#define PV_STACK_CONFIGS(X) \
+    X(12, 28, 196, 7) X(12, 30, 210, 10)
+
 void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream, int which, hipStream_t stream2) {
+#define X(k, np, x, sub) \
+    if (K == k && rxi == x) return launchStackT<k, np, x, sub>(a, stream);
+    PV_STACK_CONFIGS(X)
+#undef X
 #define X(k, r, w, sub) \
     if (K == k && rxi == r) return launchStepT<k, r, w, sub>(a, stream, which, stream2);
     PV_STEP_CONFIGS(X)
@@ -927,6 +1535,11 @@ void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream, int which
 
 void launchTileClass(int K, int rxi, const uint16_t* codes, uint8_t* tileClass, int* list, int* count,
                      const Geometry& g, hipStream_t stream) {
+#define X(k, np, x, sub) \
+    if (K == k && rxi == x) \
+        return launchTileClassT<k, x, StackGeom<k, np, 4, x>::L>(codes, tileClass, list, count, g, stream);
+    PV_STACK_CONFIGS(X)
+#undef X
 #define X(k, r, w, sub) \
     if (K == k && rxi == r) return launchTileClassT<k, r>(codes, tileClass, list, count, g, stream);
     PV_STEP_CONFIGS(X)
@@ -935,11 +1548,34 @@ void launchTileClass(int K, int rxi, const uint16_t* codes, uint8_t* tileClass, 
 
 // configurations whose merged (single-launch) kernel allocates without spills in the air-tile path (K = 8 keeps one
 // 4-byte spill in the general-slice path, outside the air tiles' code; measured: no effect on the launch time)
+// stacked configuration: rows its blocks load beyond rxi + 2K (0 for the single-wave tiles)
+int stepConfigExtraRows(int K, int rxi) {
+#define X(k, np, x, sub) \
+    if (K == k && rxi == x) return StackGeom<k, np, 4, x>::D;
+    PV_STACK_CONFIGS(X)
+#undef X
+#define X(k, r, w, sub) \
+    if (K == k && rxi == r) return GenStackGeom<k, r>::D;
+    PV_STEP_CONFIGS(X)
+#undef X
+    return 0;
+}
+
+bool stepConfigStacked(int K, int rxi) {
+#define X(k, np, x, sub) \
+    if (K == k && rxi == x) return true;
+    PV_STACK_CONFIGS(X)
+#undef X
+    return false;
+}
+
 bool mergedConfigOk(int K, int rxi) {
+    if (stepConfigStacked(K, rxi)) return true;
     return (K == 8 && rxi == 24) || (K == 4 && rxi == 32) || (K == 6 && rxi == 28) || K >= 10 || rxi >= 40;
 }
 
 bool stepConfigSupported(int K, int rxi) {
+    if (stepConfigStacked(K, rxi)) return true;
 #define X(k, r, w, sub) \
     if (K == k && rxi == r) return true;
     PV_STEP_CONFIGS(X)

@@ -12,6 +12,10 @@ namespace pva {
 // supported (K steps per launch, interior rows per tile) instantiations of the fused stencil
 bool stepConfigSupported(int K, int rxi);
 bool mergedConfigOk(int K, int rxi);
+// stacked tiles (W waves share one tall tile): always one merged launch; their blocks load
+// stepConfigExtraRows() rows beyond rxi + 2K at the bottom, which the guard band must cover
+bool stepConfigStacked(int K, int rxi);
+int stepConfigExtraRows(int K, int rxi);
 // which: bit 0 = air-tile kernel, bit 1 = general-tile kernel (both write disjoint tiles of the same planes);
 // 4 = both in ONE merged launch (general slices first, then the air tiles)
 // The general kernel goes to stream2 when given (the caller orders the two streams with events).

@@ -70,16 +70,20 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     for (auto& e : ev_)
         if (!hipOk(hipEventCreate(&e), "hipEventCreate")) return false;
 
-    // Default tile = fastest measured on MI355X for the grid's size class (tools/gpu_tune.py).  Large grids take the
-    // 60-row tile at 2 waves/SIMD with K = 12 (36 x 40 interior cells of the 60 x 64 loaded: 3.7 B of CU-level
-    // traffic per cell-step instead of 4.8 for the 40-row tile at K = 8); it needs several thousand tiles to fill
-    // 256 CUs x 8 waves a few times over.  Smaller grids are bound by launch latency and wave quantisation and
-    // prefer many small tiles.
+    // Default tile = fastest measured on MI355X for the grid's size class (tools/gpu_tune.py, profiles/r01_sizes.txt).
+    // Large grids take the 60-row tile at 2 waves/SIMD with K = 12 (36 x 40 interior cells of the 60 x 64 loaded:
+    // 3.7 B of CU-level traffic per cell-step instead of 4.8 for the 40-row tile at K = 8); it needs several
+    // thousand tiles to fill 256 CUs x 8 waves a few times over.  Around 2048^2 the 56-row tile at K = 10 fills the
+    // chip more evenly; smaller grids are bound by launch latency and wave quantisation and prefer many small tiles.
+    const long long tiles36 = (long long)ceilDiv(g_.NX, 36) * ceilDiv(g_.NY, 40);
     if (opt.K > 0 || opt.rxi > 0) {
         K_ = opt.K > 0 ? opt.K : 8;
         rxi_ = opt.rxi > 0 ? opt.rxi : 24;
-    } else if ((long long)ceilDiv(g_.NX, 36) * ceilDiv(g_.NY, 40) >= 8192) {
+    } else if (tiles36 >= 4500) {
         K_ = 12;
+        rxi_ = 36;
+    } else if (tiles36 >= 1500) {
+        K_ = 10;
         rxi_ = 36;
     } else {
         K_ = 8;
@@ -93,7 +97,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     geo_.gy = g_.gy;
     geo_.NX = g_.NX;
     geo_.NY = g_.NY;
-    const int kGuard = std::max(kMinGuard, K_);
+    const int kGuard = std::max(kMinGuard, K_ + stepConfigExtraRows(K_, rxi_));
     geo_.G = kGuard;
     geo_.rxi = rxi_;
     geo_.wi = wi_;
@@ -331,12 +335,19 @@ bool Solver::applyGeometry() {
     // coefficient LUT: Y = (1 - R) / (1 + R), FDTD.cpp:150,156
     float lut[256];
     for (float& v : lut) v = 0.f;
-    lut[kLutAir] = std::numeric_limits<float>::quiet_NaN();
+    // Sign convention the packed general slices rely on (stepSlicePacked): coefficients of an AIR cell's own faces
+    // (air sentinel, -Y_n) carry the sign bit, those of a WALL cell (+0, +Y_i) do not, so beta == signbit(ky).  It
+    // holds while every Y >= 0, i.e. R in (-1, 1]; a scene outside that (non-physical) range keeps the scalar
+    // two-kernel path, which carries beta separately.
+    const uint32_t negNaN = 0xffc00000u;
+    std::memcpy(&lut[kLutAir], &negNaN, 4);
+    lutSignOk_ = true;
     for (size_t p = 0; p < palette_.size(); ++p) {
         const float Rv = palette_[p];
         const float Y = (1.f - Rv) / (1.f + Rv);
         lut[kLutNegBase + p] = -Y;
         lut[kLutPosBase + p] = Y;
+        if (!(Y >= 0.f)) lutSignOk_ = false;
     }
     lut[kLutWall] = 0.f;
     if (!hipOk(hipMemcpyAsync(lutDev_, lut, sizeof(lut), hipMemcpyHostToDevice, stream_), "lut upload"))
@@ -454,7 +465,7 @@ bool Solver::prepareDyn(int lcx, int lcy, bool withPulse) {
     *dynHost_ = d;
 
     // general-kernel work list = wall/edge tiles + every tile whose loaded region holds the listener
-    const int rowsT = rxi_ + 2 * K_;
+    const int rowsT = rxi_ + 2 * K_ + (stepConfigStacked(K_, rxi_) ? stepConfigExtraRows(K_, rxi_) : 0);
     int n = 0;
     for (int t : wallTiles_) listHost_[n++] = t;
     if (inside) {
@@ -526,7 +537,10 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
     // tiles of the other set, so launch i+1 of EITHER kernel must wait for launch i of BOTH (RAW on the halos it
     // reads, WAR on the tiles it overwrites): one event per kernel per launch.
     // merged: one launch per K steps on one stream (no cross-stream hand-shake); not with the streaming kernel
-    const bool mergedLaunch = opt_.merged == 1 && mergedConfigOk(K_, rxi_) && opt_.streamRows == 0;
+    const bool stacked = stepConfigStacked(K_, rxi_);
+    if (stacked && !lutSignOk_) return fail("stacked tiles need wall absorption in (-1, 1]");
+    const bool mergedLaunch =
+        stacked || (opt_.merged == 1 && mergedConfigOk(K_, rxi_) && opt_.streamRows == 0 && lutSignOk_);
     const bool two = launchCap_ > 0 && !mergedLaunch;
     const int nl = ceilDiv(nsteps, K_);
     if (two) {

@@ -150,6 +150,53 @@ def test_golden_512_mode_b(pvlib):
         compare_output(s.get_output(g["emitters"][0]), g["emitter_out"][0])
 
 
+STACKED = [dict(steps_per_launch=12, tile_rows=196), dict(steps_per_launch=12, tile_rows=210)]
+
+
+@pytest.mark.parametrize("opts", STACKED)
+def test_stacked_tiles_golden_512(pvlib, opts):
+    """stacked air tiles (4 waves share one tall tile, boundary faces exchanged through LDS every step) against the
+    reference's vectors for BASELINE config 2 (Mode A): the pulse crosses several stacked tiles in x and y"""
+    g = golden("g512A_shoebox")
+    gx, gy, T, fs = (int(v) for v in g["dims"])
+    with pvlib.Solver(float(g["size"]), float(g["size"]), 275, **opts) as s:
+        assert s.info.tileRows == opts["tile_rows"]
+        for b in g["boxes"]:
+            s.add_geometry(b)
+        s.run(g["listener"])
+        res, delay = s.results()
+        c = g["cells"]
+        compare_maps(res[c[:, 0], c[:, 1]], delay[c[:, 0], c[:, 1]], g["cell_results"], g["cell_delay"], T, fs)
+        for (cx, cy), ir in zip(g["probe_cells"], g["probe_ir"]):
+            assert same_bits(s.impulse_response(cx, cy), ir).all()
+        compare_output(s.get_output(g["emitters"][0]), g["emitter_out"][0])
+
+
+@pytest.mark.parametrize("opts", STACKED)
+def test_stacked_tiles_match_single_wave_tiles_1024(pvlib, opts):
+    """same bits as the single-wave tile kernel on every cell of a 1024^2 grid: final fields, recorded planes, delay
+    and result maps (walls inside the pulse's reach, listener near a stacked tile's corner)"""
+    dx = np.float32(343.21) / np.float32(275) / np.float32(3.5)
+    size = float((1024 + 0.5) * dx)
+    L = ((196 * 2 + 0.5) * float(dx), 0.0, (40 * 9 + 1.5) * float(dx))
+    boxes = [[L[0] + 20.0, L[2] + 9.0, 30.0, 1.0, 0.85], [L[0] - 33.0, L[2] - 4.0, 1.2, 55.0, 0.5],
+             [L[0] + 3.0, L[2] - 60.0, 44.0, 2.0, 0.969536]]
+    with pvlib.Solver(size, size, 275, steps_per_launch=8, tile_rows=24) as a, \
+            pvlib.Solver(size, size, 275, **opts) as b:
+        for s in (a, b):
+            for box in boxes:
+                s.add_geometry(box)
+            s.run(L)
+        for fa, fb in zip(a.fields(), b.fields()):
+            assert same_bits(fa, fb).all()
+        for t in (0, 50, 211, 434):
+            assert same_bits(a.history_plane(t), b.history_plane(t)).all(), "recorded pr, step %d" % t
+        ra, da = a.results()
+        rb, db = b.results()
+        assert same_bits(da, db).all() and same_bits(ra, rb).all()
+        assert (da < 1e30).sum() > 100000
+
+
 def random_scene(rng, size, nbox):
     boxes = []
     for _ in range(nbox):
