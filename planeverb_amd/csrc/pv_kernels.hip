@@ -25,7 +25,6 @@
 #include <cfloat>
 #include <climits>
 #include <cstdint>
-#include <cstdlib>
 
 #include "pv_device.h"
 #include "pv_launch.h"
@@ -1471,7 +1470,6 @@ static int bandPositions(const StepArgs& a) {
 template <int K, int RXI, int WPS, int SUB>
 static void launchStepT(const StepArgs& a, hipStream_t stream, int which, hipStream_t stream2) {
     if (which == 4) {  // merged single launch: one block per general tile, then 4 air tiles per block
-        if (getenv("PVA_DEBUG_SKIP_GENERAL")) const_cast<StepArgs&>(a).numGeneral = 0;
         const int blocks = a.numGeneral + 8 * ((bandPositions(a) + 3) / 4);
         hipLaunchKernelGGL((pv_step_merged_kernel<K, RXI, WPS, SUB>), dim3(blocks), dim3(256), 0, stream, a);
         return;
@@ -1503,9 +1501,7 @@ static void launchTileClassT(const uint16_t* codes, uint8_t* tileClass, int* lis
 }
 
 template <int K, int NP, int X, int SUB>
-static void launchStackT(const StepArgs& a0, hipStream_t stream) {
-    StepArgs a = a0;
-    if (getenv("PVA_DEBUG_SKIP_GENERAL")) a.numGeneral = 0;
+static void launchStackT(const StepArgs& a, hipStream_t stream) {
     const int gblocks = (a.numGeneral * (X / SUB) + 3) / 4;
     const int blocks = gblocks + 8 * bandPositions(a);  // one block per air tile
     hipLaunchKernelGGL((pv_step_stack_kernel<K, NP, X, SUB>), dim3(blocks), dim3(256), 0, stream, a);

@@ -335,19 +335,12 @@ bool Solver::applyGeometry() {
     // coefficient LUT: Y = (1 - R) / (1 + R), FDTD.cpp:150,156
     float lut[256];
     for (float& v : lut) v = 0.f;
-    // Sign convention the packed general slices rely on (stepSlicePacked): coefficients of an AIR cell's own faces
-    // (air sentinel, -Y_n) carry the sign bit, those of a WALL cell (+0, +Y_i) do not, so beta == signbit(ky).  It
-    // holds while every Y >= 0, i.e. R in (-1, 1]; a scene outside that (non-physical) range keeps the scalar
-    // two-kernel path, which carries beta separately.
-    const uint32_t negNaN = 0xffc00000u;
-    std::memcpy(&lut[kLutAir], &negNaN, 4);
-    lutSignOk_ = true;
+    lut[kLutAir] = std::numeric_limits<float>::quiet_NaN();
     for (size_t p = 0; p < palette_.size(); ++p) {
         const float Rv = palette_[p];
         const float Y = (1.f - Rv) / (1.f + Rv);
         lut[kLutNegBase + p] = -Y;
         lut[kLutPosBase + p] = Y;
-        if (!(Y >= 0.f)) lutSignOk_ = false;
     }
     lut[kLutWall] = 0.f;
     if (!hipOk(hipMemcpyAsync(lutDev_, lut, sizeof(lut), hipMemcpyHostToDevice, stream_), "lut upload"))
@@ -537,10 +530,8 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
     // tiles of the other set, so launch i+1 of EITHER kernel must wait for launch i of BOTH (RAW on the halos it
     // reads, WAR on the tiles it overwrites): one event per kernel per launch.
     // merged: one launch per K steps on one stream (no cross-stream hand-shake); not with the streaming kernel
-    const bool stacked = stepConfigStacked(K_, rxi_);
-    if (stacked && !lutSignOk_) return fail("stacked tiles need wall absorption in (-1, 1]");
     const bool mergedLaunch =
-        stacked || (opt_.merged == 1 && mergedConfigOk(K_, rxi_) && opt_.streamRows == 0 && lutSignOk_);
+        stepConfigStacked(K_, rxi_) || (opt_.merged == 1 && mergedConfigOk(K_, rxi_) && opt_.streamRows == 0);
     const bool two = launchCap_ > 0 && !mergedLaunch;
     const int nl = ceilDiv(nsteps, K_);
     if (two) {

@@ -179,7 +179,6 @@ private:
     int numGeneral_ = 0;
     int launchCap_ = 0;  // general-list entries the general kernel's grid is sized for
     bool geometryDirty_ = true;
-    bool lutSignOk_ = true;  // every wall admittance Y >= 0: the merged kernel's packed general slices may run
     float efree_ = 0.f;
     DynParams dynCur_{};
     bool dynValid_ = false;

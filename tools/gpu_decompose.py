@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Where a 4096^2 run's time goes (development aid): stencil from zero fields with / without the general slices,
-with the pulse and the history record, and from all-non-zero fields."""
+"""Where a 4096^2 run's time goes (development aid): stencil from zero fields, from all-non-zero fields, and the
+full run with the pulse and the history record."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,16 +30,10 @@ def t_steps(label):
 z = np.zeros((s.gx + 1, s.gy + 1), np.float32)
 s.set_fields(z, z, z)
 t_steps("zero fields, no record, no pulse")
-os.environ["PVA_DEBUG_SKIP_GENERAL"] = "1"
-t_steps("  same, general slices skipped")
-del os.environ["PVA_DEBUG_SKIP_GENERAL"]
 rng = np.random.default_rng(0)
 f = [rng.standard_normal(z.shape).astype(np.float32) * 1e-3 for _ in range(3)]
 s.set_fields(*f)
 t_steps("random fields, no record")
-os.environ["PVA_DEBUG_SKIP_GENERAL"] = "1"
-t_steps("  same, general slices skipped")
-del os.environ["PVA_DEBUG_SKIP_GENERAL"]
 L = (5, 0, 4)
 s.run(L)
 best = 1e9
