@@ -7,7 +7,12 @@ per GPU; listener positions cycle through the eight of SURVEY.md 8d.  A "step" i
 field reset + T fused leapfrog steps incl. pressure-history record + per-cell IR analysis (what one iteration of the
 reference's background loop does, PvContext.cpp:80-83).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid 4096] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid 4096] [--inflight B] [--no-cpu-baseline]
+
+Runs in flight: independent runs share nothing, so a GPU can work on B of them at once (B solver instances, each with
+its own planes and HIP stream; default B = 2).  One launch of the step kernel fills the chip for ~130 us and then
+drains; a second run's launches fill the start-up and drain gaps of the first (+22 % cell-updates/s at 4096^2, +40 %
+at 2048^2).  A step is then one batch of B listener positions per GPU; --inflight 1 runs them one at a time.
 
 N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL); runs are sharded round-robin
 with no data-path collective and one all-gather of the per-emitter outputs at the end ("scaling": "weak").
@@ -92,6 +97,9 @@ def main():
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--dense-history", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="independent runs a GPU works on concurrently (one solver instance + stream each); a step "
+                         "is one batch of this many listener positions per GPU")
     ap.add_argument("--use-graph", type=int, default=0, help="0 auto (grids of <= 4096 tiles), 1 always, 2 never")
     ap.add_argument("--time-kernels", type=int, default=0,
                     help="N > 0: HIP events around every Nth step-kernel launch instead of around the whole launch loop "
@@ -130,17 +138,23 @@ def main():
         opts["tile_rows"] = args.tile_rows
     if args.dense_history:
         opts["dense_history"] = 1
-    s = api.Solver(size, size, 275, device=local_rank, **opts)
-    s.load_scene(os.path.join(ROOT, "tests", "scenes", args.scene))
+    B = max(1, args.inflight)
+    solvers = [api.Solver(size, size, 275, device=local_rank, **opts) for _ in range(B)]
+    for sv in solvers:
+        sv.load_scene(os.path.join(ROOT, "tests", "scenes", args.scene))
+    s = solvers[0]
     cells = (s.gx + 1) * (s.gy + 1)
     T = s.T
 
-    def listener(step):
-        x, z = LISTENERS[(step * world + rank) % len(LISTENERS)]
+    def run_id(step, b):  # global index of the run solver b of this rank simulates in `step`
+        return (step * B + b) * world + rank
+
+    def listener(step, b):
+        x, z = LISTENERS[run_id(step, b) % len(LISTENERS)]
         return (float(x), 0.0, float(z))
 
-    def emitters(step):
-        x, _, z = listener(step)
+    def emitters(step, b):
+        x, _, z = listener(step, b)
         return [(x, 0.0, z + 2.0), (5.0, 0.0, 6.0)]
 
     def sync():
@@ -148,22 +162,40 @@ def main():
         if use_dist:
             dist.barrier(device_ids=[local_rank])
 
+    # warm-up: one run at a time, which also gives the step kernel's duration with a single run in flight
+    single_loop_ms = []
     for w in range(args.warmup):
-        s.run(listener(w))
-    n_runs = args.steps * world
+        for b, sv in enumerate(solvers):
+            sv.run(listener(w, b))
+            single_loop_ms.append(sv.timings().stepLoopMs or sv.timings().fdtdMs)
+    n_runs = args.steps * B * world
     local = {}
     fdtd_ms, ana_ms, air_ms, gen_ms, loop_ms = [], [], [], [], []
-    sync()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        s.run(listener(k))
-        local[k * world + rank] = np.stack([s.get_output(e).as_array() for e in emitters(k)])
-        t = s.timings()
+    pending = [None] * B
+
+    def collect(b):  # wait for solver b's run, fetch its per-emitter outputs and timings
+        sv, k = solvers[b], pending[b]
+        sv.sync()
+        local[run_id(k, b)] = np.stack([sv.get_output(e).as_array() for e in emitters(k, b)])
+        t = sv.timings()
         fdtd_ms.append(t.fdtdMs)
         ana_ms.append(t.analysisMs)
         air_ms.append(t.airKernelMs)
         gen_ms.append(t.generalKernelMs)
         loop_ms.append(t.stepLoopMs)
+        pending[b] = None
+
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        for b, sv in enumerate(solvers):
+            if pending[b] is not None:
+                collect(b)  # the other solvers' runs keep the GPU busy meanwhile
+            sv.run_async(listener(k, b))
+            pending[b] = k
+    for b in range(B):
+        if pending[b] is not None:
+            collect(b)
     gathered = pvd.gather_outputs(local, n_runs, dist if use_dist else None, dev)  # the one RCCL gather
     sync()
     elapsed = time.perf_counter() - t0
@@ -190,7 +222,16 @@ def main():
             if air == 0.0:  # the run was replayed from a hipGraph (<= 4096 tiles): events sit around the whole graph
                 air = float(np.mean(fdtd_ms)) * K / T
                 how = "HIP events around the graph replay (field reset + %d launches), x K/T" % launches
-        achieved = ALG_BYTES_PER_CELL_STEP * cells * steps_per_launch_avg / (air * 1e-3) / 1e9
+        alg_bytes = ALG_BYTES_PER_CELL_STEP * cells * steps_per_launch_avg
+        # B runs are in flight: B launches of the kernel overlap, each taking `air` ms, so the chip retires B launches'
+        # algorithmic bytes per `air`.  The single-run figures come from the warm-up runs (one run at a time).
+        achieved = B * alg_bytes / (air * 1e-3) / 1e9
+        single = None
+        if single_loop_ms and args.time_kernels == 0:
+            sl = float(np.mean(single_loop_ms)) * K / T
+            single = {"launch_ms": sl, "achieved": alg_bytes / (sl * 1e-3) / 1e9,
+                      "frac": alg_bytes / (sl * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "from": "the %d warm-up runs, one run in flight" % len(single_loop_ms)}
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(pmc):
@@ -198,38 +239,45 @@ def main():
                 traffic = json.load(open(pmc)).get("%d" % args.grid, {}).get("bytes_per_launch")
             except Exception:
                 traffic = None
-        value = world * cells * T * args.steps / elapsed
+        value = world * B * cells * T * args.steps / elapsed
         fd = float(np.mean(fdtd_ms)) * 1e-3
         out = {
             "metric": "grid_cell_updates_per_s", "value": value, "unit": "cell-updates/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s in a %dx%d grid (Mode A: 275 Hz, dx=%.4f m, %.3f m), T=%d; 1 step = 1 "
-                                   "simulation run (reset + T leapfrog steps with pr-history record + per-cell IR "
-                                   "analysis) for one listener position; %d run(s) per step across %d GPU(s)" % (
-                                       args.scene, s.gx, s.gy, s.dx, size, T, world, world),
+            "config": {"workload": "%s in a %dx%d grid (Mode A: 275 Hz, dx=%.4f m, %.3f m), T=%d; 1 run = reset + T "
+                                   "leapfrog steps with pr-history record + per-cell IR analysis for one listener "
+                                   "position; 1 step = one batch of %d independent run(s) per GPU, in flight "
+                                   "together; %d run(s) per step across %d GPU(s)" % (
+                                       args.scene, s.gx, s.gy, s.dx, size, T, B, B * world, world),
                        "grid": [s.gx, s.gy], "T": T, "res": 275, "mode": "A", "steps_per_launch": K,
                        "tile": [info.tileRows, info.tileCols], "dense_history": bool(args.dense_history),
+                       "runs_in_flight_per_gpu": B,
                        "parallelism": "runs sharded round-robin, 1 all-gather of outputs"},
-            "fdtd_cell_updates_per_s": world * cells * T / fd,
-            "impulse_responses_per_s": world * s.gx * s.gy * args.steps / elapsed,
+            "fdtd_cell_updates_per_s": world * B * cells * T / fd,
+            "impulse_responses_per_s": world * B * s.gx * s.gy * args.steps / elapsed,
             "fdtd_ms": fd * 1e3, "analysis_ms": float(np.mean(ana_ms)),
-            "hbm_bytes_held": int(info.deviceBytes),
+            "hbm_bytes_held": int(info.deviceBytes) * B,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "pv_step_merged_kernel<K=%d,rows=%d> (air tiles + general slices, one launch per K "
+                         "kernel": "pv_step_merged_kernel<K=%d,rows=%d> (air tiles + general tiles, one launch per K "
                                    "steps)" % (K, info.tileRows),
                          "launch_ms": air, "launch_ms_from": how, "launches_per_run": launches,
-                         "algorithmic_bytes_per_launch": ALG_BYTES_PER_CELL_STEP * cells * steps_per_launch_avg,
+                         "concurrent_launches": B, "algorithmic_bytes_per_launch": alg_bytes,
+                         "single_run": single,
                          "note": "algorithmic = 24 B per cell-step x cells x K fused steps; K-step temporal "
-                                 "blocking makes frac > 1 possible (SURVEY.md 8d)"},
+                                 "blocking makes frac > 1 possible (SURVEY.md 8d).  achieved = concurrent_launches x "
+                                 "algorithmic_bytes_per_launch / launch_ms: the launches of the runs in flight "
+                                 "overlap, each lasting launch_ms; single_run = the same kernel with one run in "
+                                 "flight"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    s.close()
+    for sv in solvers:
+        sv.close()
     if use_dist:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()

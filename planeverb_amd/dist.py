@@ -44,18 +44,37 @@ def gather_outputs(local, n_runs, dist=None, device=None):
     return out
 
 
-def run_sharded(make_solver, listeners, emitters_for, dist=None, device=None):
+def run_sharded(make_solver, listeners, emitters_for, dist=None, device=None, inflight=2):
     """Simulate `listeners` (list of (x, y, z)) sharded over the ranks and gather all per-emitter outputs.
     make_solver() -> planeverb_amd.api.Solver bound to this rank's GPU; emitters_for(k) -> list of emitter positions
-    of run k.  Returns [n_runs, n_emitters, 8]."""
+    of run k.  Returns [n_runs, n_emitters, 8].
+
+    inflight: runs a rank works on concurrently (one solver instance + HIP stream each).  A K-step launch fills the
+    chip and then drains; a second run's launches fill those gaps (+22 % cell-updates/s at 4096^2, +40 % at 2048^2,
+    measured on MI355X), a third brings nothing more."""
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
     mine = shard_runs(len(listeners), world, rank)
     local = {}
     if mine:
-        s = make_solver()
-        for k in mine:
-            s.run(listeners[k])
-            local[k] = np.stack([s.get_output(e).as_array() for e in emitters_for(k)])
-        s.close()
+        solvers = [make_solver() for _ in range(max(1, min(inflight, len(mine))))]
+        pending = [None] * len(solvers)
+
+        def collect(b):
+            k = pending[b]
+            solvers[b].sync()
+            local[k] = np.stack([solvers[b].get_output(e).as_array() for e in emitters_for(k)])
+            pending[b] = None
+
+        for j, k in enumerate(mine):
+            b = j % len(solvers)
+            if pending[b] is not None:
+                collect(b)  # the other solvers' runs keep the GPU busy meanwhile
+            solvers[b].run_async(listeners[k])
+            pending[b] = k
+        for b in range(len(solvers)):
+            if pending[b] is not None:
+                collect(b)
+        for s in solvers:
+            s.close()
     return gather_outputs(local, len(listeners), dist, device)

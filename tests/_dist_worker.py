@@ -12,6 +12,35 @@ def fake_result(k, n_em=3):
     return np.array([[k, e, k * 10 + e, 0.5, -1, 1, 0, k + e / 8] for e in range(n_em)], np.float32)
 
 
+class FakeSolver:
+    """stands in for planeverb_amd.api.Solver in run_sharded: run k's listener is (k, 0, 0); an output can only be
+    fetched between sync() and the next run_async(), like the real one's result map"""
+    made = 0
+
+    def __init__(self):
+        FakeSolver.made += 1
+        self.k, self.done = None, False
+
+    def run_async(self, listener):
+        assert self.k is None or self.done, "run started before the previous one was collected"
+        self.k, self.done = int(listener[0]), False
+
+    def sync(self):
+        self.done = True
+
+    def get_output(self, e):
+        assert self.done
+        row = fake_result(self.k)[int(e)]
+
+        class O:
+            def as_array(_):
+                return row
+        return O()
+
+    def close(self):
+        pass
+
+
 def main():
     rank, world, port, n_runs, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), sys.argv[5]
     import torch.distributed as dist
@@ -22,6 +51,10 @@ def main():
     mine = pvd.shard_runs(n_runs, world, rank)
     local = {k: fake_result(k) for k in mine}
     res = pvd.gather_outputs(local, n_runs, dist)
+    # the same through run_sharded with two runs in flight per rank
+    res2 = pvd.run_sharded(FakeSolver, [(k, 0, 0) for k in range(n_runs)], lambda k: [0, 1, 2], dist, inflight=2)
+    assert np.array_equal(res, res2), "run_sharded differs from gather_outputs"
+    assert FakeSolver.made == min(2, len(mine))
     np.savez(out, mine=np.array(mine, np.int64), out=res)
     dist.barrier()
     dist.destroy_process_group()

@@ -699,3 +699,32 @@ def test_graph_replay_survives_device_sync(pvlib):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _GRAPH_SYNC_SCRIPT, root], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "REPLAY-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# runs in flight (independent runs per GPU)
+# ----------------------------------------------------------------------------------------------------------------
+
+def test_runs_in_flight_match_sequential_runs(pvlib):
+    """dist.run_sharded keeps two independent runs in flight on one GPU (two solver instances, two streams); the
+    per-emitter outputs must be the bits of the same runs made one after the other"""
+    from planeverb_amd import dist as pvd
+    scene = os.path.join(SCENES, "HugeRoom.pv")
+    dx = np.float32(343.21) / np.float32(275) / np.float32(3.5)
+    size = float((512 + 0.5) * dx)
+    listeners = [(5.0, 0.0, 4.0), (8.0, 0.0, 8.0), (12.0, 0.0, 6.0), (15.0, 0.0, 15.0), (20.0, 0.0, 5.0)]
+
+    def emitters_for(k):
+        x, _, z = listeners[k]
+        return [(x, 0.0, z + 2.0), (5.0, 0.0, 6.0)]
+
+    def make():
+        s = pvlib.Solver(size, size, 275)
+        s.load_scene(scene)
+        return s
+
+    seq = pvd.run_sharded(make, listeners, emitters_for, inflight=1)
+    con = pvd.run_sharded(make, listeners, emitters_for, inflight=2)
+    tri = pvd.run_sharded(make, listeners, emitters_for, inflight=3)
+    assert seq.shape == (5, 2, 8) and np.isfinite(seq[:, :, 0]).all() and (seq[:, :, 0] > 0).all()
+    assert same_bits(seq, con).all() and same_bits(seq, tri).all()
