@@ -168,6 +168,8 @@ def main():
         for b, sv in enumerate(solvers):
             sv.run(listener(w, b))
             single_loop_ms.append(sv.timings().stepLoopMs or sv.timings().fdtdMs)
+    if use_dist:  # first use of the all-gather sets up RCCL's channels: not part of the timed steps
+        pvd.gather_outputs({run_id(0, b): np.zeros((2, 8), np.float32) for b in range(B)}, B * world, dist, dev)
     n_runs = args.steps * B * world
     local = {}
     fdtd_ms, ana_ms, air_ms, gen_ms, loop_ms = [], [], [], [], []
@@ -275,12 +277,22 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        line = json.dumps(out)
     for sv in solvers:
         sv.close()
     if use_dist:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner (NCCL_DEBUG=VERSION in this image) through C stdio, which is flushed at
+        # exit when stdout is a pipe: flush it now so that the JSON line is the LAST line on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(line)
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":
