@@ -20,5 +20,6 @@ python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --grid 8192 --steps 4 --no-cpu-baseline > $O/bench_8192.json 2>> $O/bench.err
 python bench.py --grid 2048 --no-cpu-baseline > $O/bench_2048.json 2>> $O/bench.err
 python bench.py --dense-history 1 --no-cpu-baseline > $O/bench_dense.json 2>> $O/bench.err
+python bench.py --inflight 1 --no-cpu-baseline > $O/bench_inflight1.json 2>> $O/bench.err
 rm -f $O/trace/bench_kernel_trace.csv.bak
 ls -la $O
