@@ -241,10 +241,6 @@ __device__ __forceinline__ void bufStoreF(float v, rsrc_t r, int voff, int soff)
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
 }
 
-// Body shared by the two step kernels.  GENERAL = false: every face of the tile (halo included) is air|air and the
-// listener is not inside it -- no coefficient reads, no pulse.  GENERAL = true: walls / grid edges / listener.
-// They are separate kernels (not one kernel with a wave-uniform branch) so that each gets its own register
-// allocation: the air tile needs 3*ROWS VGPRs plus a handful and must not inherit the general path's pressure.
 // Streaming-analysis mode: a tile's pressure history is only consumed while one of its cells -- or a cell of the
 // tile below / to the right, whose velocity reconstruction reads this tile's last row / column -- still has an open
 // forward-analysis window, or while it holds a registered emitter.  Once all of that is closed (N_dry samples after
@@ -259,6 +255,9 @@ __device__ __forceinline__ bool historyWanted(const StepArgs& a, int ti, int tj)
     return false;
 }
 
+// Scalar tile body of the two-kernel form (pv_step_air_kernel with packed math off, pv_step_general_kernel).
+// GENERAL = false: every face of the tile (halo included) is air|air and the listener is not inside it -- no
+// coefficient reads, no pulse.  GENERAL = true: walls / grid edges / listener, coefficients resident in registers.
 // A wave advances SUB interior rows (+ K halo rows either side) of tile `tile`; `part` selects which SUB-row slice
 // of the tile's RXI rows (air tiles: SUB == RXI, part 0; general tiles are split over RXI/SUB waves to shorten the
 // latency of that small, VALU-heavier kernel).
@@ -1370,10 +1369,10 @@ __global__ __launch_bounds__(256, 2) void pv_step_general_kernel(const StepArgs 
     stepTile<K, RXI, SUB, true>(a, tile, idx % S, lane, lut);
 }
 
-// Merged form: ONE launch per K steps.  The first blocks advance the general tiles (listed, split into SUB-row
-// slices), the rest the air tiles.  Versus the two-kernel / two-stream form this removes the cross-stream event
-// hand-shake between every pair of launches; it needs the general path to fit the air path's register budget, hence
-// the smaller slices.
+// Merged form: ONE launch per K steps.  The first numGeneral blocks advance one general tile each (4 waves sharing
+// its rows, stepTileGeneral4), every other block four air tiles (one wave each).  Versus the two-kernel / two-stream
+// form this removes the cross-stream event hand-shake between every pair of launches; the general arm (~110 VGPRs)
+// fits inside the air arm's register budget.  SUB is the slice height of the two-kernel form and unused here.
 template <int K, int RXI, int WPS, int SUB>
 __global__ __launch_bounds__(256, WPS) void pv_step_merged_kernel(const StepArgs a) {
     __shared__ float lut[256];
@@ -1542,9 +1541,8 @@ void launchTileClass(int K, int rxi, const uint16_t* codes, uint8_t* tileClass, 
 #undef X
 }
 
-// configurations whose merged (single-launch) kernel allocates without spills in the air-tile path (K = 8 keeps one
-// 4-byte spill in the general-slice path, outside the air tiles' code; measured: no effect on the launch time)
-// stacked configuration: rows its blocks load beyond rxi + 2K (0 for the single-wave tiles)
+// rows a configuration's blocks load beyond rxi + 2K at the bottom (general-tile blocks: 0..3; stacked air tiles:
+// their D); the guard band covers them
 int stepConfigExtraRows(int K, int rxi) {
 #define X(k, np, x, sub) \
     if (K == k && rxi == x) return StackGeom<k, np, 4, x>::D;
@@ -1565,6 +1563,8 @@ bool stepConfigStacked(int K, int rxi) {
     return false;
 }
 
+// configurations whose merged (single-launch) kernel allocates without (or with a handful of) spills in the air-tile
+// arm; the others keep the two-kernel form
 bool mergedConfigOk(int K, int rxi) {
     if (stepConfigStacked(K, rxi)) return true;
     return (K == 8 && rxi == 24) || (K == 4 && rxi == 32) || (K == 6 && rxi == 28) || K >= 10 || rxi >= 40;

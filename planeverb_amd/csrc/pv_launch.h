@@ -17,7 +17,7 @@ bool mergedConfigOk(int K, int rxi);
 bool stepConfigStacked(int K, int rxi);
 int stepConfigExtraRows(int K, int rxi);
 // which: bit 0 = air-tile kernel, bit 1 = general-tile kernel (both write disjoint tiles of the same planes);
-// 4 = both in ONE merged launch (general slices first, then the air tiles)
+// 4 = both in ONE merged launch (one block per general tile first, then the air tiles)
 // The general kernel goes to stream2 when given (the caller orders the two streams with events).
 void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream, int which = 3, hipStream_t stream2 = nullptr);
 void launchTileClass(int K, int rxi, const uint16_t* codes, uint8_t* tileClass, int* list, int* count,

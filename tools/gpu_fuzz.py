@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Parity fuzz on the GPU box: seeded random scenes / sizes / resolutions / listener positions / kernel
+configurations, HIP path (through the C-ABI) against the pinned oracle (checker only).  Bit-exact comparison of
+recorded pressure planes, sampled impulse responses, the delay map and all eight result planes (SURVEY Q5 mask).
+Development aid beside tests/test_gpu_parity.py::test_random_scenes_vs_oracle, which holds 7 fixed seeds.
+
+usage: gpu_fuzz.py [first_seed] [count]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import planeverb_amd.api as pv  # noqa: E402
+from oracle import pvoracle  # noqa: E402  (checker)
+from conftest import same_bits  # noqa: E402
+from test_gpu_parity import compare_maps, random_scene  # noqa: E402
+
+CONFIGS = [dict(), dict(), dict(steps_per_launch=12, tile_rows=36), dict(steps_per_launch=10, tile_rows=36),
+           dict(steps_per_launch=8, tile_rows=24), dict(steps_per_launch=4, tile_rows=32),
+           dict(steps_per_launch=8, tile_rows=40), dict(small_grid_kernel=2), dict(small_grid_kernel=2, use_graph=2),
+           dict(steps_per_launch=12, tile_rows=36, merged_launch=0), dict(steps_per_launch=1, tile_rows=30)]
+
+
+def one(seed):
+    rng = np.random.default_rng(1000 + seed)
+    res = int(rng.choice([275, 275, 300, 375, 500]))
+    size = float(rng.uniform(6.0, 62.0 if res <= 300 else 30.0))
+    boxes = random_scene(rng, size, int(rng.integers(0, 26)))
+    L = (rng.uniform(0.2, size - 0.2), 0.0, rng.uniform(0.2, size - 0.2))
+    opts = CONFIGS[int(rng.integers(0, len(CONFIGS)))]
+    o = pvoracle.OracleGrid(size, size, res, boxes)
+    o.fdtd(L)
+    ef = pvoracle.free_energy(size, size, res)
+    rres, rdelay, _ = o.analyze(ef, L)
+    hp, hx, hy = o.history()
+    flat = hp.reshape(o.T, -1)
+    finite = np.isfinite(flat).all(1) & (np.abs(np.nan_to_num(flat, nan=np.inf)).max(1) < 1e30)
+    tmax = o.T - 1 if finite.all() else int(np.argmin(finite)) - 1
+    with pv.Solver(size, size, res, **opts) as s:
+        assert (s.gx, s.gy, s.T) == (o.gx, o.gy, o.T)
+        assert np.float32(s.efree) == np.float32(ef), "EFree"
+        for b in boxes:
+            s.add_geometry(b)
+        s.run(L)
+        for t in sorted(set([0, 1, 2, 3, 17, o.T // 3, o.T // 2, o.T - 2, o.T - 1])):
+            if t <= tmax:
+                assert same_bits(s.history_plane(t), hp[t]).all(), "pr step %d" % t
+        nvalid = -1
+        if tmax == o.T - 1:
+            for cx, cy in rng.integers(0, o.gx, (4, 2)):
+                ir = np.stack([hp[:, cx, cy], hx[:, cx, cy], hy[:, cx, cy]], 1)
+                assert same_bits(s.impulse_response(int(cx), int(cy)), ir).all(), "IR"
+            res8, delay = s.results()
+            nvalid = compare_maps(res8, delay, rres, rdelay, o.T, o.fs, "seed %d" % seed)
+        k, rows = s.info.stepsPerLaunch, s.info.tileRows
+    o.close()
+    return "seed %3d: %3dx%-3d res %d T %4d boxes %2d K %2d rows %2d %-40s %s" % (
+        seed, o.gx, o.gy, res, o.T, len(boxes), k, rows, opts, "diverged at t=%d (compared up to there)" % (tmax + 1)
+        if nvalid < 0 else "%d valid cells, all 8 outputs + delay + planes + IRs bit-identical" % nvalid)
+
+
+if __name__ == "__main__":
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    t0 = time.time()
+    bad = 0
+    for seed in range(first, first + count):
+        try:
+            print(one(seed), flush=True)
+        except AssertionError as e:
+            bad += 1
+            print("seed %3d: MISMATCH %s" % (seed, e), flush=True)
+    print("%d scenes, %d mismatches, %.0f s" % (count, bad, time.time() - t0))
+    sys.exit(1 if bad else 0)
