@@ -141,6 +141,9 @@ struct AnalyzeArgs {
     int pitch, G;
     int gx, gy;
     int rxi, wi, nty;
+    int winRows, winCols;  // extent of the history window in cells: the analysis kernels' launch grid
+    int* dirScratch;       // winRows x winCols ints for the listener-direction pointer jumping
+    int dirJump;           // listener direction by pointer jumping (wide windows) instead of the plain walk
     int T;
     int nDir, nDry, nWet, nCut;
     unsigned fs;

@@ -1761,12 +1761,29 @@ __device__ __forceinline__ float efreePerR(float efree, float dx, int lX, int lY
 // vx / vy are not stored: they are re-derived from the pressure history with the stencil's own recurrence
 // (v_t = v_{t-1} - C*(p_t[i] - p_t[n]) on air|air faces, k*(p_i + p_n) otherwise), bit-identical to the values
 // the step kernel held.
+// The analysis kernels run over the HISTORY WINDOW only (winRows x winCols cells from the window's origin, which
+// lives in dyn so that the launch grid does not depend on the listener): a cell outside it cannot have been reached
+// by the pulse.  What the reference computes for such a cell -- delay = FLT_MAX, direction = the unit vector from
+// the listener to the cell itself -- is written for the whole map by pv_far_cells_kernel first.  (The first version
+// launched one thread per grid cell: 67 M threads at 8192^2 to find the 0.6 M reached cells.)
+__device__ __forceinline__ bool analysisWindowCell(const AnalyzeArgs& a, const DynParams& dyn, int* X, int* Y) {
+    const int wc = blockIdx.x * blockDim.x + threadIdx.x, wr = blockIdx.y;
+    if (wc >= a.winCols) return false;
+    *X = dyn.histRow0 - a.G + wr;
+    *Y = dyn.histCol0 - a.G + wc;
+    return *X < a.gx && *Y < a.gy;
+}
+// window-local index of grid cell `cell` (= X*gy + Y), for the per-cell scratch of the direction kernels
+__device__ __forceinline__ int analysisWindowIndex(const AnalyzeArgs& a, const DynParams& dyn, int cell) {
+    const int r = cell / a.gy, c = cell - r * a.gy;
+    return (r - (dyn.histRow0 - a.G)) * a.winCols + (c - (dyn.histCol0 - a.G));
+}
+
 __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
-    const int Y = blockIdx.x * blockDim.x + threadIdx.x;
-    const int X = blockIdx.y;
-    if (Y >= a.gy || X >= a.gx) return;
-    const int s = X * a.gy + Y;
     const DynParams dyn = *a.dyn;
+    int X, Y;
+    if (!analysisWindowCell(a, dyn, &X, &Y)) return;
+    const int s = X * a.gy + Y;
 
     const int tile = (X / a.rxi) * a.nty + (Y / a.wi);
     const int prow = X + a.G, pcol = Y + a.G;
@@ -1930,10 +1947,33 @@ __device__ const int kNeighbors[8][2] = {{-1, -1}, {-1, 0}, {-1, 1}, {0, -1}, {0
 
 // Analyzer::EncodeListenerDirection, Analyzer.cpp:340-431: walk down the delay map towards the listener until
 // the path is in line of sight; one thread per result cell.
+__device__ __forceinline__ void storeDirection(const AnalyzeArgs& a, int index, int fin) {
+    const int r = fin / a.gy, c = fin - r * a.gy;
+    float ox = (float)r * a.dx - a.lx, oy = (float)c * a.dx - a.lz;
+    float len = (ox * ox) + (oy * oy);
+    if (len != 0.f) {
+        len = sqrtf(len);
+        ox /= len;
+        oy /= len;
+    }
+    a.out[4 * a.resN + index] = ox;
+    a.out[5 * a.resN + index] = oy;
+}
+
+// every cell of the map: no onset (Analyzer.cpp:64-68), listener direction = towards the cell itself (a walk that
+// finds no neighbour with a smaller delay stays where it is, Analyzer.cpp:365-391).  The window's cells are
+// overwritten by the kernels that follow.
+__global__ __launch_bounds__(256) void pv_far_cells_kernel(const AnalyzeArgs a) {
+    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= a.gx * a.gy) return;
+    a.delay[index] = FLT_MAX;
+    storeDirection(a, index, index);
+}
+
 __global__ __launch_bounds__(256) void pv_direction_kernel(const AnalyzeArgs a) {
-    const int Y = blockIdx.x * blockDim.x + threadIdx.x;
-    const int X = blockIdx.y;
-    if (Y >= a.gy || X >= a.gx) return;
+    const DynParams dyn = *a.dyn;
+    int X, Y;
+    if (!analysisWindowCell(a, dyn, &X, &Y)) return;
     const int index = X * a.gy + Y;
     float loudness = a.out[index];
     int cur = index;
@@ -1968,23 +2008,13 @@ __global__ __launch_bounds__(256) void pv_direction_kernel(const AnalyzeArgs a) 
         const float euclid = sqrtf((tx * tx) + (ty * ty));
         if (fabsf(geodesic - euclid) < thresholdDist) break;
     }
-    const int r = cur / a.gy, c = cur - r * a.gy;
-    float ox = (float)r * a.dx - a.lx, oy = (float)c * a.dx - a.lz;
-    float len = (ox * ox) + (oy * oy);
-    if (len != 0.f) {
-        len = sqrtf(len);
-        ox /= len;
-        oy /= len;
-    }
-    a.out[4 * a.resN + index] = ox;
-    a.out[5 * a.resN + index] = oy;
+    storeDirection(a, index, cur);
 }
 
-// ---- the same descent by pointer jumping (used when T is large: streaming / Mode B) -------------------------------
-// After its first move the walk's state is a function of the cell it stands on (delay = delay[cell], loudness =
-// occ[cell]), so "where does the walk end" is a functional graph: hop(p) = stop here | stop at neighbour n | continue
-// from n, and delays strictly decrease along "continue" edges.  ceil(log2 T) rounds of J[p] = J[J[p]] resolve every
-// cell; the per-cell cost no longer grows with the path length (a 4096-cell-wide room: 191 ms -> a few ms).
+// The same walk by pointer jumping: its cost per cell grows with the path length (an open field at T = 435: up to
+// 435 steps of 8 neighbour reads for each of 0.6 M cells; a 25 m room at 4096^2 cells: 191 ms), but where a walk
+// goes from a cell does not depend on where it started, so "one step from here" is a functional graph and
+// ceil(log2 T) rounds of J[p] = J[J[p]] resolve every walk.  kDirFinal marks entries that are already terminal.
 constexpr int kDirFinal = (int)0x80000000;
 
 __device__ __forceinline__ int dirBestNeighbour(const AnalyzeArgs& a, int cell, float* bestDelay) {
@@ -2015,9 +2045,13 @@ __device__ __forceinline__ bool dirLineOfSight(const AnalyzeArgs& a, int cell, f
     return fabsf(geodesic - euclid) < 0.3f * (kCDev / (float)a.res);
 }
 
+// J is indexed by window-local cell; its entries are GRID cell indices (| kDirFinal).  A hop always lands on a
+// reached cell (finite delay), i.e. inside the window.
 __global__ __launch_bounds__(256) void pv_dir_init_kernel(const AnalyzeArgs a, int* J) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= a.gx * a.gy) return;
+    const DynParams dyn = *a.dyn;
+    int X, Y;
+    if (!analysisWindowCell(a, dyn, &X, &Y)) return;
+    const int p = X * a.gy + Y;
     const float d = a.delay[p], o = a.out[p];
     int hop = p | kDirFinal;
     if (d > kDelayCloseDev && o < kDistanceGainDev) {
@@ -2025,45 +2059,41 @@ __global__ __launch_bounds__(256) void pv_dir_init_kernel(const AnalyzeArgs a, i
         const int n = dirBestNeighbour(a, p, &nd);
         if (n >= 0) hop = (nd >= d || dirLineOfSight(a, n, nd)) ? (n | kDirFinal) : n;
     }
-    J[p] = hop;
+    J[analysisWindowIndex(a, dyn, p)] = hop;
 }
 
-__global__ __launch_bounds__(256) void pv_dir_jump_kernel(int* J, int n) {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    const int h = J[p];
-    if (h < 0) return;  // final
-    J[p] = J[h];        // either the old or an already-updated entry of h: both describe the same walk
+__global__ __launch_bounds__(256) void pv_dir_jump_kernel(const AnalyzeArgs a, int* J) {
+    const DynParams dyn = *a.dyn;
+    int X, Y;
+    if (!analysisWindowCell(a, dyn, &X, &Y)) return;
+    const int wp = analysisWindowIndex(a, dyn, X * a.gy + Y);
+    const int h = J[wp];
+    if (h < 0) return;                               // final
+    J[wp] = J[analysisWindowIndex(a, dyn, h)];       // either the old or an already-updated entry of h: same walk
 }
 
 __global__ __launch_bounds__(256) void pv_dir_final_kernel(const AnalyzeArgs a, const int* J) {
-    const int index = blockIdx.x * blockDim.x + threadIdx.x;
-    if (index >= a.gx * a.gy) return;
+    const DynParams dyn = *a.dyn;
+    int X, Y;
+    if (!analysisWindowCell(a, dyn, &X, &Y)) return;
+    const int index = X * a.gy + Y;
     int fin = index;
     if (a.out[index] < kDistanceGainDev) {  // first iteration: delay = FLT_MAX, so only the loudness test applies
         float nd;
         const int n = dirBestNeighbour(a, index, &nd);
-        if (n >= 0) fin = dirLineOfSight(a, n, nd) ? n : (J[n] & ~kDirFinal);
+        if (n >= 0) fin = dirLineOfSight(a, n, nd) ? n : (J[analysisWindowIndex(a, dyn, n)] & ~kDirFinal);
     }
-    const int r = fin / a.gy, c = fin - r * a.gy;
-    float ox = (float)r * a.dx - a.lx, oy = (float)c * a.dx - a.lz;
-    float len = (ox * ox) + (oy * oy);
-    if (len != 0.f) {
-        len = sqrtf(len);
-        ox /= len;
-        oy /= len;
-    }
-    a.out[4 * a.resN + index] = ox;
-    a.out[5 * a.resN + index] = oy;
+    storeDirection(a, index, fin);
 }
 
+static dim3 analysisWindowGrid(const AnalyzeArgs& a) { return dim3((a.winCols + 255) / 256, a.winRows); }
+
 static void launchDirectionJump(const AnalyzeArgs& a, int* J, hipStream_t stream) {
-    const int n = a.gx * a.gy;
-    const dim3 grid((n + 255) / 256), block(256);
+    const dim3 grid = analysisWindowGrid(a), block(256);
     hipLaunchKernelGGL(pv_dir_init_kernel, grid, block, 0, stream, a, J);
     int rounds = 1;
     while ((1 << rounds) < a.T + 2) ++rounds;  // chains are shorter than T (delays are distinct integers < T)
-    for (int i = 0; i < rounds + 1; ++i) hipLaunchKernelGGL(pv_dir_jump_kernel, grid, block, 0, stream, J, n);
+    for (int i = 0; i < rounds + 1; ++i) hipLaunchKernelGGL(pv_dir_jump_kernel, grid, block, 0, stream, a, J);
     hipLaunchKernelGGL(pv_dir_final_kernel, grid, block, 0, stream, a, J);
 }
 
@@ -2096,10 +2126,16 @@ void launchPackResults(const float* res, long long n, float* res8, hipStream_t s
 }
 
 void launchAnalysis(const AnalyzeArgs& a, hipStream_t stream) {
-    dim3 grid((a.gy + 255) / 256, a.gx);
-    // (pv_encode_kernel writes the delay of EVERY cell, FLT_MAX where there is no onset: Analyzer.cpp:64-68,160-165)
+    const int n = a.gx * a.gy;
+    hipLaunchKernelGGL(pv_far_cells_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a);
+    const dim3 grid = analysisWindowGrid(a);
     hipLaunchKernelGGL(pv_encode_kernel, grid, dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(pv_direction_kernel, grid, dim3(256), 0, stream, a);
+    // listener direction: the plain walk where walks are short (small windows: rooms, the sandbox's grids), pointer
+    // jumping where a window is wide enough for hundreds of steps (a dozen tiny launches, path-length independent)
+    if (a.dirJump)
+        launchDirectionJump(a, a.dirScratch, stream);
+    else
+        hipLaunchKernelGGL(pv_direction_kernel, grid, dim3(256), 0, stream, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2302,8 +2338,8 @@ void launchStreamFinalize(const AnalyzeArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(pv_stream_finalize_kernel, grid, dim3(256), 0, stream, a);
     if (a.numEmitters > 0)
         hipLaunchKernelGGL(pv_stream_emitter_kernel, dim3((a.numEmitters + 63) / 64), dim3(64), 0, stream, a);
-    // T is large in this mode: resolve the delay-map descent by pointer jumping (the vx state plane is free now)
-    launchDirectionJump(a, reinterpret_cast<int*>(a.sVx), stream);
+    // T is large in this mode: resolve the delay-map descent by pointer jumping (the window is the whole grid here)
+    launchDirectionJump(a, a.dirScratch, stream);
 }
 
 // FreeGrid::CalculateEFree + SimulateFreeFieldEnergy tail, FreeGrid.cpp:86-110: sequential float sum of p^2 over

@@ -143,7 +143,8 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     if (!dalloc(&errFlag_, 1, true)) return false;
     if (!dalloc(&res_, (size_t)g_.gx * g_.gy * 8, true)) return false;  // zeroed pool: PvContext.cpp:132
     if (!dalloc(&delay_, (size_t)g_.gx * g_.gy, true)) return false;
-    scratchCount_ = std::max<size_t>((size_t)3 * std::max(T_, g_.T), (size_t)g_.NX * g_.NY * 3);
+    scratchCount_ = std::max<size_t>({(size_t)3 * std::max(T_, g_.T), (size_t)g_.NX * g_.NY * 3,
+                                     (size_t)geo_.ntx * rxi_ * geo_.nty * wi_});  // the last: direction scratch
     if (!dalloc(&scratch_, scratchCount_, true)) return false;
 
     // history window: the pulse moves at most one cell per step along each axis, so after T steps everything
@@ -642,6 +643,11 @@ AnalyzeArgs Solver::analyzeArgs(float lx, float lz) const {
     a.rxi = rxi_;
     a.wi = wi_;
     a.nty = geo_.nty;
+    a.winRows = histTilesX_ * rxi_;
+    a.winCols = histTilesY_ * wi_;
+    a.dirScratch = reinterpret_cast<int*>(scratch_);
+    // wide windows can hold walks of hundreds of steps; the dense-history (validation) mode keeps the plain walk
+    a.dirJump = (!opt_.denseHistory && a.winRows > 256 && a.winCols > 256) ? 1 : 0;
     a.T = T_;
     a.nDir = g_.nDir;
     a.nDry = g_.nDry;

@@ -728,3 +728,26 @@ def test_runs_in_flight_match_sequential_runs(pvlib):
     tri = pvd.run_sharded(make, listeners, emitters_for, inflight=3)
     assert seq.shape == (5, 2, 8) and np.isfinite(seq[:, :, 0]).all() and (seq[:, :, 0] > 0).all()
     assert same_bits(seq, con).all() and same_bits(seq, tri).all()
+
+
+@pytest.mark.parametrize("n,cell", [(1024, (512, 512)), (1024, (3, 1000)), (2048, (1500, 600))])
+def test_open_field_analysis_window_vs_dense(pvlib, n, cell):
+    """open field (walks of hundreds of steps): the windowed analysis -- far cells by formula, window cells by pointer
+    jumping -- against the dense-history mode, whose analysis visits every cell with the plain walk"""
+    dx = np.float32(343.21) / np.float32(275) / np.float32(3.5)
+    size = float((n + 0.5) * dx)
+    L = ((cell[0] + 0.5) * float(dx), 0.0, (cell[1] + 0.5) * float(dx))
+    with pvlib.Solver(size, size, 275) as s, pvlib.Solver(size, size, 275, dense_history=1) as d:
+        s.run(L)
+        d.run(L)
+        rs, ds = s.results()
+        rd, dd = d.results()
+        assert same_bits(ds, dd).all() and same_bits(rs, rd).all()
+        assert (ds < 1e30).sum() > 50000
+        # a second listener on the same solvers: stale results of the first run must be handled alike
+        L2 = (L[0] + 37.0 * float(dx), 0.0, max(0.5, L[2] - 211.0 * float(dx)))
+        s.run(L2)
+        d.run(L2)
+        rs, ds = s.results()
+        rd, dd = d.results()
+        assert same_bits(ds, dd).all() and same_bits(rs, rd).all()

@@ -11,6 +11,8 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python bench.py --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2> $O/pmc_write.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch8k -o f -- python bench.py --no-cpu-baseline --grid 8192 --steps 2 --warmup 1 > /dev/null 2> $O/pmc_fetch8k.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write8k -o w -- python bench.py --no-cpu-baseline --grid 8192 --steps 2 --warmup 1 > /dev/null 2> $O/pmc_write8k.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch2k -o f -- python bench.py --no-cpu-baseline --grid 2048 --scene BigRoom.pv --steps 3 --warmup 1 > /dev/null 2> $O/pmc_fetch2k.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write2k -o w -- python bench.py --no-cpu-baseline --grid 2048 --scene BigRoom.pv --steps 3 --warmup 1 > /dev/null 2> $O/pmc_write2k.err
 hipcc --offload-arch=gfx950 -O3 tools/hbm_calib.hip -o /tmp/hbm_calib 2>/dev/null
 /tmp/hbm_calib > $O/hbm_calib.txt
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/calib_fetch -o c -- /tmp/hbm_calib > /dev/null 2>&1
@@ -18,7 +20,8 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/calib_write 
 # the un-profiled bench line, same box
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --grid 8192 --steps 4 --no-cpu-baseline > $O/bench_8192.json 2>> $O/bench.err
-python bench.py --grid 2048 --no-cpu-baseline > $O/bench_2048.json 2>> $O/bench.err
+python bench.py --grid 2048 --scene BigRoom.pv --no-cpu-baseline > $O/bench_2048.json 2>> $O/bench.err
+python bench.py --grid 512 --scene Shoebox.pv --no-cpu-baseline > $O/bench_512.json 2>> $O/bench.err
 python bench.py --dense-history 1 --no-cpu-baseline > $O/bench_dense.json 2>> $O/bench.err
 python bench.py --inflight 1 --no-cpu-baseline > $O/bench_inflight1.json 2>> $O/bench.err
 rm -f $O/trace/bench_kernel_trace.csv.bak

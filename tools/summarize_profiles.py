@@ -35,7 +35,8 @@ def steady(v):
 
 
 shutil.copy(os.path.join(SRC, "trace", "bench_kernel_stats.csv"), os.path.join(DST, R + "_kernel_stats.csv"))
-for f in ("bench.json", "bench_8192.json", "bench_2048.json", "bench_dense.json", "bench_inflight1.json",
+for f in ("bench.json", "bench_8192.json", "bench_2048.json", "bench_512.json", "bench_dense.json",
+          "bench_inflight1.json",
           "bench_under_rocprof.json", "hbm_calib.txt"):
     p = os.path.join(SRC, f)
     if os.path.exists(p):
@@ -65,7 +66,8 @@ lines = ["# HBM-side traffic per kernel launch (rocprofv3 --pmc, separate FETCH_
          "WRITE_SIZE %.4f -> corrections x%.3f / x%.3f (MI355X_MICROARCH.md: FETCH_SIZE = 1/2 on gfx950)." % (
              cal["fetch_dword_read_ratio"], cal.get("fetch_dwordx4_copy_ratio", float("nan")),
              cal["write_dword_ratio"], fetch_corr, write_corr), ""]
-for tag, fd, wd in (("4096", "pmc_fetch", "pmc_write"), ("8192", "pmc_fetch8k", "pmc_write8k")):
+for tag, fd, wd in (("4096", "pmc_fetch", "pmc_write"), ("8192", "pmc_fetch8k", "pmc_write8k"),
+                    ("2048", "pmc_fetch2k", "pmc_write2k")):
     fp = os.path.join(SRC, fd, "f_counter_collection.csv")
     wp = os.path.join(SRC, wd, "w_counter_collection.csv")
     if not (os.path.exists(fp) and os.path.exists(wp)):
