@@ -92,7 +92,10 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--grid", type=int, default=4096)
-    ap.add_argument("--scene", default="HugeRoom.pv")
+    ap.add_argument("--scene", default="HugeRoom.pv", help="a .pv file under tests/scenes, or 'none' (empty grid)")
+    ap.add_argument("--open-field", action="store_true",
+                    help="SURVEY.md 8d config 5: empty scene, listener cells from numpy.random.default_rng(0)"
+                         ".integers(N/8, 7N/8, (64, 2)), emitters = listener + (16, 0) and + (0, 16) cells")
     ap.add_argument("--steps-per-launch", type=int, default=0)
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--dense-history", type=int, default=0)
@@ -140,9 +143,13 @@ def main():
         opts["dense_history"] = 1
     B = max(1, args.inflight)
     solvers = [api.Solver(size, size, 275, device=local_rank, **opts) for _ in range(B)]
+    if args.open_field:
+        args.scene = "none"
     for sv in solvers:
-        sv.load_scene(os.path.join(ROOT, "tests", "scenes", args.scene))
+        if args.scene != "none":
+            sv.load_scene(os.path.join(ROOT, "tests", "scenes", args.scene))
     s = solvers[0]
+    of_cells = np.random.default_rng(0).integers(args.grid // 8, 7 * args.grid // 8, size=(64, 2))
     cells = (s.gx + 1) * (s.gy + 1)
     T = s.T
 
@@ -150,11 +157,16 @@ def main():
         return (step * B + b) * world + rank
 
     def listener(step, b):
+        if args.open_field:  # cell centres, so that the metre -> cell truncation cannot land on a neighbour
+            cx, cz = of_cells[run_id(step, b) % len(of_cells)]
+            return ((cx + 0.5) * float(s.dx), 0.0, (cz + 0.5) * float(s.dx))
         x, z = LISTENERS[run_id(step, b) % len(LISTENERS)]
         return (float(x), 0.0, float(z))
 
     def emitters(step, b):
         x, _, z = listener(step, b)
+        if args.open_field:
+            return [(x + 16 * float(s.dx), 0.0, z), (x, 0.0, z + 16 * float(s.dx))]
         return [(x, 0.0, z + 2.0), (5.0, 0.0, 6.0)]
 
     def sync():
@@ -251,7 +263,9 @@ def main():
                                    "leapfrog steps with pr-history record + per-cell IR analysis for one listener "
                                    "position; 1 step = one batch of %d independent run(s) per GPU, in flight "
                                    "together; %d run(s) per step across %d GPU(s)" % (
-                                       args.scene, s.gx, s.gy, s.dx, size, T, B, B * world, world),
+                                       "empty scene (open field, SURVEY.md 8d config 5 listener cells)"
+                                       if args.open_field else args.scene, s.gx, s.gy, s.dx, size, T, B, B * world,
+                                       world),
                        "grid": [s.gx, s.gy], "T": T, "res": 275, "mode": "A", "steps_per_launch": K,
                        "tile": [info.tileRows, info.tileCols], "dense_history": bool(args.dense_history),
                        "runs_in_flight_per_gpu": B,

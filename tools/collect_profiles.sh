@@ -20,6 +20,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/calib_write 
 # the un-profiled bench line, same box
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --grid 8192 --steps 4 --no-cpu-baseline > $O/bench_8192.json 2>> $O/bench.err
+python bench.py --grid 8192 --steps 4 --open-field --no-cpu-baseline > $O/bench_8192_open.json 2>> $O/bench.err
 python bench.py --grid 2048 --scene BigRoom.pv --no-cpu-baseline > $O/bench_2048.json 2>> $O/bench.err
 python bench.py --grid 512 --scene Shoebox.pv --no-cpu-baseline > $O/bench_512.json 2>> $O/bench.err
 python bench.py --dense-history 1 --no-cpu-baseline > $O/bench_dense.json 2>> $O/bench.err
