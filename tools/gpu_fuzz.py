@@ -31,6 +31,8 @@ def one(seed):
     rng = np.random.default_rng(1000 + seed)
     res = int(rng.choice([275, 275, 300, 375, 500]))
     size = float(rng.uniform(6.0, 62.0 if res <= 300 else 30.0))
+    if res == 275 and rng.random() < 0.2:
+        size = float(rng.uniform(95.0, 135.0))  # > 256 cells: analysis windows wide enough for pointer jumping
     boxes = random_scene(rng, size, int(rng.integers(0, 26)))
     L = (rng.uniform(0.2, size - 0.2), 0.0, rng.uniform(0.2, size - 0.2))
     opts = CONFIGS[int(rng.integers(0, len(CONFIGS)))]
