@@ -6,7 +6,9 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 R=${1:-r01}
 O=gpurun_out/$R
 rm -rf $O && mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
+# (--steps 20: the kernel average below then is dominated by the timed, overlapped launches -- 2 of the 42 runs of the
+# command are warm-up runs made one at a time)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python bench.py --no-cpu-baseline --steps 20 --warmup 1 > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python bench.py --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2> $O/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python bench.py --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2> $O/pmc_write.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch8k -o f -- python bench.py --no-cpu-baseline --grid 8192 --steps 2 --warmup 1 > /dev/null 2> $O/pmc_fetch8k.err
