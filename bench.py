@@ -83,6 +83,11 @@ def cpu_baseline(grid_cells=513, scene="HugeRoom.pv"):
     except Exception:
         pass
     out["host_cpus"] = os.cpu_count()
+    try:
+        with open("/proc/cpuinfo") as f:
+            out["cpu_model"] = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except Exception:
+        out["cpu_model"] = None
     return out
 
 
