@@ -41,7 +41,7 @@ def mode_a_size(n, res=275):
     return float((n + 0.5) * dx)
 
 
-def cpu_baseline(grid_cells=513, scene="HugeRoom.pv"):
+def cpu_baseline(grid_cells=1025, scene="HugeRoom.pv"):
     """Reference algorithm on ONE host core (the reference is single-threaded: SURVEY.md 6): the unmodified
     reference compiled into oracle/_ref/libpvref.so when present ("reference"), else the C restatement ("port").
     Bounded sample: the same scene / dx / T on a (grid_cells)^2 cell array."""
