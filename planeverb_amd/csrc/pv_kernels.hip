@@ -1756,6 +1756,30 @@ __device__ __forceinline__ float efreePerR(float efree, float dx, int lX, int lY
     return efree / r;
 }
 
+// CH samples (i0, i0-1, ..., i0-CH+1; those below startingPoint are skipped) of the backward Schroeder integration
+// + regression sums, Analyzer.cpp:300-318.  Three passes over the chunk: the running energy (sequential, the
+// reference's order), 10*log10f of each partial sum (independent of each other: branch-free, so the compiler
+// interleaves the CH evaluations -- with one thread per cell and few waves this loop is bound by the latency of one
+// evaluation, ~1800 cycles per sample when they ran one after the other), the two regression sums (sequential).
+template <int CH>
+__device__ __forceinline__ void rt60Chunk(const float (&pc)[CH], const int i0, const int startingPoint, float& edc,
+                                          float& xysum, float& ysum) {
+    float e[CH], y[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        edc = (i0 - k >= startingPoint) ? edc + pc[k] * pc[k] : edc;
+        e[k] = edc;
+    }
+#pragma unroll
+    for (int k = 0; k < CH; ++k) y[k] = 10.f * pvLog10fNonNeg(e[k]);
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        const bool v = i0 - k >= startingPoint;
+        xysum = v ? xysum + y[k] * (float)(i0 - k - startingPoint) : xysum;
+        ysum = v ? ysum + y[k] : ysum;
+    }
+}
+
 // One thread per result cell (X, Y); lanes along Y so every history read is a coalesced row segment of one
 // recorded plane.  All sums are sequential float32 accumulations in the reference's order.
 // vx / vy are not stored: they are re-derived from the pressure history with the stencil's own recurrence
@@ -1916,16 +1940,7 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
             float pc[CH];
 #pragma unroll
             for (int k = 0; k < CH; ++k) pc[k] = hc.at(max(i0 - k, 0));
-#pragma unroll
-            for (int k = 0; k < CH; ++k) {
-                const int i = i0 - k;
-                if (i >= startingPoint) {
-                    edc += pc[k] * pc[k];
-                    const float y = 10.f * pvLog10f(edc);
-                    xysum += y * (float)(i - startingPoint);
-                    ysum += y;
-                }
-            }
+            rt60Chunk<CH>(pc, i0, startingPoint, edc, xysum, ysum);
         }
         const float ymean = ysum / rn;
         const float numerator = xysum - ymean * xsum - xmean * ysum + rn * xmean * ymean;
@@ -2299,11 +2314,12 @@ __global__ void pv_stream_emitter_kernel(const AnalyzeArgs a) {
     const float denominator = (1.0f / 12.0f) * rn * (rn * rn - 1.0f);
     float edc = 0.f, xysum = 0.f, ysum = 0.f;
     for (int i = T - 1; i >= endPoint && i >= 0; --i) edc += tr[i] * tr[i];
-    for (int i = endPoint - 1; i >= startingPoint; --i) {
-        edc += tr[i] * tr[i];
-        const float y = 10.f * pvLog10f(edc);
-        xysum += y * (float)(i - startingPoint);
-        ysum += y;
+    constexpr int CH = 8;
+    for (int i0 = endPoint - 1; i0 >= startingPoint; i0 -= CH) {
+        float pc[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) pc[k] = tr[max(i0 - k, 0)];
+        rt60Chunk<CH>(pc, i0, startingPoint, edc, xysum, ysum);
     }
     const float ymean = ysum / rn;
     const float numerator = xysum - ymean * xsum - xmean * ysum + rn * xmean * ymean;

@@ -13,6 +13,7 @@ int main(int argc, char** argv) {
     for (unsigned long long u = 0; u <= 0x7f800000ull; u += stride) {
         const float x = pva::pvFloatBits((uint32_t)u);
         if (u >= 1 && u < 0x7f800000ull && pva::pvBitsF(pva::pvLog10f(x)) != pva::pvBitsF(std::log10(x))) ++badLog;
+        if (u >= 1 && u < 0x7f800000ull && pva::pvBitsF(pva::pvLog10fNonNeg(x)) != pva::pvBitsF(std::log10(x))) ++badLog;
         if (pva::pvBitsF(pva::pvPowf(x, 0.8f)) != pva::pvBitsF(std::pow(x, 0.8f))) ++badPow;
         ++n;
     }
@@ -20,6 +21,11 @@ int main(int argc, char** argv) {
     const float specials[] = {0.f, -0.f, -1.f, INFINITY, NAN};
     for (float s : specials) {
         const float a = pva::pvLog10f(s), b = std::log10(s);
+        if (!((a != a && b != b) || pva::pvBitsF(a) == pva::pvBitsF(b))) ++badLog;
+    }
+    const float nonneg[] = {0.f, INFINITY, NAN, 1.f, 1.17549435e-38f, 1e-45f};  // the branch-free form's domain
+    for (float s : nonneg) {
+        const float a = pva::pvLog10fNonNeg(s), b = std::log10(s);
         if (!((a != a && b != b) || pva::pvBitsF(a) == pva::pvBitsF(b))) ++badLog;
     }
     std::printf("{\"values\": %ld, \"stride\": %u, \"log10f_mismatches\": %ld, \"powf_mismatches\": %ld}\n", n, stride,
