@@ -4,6 +4,7 @@ pulse table, rasteriser, .pv parser, cell lookups) matches the golden vectors fr
 compute is called here."""
 import os
 import re
+import subprocess
 import ctypes as C
 
 import numpy as np
@@ -182,3 +183,19 @@ def test_inline_asm_dpp_has_no_pipeline_hazard(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dpp_hazard.py"), asm],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+def test_cpp_binding_compiles_against_reference_headers():
+    """bindings/PlaneverbAmdBinding.cpp -- the forwarding unit INTEGRATION.md section 2 gives a maintainer: the
+    reference's namespace API (Planeverb.h:12-47) on top of this library's C-ABI.  Where the reference is present (the
+    build container) it must compile against the reference's OWN headers (nothing of them is copied here); and the
+    text in INTEGRATION.md must be that file."""
+    src = os.path.join(ROOT, "bindings", "PlaneverbAmdBinding.cpp")
+    code = open(src).read()
+    assert code in open(os.path.join(ROOT, "INTEGRATION.md")).read(), "INTEGRATION.md section 2 is out of date"
+    ref = "/root/reference/ProjectPlaneverb/include"
+    if not os.path.isdir(ref):
+        pytest.skip("reference headers not present on this machine")
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-w", "-D_WIN32", "-D__declspec(x)=",
+                           "-D__forceinline=inline", "-include", "cstring", "-include", "limits", "-include", "cmath",
+                           "-I", ref, "-I", os.path.join(ROOT, "include"), src])
