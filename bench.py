@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--steps-per-launch", type=int, default=0)
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--dense-history", type=int, default=0)
+    ap.add_argument("--tile-order", type=int, default=-1, help="PVA_OPT_TILE_ORDER (development: block -> tile map)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=2,
                     help="independent runs a GPU works on concurrently (one solver instance + stream each); a step "
@@ -146,6 +147,8 @@ def main():
         opts["tile_rows"] = args.tile_rows
     if args.dense_history:
         opts["dense_history"] = 1
+    if args.tile_order >= 0:
+        opts["tile_order"] = args.tile_order
     B = max(1, args.inflight)
     solvers = [api.Solver(size, size, 275, device=local_rank, **opts) for _ in range(B)]
     if args.open_field:

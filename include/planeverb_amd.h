@@ -134,7 +134,8 @@ enum {
     PVA_OPT_PACKED_MATH = 11,  /* air-tile kernel arithmetic: 1 = packed f32 (default), 0 = scalar f32 */
     PVA_OPT_STREAMING_ANALYSIS = 12, /* 1 = sparse-emitter mode: ring history + incremental analysis (see PvAmdSetEmitters) */
     PVA_OPT_STREAM_ROWS = 13,  /* M > 0: all-air chunks of M stacked tiles run in the row-streaming stencil kernel */
-    PVA_OPT_MERGED_LAUNCH = 14 /* 1 (default) = general + air tiles in one launch per K steps; 0 = two kernels, two streams */
+    PVA_OPT_MERGED_LAUNCH = 14, /* 1 (default) = general + air tiles in one launch per K steps; 0 = two kernels, two streams */
+    PVA_OPT_EDGE_TILES = 15    /* builds with -DPV_EDGE_TILES=1 only (not the shipped one): 1 = tiles whose only non-air faces are the grid's absorbing edges run the air-tile code + edge overrides; 0 = general path */
 };
 
 PVA_EXPORT int PvAmdDeviceCount(void);

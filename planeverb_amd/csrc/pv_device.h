@@ -69,6 +69,7 @@ struct StepArgs {
     int pitch;
     int G;
     int ntx, nty, ntiles;
+    int gx, gy;            // the reference's grid size (cells are 0..gx x 0..gy): edge tiles locate the ghost column
     int bandRows;          // tile rows per XCD band = ceil(ntx / 8)
     int packed;            // air kernel: packed-f32 (v_pk_*) arithmetic variant
     int streamM;           // > 0: all-air chunks of streamM vertically adjacent tiles go to the row-streaming kernel

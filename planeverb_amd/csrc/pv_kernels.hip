@@ -668,6 +668,65 @@ __device__ __forceinline__ void leapfrogStepMirror(v2f (&pr)[NP], v2f (&vx)[NP],
     mirrorVySweep<NP, G, LO>(pr, vy, C);
 }
 
+#ifndef PV_AIR_MIRROR
+#define PV_AIR_MIRROR 1
+#endif
+#ifndef PV_EDGE_TILES
+#define PV_EDGE_TILES 0
+#endif
+#ifndef PV_LOAD_FENCE
+#define PV_LOAD_FENCE 0
+#endif
+#ifndef PV_LATE_ARGS
+#define PV_LATE_ARGS 0
+#endif
+
+// Edge tiles (tile class 2): tiles of an otherwise EMPTY region that touch the grid's x = 0, y = 0 or y = gy edge.
+// Their only non-air faces are the absorbing edge itself (FDTD.cpp:201-223; codes kLutNegBase / kLutPosBase with
+// Y = 1) and the dead cells outside the grid, so they run the air tile's code plus three overrides per step instead
+// of the general path (which costs 3.7 air tiles):
+//   x = 0    (row K of the first tile row):      vx[0, y] = -p[0, y]                    after the vx sweep
+//   y = 0    (lane K of the first tile column):  vy[x, 0] = -p[x, 0]                    after the vy sweep
+//   y = gy   (the ghost column, lane eR):        p[x, gy] = 0;  vy[x, gy] = p[x, gy-1]  after the pressure / vy sweep
+// (k * (p_i + p_n) with k = -1 or +1 and the outside neighbour's p = 0, bit for bit).  Registers that hold cells
+// OUTSIDE the grid evolve as if they were air; nothing inside the grid reads them (every face between inside and
+// outside is one of the overridden ones), they are reloaded as zeros by the next launch and stored as zeros.
+// The ghost ROW x = gx sits at a run-time row of the tile, which register-resident rows cannot index: tiles that see
+// it stay on the general path.
+struct EdgeInfo {
+    bool top, left;
+    int eR;  // lane of the ghost column y = gy, or -1
+};
+
+// one step of an edge tile: every row pair on every step (the time loop of the edge tiles is a real loop: a second
+// copy of the 12 unrolled trapezoid steps in the same kernel pushes the air tiles' code out of the instruction
+// cache and slows ALL tiles by 25 %)
+template <int NP, int K>
+__device__ __forceinline__ void edgeStepMirror(v2f (&pr)[NP], v2f (&vx)[NP], v2f (&vy)[NP], float& vxS, const float C,
+                                               const EdgeInfo& e, const int lane) {
+    mirrorPressureSweep<NP, 4, 0>(pr, vx, vy, vxS, C);
+    const bool ghost = lane == e.eR;  // eR = -1: no lane
+    if (e.eR >= 0) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) pr[i] = v2f{ghost ? 0.f : pr[i].x, ghost ? 0.f : pr[i].y};
+    }
+    mirrorVxSweep<NP, 4, 0>(pr, vx, vxS, C);
+    if (e.top) vx[K].x = -pr[K].x;
+    mirrorVySweep<NP, 4, 0>(pr, vy, C);
+    if (e.left) {
+        const bool edge = lane == K;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) vy[i] = v2f{edge ? -pr[i].x : vy[i].x, edge ? -pr[i].y : vy[i].y};
+    }
+    if (e.eR >= 0) {  // (selects, not a divergent branch: the lane shift must run with every lane on)
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const float px = lanePrev(pr[i].x), py = lanePrev(pr[i].y);
+            vy[i] = v2f{ghost ? px : vy[i].x, ghost ? py : vy[i].y};
+        }
+    }
+}
+
 template <int K, int RXI, int S>
 struct MirrorSteps {
     static constexpr int ROWS = RXI + 2 * K;
@@ -693,7 +752,7 @@ struct MirrorSteps {
     }
 };
 
-template <int K, int RXI>
+template <int K, int RXI, bool EDGE = false>
 __device__ __forceinline__ void stepTileAirMirror(const StepArgs& a, const int tile, const int lane) {
     constexpr int ROWS = RXI + 2 * K;
     static_assert(ROWS % 2 == 0, "packed air tile needs an even number of rows");
@@ -706,6 +765,13 @@ __device__ __forceinline__ void stepTileAirMirror(const StepArgs& a, const int t
     const int voff = lane * 4;
     const int pitchB = a.pitch * 4;
     const int soff0 = (row0 * a.pitch + col0) * 4;
+    EdgeInfo e{false, false, -1};
+    if constexpr (EDGE) {
+        e.top = ti == 0;
+        e.left = tj == 0;
+        const int er = a.gy - (tj * WI - K);
+        e.eR = (er >= 0 && er < 64) ? er : -1;
+    }
 
     const rsrc_t rPrIn = makeRsrc(a.prIn, a.inBytes), rVxIn = makeRsrc(a.vxIn, a.inBytes),
                  rVyIn = makeRsrc(a.vyIn, a.inBytes);
@@ -721,6 +787,13 @@ __device__ __forceinline__ void stepTileAirMirror(const StepArgs& a, const int t
         vx[i].x = bufLoadF(rVxIn, voff, soT);
         vx[i].y = (i > 0) ? -bufLoadF(rVxIn, voff, soB + pitchB) : 0.f;  // face ROWS-i; face ROWS is not in the tile
     }
+    // All 3*ROWS loads are in flight before anything consumes one.  Without this fence the schedule depends on what
+    // ELSE is in the kernel: with more code (an extra tile variant, even one that never runs) the scheduler feeds the
+    // non-zero test below a few loads at a time, s_waitcnt vmcnt(5) after every group -- ten memory round trips per
+    // tile instead of one, every tile 30 % slower (SQ_WAIT_ANY x2.3, same instruction counts, same I-cache hits).
+#if PV_LOAD_FENCE
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     uint32_t nz = __float_as_uint(vxS);
 #pragma unroll
     for (int i = 0; i < NP; ++i)
@@ -744,33 +817,71 @@ __device__ __forceinline__ void stepTileAirMirror(const StepArgs& a, const int t
     const int hsoff0 = (hti * RXI - K) * hpitchB;
     const int hvoff = (htj * WI - K + lane) * 4;
 
-    MirrorSteps<K, RXI, 0>::run(pr, vx, vy, vxS, C, a, rec && inCols, hplane, hvoff, hsoff0, hpitchB);
+    if constexpr (EDGE) {
+        const bool recLane = rec && inCols;
+#pragma unroll 1
+        for (int st = 0; st < a.nsteps; ++st) {
+            edgeStepMirror<NP, K>(pr, vx, vy, vxS, C, e, lane);
+            if (recLane) {
+                const rsrc_t rH = makeRsrc(hplane, a.histPlane * 4);
+#pragma unroll
+                for (int r = K; r < ROWS - K; ++r)
+                    bufStoreF(r < NP ? pr[r].x : pr[ROWS - 1 - r].y, rH, hvoff, hsoff0 + r * hpitchB);
+            }
+            hplane += a.histPlane;
+        }
+    } else {
+        MirrorSteps<K, RXI, 0>::run(pr, vx, vy, vxS, C, a, rec && inCols, hplane, hvoff, hsoff0, hpitchB);
+    }
 
-    const rsrc_t rPrOut = makeRsrc(a.prOut, a.planeBytes), rVxOut = makeRsrc(a.vxOut, a.planeBytes),
-                 rVyOut = makeRsrc(a.vyOut, a.planeBytes);
+#if PV_LATE_ARGS
+    const StepArgs* late = (const StepArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(late));
+#else
+    const StepArgs* late = &a;
+#endif
+    const rsrc_t rPrOut = makeRsrc(late->prOut, late->planeBytes), rVxOut = makeRsrc(late->vxOut, late->planeBytes),
+                 rVyOut = makeRsrc(late->vyOut, late->planeBytes);
+    // cells past the ghost column are outside the grid: stored as the zeros they are in memory; the ghost column's
+    // own vx is zero (wall|wall face)
+    const bool outP = EDGE && e.eR >= 0 && lane > e.eR, outX = EDGE && e.eR >= 0 && lane >= e.eR;
     if (inCols) {
 #pragma unroll
         for (int r = K; r < ROWS - K; ++r) {
             const int so = soff0 + r * pitchB;
-            bufStoreF(r < NP ? pr[r].x : pr[ROWS - 1 - r].y, rPrOut, voff, so);
-            bufStoreF(r < NP ? vx[r].x : (r == NP ? vxS : -vx[ROWS - r].y), rVxOut, voff, so);
-            bufStoreF(r < NP ? vy[r].x : vy[ROWS - 1 - r].y, rVyOut, voff, so);
+            const float p = r < NP ? pr[r].x : pr[ROWS - 1 - r].y;
+            const float x = r < NP ? vx[r].x : (r == NP ? vxS : -vx[ROWS - r].y);
+            const float y = r < NP ? vy[r].x : vy[ROWS - 1 - r].y;
+            bufStoreF(outP ? 0.f : p, rPrOut, voff, so);
+            bufStoreF(outX ? 0.f : x, rVxOut, voff, so);
+            bufStoreF(outP ? 0.f : y, rVyOut, voff, so);
         }
     }
+}
+
+// does a (K, RXI) configuration have the edge-tile path?  (the mirror-pair tiles)
+template <int K, int RXI>
+constexpr bool edgeTilesOk() {
+    return PV_EDGE_TILES && PV_AIR_MIRROR >= 1 && (RXI + 2 * K) % 2 == 0 && RXI + 2 * K >= 48;
 }
 
 // Which packed form a configuration uses: the mirror pairs win on the tall tiles that run at 2 waves/SIMD (-1..2 %
 // at 4096^2 / 8192^2 with the 60-row tile) and lose 1-2 % on the 40-row tiles at 3 waves/SIMD (measured, K = 8).
 // -DPV_AIR_MIRROR=0 / =2 force one form for A/B builds.
-#ifndef PV_AIR_MIRROR
-#define PV_AIR_MIRROR 1
-#endif
 template <int K, int RXI>
-__device__ __forceinline__ void airTilePacked(const StepArgs& a, const int tile, const int lane) {
-    if constexpr (PV_AIR_MIRROR == 2 || (PV_AIR_MIRROR == 1 && RXI + 2 * K >= 48))
-        stepTileAirMirror<K, RXI>(a, tile, lane);
-    else
+__device__ __forceinline__ void airTilePacked(const StepArgs& a, const int tile, const int lane, const bool edge) {
+    if constexpr (PV_AIR_MIRROR == 2 || (PV_AIR_MIRROR == 1 && RXI + 2 * K >= 48)) {
+        if constexpr (edgeTilesOk<K, RXI>()) {
+            if (edge)
+                stepTileAirMirror<K, RXI, true>(a, tile, lane);
+            else
+                stepTileAirMirror<K, RXI, false>(a, tile, lane);
+        } else {
+            stepTileAirMirror<K, RXI, false>(a, tile, lane);
+        }
+    } else {
         stepTileAirPacked<K, RXI>(a, tile, lane);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1338,14 +1449,15 @@ __global__ __launch_bounds__(256, WPS) void pv_step_air_kernel(const StepArgs a)
         if (!xcdTile(a, blockIdx.x, wave, &ti, &tj)) return;
     }
     const int tile = ti * a.nty + tj;
-    if (a.tileClass[tile] != 0) return;
+    const int cls = a.tileClass[tile];
+    if (cls == 1) return;
     if (a.streamM > 0 && streamOwnsChunk<K, RXI>(a, ti / a.streamM, tj)) return;  // row-streaming kernel's
     if (a.withPulse) {  // the tile(s) holding the listener are on the general kernel's list
         const int lr = a.dyn->lrow - (a.G - K + ti * RXI), lc = a.dyn->lcol - (a.G - K + tj * (64 - 2 * K));
         if (lr >= 0 && lr < RXI + 2 * K && lc >= 0 && lc < 64) return;
     }
     if constexpr (PACKED && (RXI + 2 * K) % 2 == 0) {
-        airTilePacked<K, RXI>(a, tile, lane);
+        airTilePacked<K, RXI>(a, tile, lane, cls == 2);
     } else {
         stepTile<K, RXI, RXI, false>(a, tile, 0, lane, nullptr);
     }
@@ -1392,13 +1504,14 @@ __global__ __launch_bounds__(256, WPS) void pv_step_merged_kernel(const StepArgs
     int ti, tj;
     if (!xcdTile(a, b, wave, &ti, &tj)) return;
     const int tile = ti * a.nty + tj;
-    if (a.tileClass[tile] != 0) return;
+    const int cls = a.tileClass[tile];
+    if (cls == 1) return;
     if (a.withPulse) {
         const int lr = a.dyn->lrow - (a.G - K + ti * RXI), lc = a.dyn->lcol - (a.G - K + tj * (64 - 2 * K));
         if (lr >= 0 && lr < RXI + 2 * K && lc >= 0 && lc < 64) return;
     }
     if constexpr ((RXI + 2 * K) % 2 == 0) {
-        airTilePacked<K, RXI>(a, tile, lane);
+        airTilePacked<K, RXI>(a, tile, lane, cls == 2);
     } else {
         stepTile<K, RXI, RXI, false>(a, tile, 0, lane, nullptr);
     }
@@ -1440,21 +1553,52 @@ __global__ __launch_bounds__(256, 2) void pv_step_stack_kernel(const StepArgs a)
 
 // Per-tile class: 0 = every face code in the tile's loaded region is air|air, 1 = needs the general kernel.
 // One wave per tile.  Tiles of class 1 are also appended to generalList (order irrelevant).
-template <int K, int RXI, int ROWS = RXI + 2 * K>
+// face code of cell (x, y) in an EMPTY grid (pv_codes_kernel with every cell air): what an edge tile must hold
+__device__ __forceinline__ uint32_t emptyGridCode(int x, int y, const Geometry& g) {
+    if (x < 0 || x >= g.NX || y < 0 || y >= g.NY) return (uint32_t)kLutWall | ((uint32_t)kLutWall << 8);
+    uint32_t kx, ky;
+    if (x == 0)
+        kx = y < g.gy ? kLutNegBase : kLutWall;
+    else if (x == g.gx)
+        kx = y < g.gy ? kLutPosBase : kLutWall;
+    else
+        kx = y != g.gy ? kLutAir : kLutWall;
+    if (y == 0)
+        ky = x < g.gx ? kLutNegBase : kLutWall;
+    else if (y == g.gy)
+        ky = x < g.gx ? kLutPosBase : kLutWall;
+    else
+        ky = x != g.gx ? kLutAir : kLutWall;
+    return kx | (ky << 8);
+}
+
+// Per-tile class.  0 = every face code in the tile's loaded region is air|air (air path).  2 = edge tile (EDGE
+// configurations only): the codes are exactly those of an empty grid and the region does not reach the ghost row
+// x = gx -- air path plus the edge overrides (stepTileAirMirror<EDGE>).  1 = everything else: general path; these
+// are also appended to generalList (order irrelevant).  One wave per tile.
+template <int K, int RXI, int ROWS = RXI + 2 * K, bool EDGE = false>
 __global__ __launch_bounds__(256) void pv_tileclass_kernel(const uint16_t* codes, uint8_t* tileClass,
-                                                           int* generalList, int* generalCount, Geometry g) {
+                                                           int* generalList, int* generalCount, Geometry g,
+                                                           int allowEdge) {
     constexpr int WI = 64 - 2 * K;
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile >= g.ntx * g.nty) return;
     const int ti = tile / g.nty, tj = tile - ti * g.nty;
-    const size_t base = (size_t)(g.G - K + ti * RXI) * g.pitch + (g.G - K + tj * WI) + lane;
-    uint32_t any = 0;
-    for (int r = 0; r < ROWS; ++r) any |= codes[base + (size_t)r * g.pitch];
-    const bool general = __ballot(any != 0u) != 0ull;
+    const int x0 = ti * RXI - K, y = tj * WI - K + lane;  // grid coordinates of the first loaded row / this lane
+    const size_t base = (size_t)(g.G + x0) * g.pitch + (g.G + y);
+    uint32_t any = 0, diff = 0;
+    for (int r = 0; r < ROWS; ++r) {
+        const uint32_t c = codes[base + (size_t)r * g.pitch];
+        any |= c;
+        if (EDGE) diff |= c ^ emptyGridCode(x0 + r, y, g);
+    }
+    const bool air = __ballot(any != 0u) == 0ull;
+    const bool edge =
+        EDGE && allowEdge && !air && __ballot(diff != 0u) == 0ull && !(x0 <= g.gx && g.gx < x0 + ROWS);
     if (lane == 0) {
-        tileClass[tile] = general ? 1 : 0;
-        if (general) generalList[atomicAdd(generalCount, 1)] = tile;
+        tileClass[tile] = air ? 0 : edge ? 2 : 1;
+        if (!air && !edge) generalList[atomicAdd(generalCount, 1)] = tile;
     }
 }
 
@@ -1491,12 +1635,12 @@ static void launchStepT(const StepArgs& a, hipStream_t stream, int which, hipStr
     }
 }
 
-template <int K, int RXI, int ROWS = RXI + 2 * K>
+template <int K, int RXI, int ROWS = RXI + 2 * K, bool EDGE = false>
 static void launchTileClassT(const uint16_t* codes, uint8_t* tileClass, int* list, int* count, const Geometry& g,
-                             hipStream_t stream) {
+                             hipStream_t stream, int allowEdge) {
     const int blocks = (g.ntx * g.nty + 3) / 4;
-    hipLaunchKernelGGL((pv_tileclass_kernel<K, RXI, ROWS>), dim3(blocks), dim3(256), 0, stream, codes, tileClass,
-                       list, count, g);
+    hipLaunchKernelGGL((pv_tileclass_kernel<K, RXI, ROWS, EDGE>), dim3(blocks), dim3(256), 0, stream, codes,
+                       tileClass, list, count, g, allowEdge);
 }
 
 template <int K, int NP, int X, int SUB>
@@ -1529,14 +1673,16 @@ void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream, int which
 }
 
 void launchTileClass(int K, int rxi, const uint16_t* codes, uint8_t* tileClass, int* list, int* count,
-                     const Geometry& g, hipStream_t stream) {
+                     const Geometry& g, hipStream_t stream, bool allowEdge) {
 #define X(k, np, x, sub) \
     if (K == k && rxi == x) \
-        return launchTileClassT<k, x, StackGeom<k, np, 4, x>::L>(codes, tileClass, list, count, g, stream);
+        return launchTileClassT<k, x, StackGeom<k, np, 4, x>::L>(codes, tileClass, list, count, g, stream, 0);
     PV_STACK_CONFIGS(X)
 #undef X
 #define X(k, r, w, sub) \
-    if (K == k && rxi == r) return launchTileClassT<k, r>(codes, tileClass, list, count, g, stream);
+    if (K == k && rxi == r) \
+        return launchTileClassT<k, r, r + 2 * k, edgeTilesOk<k, r>()>(codes, tileClass, list, count, g, stream, \
+                                                                      allowEdge ? 1 : 0);
     PV_STEP_CONFIGS(X)
 #undef X
 }

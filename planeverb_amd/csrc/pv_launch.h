@@ -20,8 +20,10 @@ int stepConfigExtraRows(int K, int rxi);
 // 4 = both in ONE merged launch (one block per general tile first, then the air tiles)
 // The general kernel goes to stream2 when given (the caller orders the two streams with events).
 void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream, int which = 3, hipStream_t stream2 = nullptr);
+// tile classes: 0 air, 1 general (also appended to `list`), 2 edge tile (only when allowEdge and the configuration
+// has the mirror-pair air tile)
 void launchTileClass(int K, int rxi, const uint16_t* codes, uint8_t* tileClass, int* list, int* count,
-                     const Geometry& g, hipStream_t stream);
+                     const Geometry& g, hipStream_t stream, bool allowEdge);
 // cells = NX*NY must satisfy smallGridFits()
 bool smallGridFits(int NX, int NY);
 void launchSmallGrid(const SmallArgs& a, hipStream_t stream);

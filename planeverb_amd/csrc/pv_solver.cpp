@@ -348,7 +348,8 @@ bool Solver::applyGeometry() {
         return false;
     launchCodes(matDev_, codes_, geo_, stream_);
     if (!hipOk(hipMemsetAsync(generalCount_, 0, sizeof(int), stream_), "memset")) return false;
-    launchTileClass(K_, rxi_, codes_, tileClass_, generalList_, generalCount_, geo_, stream_);
+    launchTileClass(K_, rxi_, codes_, tileClass_, generalList_, generalCount_, geo_, stream_,
+                    opt_.packed && opt_.edgeTiles);
     int count = 0;
     if (!hipOk(hipMemcpyAsync(&count, generalCount_, sizeof(int), hipMemcpyDeviceToHost, stream_), "count copy"))
         return false;
@@ -469,7 +470,7 @@ bool Solver::prepareDyn(int lcx, int lcy, bool withPulse) {
         for (int ti = tiLo; ti <= tiHi; ++ti)
             for (int tj = tjLo; tj <= tjHi; ++tj) {
                 const int t = ti * geo_.nty + tj;
-                if (!tileClassHost_[(size_t)t]) listHost_[n++] = t;
+                if (tileClassHost_[(size_t)t] != 1) listHost_[n++] = t;  // air and edge tiles holding the listener
             }
     }
     numGeneral_ = n;
@@ -519,6 +520,8 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
     a.ntx = geo_.ntx;
     a.nty = geo_.nty;
     a.ntiles = geo_.ntx * geo_.nty;
+    a.gx = g_.gx;
+    a.gy = g_.gy;
     a.bandRows = ceilDiv(geo_.ntx, 8);
     a.tileOrder = opt_.tileOrder;
     a.packed = opt_.packed ? 1 : 0;

@@ -751,3 +751,59 @@ def test_open_field_analysis_window_vs_dense(pvlib, n, cell):
         rs, ds = s.results()
         rd, dd = d.results()
         assert same_bits(ds, dd).all() and same_bits(rs, rd).all()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# edge tiles (tile class 2): grid-edge tiles of empty regions on the air path + edge overrides.  The arm is compiled
+# only with -DPV_EDGE_TILES=1 (it slows the air arm of the same kernel); in the shipped build the option
+# is accepted and changes nothing, so these tests then compare the general path with itself and the golden vectors.
+# ----------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("opts", [dict(steps_per_launch=12, tile_rows=36), dict(steps_per_launch=10, tile_rows=36),
+                                  dict(steps_per_launch=8, tile_rows=40),
+                                  dict(steps_per_launch=12, tile_rows=36, merged_launch=0)])
+@pytest.mark.parametrize("name", ["g71_empty", "g71_direction"])
+def test_edge_tiles_golden(pvlib, name, opts):
+    """71^2 scenes whose border tiles are edge tiles (x = 0, y = 0, y = gy; the ghost row stays general) against the
+    reference's vectors: recorded planes incl. the ghost column, IRs, all eight outputs"""
+    g = golden(name)
+    gx, gy, T, fs = (int(v) for v in g["dims"])
+    with pvlib.Solver(float(g["size"]), float(g["size"]), int(g["res"]), **opts) as s:
+        for b in g["boxes"]:
+            s.add_geometry(b)
+        s.run(g["listener"])
+        for i, t in enumerate(g["snap_ts"]):
+            assert same_bits(s.history_plane(int(t)), g["snaps"][i][0]).all(), "recorded pr, step %d" % t
+        for (cx, cy), ir in zip(g["probe_cells"], g["probe_ir"]):
+            assert same_bits(s.impulse_response(cx, cy), ir).all()
+        res, delay = s.results()
+        compare_maps(res, delay, g["results"], g["delay"], T, fs, name)
+        pr, vx, vy = s.fields()
+        if (T - 1) in list(g["snap_ts"]):
+            last = g["snaps"][list(g["snap_ts"]).index(T - 1)]
+            lc = (int(np.float32(g["listener"][0]) / np.float32(s.dx)), int(np.float32(g["listener"][2]) / np.float32(s.dx)))
+            exp = last[0].copy()
+            exp[lc] += g["pulse"][T - 1]
+            assert same_bits(pr, exp).all() and same_bits(vx, last[1]).all() and same_bits(vy, last[2]).all()
+
+
+@pytest.mark.parametrize("cell", [(30, 40), (20, 1000), (500, 10), (100, 100)])
+def test_edge_tiles_match_general_path_1024(pvlib, cell):
+    """open 1024^2 field, listener near the x = 0 / y = 0 / y = gy edges and a corner: the wave runs along and into
+    the absorbing edges for hundreds of steps.  Edge tiles on / off must give the same bits everywhere: final fields
+    (ghost row and column included), recorded planes, delay and result maps."""
+    dx = np.float32(343.21) / np.float32(275) / np.float32(3.5)
+    size = float((1024 + 0.5) * dx)
+    L = ((cell[0] + 0.5) * float(dx), 0.0, (cell[1] + 0.5) * float(dx))
+    with pvlib.Solver(size, size, 275, steps_per_launch=12, tile_rows=36, edge_tiles=1) as a, \
+            pvlib.Solver(size, size, 275, steps_per_launch=12, tile_rows=36, edge_tiles=0) as b:
+        a.run(L)
+        b.run(L)
+        for fa, fb in zip(a.fields(), b.fields()):
+            assert same_bits(fa, fb).all()
+        for t in (0, 40, 150, 300, 434):
+            assert same_bits(a.history_plane(t), b.history_plane(t)).all(), "recorded pr, step %d" % t
+        ra, da = a.results()
+        rb, db = b.results()
+        assert same_bits(da, db).all() and same_bits(ra, rb).all()
+        assert (da < 1e30).sum() > 50000
