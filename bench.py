@@ -109,6 +109,10 @@ def main():
     ap.add_argument("--inflight", type=int, default=2,
                     help="independent runs a GPU works on concurrently (one solver instance + stream each); a step "
                          "is one batch of this many listener positions per GPU")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="runs per batched launch (PvAmdRunBatch, <= 8): every one of the --inflight groups is a "
+                         "batch of this many solvers advanced by ONE launch per K steps; the lever for launch-bound "
+                         "grids (<= 1024^2), no gain at 4096^2")
     ap.add_argument("--use-graph", type=int, default=0, help="0 auto (grids of <= 4096 tiles), 1 always, 2 never")
     ap.add_argument("--time-kernels", type=int, default=0,
                     help="N > 0: HIP events around every Nth step-kernel launch instead of around the whole launch loop "
@@ -149,7 +153,9 @@ def main():
         opts["dense_history"] = 1
     if args.tile_order >= 0:
         opts["tile_order"] = args.tile_order
-    B = max(1, args.inflight)
+    NB = max(1, min(args.batch, 8))  # runs per batched launch
+    G = max(1, args.inflight)         # groups in flight (one stream each)
+    B = G * NB                        # runs per step and GPU
     solvers = [api.Solver(size, size, 275, device=local_rank, **opts) for _ in range(B)]
     if args.open_field:
         args.scene = "none"
@@ -177,6 +183,14 @@ def main():
             return [(x + 16 * float(s.dx), 0.0, z), (x, 0.0, z + 16 * float(s.dx))]
         return [(x, 0.0, z + 2.0), (5.0, 0.0, 6.0)]
 
+    def start_group(step, g):  # enqueue the NB runs of group g: solvers g*NB .. g*NB+NB-1
+        for b in range(g * NB, (g + 1) * NB):
+            solvers[b].set_output_queries(emitters(step, b))
+        if NB == 1:
+            solvers[g].run_async(listener(step, g))
+        else:
+            api.run_batch(solvers[g * NB:(g + 1) * NB], [listener(step, g * NB + j) for j in range(NB)], wait=False)
+
     def sync():
         torch.cuda.synchronize()
         if use_dist:
@@ -191,8 +205,8 @@ def main():
                 sv.run(listener(w, b))
                 single_loop_ms.append(sv.timings().stepLoopMs or sv.timings().fdtdMs)
         else:
-            for b, sv in enumerate(solvers):
-                sv.run_async(listener(w, b))
+            for g in range(G):
+                start_group(w, g)
             for sv in solvers:
                 sv.sync()
     if use_dist:  # first use of the all-gather sets up RCCL's channels: not part of the timed steps
@@ -205,7 +219,7 @@ def main():
     def collect(b):  # wait for solver b's run, fetch its per-emitter outputs and timings
         sv, k = solvers[b], pending[b]
         sv.sync()
-        local[run_id(k, b)] = np.stack([sv.get_output(e).as_array() for e in emitters(k, b)])
+        local[run_id(k, b)] = sv.queried_outputs()  # gathered behind the run's analysis (PvAmdSetOutputQueries)
         t = sv.timings()
         fdtd_ms.append(t.fdtdMs)
         ana_ms.append(t.analysisMs)
@@ -217,11 +231,13 @@ def main():
     sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        for b, sv in enumerate(solvers):
-            if pending[b] is not None:
-                collect(b)  # the other solvers' runs keep the GPU busy meanwhile
-            sv.run_async(listener(k, b))
-            pending[b] = k
+        for g in range(G):
+            for b in range(g * NB, (g + 1) * NB):
+                if pending[b] is not None:
+                    collect(b)  # the other groups' runs keep the GPU busy meanwhile
+            start_group(k, g)
+            for b in range(g * NB, (g + 1) * NB):
+                pending[b] = k
     for b in range(B):
         if pending[b] is not None:
             collect(b)
@@ -248,7 +264,10 @@ def main():
             # the short remainder launch counted by its share of steps
             air = float(np.mean(loop_ms)) * K / T
             how = "HIP events around the %d back-to-back launches of each timed run, x K/T" % launches
-            if air == 0.0:  # the run was replayed from a hipGraph (<= 4096 tiles): events sit around the whole graph
+            if air == 0.0 and NB > 1:  # batched: one launch advances NB runs; events around the batch's launch loop
+                air = float(np.mean(fdtd_ms)) * K / T
+                how = "HIP events around the %d batched launches (%d runs each) of every batch, x K/T" % (launches, NB)
+            elif air == 0.0:  # the run was replayed from a hipGraph (<= 4096 tiles): events sit around the whole graph
                 air = float(np.mean(fdtd_ms)) * K / T
                 how = "HIP events around the graph replay (field reset + %d launches), x K/T" % launches
         alg_bytes = ALG_BYTES_PER_CELL_STEP * cells * steps_per_launch_avg
@@ -283,7 +302,7 @@ def main():
                                        world),
                        "grid": [s.gx, s.gy], "T": T, "res": 275, "mode": "A", "steps_per_launch": K,
                        "tile": [info.tileRows, info.tileCols], "dense_history": bool(args.dense_history),
-                       "runs_in_flight_per_gpu": B,
+                       "runs_in_flight_per_gpu": B, "runs_per_batched_launch": NB,
                        "parallelism": "runs sharded round-robin, 1 all-gather of outputs"},
             "fdtd_cell_updates_per_s": world * B * cells * T / fd,
             "impulse_responses_per_s": world * B * s.gx * s.gy * args.steps / elapsed,
@@ -294,7 +313,8 @@ def main():
                          "kernel": "pv_step_merged_kernel<K=%d,rows=%d> (air tiles + general tiles, one launch per K "
                                    "steps)" % (K, info.tileRows),
                          "launch_ms": air, "launch_ms_from": how, "launches_per_run": launches,
-                         "concurrent_launches": B, "algorithmic_bytes_per_launch": alg_bytes,
+                         "concurrent_launches": G, "runs_per_launch": NB,
+                         "algorithmic_bytes_per_launch": alg_bytes * NB,
                          "single_run": single,
                          "note": "algorithmic = 24 B per cell-step x cells x K fused steps; K-step temporal "
                                  "blocking makes frac > 1 possible (SURVEY.md 8d).  achieved = concurrent_launches x "

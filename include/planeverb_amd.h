@@ -166,6 +166,13 @@ PVA_EXPORT int PvAmdRun(PvAmdSolver* s, float lx, float ly, float lz);
 /* Enqueue the same work on the solver's stream without waiting; PvAmdSync waits. */
 PVA_EXPORT int PvAmdRunAsync(PvAmdSolver* s, float lx, float ly, float lz);
 PVA_EXPORT int PvAmdSync(PvAmdSolver* s);
+/* n (1..8) independent runs -- one per solver, listener i at listenersXYZ[3i..3i+2] -- advanced together by ONE
+ * kernel launch per K steps instead of n launches on n streams (the reference would make these n iterations of its
+ * background loop one after the other, PvContext.cpp:74-93).  The solvers must sit on one device and share grid
+ * size, resolution and tile configuration (scenes may differ); streaming analysis and kernel timing are excluded.
+ * Afterwards every solver holds its own run's results exactly as after PvAmdRun (same bits).  wait = 0 returns after
+ * enqueueing; PvAmdSync each solver before reading results. */
+PVA_EXPORT int PvAmdRunBatch(PvAmdSolver* const* solvers, int n, const float* listenersXYZ, int wait);
 PVA_EXPORT int PvAmdGetTimings(PvAmdSolver* s, PvAmdTimings* out);
 
 /* Streaming-analysis (sparse-emitter) mode only -- SURVEY.md 8f N3.  Registers the emitter positions (n x {x,y,z})
@@ -175,6 +182,14 @@ PVA_EXPORT int PvAmdGetTimings(PvAmdSolver* s, PvAmdTimings* out);
 PVA_EXPORT int PvAmdSetEmitters(PvAmdSolver* s, const float* xyz, int n);
 /* Analyzer::GetResponseResult + Planeverb::GetOutput (Analyzer.cpp:106-116, FDTD.cpp:16-58) */
 PVA_EXPORT int PvAmdGetOutput(PvAmdSolver* s, float ex, float ey, float ez, PlaneverbOutput* out);
+/* Output queries: the emitter positions (n <= 64, n x {x,y,z}) whose PlaneverbOutput every FOLLOWING run gathers into
+ * pinned host memory with one kernel behind its analysis -- the batch-API counterpart of the reference's registered
+ * emitters (Emit / GetOutput(id), EmissionManager.cpp:11-38, FDTD.cpp:16-58).  After PvAmdSync,
+ * PvAmdGetQueriedOutputs returns them without any further GPU work or stream synchronisation (PvAmdGetOutput costs a
+ * launch and a sync per emitter).  n must equal the registered count; positions outside the grid give the
+ * reference's sentinel (occlusion = -1, the rest 0).  Setting queries waits for a run in flight. */
+PVA_EXPORT int PvAmdSetOutputQueries(PvAmdSolver* s, const float* xyz, int n);
+PVA_EXPORT int PvAmdGetQueriedOutputs(PvAmdSolver* s, PlaneverbOutput* out, int n);
 /* Whole result map: res8 = gx*gy*8 floats in AnalyzerResult order (Analyzer.h:13-21), delay = gx*gy */
 PVA_EXPORT int PvAmdCopyResults(PvAmdSolver* s, float* res8, float* delay);
 /* Planeverb::GetImpulseResponse (FDTD.cpp:60-70): T x {pr, vx, vy} at array cell (cx, cy) */

@@ -101,9 +101,12 @@ SYMBOLS = {
     "PvAmdRun": (C.c_int, [_vp] + [C.c_float] * 3),
     "PvAmdRunAsync": (C.c_int, [_vp] + [C.c_float] * 3),
     "PvAmdSync": (C.c_int, [_vp]),
+    "PvAmdRunBatch": (C.c_int, [C.POINTER(_vp), C.c_int, _fp, C.c_int]),
     "PvAmdGetTimings": (C.c_int, [_vp, C.POINTER(PvAmdTimings)]),
     "PvAmdSetEmitters": (C.c_int, [_vp, _fp, C.c_int]),
     "PvAmdGetOutput": (C.c_int, [_vp] + [C.c_float] * 3 + [C.POINTER(PlaneverbOutput)]),
+    "PvAmdSetOutputQueries": (C.c_int, [_vp, _fp, C.c_int]),
+    "PvAmdGetQueriedOutputs": (C.c_int, [_vp, C.POINTER(PlaneverbOutput), C.c_int]),
     "PvAmdCopyResults": (C.c_int, [_vp, _fp, _fp]),
     "PvAmdGetImpulseResponse": (C.c_int, [_vp, C.c_int, C.c_int, _fp]),
     "PvAmdCopyFields": (C.c_int, [_vp, _fp, _fp, _fp]),
@@ -293,6 +296,17 @@ def device_count():
 # batch solver
 # --------------------------------------------------------------------------------------------------------------
 
+def run_batch(solvers, listeners, wait=True):
+    """PvAmdRunBatch: len(solvers) <= 8 independent runs (one listener each) advanced by ONE launch per K steps.
+    The solvers must share device, grid and tile configuration; afterwards each holds its own run's results."""
+    n = len(solvers)
+    if n != len(listeners):
+        raise ValueError("one listener position per solver")
+    hs = (_vp * n)(*[sv._h for sv in solvers])
+    xyz = (C.c_float * (3 * n))(*[float(v) for L in listeners for v in L])
+    _check(lib().PvAmdRunBatch(hs, n, xyz, 1 if wait else 0))
+
+
 class Solver:
     """Grid + FreeGrid + Analyzer of one config on one MI355X (PvAmd* handle API)."""
 
@@ -376,6 +390,19 @@ class Solver:
         o = PlaneverbOutput()
         _check(lib().PvAmdGetOutput(self._h, *[float(v) for v in emitter], o))
         return o
+
+    def set_output_queries(self, emitters):
+        """emitter positions whose outputs every following run leaves in pinned host memory (<= 64)"""
+        e = np.ascontiguousarray(np.asarray(emitters, np.float32).reshape(-1, 3))
+        self._nq = len(e)
+        _check(lib().PvAmdSetOutputQueries(self._h, _f(e), len(e)))
+
+    def queried_outputs(self):
+        """float32 [n_queries, 8] of the last run (after sync; no GPU work)"""
+        n = getattr(self, "_nq", 0)
+        out = (PlaneverbOutput * max(n, 1))()
+        _check(lib().PvAmdGetQueriedOutputs(self._h, out, n))
+        return np.frombuffer(out, np.float32).reshape(-1, 8)[:n].copy()
 
     def results(self):
         res = np.empty((self.gx, self.gy, 8), np.float32)

@@ -272,6 +272,22 @@ int PvAmdRunAsync(PvAmdSolver* h, float lx, float ly, float lz) {
     return ret(h, h->s->run(lx, ly, lz, false));
 }
 
+int PvAmdRunBatch(PvAmdSolver* const* hs, int n, const float* listenersXYZ, int wait) {
+    if (!hs || !listenersXYZ || n < 1 || n > kBatchMax) {
+        g_lastError = "PvAmdRunBatch: 1..8 solvers and their listener positions";
+        return -1;
+    }
+    Solver* s[kBatchMax];
+    for (int i = 0; i < n; ++i) {
+        if (!ensure(hs[i])) return -1;
+        s[i] = hs[i]->s;
+    }
+    std::string err;
+    if (Solver::runBatch(s, n, listenersXYZ, wait != 0, &err)) return 0;
+    g_lastError = err.empty() ? "batched run failed" : err;
+    return -1;
+}
+
 int PvAmdSync(PvAmdSolver* h) {
     if (!ensure(h)) return -1;
     return ret(h, h->s->sync());
@@ -309,6 +325,27 @@ int PvAmdGetOutput(PvAmdSolver* h, float ex, float ey, float ez, PlaneverbOutput
         return 0;
     }
     std::memcpy(out, v, sizeof(*out));
+    return 0;
+}
+
+int PvAmdSetOutputQueries(PvAmdSolver* h, const float* xyz, int n) {
+    if ((n > 0 && !xyz) || !ensure(h)) return -1;
+    return ret(h, h->s->setOutputQueries(xyz, n));
+}
+
+int PvAmdGetQueriedOutputs(PvAmdSolver* h, PlaneverbOutput* out, int n) {
+    if (n < 0 || n > Solver::kMaxQueries || (n > 0 && !out) || !ensure(h)) return -1;
+    float v[Solver::kMaxQueries * 8];
+    unsigned char valid[Solver::kMaxQueries];
+    if (!h->s->queriedOutputs(v, valid, n)) return ret(h, false);
+    for (int i = 0; i < n; ++i) {
+        if (valid[i]) {
+            std::memcpy(&out[i], v + 8 * i, sizeof(PlaneverbOutput));
+        } else {  // the reference's sentinel for a position outside the grid (FDTD.cpp:19-47)
+            std::memset(&out[i], 0, sizeof(PlaneverbOutput));
+            out[i].occlusion = kInvalidDryGain;
+        }
+    }
     return 0;
 }
 

@@ -90,6 +90,15 @@ struct StepArgs {
                            // which is the run's zero initial state (no reset pass over the planes)
 };
 
+// Batched launch (pv_step_batch_kernel): up to kBatchMax independent runs of identically configured solvers advance
+// in ONE launch, blockIdx.y = run.  The whole table travels by value in the kernarg segment (scalar loads).
+constexpr int kBatchMax = 8;
+struct BatchArgs {
+    int n;        // live runs (= gridDim.y)
+    int gblocks;  // general-tile blocks per run: max over the runs' capacities, rounded up to a multiple of 8
+    StepArgs a[kBatchMax];
+};
+
 // pv_begin_run_kernel: the per-run parameters travel from pinned host memory to HBM inside a kernel (a node of the
 // captured run graph like every other launch) together with the per-tile bookkeeping resets
 struct BeginArgs {

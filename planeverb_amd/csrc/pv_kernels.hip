@@ -1517,6 +1517,45 @@ __global__ __launch_bounds__(256, WPS) void pv_step_merged_kernel(const StepArgs
     }
 }
 
+// Batched form of the merged launch: blockIdx.y selects one of up to kBatchMax independent runs (identically
+// configured solvers on one device, each with its own planes), so that B runs cost ONE launch per K steps instead
+// of B launches on B streams.  Launch-bound grids (<= 2048^2) gain the most: a 512^2 run is 55 dependent launches of
+// ~250 waves each, and the command processor serialises the dispatches of concurrent streams.  The body is the
+// merged kernel's; the general-tile block count is padded to a multiple of 8 so that block b - gblocks still sits on
+// XCD (b - gblocks) % 8.
+template <int K, int RXI, int WPS, int SUB>
+__global__ __launch_bounds__(256, WPS) void pv_step_batch_kernel(const BatchArgs ba) {
+    __shared__ float lut[256];
+    __shared__ GenShared gsh;
+    const StepArgs& a = ba.a[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int gblocks = ba.gblocks;
+    if ((int)blockIdx.x < gblocks) {
+        if ((int)blockIdx.x >= a.dyn->numGeneral) return;
+        lut[threadIdx.x] = a.lut[threadIdx.x];
+        __syncthreads();
+        const int tile = __builtin_amdgcn_readfirstlane(a.generalList[blockIdx.x]);
+        stepTileGeneral4<K, RXI>(a, tile, wave, lane, lut, gsh);
+        return;
+    }
+    const int b = blockIdx.x - gblocks;
+    int ti, tj;
+    if (!xcdTile(a, b, wave, &ti, &tj)) return;
+    const int tile = ti * a.nty + tj;
+    const int cls = a.tileClass[tile];
+    if (cls == 1) return;
+    if (a.withPulse) {
+        const int lr = a.dyn->lrow - (a.G - K + ti * RXI), lc = a.dyn->lcol - (a.G - K + tj * (64 - 2 * K));
+        if (lr >= 0 && lr < RXI + 2 * K && lc >= 0 && lc < 64) return;
+    }
+    if constexpr ((RXI + 2 * K) % 2 == 0) {
+        airTilePacked<K, RXI>(a, tile, lane, cls == 2);
+    } else {
+        stepTile<K, RXI, RXI, false>(a, tile, 0, lane, nullptr);
+    }
+}
+
 // Stacked form of the merged launch: the first blocks advance the general tiles in SUB-row slices (one wave each,
 // as above), every other block advances ONE air tile of X rows with its W = 4 waves (stepTileStack).
 template <int K, int NP, int X, int SUB>
@@ -1635,6 +1674,12 @@ static void launchStepT(const StepArgs& a, hipStream_t stream, int which, hipStr
     }
 }
 
+template <int K, int RXI, int WPS, int SUB>
+static void launchBatchT(const BatchArgs& ba, hipStream_t stream) {
+    const int blocks = ba.gblocks + 8 * ((bandPositions(ba.a[0]) + 3) / 4);
+    hipLaunchKernelGGL((pv_step_batch_kernel<K, RXI, WPS, SUB>), dim3(blocks, ba.n), dim3(256), 0, stream, ba);
+}
+
 template <int K, int RXI, int ROWS = RXI + 2 * K, bool EDGE = false>
 static void launchTileClassT(const uint16_t* codes, uint8_t* tileClass, int* list, int* count, const Geometry& g,
                              hipStream_t stream, int allowEdge) {
@@ -1669,6 +1714,25 @@ void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream, int which
 #define X(k, r, w, sub) \
     if (K == k && rxi == r) return launchStepT<k, r, w, sub>(a, stream, which, stream2);
     PV_STEP_CONFIGS(X)
+#undef X
+}
+
+// configurations with a batched kernel: the defaults of every grid-size class (pv_solver.cpp) and the other
+// merged-launch tiles of the tuning sweeps
+#define PV_BATCH_CONFIGS(X) X(8, 24, 3, 12) X(6, 28, 3, 14) X(10, 36, 2, 9) X(12, 36, 2, 9) X(8, 40, 2, 10)
+
+bool batchConfigOk(int K, int rxi) {
+#define X(k, r, w, sub) \
+    if (K == k && rxi == r) return true;
+    PV_BATCH_CONFIGS(X)
+#undef X
+    return false;
+}
+
+void launchBatch(int K, int rxi, const BatchArgs& ba, hipStream_t stream) {
+#define X(k, r, w, sub) \
+    if (K == k && rxi == r) return launchBatchT<k, r, w, sub>(ba, stream);
+    PV_BATCH_CONFIGS(X)
 #undef X
 }
 
@@ -2280,6 +2344,23 @@ __global__ void pv_gather_output_kernel(const float* __restrict__ res, long long
 
 void launchGatherOutput(const float* res, long long n, long long cell, float* out8Host, hipStream_t stream) {
     hipLaunchKernelGGL(pv_gather_output_kernel, dim3(1), dim3(64), 0, stream, res, n, cell, out8Host);
+}
+
+// the registered output queries of a run (PvAmdSetOutputQueries): nq result cells -> nq x 8 floats in pinned host
+// memory, enqueued behind the analysis so that the caller's one stream sync also delivers the outputs.
+// cells[] lives in pinned host memory too (cell < 0: position outside the result map, left to the host's sentinel)
+__global__ void pv_gather_queries_kernel(const float* __restrict__ res, long long n, const long long* cells, int nq,
+                                         float* out) {
+    const int q = threadIdx.x >> 3, k = threadIdx.x & 7;
+    if (q < nq) {
+        const long long c = cells[q];
+        out[q * 8 + k] = c >= 0 ? res[k * n + c] : 0.f;
+    }
+}
+
+void launchGatherQueries(const float* res, long long n, const long long* cellsHost, int nq, float* outHost,
+                         hipStream_t stream) {
+    hipLaunchKernelGGL(pv_gather_queries_kernel, dim3(1), dim3(512), 0, stream, res, n, cellsHost, nq, outHost);
 }
 
 void launchPackResults(const float* res, long long n, float* res8, hipStream_t stream) {

@@ -20,6 +20,10 @@ int stepConfigExtraRows(int K, int rxi);
 // 4 = both in ONE merged launch (one block per general tile first, then the air tiles)
 // The general kernel goes to stream2 when given (the caller orders the two streams with events).
 void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream, int which = 3, hipStream_t stream2 = nullptr);
+// batched merged launch: ba.n runs (blockIdx.y) of identically configured solvers in one grid; only for
+// batchConfigOk() configurations
+bool batchConfigOk(int K, int rxi);
+void launchBatch(int K, int rxi, const BatchArgs& ba, hipStream_t stream);
 // tile classes: 0 air, 1 general (also appended to `list`), 2 edge tile (only when allowEdge and the configuration
 // has the mirror-pair air tile)
 void launchTileClass(int K, int rxi, const uint16_t* codes, uint8_t* tileClass, int* list, int* count,
@@ -32,6 +36,8 @@ void launchBeginRun(const BeginArgs& a, hipStream_t stream);
 void launchCodes(const uint8_t* mat, uint16_t* codes, const Geometry& g, hipStream_t stream);
 void launchLaneSelfTest(float* out128, hipStream_t stream);
 void launchAnalysis(const AnalyzeArgs& a, hipStream_t stream);
+void launchGatherQueries(const float* res, long long n, const long long* cellsHost, int nq, float* outHost,
+                         hipStream_t stream);  // nq <= 64
 void launchGatherOutput(const float* res, long long n, long long cell, float* out8Host, hipStream_t stream);
 void launchPackResults(const float* res, long long n, float* res8, hipStream_t stream);
 void launchStreamAccum(const AnalyzeArgs& a, const uint8_t* hasEmitter, uint8_t* tileOpen, int ntiles,

@@ -187,6 +187,8 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     }
     if (!hipOk(hipHostMalloc((void**)&dynHost_, sizeof(DynParams)), "hipHostMalloc")) return false;
     if (!hipOk(hipHostMalloc((void**)&outHost_, 8 * sizeof(float)), "hipHostMalloc")) return false;
+    if (!hipOk(hipHostMalloc((void**)&qCellsHost_, kMaxQueries * sizeof(long long)), "hipHostMalloc")) return false;
+    if (!hipOk(hipHostMalloc((void**)&qOutHost_, kMaxQueries * 8 * sizeof(float)), "hipHostMalloc")) return false;
     if (!hipOk(hipHostMalloc((void**)&listHost_, sizeof(int) * (size_t)listCap_), "hipHostMalloc")) return false;
 
     pulse_ = gaussianPulse(g_);
@@ -235,6 +237,8 @@ Solver::~Solver() {
         if (p) hipFree(p);
     if (dynHost_) hipHostFree(dynHost_);
     if (outHost_) hipHostFree(outHost_);
+    if (qCellsHost_) hipHostFree(qCellsHost_);
+    if (qOutHost_) hipHostFree(qOutHost_);
     if (listHost_) hipHostFree(listHost_);
     for (auto& e : ev_)
         if (e) hipEventDestroy(e);
@@ -499,7 +503,8 @@ void Solver::enqueueBeginRun(bool resetTiles) {
     launchBeginRun(b, stream_);
 }
 
-bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record, bool fromZero) {
+// the part of a launch's arguments that does not change from launch to launch
+StepArgs Solver::baseStepArgs(bool withPulse, bool record) const {
     StepArgs a{};
     a.codes = codes_;
     a.lut = lutDev_;
@@ -529,6 +534,28 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
     a.record = record ? 1 : 0;
     a.dense = opt_.denseHistory ? 1 : 0;
     a.courant = g_.courant;
+    return a;
+}
+
+// the per-launch part: buffer sets, step range, per-tile flag planes (li = index of the launch within the run)
+void Solver::setLaunchArgs(StepArgs& a, int t0, int k, bool firstOfRun, int li) const {
+    a.prIn = pr_[cur_];
+    a.vxIn = vx_[cur_];
+    a.vyIn = vy_[cur_];
+    a.prOut = pr_[cur_ ^ 1];
+    a.vxOut = vx_[cur_ ^ 1];
+    a.vyOut = vy_[cur_ ^ 1];
+    a.t0 = t0;
+    a.histSlot = opt_.streaming ? t0 % ring_ : t0;
+    a.nsteps = k;
+    a.inBytes = (firstOfRun && opt_.streamRows == 0) ? 0 : (int)a.planeBytes;
+    a.streamM = (k == K_) ? opt_.streamRows : 0;  // the streaming kernel always advances exactly K levels
+    a.nzIn = nz_[li & 1];
+    a.nzOut = nz_[(li & 1) ^ 1];
+}
+
+bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record, bool fromZero) {
+    StepArgs a = baseStepArgs(withPulse, record);
     // Two streams: the air-tile kernel (the bulk of the grid) on stream_, the general-tile kernel (walls, edges,
     // listener: few tiles, latency-bound) concurrently on stream2_.  Both read buffer set `cur` and write disjoint
     // tiles of the other set, so launch i+1 of EITHER kernel must wait for launch i of BOTH (RAW on the halos it
@@ -564,19 +591,7 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
     int done = 0, li = 0;
     while (done < nsteps) {
         const int k = std::min(K_, nsteps - done);
-        a.prIn = pr_[cur_];
-        a.vxIn = vx_[cur_];
-        a.vyIn = vy_[cur_];
-        a.prOut = pr_[cur_ ^ 1];
-        a.vxOut = vx_[cur_ ^ 1];
-        a.vyOut = vy_[cur_ ^ 1];
-        a.t0 = firstStep + done;
-        a.histSlot = opt_.streaming ? a.t0 % ring_ : a.t0;
-        a.nsteps = k;
-        a.inBytes = (fromZero && done == 0 && opt_.streamRows == 0) ? 0 : (int)a.planeBytes;
-        a.streamM = (k == K_) ? opt_.streamRows : 0;  // the streaming kernel always advances exactly K levels
-        a.nzIn = nz_[li & 1];
-        a.nzOut = nz_[(li & 1) ^ 1];
+        setLaunchArgs(a, firstStep + done, k, fromZero && done == 0, li);
         if (opt_.timeKernels > 0) {  // 4 timing events per sampled launch: air begin/end on stream_, general begin/end
             while ((int)kev_.size() < kevUsed_ + 4) {
                 hipEvent_t e;
@@ -720,6 +735,7 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
         hipEventRecord(ev_[1], stream_);
         launchStreamFinalize(aa, stream_);
         hipEventRecord(ev_[2], stream_);
+        enqueueQueries();
         pendingTimings_ = true;
         return hipOk(hipGetLastError(), "run launch");
     }
@@ -763,6 +779,7 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
     hipEventRecord(ev_[1], stream_);
     if (!opt_.skipAnalysis) launchAnalysis(analyzeArgs(lx, lz), stream_);
     hipEventRecord(ev_[2], stream_);
+    enqueueQueries();
     pendingTimings_ = true;
     return hipOk(hipGetLastError(), "run launch");
 }
@@ -807,6 +824,92 @@ bool Solver::buildGraph(int cap) {
     graph_ = g;
     if (!hipOk(hipGraphInstantiate(&graphExec_, graph_, nullptr, nullptr, 0), "hipGraphInstantiate")) return false;
     graphCap_ = cap;
+    return true;
+}
+
+// B independent runs of identically configured solvers, stepped in lock-step by ONE launch per K steps
+// (pv_step_batch_kernel, blockIdx.y = run) on the first solver's stream.  Each solver prepares its run on its own
+// stream (begin-run kernel) and analyses its own history there afterwards, so the analyses of the batch overlap.
+// Timings: every solver's fdtdMs spans the whole batch's step loop (the B runs share it).
+bool Solver::runBatch(Solver* const* s, int n, const float* lxyz, bool wait, std::string* err) {
+    auto bad = [&](const char* what) {
+        if (err) *err = what;
+        return false;
+    };
+    if (n < 1 || n > kBatchMax) return bad("batch size must be 1..8");
+    Solver& lead = *s[0];
+    for (int i = 0; i < n; ++i) {
+        Solver& v = *s[i];
+        for (int j = 0; j < i; ++j)
+            if (s[j] == s[i]) return bad("a solver appears twice in the batch");
+        if (v.device_ != lead.device_ || v.K_ != lead.K_ || v.rxi_ != lead.rxi_ || v.T_ != lead.T_ ||
+            v.geo_.rows != lead.geo_.rows || v.geo_.pitch != lead.geo_.pitch || v.geo_.ntx != lead.geo_.ntx ||
+            v.geo_.nty != lead.geo_.nty || v.g_.gx != lead.g_.gx || v.g_.gy != lead.g_.gy ||
+            v.opt_.tileOrder != lead.opt_.tileOrder)
+            return bad("batched solvers must share device, grid and tile configuration");
+        if (v.opt_.streaming || v.opt_.streamRows > 0 || v.opt_.timeKernels > 0 || v.opt_.merged != 1 ||
+            !v.opt_.packed || !batchConfigOk(v.K_, v.rxi_))
+            return bad("batched runs need the default merged packed-math kernel of a batch configuration, without "
+                       "streaming analysis or kernel timing");
+    }
+    if (hipSetDevice(lead.device_) != hipSuccess) return bad("hipSetDevice failed");
+    int gcap = 0;
+    for (int i = 0; i < n; ++i) {
+        Solver& v = *s[i];
+        const float lx = lxyz[3 * i], lz = lxyz[3 * i + 2];
+        int lcx, lcy;
+        listenerCell(v.g_, lx, lz, &lcx, &lcy);
+        if ((v.pendingTimings_ && !v.sync()) || !v.applyGeometry() || !v.prepareDyn(lcx, lcy, true)) {
+            if (err) *err = v.err_;
+            return false;
+        }
+        v.lastLx_ = lx;
+        v.lastLz_ = lz;
+        v.tim_.stepLaunches = 0;
+        v.kevUsed_ = 0;
+        v.loopTimed_ = false;
+        v.cur_ = 0;
+        v.launchCap_ = v.numGeneral_;
+        gcap = std::max(gcap, v.numGeneral_);
+        hipEventRecord(v.ev_[0], v.stream_);
+        v.enqueueBeginRun(true);
+        if (i > 0) {  // the shared step loop starts when every run's parameters are on the device
+            hipEventRecord(v.forkEv_, v.stream_);
+            hipStreamWaitEvent(lead.stream_, v.forkEv_, 0);
+        }
+    }
+    BatchArgs ba{};
+    ba.n = n;
+    ba.gblocks = (gcap + 7) & ~7;
+    for (int i = 0; i < n; ++i) ba.a[i] = s[i]->baseStepArgs(true, true);
+    const int T = lead.T_, K = lead.K_;
+    int li = 0;
+    for (int done = 0; done < T; done += K, ++li) {
+        const int k = std::min(K, T - done);
+        for (int i = 0; i < n; ++i) {
+            s[i]->setLaunchArgs(ba.a[i], done, k, done == 0, li);
+            s[i]->cur_ ^= 1;
+            ++s[i]->tim_.stepLaunches;
+        }
+        launchBatch(K, lead.rxi_, ba, lead.stream_);
+    }
+    hipEventRecord(lead.forkEv_, lead.stream_);
+    for (int i = 0; i < n; ++i) {
+        Solver& v = *s[i];
+        if (i > 0) hipStreamWaitEvent(v.stream_, lead.forkEv_, 0);
+        hipEventRecord(v.ev_[1], v.stream_);
+        if (!v.opt_.skipAnalysis) launchAnalysis(v.analyzeArgs(v.lastLx_, v.lastLz_), v.stream_);
+        hipEventRecord(v.ev_[2], v.stream_);
+        v.enqueueQueries();
+        v.pendingTimings_ = true;
+    }
+    if (hipGetLastError() != hipSuccess) return bad("batched run launch failed");
+    if (wait)
+        for (int i = 0; i < n; ++i)
+            if (!s[i]->sync()) {
+                if (err) *err = s[i]->err_;
+                return false;
+            }
     return true;
 }
 
@@ -888,6 +991,33 @@ bool Solver::getOutput(float ex, float ey, float ez, float out8[8], bool* valid)
     launchGatherOutput(res_, (long long)g_.gx * g_.gy, (long long)idx, outHost_, stream_);
     if (!hipOk(hipStreamSynchronize(stream_), "output sync")) return false;
     for (int k = 0; k < 8; ++k) out8[k] = outHost_[k];
+    return true;
+}
+
+bool Solver::setOutputQueries(const float* xyz, int n) {
+    if (n < 0 || n > kMaxQueries) return fail("at most 64 output queries");
+    if (pendingTimings_ && !sync()) return false;  // the gather of a run in flight still reads the cell table
+    for (int i = 0; i < n; ++i) {
+        int cx, cy;
+        qCellsHost_[i] = resultCell(g_, xyz[3 * i], xyz[3 * i + 2], &cx, &cy) ? (long long)cx * g_.gy + cy : -1;
+    }
+    numQueries_ = n;
+    return true;
+}
+
+void Solver::enqueueQueries() {
+    if (numQueries_ > 0 && !opt_.skipAnalysis)
+        launchGatherQueries(res_, (long long)g_.gx * g_.gy, qCellsHost_, numQueries_, qOutHost_, stream_);
+}
+
+// after sync(): the registered queries' outputs of the last run, straight from pinned memory
+bool Solver::queriedOutputs(float* out8n, unsigned char* valid, int n) {
+    if (n != numQueries_) return fail("queriedOutputs: count differs from the registered queries");
+    if (pendingTimings_ && !sync()) return false;
+    for (int i = 0; i < n; ++i) {
+        valid[i] = qCellsHost_[i] >= 0;
+        for (int k = 0; k < 8; ++k) out8n[8 * i + k] = qOutHost_[8 * i + k];
+    }
     return true;
 }
 

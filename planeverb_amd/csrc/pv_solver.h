@@ -74,10 +74,18 @@ public:
     bool run(float lx, float ly, float lz, bool wait);
     bool runCells(int lcx, int lcy, float lx, float lz, bool wait);
     bool sync();
+    // n <= 8 identically configured solvers of one device: n independent runs (listeners lxyz[3n]) advanced by one
+    // launch per K steps (pv_step_batch_kernel); each solver then holds its run's results as after run()
+    static bool runBatch(Solver* const* s, int n, const float* lxyz, bool wait, std::string* err);
     bool runSteps(int nsteps, bool withPulse, float lx, float lz);
     const SolverTimings& timings() const { return tim_; }
 
     bool getOutput(float ex, float ey, float ez, float out8[8], bool* valid);
+    // output queries: up to kMaxQueries emitter positions whose 8 outputs every following run leaves in pinned host
+    // memory (one gather kernel behind the analysis): after sync() they are read without any further GPU work
+    static constexpr int kMaxQueries = 64;
+    bool setOutputQueries(const float* xyz, int n);
+    bool queriedOutputs(float* out8n, unsigned char* valid, int n);
     bool copyResults(float* res8, float* delay);
     // device -> caller-provided (pinned) host buffers, asynchronously on the solver's stream
     bool copyResultsAsync(float* res8Host);
@@ -98,6 +106,8 @@ private:
     bool computeEfree();
     bool enqueueRun(int lcx, int lcy, float lx, float lz);
     bool enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record, bool fromZero = false);
+    StepArgs baseStepArgs(bool withPulse, bool record) const;
+    void setLaunchArgs(StepArgs& a, int t0, int k, bool firstOfRun, int li) const;
     bool prepareDyn(int lcx, int lcy, bool withPulse);
     void enqueueBeginRun(bool resetTiles);
     AnalyzeArgs analyzeArgs(float lx, float lz) const;
@@ -166,6 +176,10 @@ private:
     // pinned host staging
     DynParams* dynHost_ = nullptr;
     float* outHost_ = nullptr;  // 8 floats the output-gather kernel writes straight into host memory
+    long long* qCellsHost_ = nullptr;  // kMaxQueries result-cell indices (-1 = outside the map), device-visible
+    float* qOutHost_ = nullptr;        // kMaxQueries x 8 floats
+    int numQueries_ = 0;
+    void enqueueQueries();
     int* listHost_ = nullptr;
     int listCap_ = 0;
 

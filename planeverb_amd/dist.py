@@ -50,37 +50,52 @@ def default_inflight(gx, gy):
     return 2 if gx * gy > 1536 * 1536 else 4
 
 
-def run_sharded(make_solver, listeners, emitters_for, dist=None, device=None, inflight=2):
+def run_sharded(make_solver, listeners, emitters_for, dist=None, device=None, inflight=2, batch=1, run_batch=None):
     """Simulate `listeners` (list of (x, y, z)) sharded over the ranks and gather all per-emitter outputs.
     make_solver() -> planeverb_amd.api.Solver bound to this rank's GPU; emitters_for(k) -> list of emitter positions
     of run k.  Returns [n_runs, n_emitters, 8].
 
-    inflight: runs a rank works on concurrently (one solver instance + HIP stream each).  A K-step launch fills the
-    chip and then drains; a second run's launches fill those gaps (+22 % cell-updates/s at 4096^2, +40 % at 2048^2,
-    measured on MI355X), a third brings nothing more."""
+    inflight: groups of runs a rank works on concurrently (one HIP stream per group).  A K-step launch fills the
+    chip and then drains; a second group's launches fill those gaps (+22 % cell-updates/s at 4096^2, +40 % at
+    2048^2, measured on MI355X), a third brings nothing more.
+    batch: runs per group, advanced together by ONE launch per K steps (PvAmdRunBatch, <= 8): the lever for
+    launch-bound grids, where a run is a chain of short dependent launches.  (run_batch: test hook, default
+    planeverb_amd.api.run_batch.)"""
+    if run_batch is None and batch > 1:
+        from . import api
+        run_batch = api.run_batch
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
     mine = shard_runs(len(listeners), world, rank)
     local = {}
     if mine:
-        solvers = [make_solver() for _ in range(max(1, min(inflight, len(mine))))]
-        pending = [None] * len(solvers)
+        batch = max(1, min(int(batch), 8))
+        chunks = [mine[i:i + batch] for i in range(0, len(mine), batch)]
+        n_groups = max(1, min(inflight, len(chunks)))
+        groups = [[make_solver() for _ in range(min(batch, len(mine)))] for _ in range(n_groups)]
+        pending = [None] * n_groups
 
-        def collect(b):
-            k = pending[b]
-            solvers[b].sync()
-            local[k] = np.stack([solvers[b].get_output(e).as_array() for e in emitters_for(k)])
-            pending[b] = None
+        def collect(g):
+            for sv, k in zip(groups[g], pending[g]):
+                sv.sync()
+                local[k] = sv.queried_outputs()  # gathered behind the run's analysis: no further GPU work
+            pending[g] = None
 
-        for j, k in enumerate(mine):
-            b = j % len(solvers)
-            if pending[b] is not None:
-                collect(b)  # the other solvers' runs keep the GPU busy meanwhile
-            solvers[b].run_async(listeners[k])
-            pending[b] = k
-        for b in range(len(solvers)):
-            if pending[b] is not None:
-                collect(b)
-        for s in solvers:
-            s.close()
+        for j, chunk in enumerate(chunks):
+            g = j % n_groups
+            if pending[g] is not None:
+                collect(g)  # the other groups' runs keep the GPU busy meanwhile
+            for sv, k in zip(groups[g], chunk):
+                sv.set_output_queries(emitters_for(k))
+            if batch == 1:
+                groups[g][0].run_async(listeners[chunk[0]])
+            else:
+                run_batch(groups[g][:len(chunk)], [listeners[k] for k in chunk], wait=False)
+            pending[g] = chunk
+        for g in range(n_groups):
+            if pending[g] is not None:
+                collect(g)
+        for grp in groups:
+            for s in grp:
+                s.close()
     return gather_outputs(local, len(listeners), dist, device)

@@ -28,14 +28,13 @@ class FakeSolver:
     def sync(self):
         self.done = True
 
-    def get_output(self, e):
-        assert self.done
-        row = fake_result(self.k)[int(e)]
+    def set_output_queries(self, emitters):
+        assert self.k is None or self.done, "queries changed while a run is in flight"
+        self.q = [int(e) for e in emitters]
 
-        class O:
-            def as_array(_):
-                return row
-        return O()
+    def queried_outputs(self):
+        assert self.done
+        return fake_result(self.k)[self.q]
 
     def close(self):
         pass
@@ -55,6 +54,19 @@ def main():
     res2 = pvd.run_sharded(FakeSolver, [(k, 0, 0) for k in range(n_runs)], lambda k: [0, 1, 2], dist, inflight=2)
     assert np.array_equal(res, res2), "run_sharded differs from gather_outputs"
     assert FakeSolver.made == min(2, len(mine))
+    # batched: groups of 3 runs started together by one call (PvAmdRunBatch on the GPU), two groups in flight
+    calls = []
+
+    def fake_batch(solvers, listeners, wait=True):
+        assert len(solvers) == len(listeners) <= 3 and not wait
+        calls.append(len(solvers))
+        for sv, L in zip(solvers, listeners):
+            sv.run_async(L)
+
+    res3 = pvd.run_sharded(FakeSolver, [(k, 0, 0) for k in range(n_runs)], lambda k: [0, 1, 2], dist, inflight=2,
+                           batch=3, run_batch=fake_batch)
+    assert np.array_equal(res, res3), "batched run_sharded differs"
+    assert sum(calls) == len(mine) and all(c == 3 for c in calls[:-1])
     np.savez(out, mine=np.array(mine, np.int64), out=res)
     dist.barrier()
     dist.destroy_process_group()

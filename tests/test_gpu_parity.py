@@ -730,6 +730,95 @@ def test_runs_in_flight_match_sequential_runs(pvlib):
     assert same_bits(seq, con).all() and same_bits(seq, tri).all()
 
 
+def test_output_queries_equal_get_output(pvlib):
+    """PvAmdSetOutputQueries / PvAmdGetQueriedOutputs (outputs gathered behind the run's analysis into pinned memory)
+    against PvAmdGetOutput, emitter by emitter -- incl. a position outside the grid (the reference's sentinel), a
+    wall cell, a second run with other queries, and the golden emitters of the 71^2 scene"""
+    g = golden("g71_smallroom")
+    with pvlib.Solver(float(g["size"]), float(g["size"]), int(g["res"])) as s:
+        for b in g["boxes"]:
+            s.add_geometry(b)
+        ems = [tuple(e) for e in g["emitters"]] + [(-3.0, 0.0, 2.0), (12.5, 0.0, 12.5), (24.9, 0.0, 0.1)]
+        s.set_output_queries(ems)
+        s.run_async(g["listener"])
+        s.sync()
+        q = s.queried_outputs()
+        assert q.shape == (len(ems), 8)
+        for i, e in enumerate(ems):
+            assert same_bits(q[i], s.get_output(e).as_array()).all(), e
+        for i, ro in enumerate(g["emitter_out"]):
+            assert same_bits(q[i], np.asarray(ro, np.float32)).all()
+        assert q[len(g["emitters"])][0] == -1.0 and not q[len(g["emitters"])][1:].any()
+        s.set_output_queries(ems[:2])
+        s.run((10.0, 0.0, 10.0))
+        q2 = s.queried_outputs()
+        for i, e in enumerate(ems[:2]):
+            assert same_bits(q2[i], s.get_output(e).as_array()).all()
+        s.set_output_queries([])
+        s.run(g["listener"])
+        assert s.queried_outputs().shape == (0, 8)
+
+
+def test_batched_runs_match_sequential_runs(pvlib):
+    """PvAmdRunBatch: B runs advanced by one launch per K steps (blockIdx.y = run).  Per-emitter outputs through
+    dist.run_sharded(batch=...) and, solver by solver, final fields, recorded planes and whole result maps must be
+    the bits of the same runs made one at a time -- with DIFFERENT scenes in the solvers of one batch."""
+    from planeverb_amd import dist as pvd
+    scene = os.path.join(SCENES, "HugeRoom.pv")
+    dx = np.float32(343.21) / np.float32(275) / np.float32(3.5)
+    size = float((512 + 0.5) * dx)
+    listeners = [(5.0, 0.0, 4.0), (8.0, 0.0, 8.0), (12.0, 0.0, 6.0), (15.0, 0.0, 15.0), (20.0, 0.0, 5.0),
+                 (5.0, 0.0, 20.0), (20.0, 0.0, 20.0)]
+
+    def emitters_for(k):
+        x, _, z = listeners[k]
+        return [(x, 0.0, z + 2.0), (5.0, 0.0, 6.0)]
+
+    def make():
+        s = pvlib.Solver(size, size, 275)
+        s.load_scene(scene)
+        return s
+
+    seq = pvd.run_sharded(make, listeners, emitters_for, inflight=1)
+    b3 = pvd.run_sharded(make, listeners, emitters_for, inflight=1, batch=3)
+    b4x2 = pvd.run_sharded(make, listeners, emitters_for, inflight=2, batch=4)
+    assert seq.shape == (7, 2, 8) and (seq[:, :, 0] > 0).all()
+    assert same_bits(seq, b3).all() and same_bits(seq, b4x2).all()
+
+    scenes = ["HugeRoom.pv", "Shoebox.pv", None, "BigRoom.pv"]
+    Ls = [(12.0, 0.0, 6.0), (5.0, 0.0, 4.0), (90.0, 0.0, 100.0), (5.0, 0.0, 4.0)]
+    for opts in (dict(), dict(steps_per_launch=12, tile_rows=36), dict(steps_per_launch=10, tile_rows=36)):
+        batch, single = [], []
+        for sc in scenes:
+            for lst in (batch, single):
+                sv = pvlib.Solver(size, size, 275, **opts)
+                if sc:
+                    sv.load_scene(os.path.join(SCENES, sc))
+                lst.append(sv)
+        pvlib.run_batch(batch, Ls)
+        pvlib.run_batch(batch, Ls)  # a second batch on the same solvers: nothing may be left over from the first
+        for sv, L in zip(single, Ls):
+            sv.run(L)
+        for a, b in zip(batch, single):
+            for fa, fb in zip(a.fields(), b.fields()):
+                assert same_bits(fa, fb).all()
+            for t in (0, 9, 100, 300, 434):
+                assert same_bits(a.history_plane(t), b.history_plane(t)).all(), "recorded pr, step %d" % t
+            ra, da = a.results()
+            rb, db = b.results()
+            assert same_bits(da, db).all() and same_bits(ra, rb).all()
+        # a solver of the batch keeps working alone afterwards
+        batch[1].run(Ls[0])
+        single[1].run(Ls[0])
+        assert same_bits(batch[1].results()[0], single[1].results()[0]).all()
+        for sv in batch + single:
+            sv.close()
+    # mismatched configurations are refused
+    with pvlib.Solver(size, size, 275) as a, pvlib.Solver(size * 2, size * 2, 275) as b:
+        with pytest.raises(RuntimeError):
+            pvlib.run_batch([a, b], Ls[:2])
+
+
 @pytest.mark.parametrize("n,cell", [(1024, (512, 512)), (1024, (3, 1000)), (2048, (1500, 600))])
 def test_open_field_analysis_window_vs_dense(pvlib, n, cell):
     """open field (walks of hundreds of steps): the windowed analysis -- far cells by formula, window cells by pointer
