@@ -152,6 +152,7 @@ struct AnalyzeArgs {
     int gx, gy;
     int rxi, wi, nty;
     int winRows, winCols;  // extent of the history window in cells: the analysis kernels' launch grid
+    int* activeCount;      // cells of this run with an onset (reset by pv_far_cells_kernel, counted by pv_encode_kernel)
     int* dirScratch;       // winRows x winCols ints for the listener-direction pointer jumping
     int dirJump;           // listener direction by pointer jumping (wide windows) instead of the plain walk
     int T;

@@ -2049,6 +2049,30 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
     // reference's while the memory latency is paid once per chunk instead of once per sample.
     constexpr int CH = 8;
 
+    // Is there an onset at all?  A scan of the cell's own pressure, 16 samples per memory round trip.  Cells that are
+    // never audible -- walls (beta = 0: pr is identically zero, FDTD.cpp:139), the outside of a closed room inside an
+    // active tile -- leave here; through the recurrence below each of them walked three planes for all T - tFirst
+    // samples, 8 at a time, and the slowest cell sets the kernel's duration (100 of 112 us at 512^2).
+    if ((code & 0xffu) >= (uint32_t)kLutWall) {
+        a.delay[s] = FLT_MAX;
+        return;
+    }
+    {
+        constexpr int SC = 16;
+        bool audible = false;
+        for (int t0 = tFirst; t0 < T && !audible; t0 += SC) {
+            float pc[SC];
+#pragma unroll
+            for (int k = 0; k < SC; ++k) pc[k] = hc.at(min(t0 + k, T - 1));
+#pragma unroll
+            for (int k = 0; k < SC; ++k) audible = audible || fabsf(pc[k]) > kAudibleThresholdDev;
+        }
+        if (!audible) {
+            a.delay[s] = FLT_MAX;
+            return;
+        }
+    }
+
     // onset + dry energy + flux, Analyzer.cpp:146-195 (sums run from sample 0; samples before tFirst are zero)
     int onset = -1, sourceDirEnd = INT_MAX, directEnd = INT_MAX;
     float Edry = 0.f, fluxX = 0.f, fluxY = 0.f, vx = 0.f, vy = 0.f;
@@ -2099,6 +2123,10 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
         return;
     }
     a.delay[s] = (float)onset;
+    {  // cells with an onset, for the choice between the two RT60 kernels (one atomic per wave)
+        const unsigned long long m = __ballot(1);
+        if ((int)__lane_id() == __ffsll((long long)m) - 1) atomicAdd(a.activeCount, __popcll(m));
+    }
 
     // obstruction gain + source directivity, Analyzer.cpp:197-220
     const float EfreePr = efreePerR(a.efree, a.dx, a.lcx, a.lcy, X, Y);
@@ -2111,60 +2139,190 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
     const float rr = 1.0f / ((0.001f < occ) ? occ : 0.001f);
     const float lowpass = -147.f + (18390.f) / (1.f + pvPowf(rr / 12.f, 0.8f));
 
+
+    // (wet gain and decay time: pv_rt60_cell_kernel / pv_rt60_wave_kernel, which read the onset back from the delay
+    // map)
+    a.out[s] = occ;
+    a.out[3 * a.resN + s] = lowpass;
+    a.out[6 * a.resN + s] = sdx;
+    a.out[7 * a.resN + s] = sdy;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// RT60: backward Schroeder integration + linear regression (Analyzer.cpp:282-327), two forms with the same bits
+// ---------------------------------------------------------------------------------------------------------------
+// Windows with fewer cells than this that have an onset (closed rooms: a few thousand) take the wave form
+constexpr int kRt60WaveMaxCells = 65536;
+
+struct Rt60Cell {
+    int s;              // result index, < 0: nothing to do
+    CellHistory hc;
+    int startingPoint;  // onset + N_dry + 1
+};
+
+// the part shared by both forms: which cell, its history, its onset (read back from the delay map)
+__device__ __forceinline__ Rt60Cell rt60Cell(const AnalyzeArgs& a, const DynParams& dyn, int X, int Y) {
+    Rt60Cell c{-1, {nullptr, 0}, 0};
+    if (X >= a.gx || Y >= a.gy) return c;
+    const int s = X * a.gy + Y;
+    const float d = a.delay[s];
+    if (d == FLT_MAX) return c;
+    c.s = s;
+    c.hc = CellHistory{a.hist + (long long)(X + a.G - dyn.histRow0) * a.histPitch + (Y + a.G - dyn.histCol0),
+                       a.histPlane};
+    c.startingPoint = (int)d + a.nDry + 1;
+    return c;
+}
+
+__device__ __forceinline__ float rt60FromSums(const AnalyzeArgs& a, int startingPoint, float xysum, float ysum) {
+    const int endPoint = a.T - a.nCut;
+    const int regressN = endPoint - startingPoint;
+    const float rn = (float)regressN;
+    const float xmean = (rn - 1.0f) * 0.5f;
+    const float xsum = rn * xmean;
+    const float denominator = (1.0f / 12.0f) * rn * (rn * rn - 1.0f);
+    const float ymean = ysum / rn;
+    const float numerator = xysum - ymean * xsum - xmean * ysum + rn * xmean * ymean;
+    const float slopePerSample = numerator / denominator;
+    const float slopePerSec = slopePerSample * (float)a.fs;
+    return -60.f / slopePerSec;
+}
+
+// Cell form: one thread per result cell, the history walked in chunks of CH samples (loads issued together, sums in
+// the reference's order).  The form for windows full of audible cells (open fields: 760 000 cells at T = 435).
+__global__ __launch_bounds__(256) void pv_rt60_cell_kernel(const AnalyzeArgs a) {
+    if (*a.activeCount < kRt60WaveMaxCells) return;
+    const DynParams dyn = *a.dyn;
+    int X, Y;
+    if (!analysisWindowCell(a, dyn, &X, &Y)) return;
+    const Rt60Cell c = rt60Cell(a, dyn, X, Y);
+    if (c.s < 0) return;
+    constexpr int CH = 8;
+    const int T = a.T;
+    const int startingPoint = c.startingPoint, endPoint = T - a.nCut;
     // wet gain, Analyzer.cpp:235-247
     float wetEnergy = 0.f;
     {
-        int end = directEnd + 1 + a.nWet;
+        int end = startingPoint + a.nWet;
         if (T < end) end = T;
-        for (int j0 = directEnd + 1; j0 < end; j0 += CH) {
+        for (int j0 = startingPoint; j0 < end; j0 += CH) {
             float pc[CH];
 #pragma unroll
-            for (int k = 0; k < CH; ++k) pc[k] = hc.at(min(j0 + k, T - 1));
+            for (int k = 0; k < CH; ++k) pc[k] = c.hc.at(min(j0 + k, T - 1));
 #pragma unroll
             for (int k = 0; k < CH; ++k)
                 if (j0 + k < end) wetEnergy += pc[k] * pc[k];
         }
     }
-    const float wet = sqrtf(wetEnergy / a.efree);
-
-    // decay time by backward Schroeder integration + linear regression, Analyzer.cpp:282-327
-    float rt60;
-    {
-        const int startingPoint = directEnd + 1;
-        const int endPoint = T - a.nCut;
-        const int regressN = endPoint - startingPoint;
-        const float rn = (float)regressN;
-        const float xmean = (rn - 1.0f) * 0.5f;
-        const float xsum = rn * xmean;
-        const float denominator = (1.0f / 12.0f) * rn * (rn * rn - 1.0f);
-        float edc = 0.f, xysum = 0.f, ysum = 0.f;
-        for (int i0 = T - 1; i0 >= endPoint && i0 >= 0; i0 -= CH) {
-            float pc[CH];
+    a.out[a.resN + c.s] = sqrtf(wetEnergy / a.efree);
+    float edc = 0.f, xysum = 0.f, ysum = 0.f;
+    for (int i0 = T - 1; i0 >= endPoint && i0 >= 0; i0 -= CH) {
+        float pc[CH];
 #pragma unroll
-            for (int k = 0; k < CH; ++k) pc[k] = hc.at(max(i0 - k, 0));
+        for (int k = 0; k < CH; ++k) pc[k] = c.hc.at(max(i0 - k, 0));
 #pragma unroll
-            for (int k = 0; k < CH; ++k)
-                if (i0 - k >= endPoint && i0 - k >= 0) edc += pc[k] * pc[k];
-        }
-        for (int i0 = endPoint - 1; i0 >= startingPoint; i0 -= CH) {
-            float pc[CH];
-#pragma unroll
-            for (int k = 0; k < CH; ++k) pc[k] = hc.at(max(i0 - k, 0));
-            rt60Chunk<CH>(pc, i0, startingPoint, edc, xysum, ysum);
-        }
-        const float ymean = ysum / rn;
-        const float numerator = xysum - ymean * xsum - xmean * ysum + rn * xmean * ymean;
-        const float slopePerSample = numerator / denominator;
-        const float slopePerSec = slopePerSample * (float)a.fs;
-        rt60 = -60.f / slopePerSec;
+        for (int k = 0; k < CH; ++k)
+            if (i0 - k >= endPoint && i0 - k >= 0) edc += pc[k] * pc[k];
     }
+    for (int i0 = endPoint - 1; i0 >= startingPoint; i0 -= CH) {
+        float pc[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) pc[k] = c.hc.at(max(i0 - k, 0));
+        rt60Chunk<CH>(pc, i0, startingPoint, edc, xysum, ysum);
+    }
+    a.out[2 * a.resN + c.s] = rt60FromSums(a, startingPoint, xysum, ysum);
+}
 
-    a.out[s] = occ;
-    a.out[a.resN + s] = wet;
-    a.out[2 * a.resN + s] = rt60;
-    a.out[3 * a.resN + s] = lowpass;
-    a.out[6 * a.resN + s] = sdx;
-    a.out[7 * a.resN + s] = sdy;
+// Wave form: SIXTEEN lanes (one DPP row) per cell, four cells per wave.  Lane j of a row holds sample i0 - j of a
+// 16-sample chunk, walking backwards from T - 1; the chunk's 16 loads are one instruction and its 16 log10f
+// evaluations run side by side.  The three running sums stay strictly sequential, in the reference's order: each is a
+// chain of 16 steps per chunk in which lane j adds its addend to the value of lane j - 1, fetched by a DPP row
+// rotation riding on the add (v_add_f32 row_ror:1); lane 0 thereby reads lane 15, which still holds the chain's value
+// at the end of the previous chunk, so the carry between chunks needs no broadcast.  Lanes outside the regression
+// range add +0.0f, which leaves a non-negative-zero float sum unchanged bit for bit.  Sixteen times the threads of
+// the cell form, a sixteenth of its dependent work per thread: the form for the few thousand cells of a closed room,
+// which leave the cell form with 80 waves on 1024 SIMDs, each paying a memory round trip per 8 samples.
+__device__ __forceinline__ float rowRor1Add(float acc, float addend) {  // acc[lane - 1 in its row of 16] + addend
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x121, 0xf, 0xf,
+                                                                  false)) + addend;
+}
+
+template <int NCH>
+__device__ __forceinline__ void rowChains(float (&acc)[NCH], const float (&add)[NCH], const int sub) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const bool mine = sub == j;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const float t = rowRor1Add(acc[c], add[c]);
+            acc[c] = mine ? t : acc[c];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pv_rt60_wave_kernel(const AnalyzeArgs a) {
+    if (*a.activeCount >= kRt60WaveMaxCells) return;
+    const DynParams dyn = *a.dyn;
+    // 16 cells per 256-thread block along the window's columns, one window row per blockIdx.y
+    const int sub = threadIdx.x & 15;
+    const int wc = blockIdx.x * 16 + (threadIdx.x >> 4), wr = blockIdx.y;
+    Rt60Cell c{-1, {nullptr, 0}, 0};
+    if (wc < a.winCols) c = rt60Cell(a, dyn, dyn.histRow0 - a.G + wr, dyn.histCol0 - a.G + wc);
+    // a wave leaves only when none of its four cells has work: the DPP chains need whole rows, not whole waves, but
+    // keeping the wave together costs nothing
+    if (__ballot(c.s >= 0) == 0ull) return;
+    const bool live = c.s >= 0;
+    const int T = a.T;
+    const int endPoint = T - a.nCut;
+    const int startingPoint = live ? c.startingPoint : T;  // dead rows: no sample is in range
+    const int lowest = min(startingPoint, endPoint);         // the pre-sum over [endPoint, T) is not bounded by the onset
+    // wave-uniform trip count: the longest of the four cells
+    int n = max(T - lowest, 0);
+#pragma unroll
+    for (int off = 16; off < 64; off <<= 1) n = max(n, __shfl_xor(n, off));
+    float acc[3] = {0.f, 0.f, 0.f};  // edc, xysum, ysum: lane 15 of the row carries them from chunk to chunk
+    float pNext = 0.f;
+    {
+        const int i = T - 1 - sub;
+        pNext = (live && i >= lowest && i >= 0) ? c.hc.at(i) : 0.f;
+    }
+    for (int n0 = 0; n0 < n; n0 += 16) {
+        const int i = T - 1 - n0 - sub;
+        const float p = pNext;
+        {  // the next chunk's load is in flight while this chunk's chains run
+            const int in = i - 16;
+            pNext = (live && n0 + 16 < n && in >= lowest && in >= 0) ? c.hc.at(in) : 0.f;
+        }
+        float e[1] = {acc[0]};
+        const float q[1] = {p * p};  // 0 outside [lowest, T): edc + 0 = edc
+        rowChains<1>(e, q, sub);
+        acc[0] = e[0];
+        const bool regress = i >= startingPoint && i < endPoint;
+        const float y = 10.f * pvLog10fNonNeg(regress ? e[0] : 1.f);
+        const float add[2] = {regress ? y * (float)(i - startingPoint) : 0.f, regress ? y : 0.f};
+        float sums[2] = {acc[1], acc[2]};
+        rowChains<2>(sums, add, sub);
+        acc[1] = sums[0];
+        acc[2] = sums[1];
+    }
+    // wet gain (Analyzer.cpp:235-247): the same chain, forwards over [startingPoint, startingPoint + N_wet) ^ [0, T)
+    const int wetEnd = min(startingPoint + a.nWet, T);
+    int nw = max(wetEnd - startingPoint, 0);
+#pragma unroll
+    for (int off = 16; off < 64; off <<= 1) nw = max(nw, __shfl_xor(nw, off));
+    float wetAcc[1] = {0.f};
+    pNext = (live && startingPoint + sub < wetEnd) ? c.hc.at(startingPoint + sub) : 0.f;
+    for (int j0 = 0; j0 < nw; j0 += 16) {
+        const float p = pNext;
+        const int jn = startingPoint + j0 + 16 + sub;
+        pNext = (live && j0 + 16 < nw && jn < wetEnd) ? c.hc.at(jn) : 0.f;
+        const float q[1] = {p * p};
+        rowChains<1>(wetAcc, q, sub);
+    }
+    if (live && sub == 15) {
+        a.out[a.resN + c.s] = sqrtf(wetAcc[0] / a.efree);
+        a.out[2 * a.resN + c.s] = rt60FromSums(a, c.startingPoint, acc[1], acc[2]);
+    }
 }
 
 // Analyzer.cpp:332-337
@@ -2191,6 +2349,7 @@ __device__ __forceinline__ void storeDirection(const AnalyzeArgs& a, int index, 
 __global__ __launch_bounds__(256) void pv_far_cells_kernel(const AnalyzeArgs a) {
     const int index = blockIdx.x * blockDim.x + threadIdx.x;
     if (index >= a.gx * a.gy) return;
+    if (index == 0) *a.activeCount = 0;  // cells with an onset, counted by pv_encode_kernel
     a.delay[index] = FLT_MAX;
     storeDirection(a, index, index);
 }
@@ -2372,6 +2531,10 @@ void launchAnalysis(const AnalyzeArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(pv_far_cells_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a);
     const dim3 grid = analysisWindowGrid(a);
     hipLaunchKernelGGL(pv_encode_kernel, grid, dim3(256), 0, stream, a);
+    // decay time: exactly one of the two forms does the work (chosen on the device by the number of cells with an
+    // onset, which pv_encode_kernel counted); the other one's blocks leave at once
+    hipLaunchKernelGGL(pv_rt60_wave_kernel, dim3((a.winCols + 15) / 16, a.winRows), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(pv_rt60_cell_kernel, grid, dim3(256), 0, stream, a);
     // listener direction: the plain walk where walks are short (small windows: rooms, the sandbox's grids), pointer
     // jumping where a window is wide enough for hundreds of steps (a dozen tiny launches, path-length independent)
     if (a.dirJump)

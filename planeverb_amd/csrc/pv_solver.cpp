@@ -141,6 +141,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     if (!dalloc(&generalCount_, 1, true)) return false;
     if (!dalloc(&dynDev_, 1, true)) return false;
     if (!dalloc(&errFlag_, 1, true)) return false;
+    if (!dalloc(&activeCount_, 1, true)) return false;
     if (!dalloc(&res_, (size_t)g_.gx * g_.gy * 8, true)) return false;  // zeroed pool: PvContext.cpp:132
     if (!dalloc(&delay_, (size_t)g_.gx * g_.gy, true)) return false;
     scratchCount_ = std::max<size_t>({(size_t)3 * std::max(T_, g_.T), (size_t)g_.NX * g_.NY * 3,
@@ -232,7 +233,7 @@ Solver::~Solver() {
     if (emCells_) hipFree(emCells_);
     if (emTrace_) hipFree(emTrace_);
     void* ptrs[] = {codes_,     matDev_, lutDev_, pulseDev_, hist_,  tileFirst_, tileClass_, generalList_,
-                    generalCount_, dynDev_, errFlag_, res8_,     delay_, scratch_, res_};
+                    generalCount_, dynDev_, errFlag_, res8_,     delay_, scratch_, res_, activeCount_};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (dynHost_) hipHostFree(dynHost_);
@@ -663,6 +664,7 @@ AnalyzeArgs Solver::analyzeArgs(float lx, float lz) const {
     a.nty = geo_.nty;
     a.winRows = histTilesX_ * rxi_;
     a.winCols = histTilesY_ * wi_;
+    a.activeCount = activeCount_;
     a.dirScratch = reinterpret_cast<int*>(scratch_);
     // wide windows can hold walks of hundreds of steps; the dense-history (validation) mode keeps the plain walk
     a.dirJump = (!opt_.denseHistory && a.winRows > 256 && a.winCols > 256) ? 1 : 0;
