@@ -1990,6 +1990,86 @@ __device__ __forceinline__ void rt60Chunk(const float (&pc)[CH], const int i0, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// RT60: backward Schroeder integration + linear regression (Analyzer.cpp:282-327), two forms with the same bits
+// ---------------------------------------------------------------------------------------------------------------
+// Windows whose ever-non-zero tiles hold fewer cells than this (closed rooms: a few thousand reachable cells; the
+// count is pv_count_active_kernel's) take the wave form; an open field's 760 000 take the cell form
+constexpr int kRt60WaveMaxCells = 65536;
+
+struct Rt60Cell {
+    int s;              // result index, < 0: nothing to do
+    CellHistory hc;
+    int startingPoint;  // onset + N_dry + 1
+};
+
+// the part shared by both forms: which cell, its history, its onset (read back from the delay map)
+__device__ __forceinline__ Rt60Cell rt60Cell(const AnalyzeArgs& a, const DynParams& dyn, int X, int Y) {
+    Rt60Cell c{-1, {nullptr, 0}, 0};
+    if (X >= a.gx || Y >= a.gy) return c;
+    const int s = X * a.gy + Y;
+    const float d = a.delay[s];
+    if (d == FLT_MAX) return c;
+    c.s = s;
+    c.hc = CellHistory{a.hist + (long long)(X + a.G - dyn.histRow0) * a.histPitch + (Y + a.G - dyn.histCol0),
+                       a.histPlane};
+    c.startingPoint = (int)d + a.nDry + 1;
+    return c;
+}
+
+__device__ __forceinline__ float rt60FromSums(const AnalyzeArgs& a, int startingPoint, float xysum, float ysum) {
+    const int endPoint = a.T - a.nCut;
+    const int regressN = endPoint - startingPoint;
+    const float rn = (float)regressN;
+    const float xmean = (rn - 1.0f) * 0.5f;
+    const float xsum = rn * xmean;
+    const float denominator = (1.0f / 12.0f) * rn * (rn * rn - 1.0f);
+    const float ymean = ysum / rn;
+    const float numerator = xysum - ymean * xsum - xmean * ysum + rn * xmean * ymean;
+    const float slopePerSample = numerator / denominator;
+    const float slopePerSec = slopePerSample * (float)a.fs;
+    return -60.f / slopePerSec;
+}
+
+// Cell form of the wet gain (Analyzer.cpp:235-247) and the decay time: one thread per result cell, the history walked
+// in chunks of CH samples (loads issued together, sums in the reference's order).
+__device__ __forceinline__ void cellWetAndRt60(const AnalyzeArgs& a, const CellHistory& hc, const int startingPoint,
+                                               float* wet, float* rt60) {
+    constexpr int CH = 8;
+    const int T = a.T;
+    const int endPoint = T - a.nCut;
+    float wetEnergy = 0.f;
+    {
+        int end = startingPoint + a.nWet;
+        if (T < end) end = T;
+        for (int j0 = startingPoint; j0 < end; j0 += CH) {
+            float pc[CH];
+#pragma unroll
+            for (int k = 0; k < CH; ++k) pc[k] = hc.at(min(j0 + k, T - 1));
+#pragma unroll
+            for (int k = 0; k < CH; ++k)
+                if (j0 + k < end) wetEnergy += pc[k] * pc[k];
+        }
+    }
+    *wet = sqrtf(wetEnergy / a.efree);
+    float edc = 0.f, xysum = 0.f, ysum = 0.f;
+    for (int i0 = T - 1; i0 >= endPoint && i0 >= 0; i0 -= CH) {
+        float pc[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) pc[k] = hc.at(max(i0 - k, 0));
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+            if (i0 - k >= endPoint && i0 - k >= 0) edc += pc[k] * pc[k];
+    }
+    for (int i0 = endPoint - 1; i0 >= startingPoint; i0 -= CH) {
+        float pc[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) pc[k] = hc.at(max(i0 - k, 0));
+        rt60Chunk<CH>(pc, i0, startingPoint, edc, xysum, ysum);
+    }
+    *rt60 = rt60FromSums(a, startingPoint, xysum, ysum);
+}
+
 // One thread per result cell (X, Y); lanes along Y so every history read is a coalesced row segment of one
 // recorded plane.  All sums are sequential float32 accumulations in the reference's order.
 // vx / vy are not stored: they are re-derived from the pressure history with the stencil's own recurrence
@@ -2049,15 +2129,17 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
     // reference's while the memory latency is paid once per chunk instead of once per sample.
     constexpr int CH = 8;
 
-    // Is there an onset at all?  A scan of the cell's own pressure, 16 samples per memory round trip.  Cells that are
-    // never audible -- walls (beta = 0: pr is identically zero, FDTD.cpp:139), the outside of a closed room inside an
-    // active tile -- leave here; through the recurrence below each of them walked three planes for all T - tFirst
-    // samples, 8 at a time, and the slowest cell sets the kernel's duration (100 of 112 us at 512^2).
+    // Is there an onset at all?  Walls (beta = 0: pr is identically zero, FDTD.cpp:139) have none.  In a room (few
+    // reachable cells, the kernel's duration is that of its slowest thread) the cell's own pressure is scanned first, 16
+    // samples per memory round trip: the air cells outside a closed room but inside an active tile leave here; through
+    // the recurrence below each of them walked three planes for all T - tFirst samples, 8 at a time (100 of 112 us at
+    // 512^2).  An open field has next to no such cells and is bandwidth-bound: no second pass there.
     if ((code & 0xffu) >= (uint32_t)kLutWall) {
         a.delay[s] = FLT_MAX;
         return;
     }
-    {
+    const bool roomRegime = *a.activeCount < kRt60WaveMaxCells;  // few reachable cells: see pv_rt60_wave_kernel
+    if (roomRegime) {
         constexpr int SC = 16;
         bool audible = false;
         for (int t0 = tFirst; t0 < T && !audible; t0 += SC) {
@@ -2123,10 +2205,6 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
         return;
     }
     a.delay[s] = (float)onset;
-    {  // cells with an onset, for the choice between the two RT60 kernels (one atomic per wave)
-        const unsigned long long m = __ballot(1);
-        if ((int)__lane_id() == __ffsll((long long)m) - 1) atomicAdd(a.activeCount, __popcll(m));
-    }
 
     // obstruction gain + source directivity, Analyzer.cpp:197-220
     const float EfreePr = efreePerR(a.efree, a.dx, a.lcx, a.lcy, X, Y);
@@ -2140,97 +2218,18 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
     const float lowpass = -147.f + (18390.f) / (1.f + pvPowf(rr / 12.f, 0.8f));
 
 
-    // (wet gain and decay time: pv_rt60_cell_kernel / pv_rt60_wave_kernel, which read the onset back from the delay
-    // map)
+    // wet gain and decay time: here, one thread per cell, when the window is full of reachable cells (open field:
+    // the kernel streams the whole history once, at HBM speed); by pv_rt60_wave_kernel in a room
+    if (!roomRegime) {
+        float wet, rt60;
+        cellWetAndRt60(a, hc, directEnd + 1, &wet, &rt60);
+        a.out[a.resN + s] = wet;
+        a.out[2 * a.resN + s] = rt60;
+    }
     a.out[s] = occ;
     a.out[3 * a.resN + s] = lowpass;
     a.out[6 * a.resN + s] = sdx;
     a.out[7 * a.resN + s] = sdy;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// RT60: backward Schroeder integration + linear regression (Analyzer.cpp:282-327), two forms with the same bits
-// ---------------------------------------------------------------------------------------------------------------
-// Windows with fewer cells than this that have an onset (closed rooms: a few thousand) take the wave form
-constexpr int kRt60WaveMaxCells = 65536;
-
-struct Rt60Cell {
-    int s;              // result index, < 0: nothing to do
-    CellHistory hc;
-    int startingPoint;  // onset + N_dry + 1
-};
-
-// the part shared by both forms: which cell, its history, its onset (read back from the delay map)
-__device__ __forceinline__ Rt60Cell rt60Cell(const AnalyzeArgs& a, const DynParams& dyn, int X, int Y) {
-    Rt60Cell c{-1, {nullptr, 0}, 0};
-    if (X >= a.gx || Y >= a.gy) return c;
-    const int s = X * a.gy + Y;
-    const float d = a.delay[s];
-    if (d == FLT_MAX) return c;
-    c.s = s;
-    c.hc = CellHistory{a.hist + (long long)(X + a.G - dyn.histRow0) * a.histPitch + (Y + a.G - dyn.histCol0),
-                       a.histPlane};
-    c.startingPoint = (int)d + a.nDry + 1;
-    return c;
-}
-
-__device__ __forceinline__ float rt60FromSums(const AnalyzeArgs& a, int startingPoint, float xysum, float ysum) {
-    const int endPoint = a.T - a.nCut;
-    const int regressN = endPoint - startingPoint;
-    const float rn = (float)regressN;
-    const float xmean = (rn - 1.0f) * 0.5f;
-    const float xsum = rn * xmean;
-    const float denominator = (1.0f / 12.0f) * rn * (rn * rn - 1.0f);
-    const float ymean = ysum / rn;
-    const float numerator = xysum - ymean * xsum - xmean * ysum + rn * xmean * ymean;
-    const float slopePerSample = numerator / denominator;
-    const float slopePerSec = slopePerSample * (float)a.fs;
-    return -60.f / slopePerSec;
-}
-
-// Cell form: one thread per result cell, the history walked in chunks of CH samples (loads issued together, sums in
-// the reference's order).  The form for windows full of audible cells (open fields: 760 000 cells at T = 435).
-__global__ __launch_bounds__(256) void pv_rt60_cell_kernel(const AnalyzeArgs a) {
-    if (*a.activeCount < kRt60WaveMaxCells) return;
-    const DynParams dyn = *a.dyn;
-    int X, Y;
-    if (!analysisWindowCell(a, dyn, &X, &Y)) return;
-    const Rt60Cell c = rt60Cell(a, dyn, X, Y);
-    if (c.s < 0) return;
-    constexpr int CH = 8;
-    const int T = a.T;
-    const int startingPoint = c.startingPoint, endPoint = T - a.nCut;
-    // wet gain, Analyzer.cpp:235-247
-    float wetEnergy = 0.f;
-    {
-        int end = startingPoint + a.nWet;
-        if (T < end) end = T;
-        for (int j0 = startingPoint; j0 < end; j0 += CH) {
-            float pc[CH];
-#pragma unroll
-            for (int k = 0; k < CH; ++k) pc[k] = c.hc.at(min(j0 + k, T - 1));
-#pragma unroll
-            for (int k = 0; k < CH; ++k)
-                if (j0 + k < end) wetEnergy += pc[k] * pc[k];
-        }
-    }
-    a.out[a.resN + c.s] = sqrtf(wetEnergy / a.efree);
-    float edc = 0.f, xysum = 0.f, ysum = 0.f;
-    for (int i0 = T - 1; i0 >= endPoint && i0 >= 0; i0 -= CH) {
-        float pc[CH];
-#pragma unroll
-        for (int k = 0; k < CH; ++k) pc[k] = c.hc.at(max(i0 - k, 0));
-#pragma unroll
-        for (int k = 0; k < CH; ++k)
-            if (i0 - k >= endPoint && i0 - k >= 0) edc += pc[k] * pc[k];
-    }
-    for (int i0 = endPoint - 1; i0 >= startingPoint; i0 -= CH) {
-        float pc[CH];
-#pragma unroll
-        for (int k = 0; k < CH; ++k) pc[k] = c.hc.at(max(i0 - k, 0));
-        rt60Chunk<CH>(pc, i0, startingPoint, edc, xysum, ysum);
-    }
-    a.out[2 * a.resN + c.s] = rt60FromSums(a, startingPoint, xysum, ysum);
 }
 
 // Wave form: SIXTEEN lanes (one DPP row) per cell, four cells per wave.  Lane j of a row holds sample i0 - j of a
@@ -2349,7 +2348,6 @@ __device__ __forceinline__ void storeDirection(const AnalyzeArgs& a, int index, 
 __global__ __launch_bounds__(256) void pv_far_cells_kernel(const AnalyzeArgs a) {
     const int index = blockIdx.x * blockDim.x + threadIdx.x;
     if (index >= a.gx * a.gy) return;
-    if (index == 0) *a.activeCount = 0;  // cells with an onset, counted by pv_encode_kernel
     a.delay[index] = FLT_MAX;
     storeDirection(a, index, index);
 }
@@ -2526,15 +2524,34 @@ void launchPackResults(const float* res, long long n, float* res8, hipStream_t s
     hipLaunchKernelGGL(pv_pack_results_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, res, n, res8);
 }
 
+// Upper bound of the cells the pulse reached: the cells of the window's tiles that were ever non-zero.  One block;
+// its result chooses, on the device, between the cell form (inside pv_encode_kernel) and the wave form of the wet
+// gain / decay time.
+__global__ __launch_bounds__(256) void pv_count_active_kernel(const AnalyzeArgs a) {
+    __shared__ int part[256];
+    const DynParams dyn = *a.dyn;
+    int n = 0;
+    for (int i = threadIdx.x; i < dyn.histTilesX * dyn.histTilesY; i += 256) {
+        const int ti = dyn.histTileX0 + i / dyn.histTilesY, tj = dyn.histTileY0 + i % dyn.histTilesY;
+        if (a.tileFirst[ti * a.nty + tj] < a.T) n += a.rxi * a.wi;
+    }
+    part[threadIdx.x] = n;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *a.activeCount = part[0];
+}
+
 void launchAnalysis(const AnalyzeArgs& a, hipStream_t stream) {
     const int n = a.gx * a.gy;
+    hipLaunchKernelGGL(pv_count_active_kernel, dim3(1), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(pv_far_cells_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a);
     const dim3 grid = analysisWindowGrid(a);
     hipLaunchKernelGGL(pv_encode_kernel, grid, dim3(256), 0, stream, a);
-    // decay time: exactly one of the two forms does the work (chosen on the device by the number of cells with an
-    // onset, which pv_encode_kernel counted); the other one's blocks leave at once
+    // wet gain + decay time of a room's cells (an open field's were done inside pv_encode_kernel: its blocks leave at once)
     hipLaunchKernelGGL(pv_rt60_wave_kernel, dim3((a.winCols + 15) / 16, a.winRows), dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(pv_rt60_cell_kernel, grid, dim3(256), 0, stream, a);
     // listener direction: the plain walk where walks are short (small windows: rooms, the sandbox's grids), pointer
     // jumping where a window is wide enough for hundreds of steps (a dozen tiny launches, path-length independent)
     if (a.dirJump)
