@@ -24,8 +24,16 @@ python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --grid 8192 --steps 4 --no-cpu-baseline > $O/bench_8192.json 2>> $O/bench.err
 python bench.py --grid 8192 --steps 4 --open-field --no-cpu-baseline > $O/bench_8192_open.json 2>> $O/bench.err
 python bench.py --grid 2048 --scene BigRoom.pv --no-cpu-baseline > $O/bench_2048.json 2>> $O/bench.err
-python bench.py --grid 512 --scene Shoebox.pv --no-cpu-baseline > $O/bench_512.json 2>> $O/bench.err
+python bench.py --grid 512 --scene Shoebox.pv --inflight 4 --no-cpu-baseline > $O/bench_512.json 2>> $O/bench.err
+python bench.py --grid 512 --scene Shoebox.pv --inflight 2 --batch 8 --no-cpu-baseline > $O/bench_512_batch8.json 2>> $O/bench.err
+python bench.py --grid 1024 --scene Shoebox.pv --inflight 2 --batch 8 --no-cpu-baseline > $O/bench_1024_batch8.json 2>> $O/bench.err
 python bench.py --dense-history 1 --no-cpu-baseline > $O/bench_dense.json 2>> $O/bench.err
 python bench.py --inflight 1 --no-cpu-baseline > $O/bench_inflight1.json 2>> $O/bench.err
+# sizes, open fields, runs in flight, batched launches
+python tools/gpu_probe.py perf > $O/sizes.txt 2>&1
+python tools/gpu_openfield.py >> $O/sizes.txt 2>&1
+(python tools/gpu_concurrent.py 4096 2; python tools/gpu_concurrent.py 2048 2; python tools/gpu_concurrent.py 1024 4; python tools/gpu_concurrent.py 512 4; python tools/gpu_concurrent.py 8192 2) > $O/concurrent.txt 2>&1
+python tools/gpu_batch.py 512,1024,2048 "1x1 4x1 1x8 2x8" Shoebox.pv > $O/batch.txt 2>&1
+python tools/gpu_batch.py 4096 "2x1 1x2 3x1" >> $O/batch.txt 2>&1
 rm -f $O/trace/bench_kernel_trace.csv.bak
 ls -la $O

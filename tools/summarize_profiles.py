@@ -36,7 +36,8 @@ def steady(v):
 
 shutil.copy(os.path.join(SRC, "trace", "bench_kernel_stats.csv"), os.path.join(DST, R + "_kernel_stats.csv"))
 for f in ("bench.json", "bench_8192.json", "bench_8192_open.json", "bench_2048.json", "bench_512.json", "bench_dense.json",
-          "bench_inflight1.json",
+          "bench_inflight1.json", "bench_512_batch8.json", "bench_1024_batch8.json", "sizes.txt", "concurrent.txt",
+          "batch.txt",
           "bench_under_rocprof.json", "hbm_calib.txt"):
     p = os.path.join(SRC, f)
     if os.path.exists(p):
