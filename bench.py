@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--steps-per-launch", type=int, default=0)
     ap.add_argument("--tile-rows", type=int, default=0)
     ap.add_argument("--dense-history", type=int, default=0)
+    ap.add_argument("--edge-tiles", type=int, default=-1,
+                    help="PVA_OPT_EDGE_TILES: 1 = grid-border tiles on the air path (every run then goes through the "
+                         "batched kernel, also with --batch 1)")
     ap.add_argument("--tile-order", type=int, default=-1, help="PVA_OPT_TILE_ORDER (development: block -> tile map)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=2,
@@ -153,7 +156,11 @@ def main():
         opts["dense_history"] = 1
     if args.tile_order >= 0:
         opts["tile_order"] = args.tile_order
+    if args.edge_tiles >= 0:
+        opts["edge_tiles"] = args.edge_tiles
     NB = max(1, min(args.batch, 8))  # runs per batched launch
+    if NB > 1 and not args.steps_per_launch and not args.tile_rows:
+        opts.update(api.batch_solver_options(args.grid))  # mirror-pair tile + edge tiles (batched kernel only)
     G = max(1, args.inflight)         # groups in flight (one stream each)
     B = G * NB                        # runs per step and GPU
     solvers = [api.Solver(size, size, 275, device=local_rank, **opts) for _ in range(B)]

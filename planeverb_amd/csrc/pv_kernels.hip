@@ -862,16 +862,16 @@ __device__ __forceinline__ void stepTileAirMirror(const StepArgs& a, const int t
 // does a (K, RXI) configuration have the edge-tile path?  (the mirror-pair tiles)
 template <int K, int RXI>
 constexpr bool edgeTilesOk() {
-    return PV_EDGE_TILES && PV_AIR_MIRROR >= 1 && (RXI + 2 * K) % 2 == 0 && RXI + 2 * K >= 48;
+    return PV_AIR_MIRROR >= 1 && (RXI + 2 * K) % 2 == 0 && RXI + 2 * K >= 48;
 }
 
 // Which packed form a configuration uses: the mirror pairs win on the tall tiles that run at 2 waves/SIMD (-1..2 %
 // at 4096^2 / 8192^2 with the 60-row tile) and lose 1-2 % on the 40-row tiles at 3 waves/SIMD (measured, K = 8).
 // -DPV_AIR_MIRROR=0 / =2 force one form for A/B builds.
-template <int K, int RXI>
+template <int K, int RXI, bool EDGE_ARM = (PV_EDGE_TILES != 0)>
 __device__ __forceinline__ void airTilePacked(const StepArgs& a, const int tile, const int lane, const bool edge) {
     if constexpr (PV_AIR_MIRROR == 2 || (PV_AIR_MIRROR == 1 && RXI + 2 * K >= 48)) {
-        if constexpr (edgeTilesOk<K, RXI>()) {
+        if constexpr (EDGE_ARM && edgeTilesOk<K, RXI>()) {
             if (edge)
                 stepTileAirMirror<K, RXI, true>(a, tile, lane);
             else
@@ -1550,7 +1550,7 @@ __global__ __launch_bounds__(256, WPS) void pv_step_batch_kernel(const BatchArgs
         if (lr >= 0 && lr < RXI + 2 * K && lc >= 0 && lc < 64) return;
     }
     if constexpr ((RXI + 2 * K) % 2 == 0) {
-        airTilePacked<K, RXI>(a, tile, lane, cls == 2);
+        airTilePacked<K, RXI, true>(a, tile, lane, cls == 2);
     } else {
         stepTile<K, RXI, RXI, false>(a, tile, 0, lane, nullptr);
     }
@@ -1724,6 +1724,15 @@ void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream, int which
 bool batchConfigOk(int K, int rxi) {
 #define X(k, r, w, sub) \
     if (K == k && rxi == r) return true;
+    PV_BATCH_CONFIGS(X)
+#undef X
+    return false;
+}
+
+// configurations whose batched kernel has the edge-tile arm (the mirror-pair tiles)
+bool edgeConfigOk(int K, int rxi) {
+#define X(k, r, w, sub) \
+    if (K == k && rxi == r) return edgeTilesOk<k, r>();
     PV_BATCH_CONFIGS(X)
 #undef X
     return false;

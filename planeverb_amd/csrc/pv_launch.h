@@ -23,6 +23,7 @@ void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream, int which
 // batched merged launch: ba.n runs (blockIdx.y) of identically configured solvers in one grid; only for
 // batchConfigOk() configurations
 bool batchConfigOk(int K, int rxi);
+bool edgeConfigOk(int K, int rxi);  // the batched kernel of this configuration has the edge-tile arm (tile class 2)
 void launchBatch(int K, int rxi, const BatchArgs& ba, hipStream_t stream);
 // tile classes: 0 air, 1 general (also appended to `list`), 2 edge tile (only when allowEdge and the configuration
 // has the mirror-pair air tile)

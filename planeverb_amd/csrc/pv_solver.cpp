@@ -90,6 +90,10 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         rxi_ = 24;
     }
     if (!stepConfigSupported(K_, rxi_)) return fail("unsupported (stepsPerLaunch, tileRows) configuration");
+    // edge tiles are an "allow": only the batched kernels of the mirror-pair tiles have that arm
+    if (opt_.edgeTiles && !(edgeConfigOk(K_, rxi_) && opt_.packed && opt_.merged == 1 && !opt_.streaming &&
+                            opt_.streamRows == 0 && opt_.timeKernels == 0))
+        opt_.edgeTiles = false;
     wi_ = 64 - 2 * K_;
     T_ = opt.numSteps > 0 ? opt.numSteps : g_.T;
 
@@ -354,7 +358,7 @@ bool Solver::applyGeometry() {
     launchCodes(matDev_, codes_, geo_, stream_);
     if (!hipOk(hipMemsetAsync(generalCount_, 0, sizeof(int), stream_), "memset")) return false;
     launchTileClass(K_, rxi_, codes_, tileClass_, generalList_, generalCount_, geo_, stream_,
-                    opt_.packed && opt_.edgeTiles);
+                    opt_.edgeTiles);
     int count = 0;
     if (!hipOk(hipMemcpyAsync(&count, generalCount_, sizeof(int), hipMemcpyDeviceToHost, stream_), "count copy"))
         return false;
@@ -922,6 +926,13 @@ bool Solver::runCells(int lcx, int lcy, float lx, float lz, bool wait) {
 
 bool Solver::run(float lx, float ly, float lz, bool wait) {
     (void)ly;  // world y is ignored: grid-x = world x, grid-y = world z (FDTD.cpp:97-98)
+    if (opt_.edgeTiles) {  // tile class 2 exists only in the batched kernel: a batch of one
+        Solver* self = this;
+        const float xyz[3] = {lx, ly, lz};
+        std::string e;
+        if (runBatch(&self, 1, xyz, wait, &e)) return true;
+        return err_.empty() ? fail(e) : false;
+    }
     int lcx, lcy;
     listenerCell(g_, lx, lz, &lcx, &lcy);
     return runCells(lcx, lcy, lx, lz, wait);
@@ -959,6 +970,7 @@ bool Solver::sync() {
 }
 
 bool Solver::runSteps(int nsteps, bool withPulse, float lx, float lz) {
+    if (opt_.edgeTiles) return fail("stencil-only stepping is not available with edge tiles (batched kernel only)");
     if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
     if (!applyGeometry()) return false;
     int lcx, lcy;

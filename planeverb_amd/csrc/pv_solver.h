@@ -31,7 +31,8 @@ struct SolverOptions {
     int streamRows = 0;   // M > 0: all-air chunks of M stacked tiles run in the row-streaming kernel
     bool streaming = false;  // sparse-emitter mode: ring history + incremental forward analysis
     bool packed = true;   // packed-f32 arithmetic in the air-tile kernel (VALU-issue bound otherwise)
-    bool edgeTiles = true;  // grid-edge tiles of empty regions on the air path + overrides (else general path)
+    bool edgeTiles = false;  // grid-edge tiles of empty regions on the air path + overrides (tile class 2): only the
+                             // batched kernel has that arm, so every run of such a solver goes through it
     int smallGrid = 0;    // 0 = auto: grids that fit one CU's LDS run in the whole-grid-resident kernel; 2 = never
     int timeKernels = 0;  // N > 0: HIP events around every Nth step-kernel launch (bench / roofline)
 };

@@ -787,11 +787,19 @@ def test_batched_runs_match_sequential_runs(pvlib):
 
     scenes = ["HugeRoom.pv", "Shoebox.pv", None, "BigRoom.pv"]
     Ls = [(12.0, 0.0, 6.0), (5.0, 0.0, 4.0), (90.0, 0.0, 100.0), (5.0, 0.0, 4.0)]
-    for opts in (dict(), dict(steps_per_launch=12, tile_rows=36), dict(steps_per_launch=10, tile_rows=36)):
+    # (edge_tiles: the batch's solvers send their grid-border tiles down the air path, the single ones do not)
+    for opts, edge in ((dict(), 0), (dict(steps_per_launch=12, tile_rows=36), 0),
+                       (dict(steps_per_launch=10, tile_rows=36), 1), (dict(steps_per_launch=8, tile_rows=40), 1),
+                       (pvlib.batch_solver_options(512), 0)):
         batch, single = [], []
         for sc in scenes:
             for lst in (batch, single):
-                sv = pvlib.Solver(size, size, 275, **opts)
+                o = dict(opts)
+                if lst is batch and edge:
+                    o["edge_tiles"] = 1
+                elif lst is single:
+                    o.pop("edge_tiles", None)
+                sv = pvlib.Solver(size, size, 275, **o)
                 if sc:
                     sv.load_scene(os.path.join(SCENES, sc))
                 lst.append(sv)
@@ -843,21 +851,20 @@ def test_open_field_analysis_window_vs_dense(pvlib, n, cell):
 
 
 # ----------------------------------------------------------------------------------------------------------------
-# edge tiles (tile class 2): grid-edge tiles of empty regions on the air path + edge overrides.  The arm is compiled
-# only with -DPV_EDGE_TILES=1 (it slows the air arm of the same kernel); in the shipped build the option
-# is accepted and changes nothing, so these tests then compare the general path with itself and the golden vectors.
+# edge tiles (tile class 2): grid-edge tiles of empty regions on the air path + edge overrides.  The arm lives in the
+# batched kernel only (it slows the air arm of a kernel that contains it); a solver created with
+# edge_tiles=1 runs everything through that kernel (a batch of one), which is what these tests exercise.
 # ----------------------------------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("opts", [dict(steps_per_launch=12, tile_rows=36), dict(steps_per_launch=10, tile_rows=36),
-                                  dict(steps_per_launch=8, tile_rows=40),
-                                  dict(steps_per_launch=12, tile_rows=36, merged_launch=0)])
+                                  dict(steps_per_launch=8, tile_rows=40)])
 @pytest.mark.parametrize("name", ["g71_empty", "g71_direction"])
 def test_edge_tiles_golden(pvlib, name, opts):
     """71^2 scenes whose border tiles are edge tiles (x = 0, y = 0, y = gy; the ghost row stays general) against the
     reference's vectors: recorded planes incl. the ghost column, IRs, all eight outputs"""
     g = golden(name)
     gx, gy, T, fs = (int(v) for v in g["dims"])
-    with pvlib.Solver(float(g["size"]), float(g["size"]), int(g["res"]), **opts) as s:
+    with pvlib.Solver(float(g["size"]), float(g["size"]), int(g["res"]), edge_tiles=1, **opts) as s:
         for b in g["boxes"]:
             s.add_geometry(b)
         s.run(g["listener"])
