@@ -24,7 +24,9 @@ CONFIGS = [dict(), dict(), dict(steps_per_launch=12, tile_rows=36), dict(steps_p
            dict(steps_per_launch=8, tile_rows=40), dict(small_grid_kernel=2), dict(small_grid_kernel=2, use_graph=2),
            dict(steps_per_launch=12, tile_rows=36, merged_launch=0), dict(steps_per_launch=1, tile_rows=30),
            dict(streaming_analysis=1), dict(streaming_analysis=1, steps_per_launch=12, tile_rows=36),
-           dict(streaming_analysis=1, steps_per_launch=4, tile_rows=32)]
+           dict(streaming_analysis=1, steps_per_launch=4, tile_rows=32),
+           dict(steps_per_launch=8, tile_rows=40, edge_tiles=1), dict(steps_per_launch=10, tile_rows=36, edge_tiles=1),
+           dict(steps_per_launch=12, tile_rows=36, edge_tiles=1)]
 
 
 def one(seed):
