@@ -115,7 +115,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1,
                     help="runs per batched launch (PvAmdRunBatch, <= 8): every one of the --inflight groups is a "
                          "batch of this many solvers advanced by ONE launch per K steps; the lever for launch-bound "
-                         "grids (<= 1024^2), no gain at 4096^2")
+                         "grids (<= 1024^2), no gain at 4096^2; 0 = by grid size")
     ap.add_argument("--use-graph", type=int, default=0, help="0 auto (grids of <= 4096 tiles), 1 always, 2 never")
     ap.add_argument("--time-kernels", type=int, default=0,
                     help="N > 0: HIP events around every Nth step-kernel launch instead of around the whole launch loop "
@@ -158,6 +158,8 @@ def main():
         opts["tile_order"] = args.tile_order
     if args.edge_tiles >= 0:
         opts["edge_tiles"] = args.edge_tiles
+    if args.batch == 0:  # auto: batched launches pay for launch-bound grids only
+        args.batch = 8 if args.grid <= 1536 else 1
     NB = max(1, min(args.batch, 8))  # runs per batched launch
     if NB > 1 and not args.steps_per_launch and not args.tile_rows:
         opts.update(api.batch_solver_options(args.grid))  # mirror-pair tile + edge tiles (batched kernel only)

@@ -50,6 +50,12 @@ def default_inflight(gx, gy):
     return 2 if gx * gy > 1536 * 1536 else 4
 
 
+def default_batch(gx, gy):
+    """runs per batched launch for a gx x gy grid: 8 for launch-bound grids (+60 % at 512^2, +25 % at 1024^2 with
+    api.batch_solver_options), 1 (= plain runs in flight) from 2048^2 up"""
+    return 8 if gx * gy <= 1536 * 1536 else 1
+
+
 def run_sharded(make_solver, listeners, emitters_for, dist=None, device=None, inflight=2, batch=1, run_batch=None):
     """Simulate `listeners` (list of (x, y, z)) sharded over the ranks and gather all per-emitter outputs.
     make_solver() -> planeverb_amd.api.Solver bound to this rank's GPU; emitters_for(k) -> list of emitter positions

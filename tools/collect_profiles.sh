@@ -25,7 +25,7 @@ python bench.py --grid 8192 --steps 4 --no-cpu-baseline > $O/bench_8192.json 2>>
 python bench.py --grid 8192 --steps 4 --open-field --no-cpu-baseline > $O/bench_8192_open.json 2>> $O/bench.err
 python bench.py --grid 2048 --scene BigRoom.pv --no-cpu-baseline > $O/bench_2048.json 2>> $O/bench.err
 python bench.py --grid 512 --scene Shoebox.pv --inflight 4 --no-cpu-baseline > $O/bench_512.json 2>> $O/bench.err
-python bench.py --grid 512 --scene Shoebox.pv --inflight 2 --batch 8 --no-cpu-baseline > $O/bench_512_batch8.json 2>> $O/bench.err
+python bench.py --grid 512 --scene Shoebox.pv --inflight 2 --batch 0 --no-cpu-baseline > $O/bench_512_batch8.json 2>> $O/bench.err
 python bench.py --grid 1024 --scene Shoebox.pv --inflight 2 --batch 8 --no-cpu-baseline > $O/bench_1024_batch8.json 2>> $O/bench.err
 python bench.py --dense-history 1 --no-cpu-baseline > $O/bench_dense.json 2>> $O/bench.err
 python bench.py --inflight 1 --no-cpu-baseline > $O/bench_inflight1.json 2>> $O/bench.err

@@ -18,7 +18,7 @@ for n in sizes:
         for g in range(G):
             grp = []
             for b in range(B):
-                s = pv.Solver(size, size, 275)
+                s = pv.Solver(size, size, 275, **(pv.batch_solver_options(n) if B > 1 and n <= 2048 else {}))
                 if scene != "none":
                     s.load_scene(os.path.join(ROOT, "tests", "scenes", scene))
                 grp.append(s)
