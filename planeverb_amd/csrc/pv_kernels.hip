@@ -2453,14 +2453,22 @@ __global__ __launch_bounds__(256) void pv_dir_init_kernel(const AnalyzeArgs a, i
     J[analysisWindowIndex(a, dyn, p)] = hop;
 }
 
+// One launch follows every unfinished walk for kDirHops hops through the CURRENT table: each hop reads either the
+// old or an already-updated entry of the cell it stands on -- both lie further down the same walk -- so a launch
+// multiplies the distance an entry spans by at least kDirHops + 1 whatever the interleaving of the threads, and
+// ceil(log_{kDirHops+1} T) launches resolve every walk (3 at T = 435 instead of the 9 of hop-doubling: the analysis of
+// a run is a chain of dependent launches, and beside another run's stencil each one waits for its turn).
+constexpr int kDirHops = 7;
 __global__ __launch_bounds__(256) void pv_dir_jump_kernel(const AnalyzeArgs a, int* J) {
     const DynParams dyn = *a.dyn;
     int X, Y;
     if (!analysisWindowCell(a, dyn, &X, &Y)) return;
     const int wp = analysisWindowIndex(a, dyn, X * a.gy + Y);
-    const int h = J[wp];
-    if (h < 0) return;                               // final
-    J[wp] = J[analysisWindowIndex(a, dyn, h)];       // either the old or an already-updated entry of h: same walk
+    int h = J[wp];
+    if (h < 0) return;  // final
+#pragma unroll 1
+    for (int i = 0; i < kDirHops && h >= 0; ++i) h = J[analysisWindowIndex(a, dyn, h)];
+    J[wp] = h;
 }
 
 __global__ __launch_bounds__(256) void pv_dir_final_kernel(const AnalyzeArgs a, const int* J) {
@@ -2482,8 +2490,8 @@ static dim3 analysisWindowGrid(const AnalyzeArgs& a) { return dim3((a.winCols + 
 static void launchDirectionJump(const AnalyzeArgs& a, int* J, hipStream_t stream) {
     const dim3 grid = analysisWindowGrid(a), block(256);
     hipLaunchKernelGGL(pv_dir_init_kernel, grid, block, 0, stream, a, J);
-    int rounds = 1;
-    while ((1 << rounds) < a.T + 2) ++rounds;  // chains are shorter than T (delays are distinct integers < T)
+    int rounds = 1;  // chains are shorter than T (delays are distinct integers < T)
+    for (long long span = kDirHops + 1; span < a.T + 2; span *= kDirHops + 1) ++rounds;
     for (int i = 0; i < rounds + 1; ++i) hipLaunchKernelGGL(pv_dir_jump_kernel, grid, block, 0, stream, a, J);
     hipLaunchKernelGGL(pv_dir_final_kernel, grid, block, 0, stream, a, J);
 }
