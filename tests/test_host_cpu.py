@@ -199,3 +199,14 @@ def test_cpp_binding_compiles_against_reference_headers():
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-w", "-D_WIN32", "-D__declspec(x)=",
                            "-D__forceinline=inline", "-include", "cstring", "-include", "limits", "-include", "cmath",
                            "-I", ref, "-I", os.path.join(ROOT, "include"), src])
+
+
+def test_batch_policy_helpers():
+    """pure host logic: which grids are run in batches, and with which tile"""
+    from planeverb_amd import api, dist
+    assert dist.default_batch(512, 512) == 8 and dist.default_batch(1024, 1024) == 8
+    assert dist.default_batch(2048, 2048) == 1 and dist.default_batch(4096, 4096) == 1
+    assert dist.default_inflight(4096, 4096) == 2 and dist.default_inflight(512, 512) == 4
+    for n, (k, rows) in ((256, (8, 40)), (512, (8, 40)), (1024, (10, 36)), (2048, (12, 36))):
+        o = api.batch_solver_options(n)
+        assert (o["steps_per_launch"], o["tile_rows"], o["edge_tiles"]) == (k, rows, 1)
