@@ -2456,9 +2456,9 @@ __global__ __launch_bounds__(256) void pv_dir_init_kernel(const AnalyzeArgs a, i
 // One launch follows every unfinished walk for kDirHops hops through the CURRENT table: each hop reads either the
 // old or an already-updated entry of the cell it stands on -- both lie further down the same walk -- so a launch
 // multiplies the distance an entry spans by at least kDirHops + 1 whatever the interleaving of the threads, and
-// ceil(log_{kDirHops+1} T) launches resolve every walk (3 at T = 435 instead of the 9 of hop-doubling: the analysis of
+// ceil(log_{kDirHops+1} T) launches resolve every walk (2 at T = 435 instead of the 9 of hop-doubling: the analysis of
 // a run is a chain of dependent launches, and beside another run's stencil each one waits for its turn).
-constexpr int kDirHops = 7;
+constexpr int kDirHops = 20;
 __global__ __launch_bounds__(256) void pv_dir_jump_kernel(const AnalyzeArgs a, int* J) {
     const DynParams dyn = *a.dyn;
     int X, Y;
