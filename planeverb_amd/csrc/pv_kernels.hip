@@ -2003,7 +2003,7 @@ __device__ __forceinline__ void rt60Chunk(const float (&pc)[CH], const int i0, c
 // RT60: backward Schroeder integration + linear regression (Analyzer.cpp:282-327), two forms with the same bits
 // ---------------------------------------------------------------------------------------------------------------
 // Windows whose ever-non-zero tiles hold fewer cells than this (closed rooms: a few thousand reachable cells; the
-// count is pv_count_active_kernel's) take the wave form; an open field's 760 000 take the cell form
+// count is made by block 0 of pv_far_cells_kernel) take the wave form; an open field's 760 000 take the cell form
 constexpr int kRt60WaveMaxCells = 65536;
 
 struct Rt60Cell {
@@ -2354,7 +2354,28 @@ __device__ __forceinline__ void storeDirection(const AnalyzeArgs& a, int index, 
 // every cell of the map: no onset (Analyzer.cpp:64-68), listener direction = towards the cell itself (a walk that
 // finds no neighbour with a smaller delay stays where it is, Analyzer.cpp:365-391).  The window's cells are
 // overwritten by the kernels that follow.
+// Upper bound of the cells the pulse reached: the cells of the window's tiles that were ever non-zero.  Computed by
+// block 0 of pv_far_cells_kernel (the first launch of the analysis); its result chooses, on the device, between the
+// cell form (inside pv_encode_kernel) and the wave form of the wet gain / decay time.
+__device__ __forceinline__ void countActiveCells(const AnalyzeArgs& a) {
+    __shared__ int part[256];
+    const DynParams dyn = *a.dyn;
+    int n = 0;
+    for (int i = threadIdx.x; i < dyn.histTilesX * dyn.histTilesY; i += 256) {
+        const int ti = dyn.histTileX0 + i / dyn.histTilesY, tj = dyn.histTileY0 + i % dyn.histTilesY;
+        if (a.tileFirst[ti * a.nty + tj] < a.T) n += a.rxi * a.wi;
+    }
+    part[threadIdx.x] = n;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *a.activeCount = part[0];
+}
+
 __global__ __launch_bounds__(256) void pv_far_cells_kernel(const AnalyzeArgs a) {
+    if (blockIdx.x == 0) countActiveCells(a);  // (before any thread leaves: the reduction has barriers)
     const int index = blockIdx.x * blockDim.x + threadIdx.x;
     if (index >= a.gx * a.gy) return;
     a.delay[index] = FLT_MAX;
@@ -2541,29 +2562,8 @@ void launchPackResults(const float* res, long long n, float* res8, hipStream_t s
     hipLaunchKernelGGL(pv_pack_results_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, res, n, res8);
 }
 
-// Upper bound of the cells the pulse reached: the cells of the window's tiles that were ever non-zero.  One block;
-// its result chooses, on the device, between the cell form (inside pv_encode_kernel) and the wave form of the wet
-// gain / decay time.
-__global__ __launch_bounds__(256) void pv_count_active_kernel(const AnalyzeArgs a) {
-    __shared__ int part[256];
-    const DynParams dyn = *a.dyn;
-    int n = 0;
-    for (int i = threadIdx.x; i < dyn.histTilesX * dyn.histTilesY; i += 256) {
-        const int ti = dyn.histTileX0 + i / dyn.histTilesY, tj = dyn.histTileY0 + i % dyn.histTilesY;
-        if (a.tileFirst[ti * a.nty + tj] < a.T) n += a.rxi * a.wi;
-    }
-    part[threadIdx.x] = n;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *a.activeCount = part[0];
-}
-
 void launchAnalysis(const AnalyzeArgs& a, hipStream_t stream) {
     const int n = a.gx * a.gy;
-    hipLaunchKernelGGL(pv_count_active_kernel, dim3(1), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(pv_far_cells_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a);
     const dim3 grid = analysisWindowGrid(a);
     hipLaunchKernelGGL(pv_encode_kernel, grid, dim3(256), 0, stream, a);
