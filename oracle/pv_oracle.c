@@ -268,7 +268,7 @@ float pvo_free_energy(float sizeX, float sizeY, int res) {
 
 /* Analyzer.cpp:139-328 */
 static void encode_response(const PvoGrid* g, float efree, int serialIndex, int X, int Y, float lx, float lz,
-                            float* res8, float* delay, unsigned char* valid) {
+                            float* res8, float* delay, unsigned char* valid, int offX, int offY) {
     const int numSamples = g->T;
     const size_t N = (size_t)g->ncell;
     const size_t cube = (size_t)X * (unsigned)(g->gridSizeXf + 1) + (size_t)Y; /* FDTD.cpp:76-77 */
@@ -317,7 +317,7 @@ static void encode_response(const PvoGrid* g, float efree, int serialIndex, int 
         }
         const int listenerX = (int)(lx * (1.f / g->dx));
         const int listenerY = (int)(lz * (1.f / g->dx));
-        float EfreePr = pvo_efree_per_r(efree, g->dx, listenerX, listenerY, X, Y);
+        float EfreePr = pvo_efree_per_r(efree, g->dx, listenerX, listenerY, X + offX, Y + offY);
         float E = (Edry / EfreePr);
         obstructionGain = sqrtf(E);
         float norm = sqrtf(radx * radx + rady * rady);
@@ -388,7 +388,7 @@ static const int NB[8][2] = {{-1, -1}, {-1, 0}, {-1, 1}, {0, -1}, {0, 1}, {1, -1
 
 /* Analyzer.cpp:340-431 */
 static void encode_listener_direction(const PvoGrid* g, int index, float lx, float lz, const float* res8,
-                                      const float* delayMap, float* outx, float* outy) {
+                                      const float* delayMap, float* outx, float* outy, int offX, int offY) {
     const unsigned dimx = (unsigned)g->gx, dimy = (unsigned)g->gy;
     float loudness = res8[8 * (size_t)index + 0];
     int nextIndex = index;
@@ -421,14 +421,14 @@ static void encode_listener_direction(const PvoGrid* g, int index, float lx, flo
         loudness = nextLoudness;
         float geodesicDist = PV_C * nextDelay / samplingRate;
         int r2 = (int)((unsigned)nextIndex / dimx), c2 = (int)((unsigned)nextIndex % dimx);
-        float ex = (float)r2 * g->dx, ey = (float)c2 * g->dx;
+        float ex = (float)(r2 + offX) * g->dx, ey = (float)(c2 + offY) * g->dx;
         float tx = ex - lx, ty = ey - lz;
         float euclideanDist = sqrtf((tx * tx) + (ty * ty));
         float distCheck = fabsf(geodesicDist - euclideanDist);
         if (distCheck < thresholdDist) break;
     }
     int r = (int)((unsigned)nextIndex / dimx), c = (int)((unsigned)nextIndex % dimx);
-    float ex = (float)r * g->dx, ey = (float)c * g->dx;
+    float ex = (float)(r + offX) * g->dx, ey = (float)(c + offY) * g->dx;
     float ox = ex - lx, oy = ey - lz;
     float length = (ox * ox) + (oy * oy);
     if (length != 0.f) {
@@ -440,22 +440,33 @@ static void encode_listener_direction(const PvoGrid* g, int index, float lx, flo
     *outy = oy;
 }
 
-/* Analyzer.cpp:48-104 */
-void pvo_analyze(const PvoGrid* g, float efree, float lx, float lz, float* res8, float* delay,
-                 unsigned char* valid) {
+/* Analyzer.cpp:48-104.
+ * (offX, offY) = 0 is the reference.  A non-zero offset treats this grid as the window [offX, offX+gx] x
+ * [offY, offY+gy] of a LARGER grid whose listener sits at (lx, lz) metres of the large grid: the impulse responses
+ * are this grid's (an open field is translation-invariant), every piece of POSITION arithmetic -- the listener cell
+ * and the cell coordinates in GetEFreePerR (FreeGrid.cpp:41-59), cellPos in EncodeListenerDirection
+ * (Analyzer.cpp:395-398,415-417) -- uses the large grid's coordinates.  The 8-neighbour bounds test stays this
+ * window's, so only cells whose walks stay inside the window are meaningful.  Used for BASELINE config 5 (8192^2). */
+void pvo_analyze_at(const PvoGrid* g, float efree, float lx, float lz, int offX, int offY, float* res8, float* delay,
+                    unsigned char* valid) {
     const int gridSize = g->gx * g->gy;
     const unsigned dimx = (unsigned)g->gx;
     for (int i = 0; i < gridSize; ++i) delay[i] = FLT_MAX;
     for (int s = 0; s < gridSize; ++s) {
         int X = (int)((unsigned)s / dimx), Y = (int)((unsigned)s % dimx); /* INDEX_TO_POS, stride gx */
-        encode_response(g, efree, s, X, Y, lx, lz, res8, delay, valid);
+        encode_response(g, efree, s, X, Y, lx, lz, res8, delay, valid, offX, offY);
     }
     for (int s = 0; s < gridSize; ++s) {
         float ox, oy;
-        encode_listener_direction(g, s, lx, lz, res8, delay, &ox, &oy);
+        encode_listener_direction(g, s, lx, lz, res8, delay, &ox, &oy, offX, offY);
         res8[8 * (size_t)s + 4] = ox;
         res8[8 * (size_t)s + 5] = oy;
     }
+}
+
+void pvo_analyze(const PvoGrid* g, float efree, float lx, float lz, float* res8, float* delay,
+                 unsigned char* valid) {
+    pvo_analyze_at(g, efree, lx, lz, 0, 0, res8, delay, valid);
 }
 
 /* Analyzer.cpp:106-116 (keeps the reference's '>' test: SURVEY quirk Q6) */

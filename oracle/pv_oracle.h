@@ -64,6 +64,10 @@ float pvo_efree_per_r(float efree, float dx, int lX, int lY, int eX, int eY);
  * valid: gx*gy (1 where the reference reads no memory past the IR: SURVEY Q5; may be NULL). */
 void pvo_analyze(const PvoGrid* g, float efree, float lx, float lz, float* res8, float* delay,
                  unsigned char* valid);
+/* The same with this grid taken as the window at cell offset (offX, offY) of a larger open grid (see pv_oracle.c);
+ * pvo_analyze == pvo_analyze_at(..., 0, 0, ...), which is the form pinned against the compiled reference. */
+void pvo_analyze_at(const PvoGrid* g, float efree, float lx, float lz, int offX, int offY, float* res8, float* delay,
+                    unsigned char* valid);
 
 /* Analyzer.cpp:106-116 : returns result-map index or -1 */
 int pvo_result_index(const PvoGrid* g, float ex, float ez);

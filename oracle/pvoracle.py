@@ -54,6 +54,8 @@ def lib():
         L.pvo_efree_per_r.restype = C.c_float
         L.pvo_efree_per_r.argtypes = [C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]
         L.pvo_analyze.argtypes = [gp, C.c_float, C.c_float, C.c_float, fp, fp, C.POINTER(C.c_ubyte)]
+        L.pvo_analyze_at.argtypes = [gp, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, fp, fp,
+                                     C.POINTER(C.c_ubyte)]
         L.pvo_result_index.restype = C.c_int
         L.pvo_result_index.argtypes = [gp, C.c_float, C.c_float]
         L.pvo_find_gains.argtypes = [C.c_float, C.c_float, fp, fp, fp]
@@ -145,13 +147,15 @@ class OracleGrid:
         n = self.T * self.ncell
         return tuple(np.ctypeslib.as_array(p, (n,)).reshape(shp) for p in (g.hist_pr, g.hist_vx, g.hist_vy))
 
-    def analyze(self, efree, listener):
+    def analyze(self, efree, listener, offset=(0, 0)):
+        """offset != (0, 0): this grid is the window at that cell offset of a larger open grid and `listener` is in
+        the larger grid's metres (pvo_analyze_at)"""
         n = self.gx * self.gy
         res = np.zeros((n, 8), np.float32)
         delay = np.empty(n, np.float32)
         valid = np.zeros(n, np.uint8)
-        lib().pvo_analyze(self._g, efree, float(listener[0]), float(listener[2]), _fp(res), _fp(delay),
-                          valid.ctypes.data_as(C.POINTER(C.c_ubyte)))
+        lib().pvo_analyze_at(self._g, efree, float(listener[0]), float(listener[2]), int(offset[0]), int(offset[1]),
+                             _fp(res), _fp(delay), valid.ctypes.data_as(C.POINTER(C.c_ubyte)))
         return (res.reshape(self.gx, self.gy, 8), delay.reshape(self.gx, self.gy),
                 valid.reshape(self.gx, self.gy).astype(bool))
 

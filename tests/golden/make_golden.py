@@ -8,6 +8,8 @@ IR traces, result / delay maps).  No reference source text is stored.
     python tests/golden/make_golden.py small      # 25 m @ 275 Hz scenes (seconds)
     python tests/golden/make_golden.py modeA512   # Shoebox, 512^2 at 275 Hz   (~1 min, 4 GB)
     python tests/golden/make_golden.py modeB512   # Shoebox, 25 m at res 2009  (~3 min, 27 GB)
+    python tests/golden/make_golden.py cfg4       # HugeRoom, the 8 listeners of BASELINE config 4 (seconds)
+    python tests/golden/make_golden.py open_offset  # open 640^2 field, listener off-centre (~1 min, 3 GB)
 """
 import os
 import sys
@@ -76,8 +78,72 @@ def run(name, scene, size, res, listener, emitters, snap_ts, nprobe, full_map, s
     print(name, "->", path, "%.1f kB" % (os.path.getsize(path) / 1e3), "fdtd %.2fs analysis %.2fs" % (t_f, t_a))
 
 
+# 8 listener positions (x, z metres) inside HugeRoom.pv's 25 m room; emitter A = listener +
+# (0, 2) m, emitter B = (5, 0, 6).  The room is closed, so the 71^2 (25 m) run equals the 4096^2 Mode A run bit for bit
+# for every cell of the room (closed-room isolation) -- this file is what bench.py and the -m gpu tests compare with.
+CFG4_LISTENERS = [(5, 4), (8, 8), (12, 6), (15, 15), (20, 5), (5, 20), (20, 20), (12.5, 18)]
+
+
+def run_cfg4():
+    boxes = pvref.load_pv(os.path.join(REF, "HugeRoom.pv"))
+    r = pvref.RefSolver(25.0, 25.0, 275, boxes)
+    listeners, emitters, outs, maps, delays = [], [], [], [], []
+    for x, z in CFG4_LISTENERS:
+        L = (float(x), 0.0, float(z))
+        E = [(float(x), 0.0, float(z) + 2.0), (5.0, 0.0, 6.0)]
+        # a fresh Analyzer pool per listener is what a fresh context gives; the harness re-zeroes it
+        r.close()
+        r = pvref.RefSolver(25.0, 25.0, 275, boxes)
+        r.generate(L)
+        r.analyze(L)
+        res8, delay = r.results()
+        listeners.append(L)
+        emitters.append(E)
+        outs.append(np.stack([r.output(e) for e in E]))
+        maps.append(res8)
+        delays.append(delay)
+    b, R = r.material()
+    d = dict(boxes=boxes, size=np.float32(25.0), res=np.int32(275), dims=np.array([r.gx, r.gy, r.T, r.fs], np.int32),
+             efree=np.float32(r.efree), listeners=np.array(listeners, np.float32),
+             emitters=np.array(emitters, np.float32), emitter_out=np.stack(outs), results=np.stack(maps),
+             delay=np.stack(delays), beta=b.astype(np.uint8))
+    r.close()
+    path = os.path.join(OUT, "g71_hugeroom_cfg4.npz")
+    np.savez_compressed(path, **d)
+    print("cfg4 ->", path, "%.1f kB" % (os.path.getsize(path) / 1e3))
+
+
+def run_open_offset():
+    """Open field, listener off-centre in a 640^2 grid: the result / delay maps of the 141 x 141 cells around the
+    listener, which no grid edge can have influenced within T steps.  Pins oracle.pvo_analyze_at (the oracle run on a
+    513^2 window with a cell offset, used for BASELINE config 5 at 8192^2) against the compiled reference."""
+    n, lc, R = 640, (352, 300), 70
+    r = pvref.RefSolver(1, 1, 275, None, False)
+    dx = np.float32(r.dx)
+    r.close()
+    size = float((n + 0.5) * dx)
+    L = ((lc[0] + 0.5) * float(dx), 0.0, (lc[1] + 0.5) * float(dx))
+    r = pvref.RefSolver(size, size, 275, None)
+    assert (r.gx, r.gy) == (n, n)
+    r.generate(L)
+    r.analyze(L)
+    res8, delay = r.results()
+    sl = (slice(lc[0] - R, lc[0] + R + 1), slice(lc[1] - R, lc[1] + R + 1))
+    d = dict(n=np.int32(n), size=np.float32(size), listener=np.array(L, np.float32), listener_cell=np.array(lc, np.int32),
+             R=np.int32(R), efree=np.float32(r.efree), results=res8[sl], delay=delay[sl],
+             dims=np.array([r.gx, r.gy, r.T, r.fs], np.int32))
+    r.close()
+    path = os.path.join(OUT, "g640_open_offset.npz")
+    np.savez_compressed(path, **d)
+    print("open_offset ->", path, "%.1f kB" % (os.path.getsize(path) / 1e3))
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "small"
+    if what == "cfg4":
+        return run_cfg4()
+    if what == "open_offset":
+        return run_open_offset()
     if what == "small":
         for name, scene in SMALL.items():
             run("g71_" + name, scene, 25.0, 275, (5, 0, 4), [(5, 0, 6), (12, 0, 9), (20.5, 0, 3.2)],

@@ -94,3 +94,52 @@ def test_pv_scene_files_parse():
     for f in sorted(os.listdir(SCENES)):
         boxes = pvref.load_pv(os.path.join(SCENES, f))
         assert boxes.shape[1] == 5 and len(boxes) >= 1
+
+
+class OpenFieldWindowOracle:
+    """Oracle for an open field too large to simulate (BASELINE config 5, 8192^2): a 513^2 window with the listener at
+    its centre cell c = 256 (the open field is translation-invariant, so ONE FDTD run serves every listener cell),
+    analysed with the LARGE grid's position arithmetic (pvo_analyze_at).  Valid for the (2R+1)^2 cells around the
+    listener that no window edge can have influenced within T steps (256 + (256 - R) > 434)."""
+
+    def __init__(self, oracle, n_small=512):
+        self.dx = np.float32(343.21) / np.float32(275) / np.float32(3.5)
+        size_small = float((n_small + 0.5) * self.dx)
+        self.c, self.R = n_small // 2, 70
+        Ls = ((self.c + 0.5) * float(self.dx), 0.0, (self.c + 0.5) * float(self.dx))
+        self.o = oracle.OracleGrid(size_small, size_small, 275, None)
+        assert self.o.listener_cell(np.float32(Ls[0]), np.float32(Ls[2])) == (self.c, self.c)
+        self.o.fdtd(Ls)
+        self.hist_pr = self.o.history()[0]
+
+    def listener_metres(self, cell):
+        return ((cell[0] + 0.5) * float(self.dx), 0.0, (cell[1] + 0.5) * float(self.dx))
+
+    def analyze(self, listener_cell, efree=np.float32(0.0447895788)):
+        """(res8, delay) of the window for a listener at `listener_cell` of the large grid"""
+        res, delay, _ = self.o.analyze(efree, self.listener_metres(listener_cell),
+                                       offset=(listener_cell[0] - self.c, listener_cell[1] - self.c))
+        return res, delay
+
+    def close(self):
+        self.o.close()
+
+
+def test_window_oracle_with_offset_reproduces_reference(oracle):
+    """pvo_analyze_at pinned: the reference itself on an open 640^2 grid with the listener off-centre at (352, 300)
+    against the oracle's 513^2 window + cell offset, on all 141 x 141 cells both can vouch for, all 8 result members"""
+    g = golden("g640_open_offset")
+    lc = tuple(int(v) for v in g["listener_cell"])
+    w = OpenFieldWindowOracle(oracle)
+    res, delay = w.analyze(lc, g["efree"])
+    c, R = w.c, w.R
+    w.close()
+    assert R == int(g["R"])
+    sl = (slice(c - R, c + R + 1), slice(c - R, c + R + 1))
+    assert same_bits(delay[sl], g["delay"]).all()
+    T, fs = int(g["dims"][2]), int(g["dims"][3])
+    valid = valid_mask(g["delay"], T, fs)
+    assert valid.sum() > 15000
+    for k in range(8):
+        m = valid if k not in (4, 5) else np.ones_like(valid)
+        assert same_bits(res[sl][..., k][m], g["results"][..., k][m]).all(), k
