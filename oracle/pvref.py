@@ -13,8 +13,32 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_ref", "libpvref.so")
 
 
+DSP_LIB_PATH = os.path.join(_HERE, "_ref", "libpvrefdsp.so")
+
+
 def available():
     return os.path.exists(LIB_PATH)
+
+
+def dsp_available():
+    return os.path.exists(DSP_LIB_PATH)
+
+
+_dsp = None
+
+
+def find_gains(rt60, wet):
+    """(A, B, C) from the reference's own compiled FindGainA/B/C (PlaneverbDSP/src/PvDSPContext.cpp:165-228,
+    oracle/ref_dsp_harness.cpp)"""
+    global _dsp
+    if _dsp is None:
+        L = C.CDLL(DSP_LIB_PATH)
+        for f in "abc":
+            fn = getattr(L, "pvrefdsp_find_gain_" + f)
+            fn.restype = C.c_float
+            fn.argtypes = [C.c_float, C.c_float]
+        _dsp = L
+    return tuple(getattr(_dsp, "pvrefdsp_find_gain_" + f)(float(rt60), float(wet)) for f in "abc")
 
 
 def load_pv(path):

@@ -10,6 +10,7 @@ IR traces, result / delay maps).  No reference source text is stored.
     python tests/golden/make_golden.py modeB512   # Shoebox, 25 m at res 2009  (~3 min, 27 GB)
     python tests/golden/make_golden.py cfg4       # HugeRoom, the 8 listeners of BASELINE config 4 (seconds)
     python tests/golden/make_golden.py open_offset  # open 640^2 field, listener off-centre (~1 min, 3 GB)
+    python tests/golden/make_golden.py findgain   # FindGainA/B/C table from PlaneverbDSP's compiled context file
 """
 import os
 import sys
@@ -107,6 +108,8 @@ def run_cfg4():
              efree=np.float32(r.efree), listeners=np.array(listeners, np.float32),
              emitters=np.array(emitters, np.float32), emitter_out=np.stack(outs), results=np.stack(maps),
              delay=np.stack(delays), beta=b.astype(np.uint8))
+    # the "RT60 bucket" of every record: the reference's compiled FindGainA/B/C on (rt60, wetGain) (row 24)
+    d["bus_gains"] = np.array([[pvref.find_gains(o[2], o[1]) for o in rec] for rec in d["emitter_out"]], np.float32)
     r.close()
     path = os.path.join(OUT, "g71_hugeroom_cfg4.npz")
     np.savez_compressed(path, **d)
@@ -138,8 +141,30 @@ def run_open_offset():
     print("open_offset ->", path, "%.1f kB" % (os.path.getsize(path) / 1e3))
 
 
+def findgain_inputs():
+    """(rt60, wet) sweep for SURVEY.md 8a row 24: dense in rt60 incl. the 0.5 / 1.0 / 3.0 s bucket edges and their
+    float neighbours, the analysis' degenerate values (0, negative, inf, NaN), a few wet gains"""
+    f32 = np.float32
+    rt = list(np.linspace(0.05, 4.0, 791, dtype=np.float32))
+    for e in (0.5, 1.0, 3.0):
+        rt += [np.nextafter(f32(e), f32(0)), f32(e), np.nextafter(f32(e), f32(10))]
+    rt += [f32(0), f32(-1.5), f32(np.inf), f32(-np.inf), f32(np.nan), f32(1e-30), f32(1e30)]
+    wet = [f32(0), f32(0.0924116895), f32(0.5), f32(0.700975895), f32(1.73174453), f32(25.0)]
+    return np.array([(r, w) for r in rt for w in wet], np.float32)
+
+
+def run_findgain():
+    x = findgain_inputs()
+    y = np.array([pvref.find_gains(r, w) for r, w in x], np.float32)
+    path = os.path.join(OUT, "g_findgain.npz")
+    np.savez_compressed(path, inputs=x, gains=y)
+    print("findgain ->", path, len(x), "pairs, %.1f kB" % (os.path.getsize(path) / 1e3))
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "small"
+    if what == "findgain":
+        return run_findgain()
     if what == "cfg4":
         return run_cfg4()
     if what == "open_offset":

@@ -42,6 +42,9 @@ def test_config4_hugeroom_4096_all_listeners(pvlib):
                 assert same_bits(q[j], g["emitter_out"][i, j]).all(), "listener %d emitter %d: %r vs %r" % (
                     i, j, q[j], g["emitter_out"][i, j])
                 compare_output(s.get_output(g["emitters"][i, j]), g["emitter_out"][i, j], "listener %d" % i)
+                # row 24: the reverb-bus split ("RT60 bucket") of the GPU's record vs the reference's compiled FindGain*
+                bus = np.array(pvlib.reverb_bus_gains(float(q[j][2]), float(q[j][1])), np.float32)
+                assert same_bits(bus, g["bus_gains"][i, j]).all(), (i, j, bus, g["bus_gains"][i, j])
             res, delay = s.results()
             n = compare_maps(res[:70, :70], delay[:70, :70], g["results"][i], g["delay"][i], 435, 1443,
                              "listener %d, 25 m block" % i)

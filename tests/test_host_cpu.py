@@ -132,6 +132,14 @@ def test_reverb_bus_gains_match_oracle(pvlib, oracle):
                              np.array(oracle.find_gains(rt, w), np.float32)).all()
 
 
+def test_reverb_bus_gains_match_compiled_reference(pvlib):
+    """SURVEY.md 8a row 24 pinned for the PRODUCT: PvAmdReverbBusGains against the table generated from the reference's
+    own compiled FindGainA/B/C (PlaneverbDSP/src/PvDSPContext.cpp:165-228; tests/golden/make_golden.py findgain)"""
+    g = golden("g_findgain")
+    for (rt, w), want in zip(g["inputs"], g["gains"]):
+        assert same_bits(np.array(pvlib.reverb_bus_gains(rt, w), np.float32), want).all(), (rt, w)
+
+
 def test_pv_save_load_round_trip(pvlib, tmp_path):
     """Editor::SaveGeometry / LoadGeometry (Editor.cpp:219-281): what is written is read back unchanged"""
     for f in sorted(os.listdir(SCENES)):

@@ -88,6 +88,13 @@ def test_reverb_bus_split(oracle):
     assert a == 0.0 and c == 1.0
 
 
+def test_find_gains_golden(oracle):
+    """row 24 pinned: the table generated from the reference's compiled FindGainA/B/C (make_golden.py findgain)"""
+    g = golden("g_findgain")
+    for (rt, w), want in zip(g["inputs"], g["gains"]):
+        assert same_bits(np.array(oracle.find_gains(rt, w), np.float32), want).all(), (rt, w)
+
+
 def test_pv_scene_files_parse():
     import os
     from oracle import pvref

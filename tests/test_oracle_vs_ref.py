@@ -70,3 +70,16 @@ def test_free_energy_incl_truncation_quirk(oracle, size, res):
     if (size, res) == (40.0, 275):
         assert np.float32(r.efree) == np.float32(0.028847147)
     r.close()
+
+
+@pytest.mark.skipif(not pvref.dsp_available(), reason="oracle/_ref/libpvrefdsp.so not built")
+def test_find_gains_equal_compiled_reference(oracle):
+    """the oracle's restatement of FindGainA/B/C against the reference's own compiled
+    PvDSPContext.cpp:165-228 (oracle/ref_dsp_harness.cpp), dense sweep incl. the 0.5 / 1.0 / 3.0 s edges"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import findgain_inputs
+    for rt, w in findgain_inputs():
+        want = np.array(pvref.find_gains(rt, w), np.float32)
+        got = np.array(oracle.find_gains(rt, w), np.float32)
+        assert same_bits(got, want).all(), (rt, w, got, want)
