@@ -1,5 +1,6 @@
 // PlaneverbAmdBinding.cpp -- link with -lplaneverb_amd instead of ProjectPlaneverb.lib
 #include <Planeverb.h>
+#include <vector>
 #include "planeverb_amd.h"
 namespace Planeverb {
 void Init(const PlaneverbConfig* c) {
@@ -28,4 +29,17 @@ void UpdateGeometry(PlaneObjectID id, const AABB* t) {
 }
 void RemoveGeometry(PlaneObjectID id) { PlaneverbRemoveGeometry((int)id); }
 void SetListenerPosition(const vec3& p) { PlaneverbSetListenerPosition(p.x, p.y, p.z); }
+// Planeverb.h:47, FDTD.cpp:60-79.  The reference returns a pointer into its IR cube; here the AoS Cells are
+// materialised on demand (the GPU keeps a pressure history and re-derives vx, vy) into a buffer this binding owns:
+// valid until the calling thread's next GetImpulseResponse, like upstream's until the next iteration overwrites it.
+std::pair<const Cell*, unsigned> GetImpulseResponse(const vec3& p) {
+    static_assert(sizeof(Cell) == sizeof(PlaneverbCell), "PvTypes.h:106-121 vs planeverb_amd.h");
+    static thread_local std::vector<Cell> buf;
+    const int T = PlaneverbGetImpulseResponse(p.x, p.y, p.z, nullptr, 0);
+    if (T <= 0) return std::make_pair((const Cell*)nullptr, 0u);
+    buf.resize((size_t)T);
+    if (PlaneverbGetImpulseResponse(p.x, p.y, p.z, reinterpret_cast<PlaneverbCell*>(buf.data()), T) != T)
+        return std::make_pair((const Cell*)nullptr, 0u);
+    return std::make_pair((const Cell*)buf.data(), (unsigned)T);
+}
 }  // namespace Planeverb

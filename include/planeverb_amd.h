@@ -74,14 +74,26 @@ PVA_EXPORT void PlaneverbRemoveGeometry(int id);
 /* PlaneverbUnity.cpp:131-135 */
 PVA_EXPORT void PlaneverbSetListenerPosition(float x, float y, float z);
 
-/* Extensions to the live module (not in the reference ABI) */
+/* Extensions to the live module (not in the reference's flat ABI) */
+/* One sample of an impulse response as the reference stores it (Cell, PvTypes.h:106-121: 16 bytes) */
+typedef struct PlaneverbCell {
+    float pr, vx, vy;
+    short b;  /* beta of the cell during the run (0 = wall / ghost row or column) */
+    short by; /* never read by the solver; carried for layout compatibility (Grid.cpp:93-108,241-242,281-290) */
+} PlaneverbCell;
+/* Planeverb::GetImpulseResponse (Planeverb.h:47, FDTD.cpp:60-79) for the live module: the impulse response of the
+ * last COMPLETED iteration at the cell holding world position (x, z) -- (int)(x/dx), (int)(z/dx) -- as reference
+ * Cells.  Writes min(capacity, T) cells to `out` and returns T (the response length; call with capacity 0 to size the
+ * buffer), 0 for a position outside the cell array, -1 when the module is not initialised / on error.  Waits for the
+ * iteration in flight (the reference reads the cube while the worker rewrites it); a debugging call, like upstream. */
+PVA_EXPORT int PlaneverbGetImpulseResponse(float x, float y, float z, PlaneverbCell* out, int capacity);
 /* Load a .pv scene (PlaneverbSandbox/src/Editor/Editor.cpp:245-281) into the live module; returns #boxes or <0 */
 PVA_EXPORT int PlaneverbLoadScene(const char* pvPath);
 /* Number of completed simulation iterations since Init (an iteration = FDTD + analysis, PvContext.cpp:74-93) */
 PVA_EXPORT long long PlaneverbIterationCount(void);
 /* Block until at least `count` iterations have completed, or timeoutMs elapsed; returns the iteration count */
 PVA_EXPORT long long PlaneverbWaitIterations(long long count, int timeoutMs);
-/* 1 if the module is initialised */
+/* 1 if the module is initialised and its simulation worker is alive (0 after a worker error: PvAmdLastError) */
 PVA_EXPORT int PlaneverbIsRunning(void);
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -194,6 +206,8 @@ PVA_EXPORT int PvAmdGetQueriedOutputs(PvAmdSolver* s, PlaneverbOutput* out, int 
 PVA_EXPORT int PvAmdCopyResults(PvAmdSolver* s, float* res8, float* delay);
 /* Planeverb::GetImpulseResponse (FDTD.cpp:60-70): T x {pr, vx, vy} at array cell (cx, cy) */
 PVA_EXPORT int PvAmdGetImpulseResponse(PvAmdSolver* s, int cx, int cy, float* out3T);
+/* the same as T reference Cells (pr, vx, vy + the cell's b / by), the layout Planeverb::GetImpulseResponse hands out */
+PVA_EXPORT int PvAmdGetImpulseResponseCells(PvAmdSolver* s, int cx, int cy, PlaneverbCell* outT);
 /* Final fields of the last run, (gx+1)*(gy+1) each, reference order (x*(gy+1)+y) */
 PVA_EXPORT int PvAmdCopyFields(PvAmdSolver* s, float* pr, float* vx, float* vy);
 /* Recorded pressure plane of step t (zeros where the history was provably zero and not stored) */

@@ -73,6 +73,7 @@ def lib():
         L.pvref_analyze.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
         L.pvref_results.argtypes = [C.c_void_p, fp, fp]
         L.pvref_ir.argtypes = [C.c_void_p, C.c_int, C.c_int, fp]
+        L.pvref_ir_cells.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.pvref_snapshot.argtypes = [C.c_void_p, C.c_int, fp, fp, fp]
         L.pvref_output.restype = C.c_int
         L.pvref_output.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, fp]
@@ -146,6 +147,12 @@ class RefSolver:
     def ir(self, cx, cy):
         out = np.empty((self.T, 3), np.float32)
         lib().pvref_ir(self._h, int(cx), int(cy), _fp(out))
+        return out
+
+    def ir_cells(self, cx, cy):
+        """raw reference Cells of one IR: uint8 [T, 16] = {f32 pr, vx, vy; i16 b, by} (PvTypes.h:106-121)"""
+        out = np.empty((self.T, 16), np.uint8)
+        lib().pvref_ir_cells(self._h, int(cx), int(cy), out.ctypes.data_as(C.c_void_p))
         return out
 
     def snapshot(self, t):

@@ -163,6 +163,14 @@ void pvref_ir(PvRef* r, int cx, int cy, float* out) {
     }
 }
 
+// the same IR as raw 16-byte reference Cells {pr, vx, vy, short b, short by} (PvTypes.h:106-121): what
+// Planeverb::GetImpulseResponse hands its caller (FDTD.cpp:60-70)
+void pvref_ir_cells(PvRef* r, int cx, int cy, void* out16T) {
+    const Cell* c = r->grid->GetResponse(vec2((float)cx, (float)cy));
+    static_assert(sizeof(Cell) == 16, "reference Cell is 16 bytes");
+    std::memcpy(out16T, c, sizeof(Cell) * r->grid->GetResponseSize());
+}
+
 // recorded fields of step t for every cell of the (gx+1)x(gy+1) cube, reference linear order
 void pvref_snapshot(PvRef* r, int t, float* pr, float* vx, float* vy) {
     int n = ((int)r->grid->m_gridSize.x + 1) * ((int)r->grid->m_gridSize.y + 1);

@@ -51,6 +51,14 @@ class PlaneverbOutput(C.Structure):
                          self.sourceDirectionX, self.sourceDirectionY], np.float32)
 
 
+class PlaneverbCell(C.Structure):
+    """PvTypes.h:106-121"""
+    _fields_ = [("pr", C.c_float), ("vx", C.c_float), ("vy", C.c_float), ("b", C.c_short), ("by", C.c_short)]
+
+
+CELL_DTYPE = np.dtype([("pr", np.float32), ("vx", np.float32), ("vy", np.float32), ("b", np.int16), ("by", np.int16)])
+
+
 class PvAmdInfo(C.Structure):
     _fields_ = [("gx", C.c_int), ("gy", C.c_int), ("T", C.c_int), ("fs", C.c_int), ("res", C.c_int),
                 ("dx", C.c_float), ("dt", C.c_float), ("efree", C.c_float), ("device", C.c_int),
@@ -85,6 +93,7 @@ SYMBOLS = {
     "PlaneverbIterationCount": (C.c_longlong, []),
     "PlaneverbWaitIterations": (C.c_longlong, [C.c_longlong, C.c_int]),
     "PlaneverbIsRunning": (C.c_int, []),
+    "PlaneverbGetImpulseResponse": (C.c_int, [C.c_float] * 3 + [C.POINTER(PlaneverbCell), C.c_int]),
     "PvAmdDeviceCount": (C.c_int, []),
     "PvAmdLastError": (C.c_char_p, []),
     "PvAmdVersion": (C.c_char_p, []),
@@ -109,6 +118,7 @@ SYMBOLS = {
     "PvAmdGetQueriedOutputs": (C.c_int, [_vp, C.POINTER(PlaneverbOutput), C.c_int]),
     "PvAmdCopyResults": (C.c_int, [_vp, _fp, _fp]),
     "PvAmdGetImpulseResponse": (C.c_int, [_vp, C.c_int, C.c_int, _fp]),
+    "PvAmdGetImpulseResponseCells": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(PlaneverbCell)]),
     "PvAmdCopyFields": (C.c_int, [_vp, _fp, _fp, _fp]),
     "PvAmdCopyHistoryPlane": (C.c_int, [_vp, C.c_int, _fp]),
     "PvAmdCopyPulse": (C.c_int, [_vp, _fp]),
@@ -217,6 +227,25 @@ def RemoveGeometry(gid):
 
 def SetListenerPosition(pos):
     lib().PlaneverbSetListenerPosition(*[float(v) for v in pos])
+
+
+def GetImpulseResponse(pos):
+    """Planeverb::GetImpulseResponse (Planeverb.h:47): structured array [T] of (pr, vx, vy, b, by) at a world position,
+    from the last completed iteration; empty for a position outside the cell array"""
+    n = lib().PlaneverbGetImpulseResponse(float(pos[0]), float(pos[1]), float(pos[2]), None, 0)
+    if n < 0:
+        raise PlaneverbError(last_error())
+    out = np.zeros(n, CELL_DTYPE)
+    if n:
+        got = lib().PlaneverbGetImpulseResponse(float(pos[0]), float(pos[1]), float(pos[2]),
+                                                out.ctypes.data_as(C.POINTER(PlaneverbCell)), n)
+        if got != n:
+            raise PlaneverbError(last_error())
+    return out
+
+
+def IsRunning():
+    return bool(lib().PlaneverbIsRunning())
 
 
 def LoadScene(path):
@@ -424,6 +453,12 @@ class Solver:
     def impulse_response(self, cx, cy):
         out = np.empty((self.T, 3), np.float32)
         _check(lib().PvAmdGetImpulseResponse(self._h, int(cx), int(cy), _f(out)))
+        return out
+
+    def impulse_response_cells(self, cx, cy):
+        """structured array [T] of reference Cells (pr, vx, vy, b, by)"""
+        out = np.zeros(self.T, CELL_DTYPE)
+        _check(lib().PvAmdGetImpulseResponseCells(self._h, int(cx), int(cy), out.ctypes.data_as(C.POINTER(PlaneverbCell))))
         return out
 
     def fields(self):

@@ -7,12 +7,15 @@
 #include "../../include/planeverb_amd.h"
 #include "pv_context.h"
 #include "pv_core.h"
+#ifndef PVA_HOST_TEST  // (tests/host/: HIP-less sanitizer build of the live module against a fake Solver)
 #include "pv_solver.h"
+#endif
 
 using namespace pva;
 
 static thread_local std::string g_lastError;
 
+#ifndef PVA_HOST_TEST
 struct PvAmdSolver {
     Solver* s = nullptr;
     SolverOptions opt;
@@ -35,6 +38,7 @@ static int ret(PvAmdSolver* h, bool ok) {
     if (h && h->s && !h->s->lastError().empty()) g_lastError = h->s->lastError();
     return -1;
 }
+#endif  // !PVA_HOST_TEST
 
 extern "C" {
 
@@ -74,22 +78,24 @@ void PlaneverbExit(void) {
 }
 
 int PlaneverbEmit(float x, float y, float z) {
-    Context* c = Context::get();
+    Context::Ref c;
     return c ? c->emit(x, y, z) : -1;
 }
 
 void PlaneverbUpdateEmission(int id, float x, float y, float z) {
-    if (Context* c = Context::get()) c->updateEmission(id, x, y, z);
+    Context::Ref c;
+    if (c) c->updateEmission(id, x, y, z);
 }
 
 void PlaneverbEndEmission(int id) {
-    if (Context* c = Context::get()) c->endEmission(id);
+    Context::Ref c;
+    if (c) c->endEmission(id);
 }
 
 PlaneverbOutput PlaneverbGetOutput(int emissionID) {
     PlaneverbOutput o;
     std::memset(&o, 0, sizeof(o));
-    Context* c = Context::get();
+    Context::Ref c;
     if (!c) {  // FDTD.cpp:22-26
         o.occlusion = kInvalidDryGain;
         return o;
@@ -100,24 +106,27 @@ PlaneverbOutput PlaneverbGetOutput(int emissionID) {
 }
 
 int PlaneverbAddGeometry(float posX, float posY, float width, float height, float absorption) {
-    Context* c = Context::get();
+    Context::Ref c;
     return c ? c->addGeometry(Box{posX, posY, width, height, absorption}) : -1;
 }
 
 void PlaneverbUpdateGeometry(int id, float posX, float posY, float width, float height, float absorption) {
-    if (Context* c = Context::get()) c->updateGeometry(id, Box{posX, posY, width, height, absorption});
+    Context::Ref c;
+    if (c) c->updateGeometry(id, Box{posX, posY, width, height, absorption});
 }
 
 void PlaneverbRemoveGeometry(int id) {
-    if (Context* c = Context::get()) c->removeGeometry(id);
+    Context::Ref c;
+    if (c) c->removeGeometry(id);
 }
 
 void PlaneverbSetListenerPosition(float x, float y, float z) {
-    if (Context* c = Context::get()) c->setListener(x, y, z);
+    Context::Ref c;
+    if (c) c->setListener(x, y, z);
 }
 
 int PlaneverbLoadScene(const char* pvPath) {
-    Context* c = Context::get();
+    Context::Ref c;
     if (!c || !pvPath) return -1;
     std::vector<Box> boxes;
     if (!loadPv(pvPath, &boxes, &g_lastError)) return -1;
@@ -126,29 +135,48 @@ int PlaneverbLoadScene(const char* pvPath) {
 }
 
 long long PlaneverbIterationCount(void) {
-    Context* c = Context::get();
+    Context::Ref c;
     return c ? c->iterations() : 0;
 }
 
 long long PlaneverbWaitIterations(long long count, int timeoutMs) {
-    Context* c = Context::get();
+    Context::Ref c;
     return c ? c->waitIterations(count, timeoutMs) : 0;
 }
 
-int PlaneverbIsRunning(void) { return Context::get() ? 1 : 0; }
+// 0 also when the simulation worker has stopped on an error (PvAmdLastError then says why)
+int PlaneverbIsRunning(void) {
+    Context::Ref c;
+    return (c && !c->failed()) ? 1 : 0;
+}
+
+int PlaneverbGetImpulseResponse(float x, float y, float z, PlaneverbCell* out, int capacity) {
+    Context::Ref c;
+    if (!c || capacity < 0) return -1;
+    const int n = c->impulseResponse(x, y, z, out, capacity);
+    if (n < 0) g_lastError = "impulse response not available (no completed iteration yet, or solver error)";
+    return n;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Part 2: batch solver handle
 // ---------------------------------------------------------------------------------------------------------------
 
+const char* PvAmdLastError(void) {
+    {  // a live module whose worker died reports that before anything else
+        Context::Ref c;
+        if (c && c->failed()) g_lastError = "simulation worker stopped: " + c->workerError();
+    }
+    return g_lastError.c_str();
+}
+const char* PvAmdVersion(void) { return "planeverb_amd 0.2 (gfx950)"; }
+
+#ifndef PVA_HOST_TEST
 int PvAmdDeviceCount(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
-
-const char* PvAmdLastError(void) { return g_lastError.c_str(); }
-const char* PvAmdVersion(void) { return "planeverb_amd 0.1 (gfx950)"; }
 
 PvAmdSolver* PvAmdCreate(float gridSizeX, float gridSizeY, int gridResolution, int device) {
     if (gridResolution < kLowResolution || gridSizeX == 0.f || gridSizeY == 0.f) {
@@ -359,6 +387,12 @@ int PvAmdGetImpulseResponse(PvAmdSolver* h, int cx, int cy, float* out3T) {
     return ret(h, h->s->impulseResponse(cx, cy, out3T));
 }
 
+int PvAmdGetImpulseResponseCells(PvAmdSolver* h, int cx, int cy, PlaneverbCell* outT) {
+    if (!outT || !ensure(h)) return -1;
+    static_assert(sizeof(PlaneverbCell) == 16, "PvTypes.h:106-121");
+    return ret(h, h->s->impulseResponseCells(cx, cy, outT));
+}
+
 int PvAmdCopyFields(PvAmdSolver* h, float* pr, float* vx, float* vy) {
     if (!ensure(h)) return -1;
     return ret(h, h->s->copyFields(pr, vx, vy));
@@ -388,6 +422,8 @@ int PvAmdRunSteps(PvAmdSolver* h, int nsteps, int withPulse, float lx, float lz)
     if (!ensure(h)) return -1;
     return ret(h, h->s->runSteps(nsteps, withPulse != 0, lx, lz));
 }
+
+#endif  // !PVA_HOST_TEST
 
 int PvAmdHostGridInfo(float sx, float sy, int res, PvAmdInfo* out) {
     if (!out || res < kLowResolution) return -1;

@@ -1,23 +1,52 @@
 // pv_context.cpp -- see pv_context.h
 #include "pv_context.h"
 
+#include <algorithm>
 #include <chrono>
+#include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
 namespace pva {
 
-static Context* g_context = nullptr;
-static std::mutex g_contextMutex;
+// ----------------------------------------------------------------------------------------------------------------
+// lifetime: one published pointer, pinned by every API call for its duration
+// ----------------------------------------------------------------------------------------------------------------
 
-Context* Context::get() { return g_context; }
+static std::atomic<Context*> g_context{nullptr};
+static std::atomic<int> g_pinned{0};  // callers between Ref() and ~Ref() that hold a non-null context
+static std::mutex g_lifeMutex;        // serialises Init / Exit
+
+Context::Ref::Ref() {
+    // Load, pin, re-check: once Exit has unpublished the pointer no new caller touches the counter, so the counter
+    // only drains and Exit's wait ends.  A caller that loses the race between its two loads backs off without
+    // having dereferenced anything.
+    Context* c = g_context.load(std::memory_order_seq_cst);
+    if (c) {
+        g_pinned.fetch_add(1, std::memory_order_seq_cst);
+        if (g_context.load(std::memory_order_seq_cst) != c) {
+            g_pinned.fetch_sub(1, std::memory_order_seq_cst);
+            c = nullptr;
+        }
+    }
+    c_ = c;
+}
+
+Context::Ref::~Ref() {
+    if (c_) g_pinned.fetch_sub(1, std::memory_order_seq_cst);
+}
+
+static void retireContext(Context* c, void (*destroy)(Context*)) {
+    if (!c) return;
+    while (g_pinned.load(std::memory_order_seq_cst) != 0) std::this_thread::yield();  // callers still inside
+    destroy(c);
+}
 
 bool Context::init(const LiveConfig& cfg, std::string* err) {
-    std::lock_guard<std::mutex> lock(g_contextMutex);
-    if (g_context) {  // Init while running = Exit + Init, PvContext.cpp:27-31
-        delete g_context;
-        g_context = nullptr;
-    }
+    std::lock_guard<std::mutex> lock(g_lifeMutex);
+    // Init while running = Exit + Init, PvContext.cpp:27-31
+    retireContext(g_context.exchange(nullptr, std::memory_order_seq_cst), [](Context* c) { delete c; });
     // PvContext.cpp:101-107
     if (cfg.res < kLowResolution || cfg.sizeX == 0.f || cfg.sizeY == 0.f || cfg.tempDir == nullptr ||
         cfg.maxThreads < 0) {
@@ -27,6 +56,10 @@ bool Context::init(const LiveConfig& cfg, std::string* err) {
     int device = 0;
     if (const char* e = std::getenv("PLANEVERB_AMD_DEVICE")) device = std::atoi(e);
     GridSpec spec = makeGridSpec(cfg.sizeX, cfg.sizeY, cfg.res);
+    if (spec.gx != spec.gy)
+        std::fprintf(stderr, "[planeverb_amd] warning: %d x %d grid -- the reference indexes non-square grids "
+                             "inconsistently (SURVEY.md Q1); results there are defined by this library (cell array "
+                             "stride gy+1 throughout), not by the reference\n", spec.gx, spec.gy);
     SolverOptions opt;
     Context* c = new Context();
     c->solver_ = Solver::create(spec, device, opt, err);
@@ -34,55 +67,60 @@ bool Context::init(const LiveConfig& cfg, std::string* err) {
         delete c;
         return false;
     }
-    const size_t bytes = (size_t)spec.gx * spec.gy * 32;
-    for (int i = 0; i < 2; ++i) {
-        if (hipHostMalloc((void**)&c->resHost_[i], bytes) != hipSuccess) {
-            if (err) *err = "hipHostMalloc failed for the published result map";
+    const size_t bytes = c->solver_->windowCapacity() * 32;
+    for (Slot& s : c->slots_) {
+        s.data = static_cast<float*>(Solver::hostAlloc(bytes));
+        if (!s.data) {
+            if (err) *err = "pinned host allocation failed for the published result block";
             delete c;
             return false;
         }
-        std::memset(c->resHost_[i], 0, bytes);  // fresh context: all-zero results, PvContext.cpp:132
     }
     c->running_.store(true);
     c->worker_ = std::thread(&Context::workerLoop, c);  // PvContext.cpp:160
-    g_context = c;
+    g_context.store(c, std::memory_order_seq_cst);
     return true;
 }
 
 void Context::exit() {
-    std::lock_guard<std::mutex> lock(g_contextMutex);
-    if (g_context) {
-        delete g_context;
-        g_context = nullptr;
-    }
+    std::lock_guard<std::mutex> lock(g_lifeMutex);
+    retireContext(g_context.exchange(nullptr, std::memory_order_seq_cst), [](Context* c) { delete c; });
 }
 
 Context::~Context() {
     running_.store(false);  // PvContext.cpp:166-167
     if (worker_.joinable()) worker_.join();
     delete solver_;
-    for (float* p : resHost_)
-        if (p) hipHostFree(p);
+    for (Slot& s : slots_) Solver::hostFree(s.data);
+    std::free(base_.load());
     for (auto& c : chunks_) {
         Emitter* p = c.load();
         delete[] p;
     }
 }
 
-// PvContext.cpp:63-94
+// ----------------------------------------------------------------------------------------------------------------
+// worker: PvContext.cpp:63-94
+// ----------------------------------------------------------------------------------------------------------------
+
 void Context::workerLoop() {
     float lx = lx_.load(), ly = ly_.load(), lz = lz_.load();
+    std::unique_lock<std::mutex> solverLock(solverMutex_);
     while (running_.load(std::memory_order_acquire)) {
-        bool ok = solver_->run(lx, ly, lz, /*wait=*/false);
-        const int back = front_.load() ^ 1;
-        ok = ok && solver_->copyResultsAsync(resHost_[back]) && solver_->sync();
+        const bool ok = solver_->run(lx, ly, lz, /*wait=*/false) && publish();
         if (!ok) {
-            workerErr_ = solver_->lastError();
+            // The worker stops; the host can see it: IsRunning reports 0, PvAmdLastError carries the reason, GetOutput
+            // keeps serving the last published iteration.
+            std::string e = solver_->lastError();
+            std::fprintf(stderr, "[planeverb_amd] simulation worker stopped: %s\n", e.c_str());
+            {
+                std::lock_guard<std::mutex> lock(errMutex_);
+                workerErr_ = std::move(e);
+            }
+            failed_.store(true, std::memory_order_release);
             running_.store(false);
             break;
         }
-        front_.store(back, std::memory_order_release);
-        published_.store(true, std::memory_order_release);
         {
             std::lock_guard<std::mutex> lock(iterMutex_);
             iterations_.fetch_add(1, std::memory_order_acq_rel);
@@ -92,8 +130,19 @@ void Context::workerLoop() {
         lx = lx_.load();        // PvContext.cpp:89
         ly = ly_.load();
         lz = lz_.load();
+        if (solverWaiters_.load(std::memory_order_acquire) > 0) {  // a GetImpulseResponse call wants the solver
+            solverLock.unlock();
+            while (solverWaiters_.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+            solverLock.lock();
+        }
     }
+    solverLock.unlock();
     iterCv_.notify_all();
+}
+
+std::string Context::workerError() {
+    std::lock_guard<std::mutex> lock(errMutex_);
+    return workerErr_;
 }
 
 long long Context::waitIterations(long long count, int timeoutMs) {
@@ -107,6 +156,114 @@ void Context::setListener(float x, float y, float z) {
     lx_.store(x);
     ly_.store(y);
     lz_.store(z);
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// publish / read
+// ----------------------------------------------------------------------------------------------------------------
+
+namespace {
+// 32-bit relaxed atomic accesses: readers may overlap a writer (they then discard what they read, see pubSeq_)
+inline void storeRelaxed(float* dst, const float* src, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t v;
+        std::memcpy(&v, src + i, 4);
+        __atomic_store_n(reinterpret_cast<uint32_t*>(dst) + i, v, __ATOMIC_RELAXED);
+    }
+}
+inline void loadRelaxed(float* dst, const float* src, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t v = __atomic_load_n(reinterpret_cast<const uint32_t*>(src) + i, __ATOMIC_RELAXED);
+        std::memcpy(dst + i, &v, 4);
+    }
+}
+}  // namespace
+
+// Copy the block the finished iteration can have changed into the back slot, keep what leaves the window, flip.
+bool Context::publish() {
+    const int f = front_.load(std::memory_order_relaxed);
+    const int back = f < 0 ? 0 : f ^ 1;
+    Solver::WindowBlock w;
+    if (!solver_->publishWindowAsync(slots_[back].data, &w) || !solver_->sync()) return false;
+    if (f >= 0) {
+        // Cells of the old block outside the new one keep the old block's values from now on (the reference leaves
+        // m_results untouched where an iteration finds no onset, Analyzer.cpp:160-165).  Nobody can be reading these
+        // cells from base_ now: a reader that started after the last publish takes them from the front slot, and one
+        // that started before it repeats.
+        const Slot& o = slots_[f];
+        const int or0 = o.r0.load(std::memory_order_relaxed), oc0 = o.c0.load(std::memory_order_relaxed);
+        const int onr = o.nr.load(std::memory_order_relaxed), onc = o.nc.load(std::memory_order_relaxed);
+        const bool same = or0 == w.r0 && oc0 == w.c0 && onr == w.nr && onc == w.nc;
+        if (!same && onr > 0 && onc > 0) {
+            const int gy = solver_->spec().gy;
+            float* b = base_.load(std::memory_order_relaxed);
+            if (!b) {
+                b = static_cast<float*>(std::calloc((size_t)solver_->spec().gx * gy, 32));
+                if (!b) return false;
+                base_.store(b, std::memory_order_release);
+            }
+            for (int r = or0; r < or0 + onr; ++r) {
+                const bool rowInside = r >= w.r0 && r < w.r0 + w.nr;
+                for (int c = oc0; c < oc0 + onc;) {
+                    if (rowInside && c >= w.c0 && c < w.c0 + w.nc) {
+                        c = w.c0 + w.nc;  // the part of the row the new block covers
+                        continue;
+                    }
+                    const int end = (rowInside && c < w.c0) ? std::min(oc0 + onc, w.c0) : oc0 + onc;
+                    storeRelaxed(b + ((size_t)r * gy + c) * 8, o.data + ((size_t)(r - or0) * onc + (c - oc0)) * 8,
+                                 (size_t)(end - c) * 8);
+                    c = end;
+                }
+            }
+        }
+    }
+    pubSeq_.fetch_add(1, std::memory_order_seq_cst);  // odd: publish in progress
+    Slot& s = slots_[back];
+    s.r0.store(w.r0, std::memory_order_relaxed);
+    s.c0.store(w.c0, std::memory_order_relaxed);
+    s.nr.store(w.nr, std::memory_order_relaxed);
+    s.nc.store(w.nc, std::memory_order_relaxed);
+    s.lx.store(w.lx, std::memory_order_relaxed);
+    s.lz.store(w.lz, std::memory_order_relaxed);
+    front_.store(back, std::memory_order_relaxed);
+    pubSeq_.fetch_add(1, std::memory_order_seq_cst);  // even
+    return true;
+}
+
+Out8 Context::outputAt(int cx, int cy) {
+    const GridSpec& g = solver_->spec();
+    for (;;) {
+        const uint64_t s1 = pubSeq_.load(std::memory_order_acquire);
+        if (s1 & 1) continue;  // the worker is between its two stores
+        Out8 o;
+        std::memset(&o, 0, sizeof(o));  // nothing published yet: the zeroed pool of a fresh context, PvContext.cpp:132
+        const int f = front_.load(std::memory_order_relaxed);
+        if (f >= 0) {
+            const Slot& s = slots_[f];
+            const int r0 = s.r0.load(std::memory_order_relaxed), c0 = s.c0.load(std::memory_order_relaxed);
+            const int nr = s.nr.load(std::memory_order_relaxed), nc = s.nc.load(std::memory_order_relaxed);
+            if (cx >= r0 && cx < r0 + nr && cy >= c0 && cy < c0 + nc) {
+                loadRelaxed(o.v, s.data + ((size_t)(cx - r0) * nc + (cy - c0)) * 8, 8);
+            } else {
+                if (const float* b = base_.load(std::memory_order_acquire))
+                    loadRelaxed(o.v, b + ((size_t)cx * g.gy + cy) * 8, 8);
+                // no neighbour of a cell out here has an onset, so the listener-direction walk stays put
+                // (Analyzer.cpp:365-391) and the direction is the normalised (cellPos - listener), :415-428
+                float ox = (float)cx * g.dx - s.lx.load(std::memory_order_relaxed);
+                float oy = (float)cy * g.dx - s.lz.load(std::memory_order_relaxed);
+                float len = (ox * ox) + (oy * oy);
+                if (len != 0.f) {
+                    len = std::sqrt(len);
+                    ox /= len;
+                    oy /= len;
+                }
+                o.v[4] = ox;
+                o.v[5] = oy;
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (pubSeq_.load(std::memory_order_relaxed) == s1) return o;
+    }
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -167,9 +324,24 @@ Out8 Context::getOutput(int id) {
         o.v[0] = kInvalidDryGain;
         return o;
     }
-    const float* map = resHost_[front_.load(std::memory_order_acquire)];
-    std::memcpy(o.v, map + 8 * ((size_t)cx * solver_->spec().gy + cy), 32);
-    return o;
+    return outputAt(cx, cy);
+}
+
+// FDTD.cpp:60-79: cell = ((int)(x / dx), (int)(z / dx)) of the (gx+1) x (gy+1) array
+int Context::impulseResponse(float x, float y, float z, void* cells16, int cap) {
+    (void)y;
+    const GridSpec& g = solver_->spec();
+    const int cx = (int)(x / g.dx), cy = (int)(z / g.dx);
+    if (cx < 0 || cx > g.gx || cy < 0 || cy > g.gy) return 0;  // (the reference indexes past its array here)
+    solverWaiters_.fetch_add(1, std::memory_order_acq_rel);
+    std::unique_lock<std::mutex> lock(solverMutex_);
+    solverWaiters_.fetch_sub(1, std::memory_order_acq_rel);
+    const int T = solver_->T();
+    std::vector<char> buf((size_t)T * 16);
+    if (!solver_->impulseResponseCells(cx, cy, buf.data())) return -1;
+    lock.unlock();
+    if (cells16 && cap > 0) std::memcpy(cells16, buf.data(), (size_t)std::min(cap, T) * 16);
+    return T;
 }
 
 // ----------------------------------------------------------------------------------------------------------------

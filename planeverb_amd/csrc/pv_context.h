@@ -4,19 +4,33 @@
 // emission tables, and one library-owned worker that loops
 //     GenerateResponse(listener) -> AnalyzeResponses(listener) -> PushGeometryChanges() -> latch listener
 // (PvContext.cpp:63-94).  Here the worker owns a Solver (one HIP stream on one MI355X) instead of running the
-// sweeps itself, and publishes each finished result map into a pinned host double buffer so that GetOutput stays
-// O(1) and never touches the device (the reference reads the result grid unsynchronised while it is rewritten).
+// sweeps itself, and publishes what each iteration can have changed -- the history-window block of the result map
+// -- into a pinned host double buffer, so that GetOutput stays O(1), never touches the device and never takes a
+// lock (the reference reads the result grid unsynchronised while it is rewritten).
+//
+// Threading contract (checked under ThreadSanitizer / AddressSanitizer by tests/host/, a HIP-less build of this
+// file and pv_core.cpp against a fake Solver):
+//   * any API function may be called from any thread at any time, including concurrently with Exit / re-Init:
+//     entry points pin the context with Context::Ref (one fetch_add + one load, wait-free); Exit unpublishes the
+//     pointer and waits for the pinned callers to leave before it deletes anything;
+//   * GetOutput reads one consistent iteration through a sequence lock around the publish step (a few stores),
+//     so a reader repeats only if a publish happened while it copied its 32 bytes.
 #pragma once
 
 #include <atomic>
 #include <condition_variable>
+#include <cstdint>
 #include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "pv_core.h"
+#ifdef PVA_HOST_TEST
+#include "fake_solver.h"  // tests/host/: same interface, no HIP
+#else
 #include "pv_solver.h"
+#endif
 
 namespace pva {
 
@@ -39,7 +53,20 @@ public:
     // reference throws pv_InvalidConfig / pv_NotEnoughMemory.
     static bool init(const LiveConfig& cfg, std::string* err);
     static void exit();
-    static Context* get();
+
+    // Pins the current context for the duration of one API call (see the threading contract above).
+    class Ref {
+    public:
+        Ref();
+        ~Ref();
+        Ref(const Ref&) = delete;
+        Ref& operator=(const Ref&) = delete;
+        explicit operator bool() const { return c_ != nullptr; }
+        Context* operator->() const { return c_; }
+
+    private:
+        Context* c_;
+    };
 
     // EmissionManager (Emissions/EmissionManager.cpp:37-75)
     int emit(float x, float y, float z);
@@ -47,6 +74,8 @@ public:
     void endEmission(int id);
     // Planeverb::GetOutput (FDTD.cpp:16-58)
     Out8 getOutput(int id);
+    // the published result record of result cell (cx, cy) (what GetOutput reads after its position -> cell step)
+    Out8 outputAt(int cx, int cy);
 
     // GeometryManager (Geometry/GeometryManager.cpp:67-152)
     int addGeometry(const Box& b);
@@ -54,24 +83,37 @@ public:
     void removeGeometry(int id);
 
     void setListener(float x, float y, float z);  // PvContext.cpp:50-56
+    // Planeverb::GetImpulseResponse (FDTD.cpp:60-70): the IR of the last COMPLETED iteration at a world position as
+    // reference Cells (16 B each).  Waits for the iteration in flight.  Returns the response length T (cells16 gets
+    // min(cap, T) cells), 0 for a position outside the cell array, -1 on error.
+    int impulseResponse(float x, float y, float z, void* cells16, int cap);
+
     long long iterations() const { return iterations_.load(std::memory_order_acquire); }
     long long waitIterations(long long count, int timeoutMs);
     const GridSpec& spec() const { return solver_->spec(); }
-    const std::string& workerError() const { return workerErr_; }
+    // the worker stops for good on a solver error: then this is true, workerError() says why and IsRunning reports 0
+    bool failed() const { return failed_.load(std::memory_order_acquire); }
+    std::string workerError();
 
 private:
     Context() = default;
     ~Context();
     void workerLoop();
     void pushGeometryChanges();
+    bool publish();
 
     Solver* solver_ = nullptr;
     std::thread worker_;
     std::atomic<bool> running_{false};
+    std::atomic<bool> failed_{false};
     std::atomic<long long> iterations_{0};
     std::mutex iterMutex_;
     std::condition_variable iterCv_;
+    std::mutex errMutex_;
     std::string workerErr_;
+    // the worker holds this while it uses the solver (an iteration + the geometry push); GetImpulseResponse takes it
+    std::mutex solverMutex_;
+    std::atomic<int> solverWaiters_{0};
 
     // listener (plain fields in the reference, PvContext.h:40)
     std::atomic<float> lx_{0.f}, ly_{0.f}, lz_{0.f};
@@ -97,10 +139,22 @@ private:
     std::vector<Change> changes_;
     std::mutex geomMutex_;
 
-    // published results: two pinned host maps, front_ selects the readable one
-    float* resHost_[2] = {nullptr, nullptr};
-    std::atomic<int> front_{0};
-    std::atomic<bool> published_{false};
+    // Published results.  Only the block of the map an iteration can have changed (the history window) crosses PCIe:
+    // two pinned slots of windowCapacity() records, `front_` selects the readable one, `pubSeq_` is the sequence lock
+    // of the publish step (odd while the worker flips front_ and the slot's block description).  Cells outside the
+    // front block keep the values they had when they were last inside one -- `base_`, a full-size map allocated the
+    // first time the window moves (all zeros before: a fresh context's pool, PvContext.cpp:132) -- except the listener
+    // direction, which the reference recomputes for every cell on every iteration and which is the unit vector
+    // listener -> cell there (Analyzer.cpp:365-391,415-428).
+    struct Slot {
+        float* data = nullptr;
+        std::atomic<int> r0{0}, c0{0}, nr{0}, nc{0};
+        std::atomic<float> lx{0.f}, lz{0.f};
+    };
+    Slot slots_[2];
+    std::atomic<int> front_{-1};
+    std::atomic<uint64_t> pubSeq_{0};
+    std::atomic<float*> base_{nullptr};
 };
 
 }  // namespace pva

@@ -98,10 +98,13 @@ void MaterialPlane::init(const GridSpec& g) {
     g_ = g;
     const size_t n = (size_t)g.NX * g.NY;
     beta_.assign(n, 1);
+    by_.assign(n, 1);
     R_.assign(n, 0.f);
     for (int x = 0; x < g.NX; ++x)
-        for (int y = 0; y < g.NY; ++y)
-            if (x == g.gx || y == g.gy) beta_[(size_t)x * g.NY + y] = 0;  // Grid.cpp:93-97
+        for (int y = 0; y < g.NY; ++y) {
+            if (x == g.gx || y == g.gy) beta_[(size_t)x * g.NY + y] = by_[(size_t)x * g.NY + y] = 0;  // Grid.cpp:93-97
+            else if (y == 0) by_[(size_t)x * g.NY + y] = 0;                                            // Grid.cpp:98-102
+        }
     markAllDirty();
 }
 
@@ -124,6 +127,7 @@ void MaterialPlane::add(const Box& b) {
             const size_t i = (size_t)x * g_.NY + y;
             R_[i] = b.R;
             beta_[i] = 0;
+            by_[i] = 0;  // Grid.cpp:241-242
             dirtyLo_ = std::min(dirtyLo_, x);
             dirtyHi_ = std::max(dirtyHi_, x + 1);
         }
@@ -142,6 +146,9 @@ void MaterialPlane::remove(const Box& b) {
             // Grid.cpp:276 tests (y == gx || x == gy); identical to the ghost test on square grids, which
             // are the only self-consistent ones.  The ghost row/column is always beta = 0 here.
             beta_[i] = (x == g_.gx || y == g_.gy) ? 0 : 1;
+            // Grid.cpp:281-290: by comes back as 0 on the x == 0 ROW ("j == 0", j being x), not on the y == 0 column
+            // the constructor cleared
+            by_[i] = (x == g_.gx || y == g_.gy || x == 0) ? 0 : 1;
             dirtyLo_ = std::min(dirtyLo_, x);
             dirtyHi_ = std::max(dirtyHi_, x + 1);
         }

@@ -64,6 +64,8 @@ public:
     void remove(const Box& b);  // Grid::RemoveAABB (clears overlaps of other boxes too: SURVEY Q4)
     const std::vector<uint8_t>& beta() const { return beta_; }
     const std::vector<float>& R() const { return R_; }
+    // Cell::by (PvTypes.h:113): never read by the solver, but part of the AoS Cell GetImpulseResponse hands out
+    const std::vector<uint8_t>& by() const { return by_; }
     // dirty row range [lo, hi) since the last clearDirty(); empty when lo >= hi
     int dirtyLo() const { return dirtyLo_; }
     int dirtyHi() const { return dirtyHi_; }
@@ -73,7 +75,7 @@ public:
 private:
     void bounds(const Box& b, int* sx, int* sy, int* ex, int* ey) const;
     GridSpec g_;
-    std::vector<uint8_t> beta_;
+    std::vector<uint8_t> beta_, by_;
     std::vector<float> R_;
     int dirtyLo_ = 0, dirtyHi_ = 0;
 };

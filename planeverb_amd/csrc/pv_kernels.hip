@@ -2532,6 +2532,27 @@ __global__ void pv_pack_results_kernel(const float* __restrict__ res, long long 
     reinterpret_cast<float4*>(res8)[2 * i + 1] = hi;
 }
 
+// the nr x nc block of the result map whose first cell is (r0, c0) as AoS records (the live module publishes only
+// the history window's block of every iteration: everything outside it is stale values + a closed-form direction)
+__global__ void pv_pack_window_kernel(const float* __restrict__ res, long long n, int gy, int r0, int c0, int nr, int nc,
+                                      float* __restrict__ out8) {
+    const int wc = blockIdx.x * blockDim.x + threadIdx.x, wr = blockIdx.y;
+    if (wc >= nc || wr >= nr) return;
+    const long long i = (long long)(r0 + wr) * gy + (c0 + wc);
+    const long long o = (long long)wr * nc + wc;
+    float4 lo = make_float4(res[i], res[n + i], res[2 * n + i], res[3 * n + i]);
+    float4 hi = make_float4(res[4 * n + i], res[5 * n + i], res[6 * n + i], res[7 * n + i]);
+    reinterpret_cast<float4*>(out8)[2 * o] = lo;
+    reinterpret_cast<float4*>(out8)[2 * o + 1] = hi;
+}
+
+void launchPackWindow(const float* res, long long n, int gy, int r0, int c0, int nr, int nc, float* out8,
+                      hipStream_t stream) {
+    if (nr <= 0 || nc <= 0) return;
+    hipLaunchKernelGGL(pv_pack_window_kernel, dim3((unsigned)((nc + 255) / 256), (unsigned)nr), dim3(256), 0, stream, res,
+                       n, gy, r0, c0, nr, nc, out8);
+}
+
 // one cell of the result map -> 8 floats in pinned host memory (Analyzer::GetResponseResult, Analyzer.cpp:106-116)
 __global__ void pv_gather_output_kernel(const float* __restrict__ res, long long n, long long cell, float* out8) {
     if (threadIdx.x < 8) out8[threadIdx.x] = res[threadIdx.x * n + cell];

@@ -41,6 +41,8 @@ void launchGatherQueries(const float* res, long long n, const long long* cellsHo
                          hipStream_t stream);  // nq <= 64
 void launchGatherOutput(const float* res, long long n, long long cell, float* out8Host, hipStream_t stream);
 void launchPackResults(const float* res, long long n, float* res8, hipStream_t stream);
+void launchPackWindow(const float* res, long long n, int gy, int r0, int c0, int nr, int nc, float* out8,
+                      hipStream_t stream);
 void launchStreamAccum(const AnalyzeArgs& a, const uint8_t* hasEmitter, uint8_t* tileOpen, int ntiles,
                        hipStream_t stream);
 void launchStreamFinalize(const AnalyzeArgs& a, hipStream_t stream);

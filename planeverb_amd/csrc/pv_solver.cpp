@@ -204,6 +204,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
 
     mat_.init(g_);
     matHost_.assign((size_t)g_.NX * g_.NY, 0);
+    byHost_.assign((size_t)g_.NX * g_.NY, 0);
     palette_.assign(1, 0.f);
     paletteIndex_.clear();
     uint32_t zeroBits = 0;
@@ -237,7 +238,7 @@ Solver::~Solver() {
     if (emCells_) hipFree(emCells_);
     if (emTrace_) hipFree(emTrace_);
     void* ptrs[] = {codes_,     matDev_, lutDev_, pulseDev_, hist_,  tileFirst_, tileClass_, generalList_,
-                    generalCount_, dynDev_, errFlag_, res8_,     delay_, scratch_, res_, activeCount_};
+                    generalCount_, dynDev_, errFlag_, res8_,     delay_, scratch_, res_, activeCount_, win8_};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (dynHost_) hipHostFree(dynHost_);
@@ -335,6 +336,7 @@ bool Solver::applyGeometry() {
                     }
                 }
                 matHost_[i] = (uint8_t)((beta[i] ? 1 : 0) | (p << 1));
+                byHost_[i] = mat_.by()[i];
             }
         }
         if (!hipOk(hipMemcpyAsync(matDev_ + (size_t)lo * g_.NY, matHost_.data() + (size_t)lo * g_.NY,
@@ -1063,6 +1065,36 @@ bool Solver::copyResultsAsync(float* res8Host) {
     return hipOk(hipMemcpyAsync(res8Host, res8_, n * 32, hipMemcpyDeviceToHost, stream_), "results copy");
 }
 
+size_t Solver::windowCapacity() const {
+    return (size_t)std::min(histTilesX_ * rxi_, g_.gx) * (size_t)std::min(histTilesY_ * wi_, g_.gy);
+}
+
+bool Solver::publishWindowAsync(float* hostDst, WindowBlock* info) {
+    if (!dynValid_) return fail("no simulation has run yet");
+    WindowBlock w;
+    w.r0 = dynCur_.histRow0 - geo_.G;
+    w.c0 = dynCur_.histCol0 - geo_.G;
+    w.nr = std::max(0, std::min(histTilesX_ * rxi_, g_.gx - w.r0));
+    w.nc = std::max(0, std::min(histTilesY_ * wi_, g_.gy - w.c0));
+    w.lx = lastLx_;
+    w.lz = lastLz_;
+    if (!win8_ && !dalloc(&win8_, windowCapacity() * 8, false)) return false;
+    launchPackWindow(res_, (long long)g_.gx * g_.gy, g_.gy, w.r0, w.c0, w.nr, w.nc, win8_, stream_);
+    if (!hipOk(hipGetLastError(), "pack window")) return false;
+    *info = w;
+    if (w.nr == 0 || w.nc == 0) return true;
+    return hipOk(hipMemcpyAsync(hostDst, win8_, (size_t)w.nr * w.nc * 32, hipMemcpyDeviceToHost, stream_), "window copy");
+}
+
+void* Solver::hostAlloc(size_t bytes) {
+    void* p = nullptr;
+    return hipHostMalloc(&p, bytes) == hipSuccess ? p : nullptr;
+}
+
+void Solver::hostFree(void* p) {
+    if (p) hipHostFree(p);
+}
+
 bool Solver::setEmitters(const float* xyz, int n) {
     if (!opt_.streaming) return fail("emitters are registered only in streaming-analysis mode");
     if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
@@ -1100,6 +1132,21 @@ bool Solver::impulseResponse(int cx, int cy, float* out3T) {
     if (!hipOk(hipMemcpyAsync(out3T, scratch_, (size_t)3 * T_ * 4, hipMemcpyDeviceToHost, stream_), "ir copy"))
         return false;
     return hipOk(hipStreamSynchronize(stream_), "ir sync");
+}
+
+bool Solver::impulseResponseCells(int cx, int cy, void* out16T) {
+    std::vector<float> f((size_t)3 * T_);
+    if (!impulseResponse(cx, cy, f.data())) return false;
+    struct RefCell {
+        float pr, vx, vy;
+        short b, by;
+    };
+    static_assert(sizeof(RefCell) == 16, "PvTypes.h:106-121");
+    const size_t i = (size_t)cx * g_.NY + cy;
+    const short b = (short)(matHost_[i] & 1), by = (short)byHost_[i];
+    RefCell* out = static_cast<RefCell*>(out16T);
+    for (int t = 0; t < T_; ++t) out[t] = RefCell{f[(size_t)3 * t], f[(size_t)3 * t + 1], f[(size_t)3 * t + 2], b, by};
+    return true;
 }
 
 bool Solver::copyFields(float* pr, float* vx, float* vy) {

@@ -90,7 +90,23 @@ public:
     bool copyResults(float* res8, float* delay);
     // device -> caller-provided (pinned) host buffers, asynchronously on the solver's stream
     bool copyResultsAsync(float* res8Host);
+    // The block of the result map the LAST run could have changed: the history window, clipped to the map (everything
+    // outside it keeps its earlier values, except the listener direction, which is the unit vector from the listener
+    // to the cell: Analyzer.cpp:64-68,365-391,415-428).  publishWindowAsync packs that block as nr*nc AoS records
+    // and copies it to hostDst (pinned, >= windowCapacity() records) on the solver's stream.
+    struct WindowBlock {
+        int r0 = 0, c0 = 0, nr = 0, nc = 0;  // result-map cells [r0, r0+nr) x [c0, c0+nc)
+        float lx = 0, lz = 0;                // the run's listener position, metres
+    };
+    size_t windowCapacity() const;  // records: upper bound of nr*nc for any listener position
+    bool publishWindowAsync(float* hostDst, WindowBlock* info);
+    // pinned host memory for the buffers above
+    static void* hostAlloc(size_t bytes);
+    static void hostFree(void* p);
     bool impulseResponse(int cx, int cy, float* out3T);
+    // the same as T reference Cells {f32 pr, vx, vy; i16 b, by} (PvTypes.h:106-121; recorded at FDTD.cpp:226-230 with
+    // the b / by the cell had during the run)
+    bool impulseResponseCells(int cx, int cy, void* out16T);
     bool copyFields(float* pr, float* vx, float* vy);
     bool setFields(const float* pr, const float* vx, const float* vy);
     bool copyHistoryPlane(int t, float* pr);
@@ -160,6 +176,7 @@ private:
     int* activeCount_ = nullptr;  // cells with an onset in the last analysis (chooses the RT60 kernel on the device)
     float* res_ = nullptr;   // 8 SoA result planes (see AnalyzeArgs::res)
     float* res8_ = nullptr;  // AoS copy for whole-map read-backs, allocated and packed on demand
+    float* win8_ = nullptr;  // AoS staging of the window block (publishWindowAsync), allocated on demand
     bool packResults();
     float* delay_ = nullptr;
     // streaming analysis state
@@ -188,6 +205,7 @@ private:
     // host state
     MaterialPlane mat_;
     std::vector<uint8_t> matHost_;
+    std::vector<uint8_t> byHost_;  // Cell::by as of the last applyGeometry() (= during the last run)
     std::vector<float> palette_;  // R values; [0] = 0
     std::unordered_map<uint32_t, int> paletteIndex_;
     std::vector<float> pulse_;

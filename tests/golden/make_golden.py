@@ -10,6 +10,7 @@ IR traces, result / delay maps).  No reference source text is stored.
     python tests/golden/make_golden.py modeB512   # Shoebox, 25 m at res 2009  (~3 min, 27 GB)
     python tests/golden/make_golden.py cfg4       # HugeRoom, the 8 listeners of BASELINE config 4 (seconds)
     python tests/golden/make_golden.py open_offset  # open 640^2 field, listener off-centre (~1 min, 3 GB)
+    python tests/golden/make_golden.py cells      # raw reference Cells of a few IRs (GetImpulseResponse layout)
     python tests/golden/make_golden.py findgain   # FindGainA/B/C table from PlaneverbDSP's compiled context file
 """
 import os
@@ -141,6 +142,29 @@ def run_open_offset():
     print("open_offset ->", path, "%.1f kB" % (os.path.getsize(path) / 1e3))
 
 
+def run_cells():
+    """Planeverb::GetImpulseResponse hands out raw 16-byte Cells {pr, vx, vy, short b, short by} (PvTypes.h:106-121,
+    FDTD.cpp:60-79,226-230).  Two cases: the static sandbox scene, and the same scene after a box over the x = 0 / y = 0
+    corner was added and removed again (RemoveAABB restores `by` with its own rule, Grid.cpp:281-290)."""
+    boxes = pvref.load_pv(os.path.join(REF, SMALL["smallroom"]))
+    L = (5.0, 0.0, 4.0)
+    cells = np.array([(14, 16), (14, 11), (0, 5), (5, 0), (0, 0), (3, 3), (70, 10), (10, 70), (33, 20), (1, 1), (2, 0),
+                      (0, 2), (40, 40)], np.int32)
+    corner = np.array([0.5, 0.5, 2.0, 2.0, 0.5], np.float32)
+    d = dict(boxes=boxes, listener=np.array(L, np.float32), cells=cells, corner_box=corner)
+    for tag in ("static", "removed"):
+        r = pvref.RefSolver(25.0, 25.0, 275, boxes, with_free_grid=False)
+        if tag == "removed":
+            r.add_aabb(corner)
+            r.remove_aabb(corner)
+        r.generate(L)
+        d["ir_" + tag] = np.stack([r.ir_cells(x, y) for x, y in cells])  # [ncells, T, 16] bytes
+        r.close()
+    path = os.path.join(OUT, "g71_smallroom_cells.npz")
+    np.savez_compressed(path, **d)
+    print("cells ->", path, "%.1f kB" % (os.path.getsize(path) / 1e3))
+
+
 def findgain_inputs():
     """(rt60, wet) sweep for SURVEY.md 8a row 24: dense in rt60 incl. the 0.5 / 1.0 / 3.0 s bucket edges and their
     float neighbours, the analysis' degenerate values (0, negative, inf, NaN), a few wet gains"""
@@ -165,6 +189,8 @@ def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "small"
     if what == "findgain":
         return run_findgain()
+    if what == "cells":
+        return run_cells()
     if what == "cfg4":
         return run_cfg4()
     if what == "open_offset":

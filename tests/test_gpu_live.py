@@ -81,6 +81,112 @@ def test_listener_and_geometry_updates(module):
     assert not np.array_equal(o_moved, pv.GetOutput(e).as_array())
 
 
+def test_live_publish_window_only_1024(pvlib):
+    """The live module copies only the history-window block of the result map per iteration; cells outside it are
+    answered on the host: earlier values (the reference leaves m_results untouched where an iteration finds
+    no onset) + the closed-form listener direction.  Checked against a batch solver that makes the same sequence of runs
+    and reads its full device map: emitters inside the window, far outside it, and -- after the listener (and with it the
+    window) has moved 600 cells away -- an emitter whose cell was inside the FIRST window only."""
+    dx = np.float32(343.21) / np.float32(275) / np.float32(3.5)
+    size = float((2048 + 0.5) * dx)
+    cell = lambda cx, cy: ((cx + 0.5) * float(dx), 0.0, (cy + 0.5) * float(dx))
+    L1, L2 = cell(700, 800), cell(1500, 1200)
+    boxes = [[L1[0] + 8.0, L1[2] + 1.0, 1.0, 30.0, 0.9], [L2[0] - 9.0, L2[2], 1.0, 25.0, 0.8]]
+    emitters = [cell(712, 806), cell(700, 800), cell(705, 700), cell(1900, 100), cell(30, 2000), cell(1490, 1215),
+                cell(1100, 1000)]
+    pvlib.Init(pvlib.Config((size, size), 275, 0, ".", 0, pvlib.pv_GPU))
+    try:
+        with pvlib.Solver(size, size, 275) as ref:
+            ref.run((0.0, 0.0, 0.0))  # the module's first iteration: listener still (0,0,0), no geometry yet (SURVEY Q3)
+            for b in boxes:
+                pvlib.AddGeometry(b)
+                ref.add_geometry(b)
+            pvlib.SetListenerPosition(L1)
+            ids = [pvlib.Emit(e) for e in emitters]
+            settle(pvlib, 3)
+            ref.run(L1)
+            ref.run(L1)  # (the module has run L1 more than once: same values, the map is idempotent for one listener)
+            for i, e in zip(ids, emitters):
+                compare_output(pvlib.GetOutput(i), ref.get_output(e).as_array(), "listener 1, emitter %s" % (e,))
+            assert pvlib.GetOutput(ids[0]).occlusion > 0 and pvlib.GetOutput(ids[3]).occlusion == 0
+            # move the listener: the window follows it, emitter 0's cell keeps its values from the first window
+            pvlib.SetListenerPosition(L2)
+            settle(pvlib, 3)
+            ref.run(L2)
+            for i, e in zip(ids, emitters):
+                compare_output(pvlib.GetOutput(i), ref.get_output(e).as_array(), "listener 2, emitter %s" % (e,))
+            o0 = pvlib.GetOutput(ids[0])
+            assert o0.occlusion > 0 and pvlib.GetOutput(ids[5]).occlusion > 0
+            # ... and an emitter moved between iterations is looked up at its new cell at once (FDTD.cpp:16-58)
+            pvlib.UpdateEmission(ids[3], emitters[5])
+            compare_output(pvlib.GetOutput(ids[3]), ref.get_output(emitters[5]).as_array(), "moved emitter")
+    finally:
+        pvlib.Exit()
+
+
+def test_get_impulse_response_live(module):
+    """Planeverb::GetImpulseResponse (Planeverb.h:47, FDTD.cpp:60-79) through the live module: raw reference Cells
+    {pr, vx, vy, b, by} of the last completed iteration, bit-identical to the reference's cube (incl. b / by of wall,
+    ghost, x = 0 and y = 0 cells)"""
+    pv = module
+    g = golden("g71_smallroom_cells")
+    pv.SetListenerPosition(g["listener"])
+    for b in g["boxes"]:
+        pv.AddGeometry(b)
+    settle(pv)
+    dx = float(pv.host_grid_info(25.0, 25.0, 275).dx)
+    for (cx, cy), want in zip(g["cells"], g["ir_static"]):
+        got = pv.GetImpulseResponse(((cx + 0.5) * dx, 0.0, (cy + 0.5) * dx))
+        assert got.shape == (435,)
+        assert np.array_equal(got.view(np.uint8).reshape(435, 16), want), "cell %d,%d" % (cx, cy)
+    assert len(pv.GetImpulseResponse((40.0, 0.0, 3.0))) == 0  # outside the cell array
+    assert pv.IsRunning()
+
+
+def test_impulse_response_cells_after_remove(pvlib):
+    """b / by of the recorded Cells follow Grid::RemoveAABB's own restore rule (Grid.cpp:281-290: `by` comes back as 0
+    on the x = 0 row, not on the y = 0 column the constructor cleared)"""
+    g = golden("g71_smallroom_cells")
+    with pvlib.Solver(25.0, 25.0, 275) as s:
+        for b in g["boxes"]:
+            s.add_geometry(b)
+        gid = s.add_geometry(g["corner_box"])
+        s.remove_geometry(gid)
+        s.run(g["listener"])
+        for (cx, cy), want in zip(g["cells"], g["ir_removed"]):
+            got = s.impulse_response_cells(cx, cy)
+            assert np.array_equal(got.view(np.uint8).reshape(435, 16), want), "cell %d,%d" % (cx, cy)
+
+
+def test_sandbox_probe_linked_against_binding(pvlib):
+    """A C++ program written against the reference's Planeverb.h ONLY (tests/host/sandbox_probe.cpp: the Sandbox's
+    config, LoadGeometry, Emit, GetOutput, GetImpulseResponse + the other 7 namespace functions), linked with
+    bindings/PlaneverbAmdBinding.cpp + libplaneverb_amd.so in the build container (`make -C oracle ref`; it needs the
+    reference's headers, which do not exist on the GPU box) and run here as its own process"""
+    import json
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "oracle", "_ref", "sandbox_probe")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/sandbox_probe not built (needs the reference's headers: make -C oracle ref)")
+    g, gc = golden("g71_smallroom"), golden("g71_smallroom_cells")
+    dx = float(pvlib.host_grid_info(25.0, 25.0, 275).dx)
+    args = [exe, os.path.join(SCENES, "SmallRoomScene.pv"), "5", "4", "5", "6"]
+    cells = gc["cells"][:6]
+    for cx, cy in cells:
+        args += [repr((cx + 0.5) * dx), repr((cy + 0.5) * dx)]
+    r = subprocess.run(args, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["emitter_id"] == 0 and out["geometry_id"] == 5 and out["off_grid_occlusion"] == -1.0
+    got = np.array(out["output_bits"], np.uint32).view(np.float32)
+    want = g["emitter_out"][0]
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (got, want)
+    for ir, want_cells in zip(out["irs"], gc["ir_static"]):
+        assert ir["n"] == 435
+        assert np.array_equal(np.frombuffer(bytes.fromhex(ir["cells_hex"]), np.uint8).reshape(435, 16), want_cells)
+
+
 def test_reinit_while_running(pvlib):
     """Init while running == Exit + Init (PvContext.cpp:27-31); Exit twice is harmless"""
     pvlib.Init(pvlib.Config((25.0, 25.0), 275, 0, ".", 0, 1))

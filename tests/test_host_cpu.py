@@ -193,20 +193,29 @@ def test_inline_asm_dpp_has_no_pipeline_hazard(tmp_path):
     assert r.returncode == 0, r.stdout[-3000:]
 
 
-def test_cpp_binding_compiles_against_reference_headers():
+def test_cpp_binding_links_against_reference_headers():
     """bindings/PlaneverbAmdBinding.cpp -- the forwarding unit INTEGRATION.md section 2 gives a maintainer: the
-    reference's namespace API (Planeverb.h:12-47) on top of this library's C-ABI.  Where the reference is present (the
-    build container) it must compile against the reference's OWN headers (nothing of them is copied here); and the
-    text in INTEGRATION.md must be that file."""
+    reference's namespace API (Planeverb.h:12-47, all 12 functions) on top of this library's C-ABI.  Where the reference
+    is present (the build container) a caller written against the reference's OWN header (tests/host/sandbox_probe.cpp)
+    must COMPILE AND LINK with it + -lplaneverb_amd (run on the GPU: tests/test_gpu_live.py); and the text in
+    INTEGRATION.md must be that file."""
     src = os.path.join(ROOT, "bindings", "PlaneverbAmdBinding.cpp")
     code = open(src).read()
     assert code in open(os.path.join(ROOT, "INTEGRATION.md")).read(), "INTEGRATION.md section 2 is out of date"
-    ref = "/root/reference/ProjectPlaneverb/include"
-    if not os.path.isdir(ref):
+    if not os.path.isdir("/root/reference/ProjectPlaneverb/include"):
         pytest.skip("reference headers not present on this machine")
-    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-w", "-D_WIN32", "-D__declspec(x)=",
-                           "-D__forceinline=inline", "-include", "cstring", "-include", "limits", "-include", "cmath",
-                           "-I", ref, "-I", os.path.join(ROOT, "include"), src])
+    import planeverb_amd
+    planeverb_amd.build()
+    exe = os.path.join(ROOT, "oracle", "_ref", "sandbox_probe")
+    if os.path.exists(exe):
+        os.remove(exe)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "_ref/sandbox_probe"], stdout=subprocess.DEVNULL)
+    undefined = subprocess.run(["nm", "-u", "-C", exe], capture_output=True, text=True, check=True).stdout
+    assert "Planeverb::" not in undefined, undefined  # every namespace function the probe calls came from the binding
+    defined = subprocess.run(["nm", "-C", "--defined-only", exe], capture_output=True, text=True, check=True).stdout
+    for fn in ["Init", "Exit", "ChangeSettings", "Emit", "UpdateEmission", "EndEmission", "GetOutput", "AddGeometry",
+               "UpdateGeometry", "RemoveGeometry", "SetListenerPosition", "GetImpulseResponse"]:
+        assert re.search(r"\bPlaneverb::%s\(" % fn, defined), fn
 
 
 def test_batch_policy_helpers():
@@ -218,3 +227,20 @@ def test_batch_policy_helpers():
     for n, (k, rows) in ((256, (8, 40)), (512, (8, 40)), (1024, (10, 36)), (2048, (12, 36))):
         o = api.batch_solver_options(n)
         assert (o["steps_per_launch"], o["tile_rows"], o["edge_tiles"]) == (k, rows, 1)
+
+
+@pytest.mark.parametrize("san", ["tsan", "asan"])
+def test_live_module_host_side_under_sanitizers(san, tmp_path):
+    """SURVEY.md section 5 ("run host code under TSan/ASan"): a HIP-less build of pv_core.cpp + pv_context.cpp +
+    pv_capi.cpp (Part 1) against tests/host/fake_solver.h, hammered through the C-ABI by 4 threads (GetOutput /
+    Emit / UpdateEmission / EndEmission / Add-Update-RemoveGeometry / SetListenerPosition / GetImpulseResponse) while
+    the main thread cycles Exit / Init, then a worker failure.  ThreadSanitizer resp. AddressSanitizer + UBSan must stay
+    silent and every record read must come from one iteration and belong to the cell asked for."""
+    out = str(tmp_path / "build")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "host"), "OUT=" + out, out + "/hammer_" + san],
+                          stdout=subprocess.DEVNULL)
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66", ASAN_OPTIONS="detect_leaks=1 exitcode=67")
+    r = subprocess.run([out + "/hammer_" + san, "1.5"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    assert "Sanitizer" not in r.stderr, r.stderr[-4000:]
+    assert " 0 bad, phase3 flags 0" in r.stdout, r.stdout
