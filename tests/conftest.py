@@ -31,6 +31,18 @@ def same_bits(a, b):
     return (bits(a) == bits(b)) | ((a == 0) & (b == 0)) | (np.isnan(a) & np.isnan(b))
 
 
+CELL_DTYPE = np.dtype([("pr", np.float32), ("vx", np.float32), ("vy", np.float32), ("b", np.int16), ("by", np.int16)])
+
+
+def same_cells(got, want):
+    """two arrays of reference Cells (PvTypes.h:106-121; any of: structured, uint8 [T, 16], bytes): pr / vx / vy
+    bit-identical modulo the sign of zero (the reference's ghost cells hold -0: beta * negative), b / by equal"""
+    a = np.frombuffer(np.ascontiguousarray(got).tobytes(), CELL_DTYPE)
+    b = np.frombuffer(np.ascontiguousarray(want).tobytes(), CELL_DTYPE)
+    return (a.shape == b.shape and all(same_bits(a[f], b[f]).all() for f in ("pr", "vx", "vy")) and
+            np.array_equal(a["b"], b["b"]) and np.array_equal(a["by"], b["by"]))
+
+
 def rel_err(a, b):
     a = np.atleast_1d(np.asarray(a, np.float64))
     b = np.atleast_1d(np.asarray(b, np.float64))
