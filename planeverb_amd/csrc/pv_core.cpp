@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <cmath>
 #include <fstream>
+#include <iomanip>
+#include <limits>
 #include <sstream>
 
 namespace pva {
@@ -193,6 +195,9 @@ bool savePv(const std::string& path, const std::vector<std::pair<int, Box>>& box
         if (err) *err = "cannot write scene file: " + path;
         return false;
     }
+    // max_digits10: every float survives the text round trip, so a saved scene rasterises to the same cells (the
+    // Editor writes 6 significant digits, Editor.cpp:229-241; its operator>> loader reads either form)
+    f << std::setprecision(std::numeric_limits<float>::max_digits10);
     f << boxes.size() << std::endl;  // Editor.cpp:229-230
     for (const auto& p : boxes) {
         const Box& b = p.second;

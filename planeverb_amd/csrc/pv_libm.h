@@ -12,6 +12,10 @@
 // values) and every non-negative float for powf(x, 0.8f) (2 139 095 041 values) match bit for bit on this image.
 // Must be compiled without FP contraction (-ffp-contract=off); results do not depend on it for these inputs (checked
 // both ways), but the step kernels need the flag anyway.
+//
+// Licences of the restated material (full notices in /LICENSE): ARM Optimized Routines -- Copyright (c) 2017-2018, Arm
+// Limited, MIT; fdlibm -- Copyright (C) 1993 by Sun Microsystems, Inc. ("Permission to use, copy, modify, and distribute
+// this software is freely granted, provided that this notice is preserved").
 #pragma once
 
 #include <cstdint>

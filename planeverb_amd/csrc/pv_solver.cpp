@@ -313,31 +313,46 @@ std::vector<std::pair<int, Box>> Solver::boxes() const {
 bool Solver::applyGeometry() {
     if (!geometryDirty_ && mat_.dirtyLo() >= mat_.dirtyHi()) return true;
     const auto t0 = std::chrono::steady_clock::now();
-    const int lo = mat_.dirtyLo(), hi = mat_.dirtyHi();
+    int lo = mat_.dirtyLo(), hi = mat_.dirtyHi();
     if (lo < hi) {
         const auto& beta = mat_.beta();
         const auto& R = mat_.R();
-        for (int x = lo; x < hi; ++x) {
-            for (int y = 0; y < g_.NY; ++y) {
-                const size_t i = (size_t)x * g_.NY + y;
-                int p = 0;
-                if (R[i] != 0.f) {
-                    uint32_t bits;
-                    std::memcpy(&bits, &R[i], 4);
-                    auto it = paletteIndex_.find(bits);
-                    if (it == paletteIndex_.end()) {
-                        if ((int)palette_.size() >= kPaletteMax)
-                            return fail("more than 127 distinct absorption values in the scene");
-                        p = (int)palette_.size();
-                        palette_.push_back(R[i]);
-                        paletteIndex_[bits] = p;
-                    } else {
-                        p = it->second;
+        // material byte of every cell of rows [a, b): beta | palette index << 1; false = a value found no free slot
+        auto encodeRows = [&](int a, int b) {
+            for (int x = a; x < b; ++x) {
+                for (int y = 0; y < g_.NY; ++y) {
+                    const size_t i = (size_t)x * g_.NY + y;
+                    int p = 0;
+                    if (R[i] != 0.f) {
+                        uint32_t bits;
+                        std::memcpy(&bits, &R[i], 4);
+                        auto it = paletteIndex_.find(bits);
+                        if (it == paletteIndex_.end()) {
+                            if ((int)palette_.size() > kPaletteMax - 1) return false;
+                            p = (int)palette_.size();
+                            palette_.push_back(R[i]);
+                            paletteIndex_[bits] = p;
+                        } else {
+                            p = it->second;
+                        }
                     }
+                    matHost_[i] = (uint8_t)((beta[i] ? 1 : 0) | (p << 1));
+                    byHost_[i] = mat_.by()[i];
                 }
-                matHost_[i] = (uint8_t)((beta[i] ? 1 : 0) | (p << 1));
-                byHost_[i] = mat_.by()[i];
             }
+            return true;
+        };
+        if (!encodeRows(lo, hi)) {
+            // The palette only grows while boxes come and go (a long session that keeps changing absorptions through
+            // UpdateGeometry).  Rebuild it from what the plane holds NOW; only more than 127 values alive at the same
+            // time is an error (the reference has no such limit: DESIGN.md section 3).
+            palette_.assign(1, 0.f);
+            paletteIndex_.clear();
+            paletteIndex_[0u] = 0;
+            lo = 0;
+            hi = g_.NX;
+            if (!encodeRows(lo, hi))
+                return fail("more than 127 distinct absorption values alive in the scene at once");
         }
         if (!hipOk(hipMemcpyAsync(matDev_ + (size_t)lo * g_.NY, matHost_.data() + (size_t)lo * g_.NY,
                                   (size_t)(hi - lo) * g_.NY, hipMemcpyHostToDevice, stream_),

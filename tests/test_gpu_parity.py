@@ -307,6 +307,29 @@ def test_output_sentinels_and_palette_limit(pvlib):
             s.run((12, 0, 12))
 
 
+def test_palette_is_rebuilt_when_values_come_and_go(pvlib, oracle):
+    """A long session that keeps changing one wall's absorption through UpdateGeometry passes 127 distinct values since
+    creation with only a handful alive: the palette is rebuilt from the live plane instead of failing (the reference
+    accepts any number of values), and the results still equal the oracle's for the final scene"""
+    g = golden("g71_smallroom")
+    L = g["listener"]
+    with pvlib.Solver(25.0, 25.0, 275) as s:
+        ids = [s.add_geometry(b) for b in g["boxes"]]
+        extra = s.add_geometry([18.0, 18.0, 3.0, 0.8, 0.5])
+        for i in range(300):
+            s.update_geometry(extra, [18.0, 18.0, 3.0, 0.8, 0.05 + i * 0.003])
+            if i % 50 == 49:
+                s.run(L)  # applies the queued rasterisation (and, eventually, the rebuild)
+        s.run(L)
+        res, delay = s.results()
+    boxes = np.concatenate([g["boxes"], np.array([[18.0, 18.0, 3.0, 0.8, 0.05 + 299 * 0.003]], np.float32)])
+    o = oracle.OracleGrid(25.0, 25.0, 275, boxes)
+    o.fdtd(L)
+    rres, rdelay, _ = o.analyze(oracle.free_energy(25.0, 25.0, 275), L)
+    o.close()
+    compare_maps(res, delay, rres, rdelay, 435, 1443, "after 300 absorption changes")
+
+
 def test_step_composition_and_zero_fixed_point(pvlib):
     """raw stencil properties: 2n steps == n steps twice (any K), and an all-zero field stays all-zero"""
     rng = np.random.default_rng(11)

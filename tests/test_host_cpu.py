@@ -151,6 +151,21 @@ def test_pv_save_load_round_trip(pvlib, tmp_path):
         assert int(first[0]) == len(boxes) and int(first[1]) == len(boxes) - 1  # count, then the first id
 
 
+def test_pv_save_keeps_every_float_bit(pvlib, tmp_path):
+    """values that are not short decimals survive Save -> Load bit for bit (max_digits10), so the rasterised walls of
+    a round-tripped scene cannot move across a cell boundary"""
+    rng = np.random.default_rng(5)
+    boxes = (rng.random((64, 5)) * np.array([25, 25, 6, 6, 1])).astype(np.float32)
+    boxes[0] = [np.float32(1) / np.float32(3), np.nextafter(np.float32(7.1317368), np.float32(8)), 1e-3, 2.0000002, 0.969536]
+    out = str(tmp_path / "odd.pv")
+    pvlib.save_pv(out, boxes)
+    back = pvlib.load_pv(out)
+    assert np.array_equal(back.view(np.uint32), boxes.view(np.uint32))
+    b0, R0 = pvlib.host_rasterize(25.0, 25.0, 275, boxes)
+    b1, R1 = pvlib.host_rasterize(25.0, 25.0, 275, back)
+    assert np.array_equal(b0, b1) and np.array_equal(R0.view(np.uint32), R1.view(np.uint32))
+
+
 def test_cli_save_without_gpu(pvlib, tmp_path):
     import subprocess
     import sys
