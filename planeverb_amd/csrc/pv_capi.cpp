@@ -230,6 +230,7 @@ int PvAmdSetOption(PvAmdSolver* h, int key, long long value) {
         case PVA_OPT_STREAM_ROWS: h->opt.streamRows = (int)value; break;
         case PVA_OPT_MERGED_LAUNCH: h->opt.merged = (int)value; break;
         case PVA_OPT_EDGE_TILES: h->opt.edgeTiles = value != 0; break;
+        case PVA_OPT_ROW_BANDS: h->opt.rowBands = (int)value; break;
         default: g_lastError = "unknown option"; return -1;
     }
     return 0;

@@ -114,6 +114,11 @@ struct BeginArgs {
     int ntiles;
     int tileFirstInit;         // INT_MAX (recorded from the first non-zero launch) or 0 (dense history)
     int listCap;
+    // row bands (Solver::enqueueSteps): each band of tile rows is launched with its own view of the run parameters
+    // (listener row, window origin and general-tile count relative to the band's first tile row)
+    const DynParams* dynBandsHost;  // pinned, nbands entries (NULL when the run is not banded)
+    DynParams* dynBands;
+    int nbands;
 };
 
 // whole-grid-resident kernel for grids that fit one CU's LDS (pv_small_grid_kernel)

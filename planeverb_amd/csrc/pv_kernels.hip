@@ -1809,6 +1809,7 @@ __global__ void pv_begin_run_kernel(BeginArgs a) {
         *a.dyn = *a.dynHost;
         *a.errFlag = 0;
     }
+    if (i < a.nbands) a.dynBands[i] = a.dynBandsHost[i];
     if (a.tileFirst && i < a.ntiles) {
         a.tileFirst[i] = a.tileFirstInit;
         a.nz0[i] = 0;

@@ -14,6 +14,10 @@
 namespace pva {
 
 namespace {
+// Row bands per sweep when the option is left at "auto": 1 = off.  Measured on MI355X (profiles/r02_bands.txt): the
+// banded sweeps are bit-exact but 6-35 % SLOWER than one launch per sweep at 4096^2 and 8192^2 for every band count --
+// two cross-stream event waits per band and sweep cost more than the chip-wide drain they remove.
+constexpr int kAutoRowBands = 1;
 constexpr int kMinGuard = 8;  // guard width = max(this, K): a tile's halo never leaves the allocation
 inline int roundUp(int v, int m) { return (v + m - 1) / m * m; }
 inline int ceilDiv(int a, int b) { return (a + b - 1) / b; }
@@ -196,6 +200,30 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     if (!hipOk(hipHostMalloc((void**)&qOutHost_, kMaxQueries * 8 * sizeof(float)), "hipHostMalloc")) return false;
     if (!hipOk(hipHostMalloc((void**)&listHost_, sizeof(int) * (size_t)listCap_), "hipHostMalloc")) return false;
 
+    // Row bands (see enqueueSteps): worth it where a sweep is thousands of tiles; measured on MI355X at 4096^2 / 8192^2
+    {
+        const bool mergedLaunch = !stepConfigStacked(K_, rxi_) && opt_.merged == 1 && mergedConfigOk(K_, rxi_);
+        int want = opt_.rowBands;
+        if (want == 0) want = kAutoRowBands;
+        if (!mergedLaunch || opt_.streaming || opt_.streamRows > 0 || opt_.edgeTiles || opt_.timeKernels > 0) want = 1;
+        // a band must be tall enough that only ADJACENT bands share halos: >= 2 tile rows each
+        want = std::max(1, std::min(want, geo_.ntx / 2));
+        nb_ = want;
+        bandRow_.resize((size_t)nb_ + 1);
+        for (int b = 0; b <= nb_; ++b) bandRow_[(size_t)b] = (int)((long long)geo_.ntx * b / nb_);
+        bandStream_.assign((size_t)nb_, stream_);
+        for (int b = 1; b < nb_; ++b)
+            if (!hipOk(hipStreamCreateWithFlags(&bandStream_[(size_t)b], hipStreamNonBlocking), "hipStreamCreate"))
+                return false;
+        bandEv_.resize((size_t)2 * nb_);
+        for (auto& e : bandEv_)
+            if (!hipOk(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate")) return false;
+        bandListOff_.assign((size_t)nb_ + 1, 0);
+        bandListCount_.assign((size_t)nb_, 0);
+        if (!dalloc(&dynBandsDev_, (size_t)nb_, true)) return false;
+        if (!hipOk(hipHostMalloc((void**)&dynBandsHost_, sizeof(DynParams) * (size_t)nb_), "hipHostMalloc")) return false;
+    }
+
     pulse_ = gaussianPulse(g_);
     pulse_.resize((size_t)std::max(T_, g_.T), 0.f);  // an extended run (numSteps > T) injects nothing after T
     if (!hipOk(hipMemcpyAsync(pulseDev_, pulse_.data(), pulse_.size() * 4, hipMemcpyHostToDevice, stream_),
@@ -241,6 +269,15 @@ Solver::~Solver() {
                     generalCount_, dynDev_, errFlag_, res8_,     delay_, scratch_, res_, activeCount_, win8_};
     for (void* p : ptrs)
         if (p) hipFree(p);
+    for (size_t b = 1; b < bandStream_.size(); ++b)
+        if (bandStream_[b]) {
+            hipStreamSynchronize(bandStream_[b]);
+            hipStreamDestroy(bandStream_[b]);
+        }
+    for (auto& e : bandEv_)
+        if (e) hipEventDestroy(e);
+    if (dynBandsDev_) hipFree(dynBandsDev_);
+    if (dynBandsHost_) hipHostFree(dynBandsHost_);
     if (dynHost_) hipHostFree(dynHost_);
     if (outHost_) hipHostFree(outHost_);
     if (qCellsHost_) hipHostFree(qCellsHost_);
@@ -462,7 +499,8 @@ bool Solver::computeEfree() {
 // run
 // ----------------------------------------------------------------------------------------------------------------
 
-bool Solver::prepareDyn(int lcx, int lcy, bool withPulse) {
+bool Solver::prepareDyn(int lcx, int lcy, bool withPulse, bool banded) {
+    bandedRun_ = banded && nb_ > 1;
     DynParams d{};
     const bool inside = withPulse && lcx >= 0 && lcx <= g_.gx && lcy >= 0 && lcy <= g_.gy;
     d.lrow = inside ? lcx + geo_.G : -100000;
@@ -502,6 +540,33 @@ bool Solver::prepareDyn(int lcx, int lcy, bool withPulse) {
     numGeneral_ = n;
     dynCur_.numGeneral = n;
     dynHost_->numGeneral = n;
+    if (bandedRun_) {
+        // the list, band by band, as LOCAL tile ids of each band's own tile-row range; each band gets its own view of
+        // the run parameters (the kernels then see a grid that starts at the band's first tile row)
+        std::vector<int> all(listHost_, listHost_ + n);
+        std::stable_sort(all.begin(), all.end());
+        int pos = 0, b = 0;
+        bandListOff_[0] = 0;
+        for (int t : all) {
+            const int ti = t / geo_.nty;
+            while (ti >= bandRow_[(size_t)b + 1]) {
+                ++b;
+                bandListOff_[(size_t)b] = pos;
+            }
+            listHost_[pos++] = (ti - bandRow_[(size_t)b]) * geo_.nty + (t - ti * geo_.nty);
+        }
+        while (b < nb_) bandListOff_[(size_t)++b] = pos;
+        for (int k = 0; k < nb_; ++k) {
+            bandListCount_[(size_t)k] = bandListOff_[(size_t)k + 1] - bandListOff_[(size_t)k];
+            DynParams v = d;
+            const int r0 = bandRow_[(size_t)k];
+            if (inside) v.lrow -= r0 * rxi_;
+            v.histTileX0 -= r0;
+            v.histRow0 -= r0 * rxi_;
+            v.numGeneral = bandListCount_[(size_t)k];
+            dynBandsHost_[k] = v;
+        }
+    }
     dynValid_ = true;
     return true;
 }
@@ -522,6 +587,9 @@ void Solver::enqueueBeginRun(bool resetTiles) {
     b.ntiles = geo_.ntx * geo_.nty;
     b.tileFirstInit = opt_.denseHistory ? 0 : INT_MAX;
     b.listCap = listCap_;
+    b.dynBandsHost = bandedRun_ ? dynBandsHost_ : nullptr;
+    b.dynBands = dynBandsDev_;
+    b.nbands = bandedRun_ ? nb_ : 0;
     launchBeginRun(b, stream_);
 }
 
@@ -576,6 +644,36 @@ void Solver::setLaunchArgs(StepArgs& a, int t0, int k, bool firstOfRun, int li) 
     a.nzOut = nz_[(li & 1) ^ 1];
 }
 
+bool Solver::bandsActive() const { return bandedRun_; }
+
+// the launch arguments of band b: the same kernels, shown a grid that starts at the band's first tile row
+StepArgs Solver::bandStepArgs(const StepArgs& a, int b) const {
+    StepArgs v = a;
+    const int r0 = bandRow_[(size_t)b], nr = bandRow_[(size_t)b + 1] - r0;
+    const long long off = (long long)r0 * rxi_ * geo_.pitch;  // floats
+    v.prIn += off;
+    v.vxIn += off;
+    v.vyIn += off;
+    v.prOut += off;
+    v.vxOut += off;
+    v.vyOut += off;
+    v.codes += off;
+    v.tileFirst += (long long)r0 * geo_.nty;
+    v.tileClass += (long long)r0 * geo_.nty;
+    if (v.tileOpen) v.tileOpen += (long long)r0 * geo_.nty;
+    v.nzIn += (long long)r0 * geo_.nty;
+    v.nzOut += (long long)r0 * geo_.nty;
+    v.generalList += bandListOff_[(size_t)b];
+    v.numGeneral = bandListCount_[(size_t)b];
+    v.dyn = dynBandsDev_ + b;
+    v.ntx = nr;
+    v.ntiles = nr * geo_.nty;
+    v.bandRows = ceilDiv(nr, 8);
+    v.planeBytes = a.planeBytes - off * 4;
+    if (v.inBytes != 0) v.inBytes = (int)v.planeBytes;
+    return v;
+}
+
 bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record, bool fromZero) {
     StepArgs a = baseStepArgs(withPulse, record);
     // Two streams: the air-tile kernel (the bulk of the grid) on stream_, the general-tile kernel (walls, edges,
@@ -609,6 +707,35 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
         launchZero(pr_[cur_], n, stream_);
         launchZero(vx_[cur_], n, stream_);
         launchZero(vy_[cur_], n, stream_);
+    }
+    if (mergedLaunch && bandsActive()) {
+        // Row bands: sweep n of band b reads buffer set A (its own rows + K halo rows of bands b-1, b+1) and writes its
+        // rows of set B.  So sweep n+1 of band b -- which reads set B around band b and overwrites set A's rows of band b
+        // -- may start as soon as sweep n of bands b-1, b, b+1 is complete: its own stream orders it behind band b, two
+        // event waits behind the neighbours.  Nothing ever waits for a whole sweep, so the chip does not drain between
+        // the launches of one run.  (Bands two apart never touch each other's rows: a band is >= 2 tile rows >= K rows.)
+        hipEventRecord(forkEv_, stream_);  // begin-run kernel, dyn / list upload
+        for (int b = 1; b < nb_; ++b) hipStreamWaitEvent(bandStream_[(size_t)b], forkEv_, 0);
+        int done = 0, li = 0;
+        while (done < nsteps) {
+            const int k = std::min(K_, nsteps - done);
+            setLaunchArgs(a, firstStep + done, k, fromZero && done == 0, li);
+            for (int b = 0; b < nb_; ++b) {
+                hipStream_t sb = bandStream_[(size_t)b];
+                if (li > 0) {
+                    if (b > 0) hipStreamWaitEvent(sb, bandEv_[(size_t)2 * (b - 1) + ((li - 1) & 1)], 0);
+                    if (b + 1 < nb_) hipStreamWaitEvent(sb, bandEv_[(size_t)2 * (b + 1) + ((li - 1) & 1)], 0);
+                }
+                launchStep(K_, rxi_, bandStepArgs(a, b), sb, 4);
+                hipEventRecord(bandEv_[(size_t)2 * b + (li & 1)], sb);
+            }
+            cur_ ^= 1;
+            done += k;
+            ++li;
+            ++tim_.stepLaunches;
+        }
+        for (int b = 1; b < nb_; ++b) hipStreamWaitEvent(stream_, bandEv_[(size_t)2 * b + ((li - 1) & 1)], 0);  // join
+        return hipOk(hipGetLastError(), "step launch");
     }
     int done = 0, li = 0;
     while (done < nsteps) {
@@ -721,7 +848,10 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
     // one run in flight at a time: the pinned staging of the per-run parameters is reused
     if (pendingTimings_ && !sync()) return false;
     if (!applyGeometry()) return false;
-    if (!prepareDyn(lcx, lcy, true)) return false;
+    const int ntiles = geo_.ntx * geo_.nty;
+    const bool graph = !opt_.timeKernels && !opt_.streaming &&
+                       (opt_.useGraph == 1 || (opt_.useGraph == 0 && ntiles <= 4096));
+    if (!prepareDyn(lcx, lcy, true, /*banded=*/!graph)) return false;
     lastLx_ = lx;
     lastLz_ = lz;
     tim_.stepLaunches = 0;
@@ -729,9 +859,6 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
     loopTimed_ = false;
     cur_ = 0;  // the reset clears set 0; a run never depends on the previous run's fields
     hipEventRecord(ev_[0], stream_);
-    const int ntiles = geo_.ntx * geo_.nty;
-    const bool graph = !opt_.timeKernels && !opt_.streaming &&
-                       (opt_.useGraph == 1 || (opt_.useGraph == 0 && ntiles <= 4096));
     // (an explicit tile configuration means "use the tile kernels")
     const bool small = opt_.smallGrid != 2 && opt_.K == 0 && opt_.rxi == 0 && !opt_.timeKernels &&
                        opt_.useGraph != 1 && !opt_.streaming && smallGridFits(g_.NX, g_.NY) &&
@@ -882,7 +1009,7 @@ bool Solver::runBatch(Solver* const* s, int n, const float* lxyz, bool wait, std
         const float lx = lxyz[3 * i], lz = lxyz[3 * i + 2];
         int lcx, lcy;
         listenerCell(v.g_, lx, lz, &lcx, &lcy);
-        if ((v.pendingTimings_ && !v.sync()) || !v.applyGeometry() || !v.prepareDyn(lcx, lcy, true)) {
+        if ((v.pendingTimings_ && !v.sync()) || !v.applyGeometry() || !v.prepareDyn(lcx, lcy, true, false)) {
             if (err) *err = v.err_;
             return false;
         }
@@ -992,7 +1119,7 @@ bool Solver::runSteps(int nsteps, bool withPulse, float lx, float lz) {
     if (!applyGeometry()) return false;
     int lcx, lcy;
     listenerCell(g_, lx, lz, &lcx, &lcy);
-    if (!prepareDyn(lcx, lcy, withPulse)) return false;
+    if (!prepareDyn(lcx, lcy, withPulse, true)) return false;
     tim_.stepLaunches = 0;
     kevUsed_ = 0;
     loopTimed_ = false;

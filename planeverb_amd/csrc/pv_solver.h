@@ -35,6 +35,8 @@ struct SolverOptions {
                              // batched kernel has that arm, so every run of such a solver goes through it
     int smallGrid = 0;    // 0 = auto: grids that fit one CU's LDS run in the whole-grid-resident kernel; 2 = never
     int timeKernels = 0;  // N > 0: HIP events around every Nth step-kernel launch (bench / roofline)
+    int rowBands = 0;     // B > 1: each sweep = B launches (bands of tile rows, one stream each) with 3-point
+                          // dependencies between consecutive sweeps; 0 = auto, 1 = off
 };
 
 struct SolverTimings {
@@ -125,7 +127,7 @@ private:
     bool enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record, bool fromZero = false);
     StepArgs baseStepArgs(bool withPulse, bool record) const;
     void setLaunchArgs(StepArgs& a, int t0, int k, bool firstOfRun, int li) const;
-    bool prepareDyn(int lcx, int lcy, bool withPulse);
+    bool prepareDyn(int lcx, int lcy, bool withPulse, bool banded);
     void enqueueBeginRun(bool resetTiles);
     AnalyzeArgs analyzeArgs(float lx, float lz) const;
     bool fail(const std::string& what);
@@ -223,6 +225,18 @@ private:
     std::vector<Box> boxTable_;
     std::vector<uint8_t> boxUsed_;
     std::vector<int> boxFree_;
+
+    // row bands: band b covers tile rows [bandRow_[b], bandRow_[b+1])
+    int nb_ = 1;
+    std::vector<int> bandRow_;
+    std::vector<hipStream_t> bandStream_;  // [0] = stream_
+    std::vector<hipEvent_t> bandEv_;       // 2 per band: sweep parity
+    std::vector<int> bandListOff_, bandListCount_;
+    DynParams* dynBandsDev_ = nullptr;
+    DynParams* dynBandsHost_ = nullptr;
+    bool bandedRun_ = false;  // the run prepared last is launched band by band
+    bool bandsActive() const;
+    StepArgs bandStepArgs(const StepArgs& a, int b) const;
 
     std::vector<hipEvent_t> kev_;  // 3 events per step launch when opt_.timeKernels
     int kevUsed_ = 0;

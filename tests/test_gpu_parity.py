@@ -197,6 +197,46 @@ def test_stacked_tiles_match_single_wave_tiles_1024(pvlib, opts):
         assert (da < 1e30).sum() > 100000
 
 
+@pytest.mark.parametrize("bands", [2, 3, 5])
+def test_row_bands_match_single_launch_sweeps_1024(pvlib, bands):
+    """PVA_OPT_ROW_BANDS: every sweep launched as bands of tile rows on their own streams, band b of sweep n+1 ordered
+    only behind bands b-1, b, b+1 of sweep n.  Same bits as one launch per sweep on every cell: final fields, recorded
+    planes, delay and result maps -- listener ON a band boundary row, walls crossing the boundaries, a second run with
+    the listener elsewhere on the same solver"""
+    dx = np.float32(343.21) / np.float32(275) / np.float32(3.5)
+    size = float((1024 + 0.5) * dx)
+    with pvlib.Solver(size, size, 275, steps_per_launch=8, tile_rows=24, row_bands=1) as a, \
+            pvlib.Solver(size, size, 275, steps_per_launch=8, tile_rows=24, row_bands=bands) as b:
+        ntx = -(-1025 // 24)
+        edge = (ntx * 1 // bands) * 24  # first row of band 1
+        Ls = [((edge + 0.5) * float(dx), 0.0, 400.5 * float(dx)), ((edge - 3 + 0.5) * float(dx), 0.0, 700.5 * float(dx)),
+              (150.5 * float(dx), 0.0, 150.5 * float(dx))]
+        boxes = [[Ls[0][0] + 1.0, Ls[0][2] + 9.0, 40.0, 1.0, 0.85], [Ls[0][0] - 20.0, Ls[0][2] - 4.0, 1.2, 55.0, 0.5],
+                 [Ls[0][0] + 3.0, Ls[0][2] - 30.0, 44.0, 2.0, 0.969536]]
+        for s in (a, b):
+            for box in boxes:
+                s.add_geometry(box)
+        for L in Ls:
+            a.run(L)
+            b.run(L)
+            for fa, fb in zip(a.fields(), b.fields()):
+                assert same_bits(fa, fb).all()
+            for t in (0, 7, 8, 50, 211, 434):
+                assert same_bits(a.history_plane(t), b.history_plane(t)).all(), "recorded pr, step %d" % t
+            ra, da = a.results()
+            rb, db = b.results()
+            assert same_bits(da, db).all() and same_bits(ra, rb).all()
+            assert (da < 1e30).sum() > 100000
+        # the raw stencil on all-non-zero fields
+        rng = np.random.default_rng(3)
+        f = [(rng.random((1025, 1025), np.float32) - np.float32(0.5)) for _ in range(3)]
+        for s in (a, b):
+            s.set_fields(*f)
+            s.run_steps(40)
+        for fa, fb in zip(a.fields(), b.fields()):
+            assert same_bits(fa, fb).all()
+
+
 def random_scene(rng, size, nbox):
     boxes = []
     for _ in range(nbox):
