@@ -159,6 +159,24 @@ PVA_EXPORT const char* PvAmdVersion(void);
  * `device`.  PlaneverbCreateGrid is the same function under the name BASELINE.json uses. */
 PVA_EXPORT PvAmdSolver* PvAmdCreate(float gridSizeX, float gridSizeY, int gridResolution, int device);
 PVA_EXPORT PvAmdSolver* PlaneverbCreateGrid(float gridSizeX, float gridSizeY, int gridResolution, int device);
+/* SURVEY.md 8f N4 -- ONE grid decomposed into `nslabs` row slabs (whole tile rows), slab i on HIP device devices[i] (all
+ * equal: several slabs on one GPU).  Each slab holds planes, pressure history and result maps for its own rows only;
+ * per K-step launch the K boundary rows of pr, vx, vy travel into the neighbours' guard bands, per run the boundary rows'
+ * pressure histories and the window block of the per-slab result maps.  The reference has no
+ * counterpart (its loop advances the whole grid, PvContext.cpp:63-94); results are bit-identical to PvAmdCreate's.
+ * The handle supports: SetOption (tile / step options), GetInfo, Add / Update / RemoveGeometry, LoadScene, Run,
+ * GetOutput, CopyResults, CopyFields, CopyHistoryPlane, GetImpulseResponse, CopyPulse, CopyMaterial, GetTimings,
+ * GetSlabInfo, Destroy; the other PvAmd* calls return -1 for it. */
+PVA_EXPORT PvAmdSolver* PvAmdCreateSlabs(float gridSizeX, float gridSizeY, int gridResolution, const int* devices,
+                                         int nslabs);
+typedef struct PvAmdSlabInfo {
+    int nslabs;
+    int row0[16], rows[16], device[16];  /* cell-array rows [row0, row0 + rows) of slab i */
+    long long haloBytesPerLaunch;        /* pr, vx, vy boundary rows moved between slabs per K-step launch */
+    long long exchangeBytesPerRun;       /* boundary histories + result blocks of the last run */
+    long long deviceBytes[16];           /* HBM held by slab i (whole-grid result maps: see PvAmdGetInfo) */
+} PvAmdSlabInfo;
+PVA_EXPORT int PvAmdGetSlabInfo(PvAmdSolver* s, PvAmdSlabInfo* out);
 PVA_EXPORT void PvAmdDestroy(PvAmdSolver* s);
 PVA_EXPORT int PvAmdSetOption(PvAmdSolver* s, int key, long long value);
 PVA_EXPORT int PvAmdGetInfo(PvAmdSolver* s, PvAmdInfo* out);

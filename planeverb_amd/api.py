@@ -68,6 +68,12 @@ class PvAmdInfo(C.Structure):
                 ("deviceBytes", C.c_longlong)]
 
 
+class PvAmdSlabInfo(C.Structure):
+    _fields_ = [("nslabs", C.c_int), ("row0", C.c_int * 16), ("rows", C.c_int * 16), ("device", C.c_int * 16),
+                ("haloBytesPerLaunch", C.c_longlong), ("exchangeBytesPerRun", C.c_longlong),
+                ("deviceBytes", C.c_longlong * 16)]
+
+
 class PvAmdTimings(C.Structure):
     _fields_ = [("fdtdMs", C.c_float), ("analysisMs", C.c_float), ("geometryMs", C.c_float),
                 ("stepKernelMs", C.c_float), ("stepLaunches", C.c_int), ("airKernelMs", C.c_float), ("generalKernelMs", C.c_float), ("airLaunches", C.c_int),
@@ -100,6 +106,8 @@ SYMBOLS = {
     "PvAmdVersion": (C.c_char_p, []),
     "PvAmdCreate": (_vp, [C.c_float, C.c_float, C.c_int, C.c_int]),
     "PlaneverbCreateGrid": (_vp, [C.c_float, C.c_float, C.c_int, C.c_int]),
+    "PvAmdCreateSlabs": (_vp, [C.c_float, C.c_float, C.c_int, C.POINTER(C.c_int), C.c_int]),
+    "PvAmdGetSlabInfo": (C.c_int, [_vp, C.POINTER(PvAmdSlabInfo)]),
     "PvAmdDestroy": (None, [_vp]),
     "PvAmdSetOption": (C.c_int, [_vp, C.c_int, C.c_longlong]),
     "PvAmdGetInfo": (C.c_int, [_vp, C.POINTER(PvAmdInfo)]),
@@ -351,8 +359,14 @@ def run_batch(solvers, listeners, wait=True):
 class Solver:
     """Grid + FreeGrid + Analyzer of one config on one MI355X (PvAmd* handle API)."""
 
-    def __init__(self, size_x, size_y, res, device=0, **options):
-        self._h = lib().PvAmdCreate(float(size_x), float(size_y), int(res), int(device))
+    def __init__(self, size_x, size_y, res, device=0, slabs=None, **options):
+        """slabs = list of HIP devices, one per row slab: ONE grid decomposed into len(slabs) slabs (PvAmdCreateSlabs;
+        all devices equal = several slabs on one GPU).  Same results, bit for bit."""
+        if slabs is not None:
+            dev = (C.c_int * len(slabs))(*[int(d) for d in slabs])
+            self._h = lib().PvAmdCreateSlabs(float(size_x), float(size_y), int(res), dev, len(slabs))
+        else:
+            self._h = lib().PvAmdCreate(float(size_x), float(size_y), int(res), int(device))
         if not self._h:
             raise PlaneverbError(last_error())
         keys = {"dense_history": PVA_OPT_DENSE_HISTORY, "num_steps": PVA_OPT_NUM_STEPS,
@@ -386,6 +400,11 @@ class Solver:
 
     def __exit__(self, *a):
         self.close()
+
+    def slab_info(self):
+        i = PvAmdSlabInfo()
+        _check(lib().PvAmdGetSlabInfo(self._h, i))
+        return i
 
     def load_scene(self, path):
         n = lib().PvAmdLoadScene(self._h, path.encode())

@@ -8,6 +8,7 @@
 #include "pv_context.h"
 #include "pv_core.h"
 #ifndef PVA_HOST_TEST  // (tests/host/: HIP-less sanitizer build of the live module against a fake Solver)
+#include "pv_slabs.h"
 #include "pv_solver.h"
 #endif
 
@@ -18,15 +19,26 @@ static thread_local std::string g_lastError;
 #ifndef PVA_HOST_TEST
 struct PvAmdSolver {
     Solver* s = nullptr;
+    SlabGroup* g = nullptr;     // a slab group instead of one solver (PvAmdCreateSlabs)
+    std::vector<int> slabDevices;
     SolverOptions opt;
     GridSpec spec;
     int device = 0;
 };
 
-static bool ensure(PvAmdSolver* h) {
+// creates the solver / slab group on first use (options come first); `slabsOk` = the call is implemented for groups
+static bool ensure(PvAmdSolver* h, bool slabsOk = false) {
     if (!h) {
         g_lastError = "null solver handle";
         return false;
+    }
+    if (!h->slabDevices.empty()) {
+        if (!slabsOk) {
+            g_lastError = "not available for a slab group (PvAmdCreateSlabs)";
+            return false;
+        }
+        if (!h->g) h->g = SlabGroup::create(h->spec, h->slabDevices, h->opt, &g_lastError);
+        return h->g != nullptr;
     }
     if (h->s) return true;
     h->s = Solver::create(h->spec, h->device, h->opt, &g_lastError);
@@ -36,6 +48,7 @@ static bool ensure(PvAmdSolver* h) {
 static int ret(PvAmdSolver* h, bool ok) {
     if (ok) return 0;
     if (h && h->s && !h->s->lastError().empty()) g_lastError = h->s->lastError();
+    if (h && h->g && !h->g->lastError().empty()) g_lastError = h->g->lastError();
     return -1;
 }
 #endif  // !PVA_HOST_TEST
@@ -202,15 +215,50 @@ PvAmdSolver* PlaneverbCreateGrid(float gridSizeX, float gridSizeY, int gridResol
     return PvAmdCreate(gridSizeX, gridSizeY, gridResolution, device);
 }
 
+PvAmdSolver* PvAmdCreateSlabs(float gridSizeX, float gridSizeY, int gridResolution, const int* devices, int nslabs) {
+    if (!devices || nslabs < 2 || nslabs > 16) {
+        g_lastError = "PvAmdCreateSlabs: 2..16 slabs and their devices";
+        return nullptr;
+    }
+    PvAmdSolver* h = PvAmdCreate(gridSizeX, gridSizeY, gridResolution, devices[0]);
+    if (!h) return nullptr;
+    const int n = PvAmdDeviceCount();
+    for (int i = 0; i < nslabs; ++i) {
+        if (devices[i] < 0 || devices[i] >= n) {
+            g_lastError = "HIP device index out of range";
+            delete h;
+            return nullptr;
+        }
+        h->slabDevices.push_back(devices[i]);
+    }
+    return h;
+}
+
+int PvAmdGetSlabInfo(PvAmdSolver* h, PvAmdSlabInfo* out) {
+    if (!out || !ensure(h, true) || !h->g) return -1;
+    std::memset(out, 0, sizeof(*out));
+    out->nslabs = h->g->numSlabs();
+    for (int i = 0; i < out->nslabs; ++i) {
+        out->row0[i] = h->g->slabRow0(i);
+        out->rows[i] = h->g->slabRows(i);
+        out->device[i] = h->g->slab(i)->device();
+        out->deviceBytes[i] = h->g->slab(i)->deviceBytes();
+    }
+    out->haloBytesPerLaunch = h->g->haloBytesPerLaunch();
+    out->exchangeBytesPerRun = h->g->exchangeBytesPerRun();
+    return 0;
+}
+
 void PvAmdDestroy(PvAmdSolver* h) {
     if (!h) return;
     delete h->s;
+    delete h->g;
     delete h;
 }
 
 int PvAmdSetOption(PvAmdSolver* h, int key, long long value) {
     if (!h) return -1;
-    if (h->s) {
+    if (h->s || h->g) {
         g_lastError = "options must be set before the solver is first used";
         return -1;
     }
@@ -237,7 +285,31 @@ int PvAmdSetOption(PvAmdSolver* h, int key, long long value) {
 }
 
 int PvAmdGetInfo(PvAmdSolver* h, PvAmdInfo* out) {
-    if (!out || !ensure(h)) return -1;
+    if (!out || !ensure(h, true)) return -1;
+    if (h->g) {
+        const GridSpec& g = h->g->spec();
+        const Solver* s0 = h->g->slab(0);
+        std::memset(out, 0, sizeof(*out));
+        out->gx = g.gx;
+        out->gy = g.gy;
+        out->T = h->g->T();
+        out->fs = (int)g.fs;
+        out->res = g.res;
+        out->dx = g.dx;
+        out->dt = g.dt;
+        out->efree = h->g->efree();
+        out->device = s0->device();
+        out->stepsPerLaunch = s0->K();
+        out->tileRows = s0->geometry().rxi;
+        out->tileCols = s0->geometry().wi;
+        out->pitch = s0->geometry().pitch;
+        out->rows = s0->geometry().rows;
+        out->histRows = s0->histRows();
+        out->histPitch = s0->histPitch();
+        out->numGeometry = h->g->numBoxes();
+        out->deviceBytes = h->g->deviceBytes();
+        return 0;
+    }
     const GridSpec& g = h->s->spec();
     const Geometry& geo = h->s->geometry();
     std::memset(out, 0, sizeof(*out));
@@ -263,26 +335,34 @@ int PvAmdGetInfo(PvAmdSolver* h, PvAmdInfo* out) {
 }
 
 int PvAmdAddGeometry(PvAmdSolver* h, float posX, float posY, float width, float height, float absorption) {
-    if (!ensure(h)) return -1;
+    if (!ensure(h, true)) return -1;
+    if (h->g) return h->g->addBox(Box{posX, posY, width, height, absorption});
     return h->s->addBox(Box{posX, posY, width, height, absorption});
 }
 
 int PvAmdUpdateGeometry(PvAmdSolver* h, int id, float posX, float posY, float width, float height,
                         float absorption) {
-    if (!ensure(h)) return -1;
+    if (!ensure(h, true)) return -1;
+    if (h->g) return ret(h, h->g->updateBox(id, Box{posX, posY, width, height, absorption}));
     return ret(h, h->s->updateBox(id, Box{posX, posY, width, height, absorption}));
 }
 
 int PvAmdRemoveGeometry(PvAmdSolver* h, int id) {
-    if (!ensure(h)) return -1;
+    if (!ensure(h, true)) return -1;
+    if (h->g) return ret(h, h->g->removeBox(id));
     return ret(h, h->s->removeBox(id));
 }
 
 int PvAmdLoadScene(PvAmdSolver* h, const char* pvPath) {
-    if (!ensure(h) || !pvPath) return -1;
+    if (!ensure(h, true) || !pvPath) return -1;
     std::vector<Box> boxes;
     if (!loadPv(pvPath, &boxes, &g_lastError)) return -1;
-    for (const Box& b : boxes) h->s->addBox(b);
+    for (const Box& b : boxes) {
+        if (h->g)
+            h->g->addBox(b);
+        else
+            h->s->addBox(b);
+    }
     return (int)boxes.size();
 }
 
@@ -292,7 +372,8 @@ int PvAmdSaveScene(PvAmdSolver* h, const char* pvPath) {
 }
 
 int PvAmdRun(PvAmdSolver* h, float lx, float ly, float lz) {
-    if (!ensure(h)) return -1;
+    if (!ensure(h, true)) return -1;
+    if (h->g) return ret(h, h->g->run(lx, ly, lz));
     return ret(h, h->s->run(lx, ly, lz, true));
 }
 
@@ -323,8 +404,8 @@ int PvAmdSync(PvAmdSolver* h) {
 }
 
 int PvAmdGetTimings(PvAmdSolver* h, PvAmdTimings* out) {
-    if (!out || !ensure(h)) return -1;
-    const SolverTimings& t = h->s->timings();
+    if (!out || !ensure(h, true)) return -1;
+    const SolverTimings& t = h->g ? h->g->timings() : h->s->timings();
     out->fdtdMs = t.fdtdMs;
     out->analysisMs = t.analysisMs;
     out->geometryMs = t.geometryMs;
@@ -344,10 +425,10 @@ int PvAmdSetEmitters(PvAmdSolver* h, const float* xyz, int n) {
 }
 
 int PvAmdGetOutput(PvAmdSolver* h, float ex, float ey, float ez, PlaneverbOutput* out) {
-    if (!out || !ensure(h)) return -1;
+    if (!out || !ensure(h, true)) return -1;
     float v[8];
     bool valid = false;
-    if (!h->s->getOutput(ex, ey, ez, v, &valid)) return ret(h, false);
+    if (!(h->g ? h->g->getOutput(ex, ey, ez, v, &valid) : h->s->getOutput(ex, ey, ez, v, &valid))) return ret(h, false);
     if (!valid) {
         std::memset(out, 0, sizeof(*out));
         out->occlusion = kInvalidDryGain;
@@ -379,13 +460,13 @@ int PvAmdGetQueriedOutputs(PvAmdSolver* h, PlaneverbOutput* out, int n) {
 }
 
 int PvAmdCopyResults(PvAmdSolver* h, float* res8, float* delay) {
-    if (!ensure(h)) return -1;
-    return ret(h, h->s->copyResults(res8, delay));
+    if (!ensure(h, true)) return -1;
+    return ret(h, h->g ? h->g->copyResults(res8, delay) : h->s->copyResults(res8, delay));
 }
 
 int PvAmdGetImpulseResponse(PvAmdSolver* h, int cx, int cy, float* out3T) {
-    if (!out3T || !ensure(h)) return -1;
-    return ret(h, h->s->impulseResponse(cx, cy, out3T));
+    if (!out3T || !ensure(h, true)) return -1;
+    return ret(h, h->g ? h->g->impulseResponse(cx, cy, out3T) : h->s->impulseResponse(cx, cy, out3T));
 }
 
 int PvAmdGetImpulseResponseCells(PvAmdSolver* h, int cx, int cy, PlaneverbCell* outT) {
@@ -395,23 +476,23 @@ int PvAmdGetImpulseResponseCells(PvAmdSolver* h, int cx, int cy, PlaneverbCell* 
 }
 
 int PvAmdCopyFields(PvAmdSolver* h, float* pr, float* vx, float* vy) {
-    if (!ensure(h)) return -1;
-    return ret(h, h->s->copyFields(pr, vx, vy));
+    if (!ensure(h, true)) return -1;
+    return ret(h, h->g ? h->g->copyFields(pr, vx, vy) : h->s->copyFields(pr, vx, vy));
 }
 
 int PvAmdCopyHistoryPlane(PvAmdSolver* h, int t, float* pr) {
-    if (!pr || !ensure(h)) return -1;
-    return ret(h, h->s->copyHistoryPlane(t, pr));
+    if (!pr || !ensure(h, true)) return -1;
+    return ret(h, h->g ? h->g->copyHistoryPlane(t, pr) : h->s->copyHistoryPlane(t, pr));
 }
 
 int PvAmdCopyPulse(PvAmdSolver* h, float* out) {
-    if (!out || !ensure(h)) return -1;
-    return ret(h, h->s->copyPulse(out));
+    if (!out || !ensure(h, true)) return -1;
+    return ret(h, h->g ? h->g->copyPulse(out) : h->s->copyPulse(out));
 }
 
 int PvAmdCopyMaterial(PvAmdSolver* h, uint8_t* beta, float* R) {
-    if (!ensure(h)) return -1;
-    return ret(h, h->s->copyMaterial(beta, R));
+    if (!ensure(h, true)) return -1;
+    return ret(h, h->g ? h->g->copyMaterial(beta, R) : h->s->copyMaterial(beta, R));
 }
 
 int PvAmdSetFields(PvAmdSolver* h, const float* pr, const float* vx, const float* vy) {

@@ -36,6 +36,9 @@ struct Geometry {
     int rxi, wi;     // tile interior rows / columns
     int ntx, nty;    // tiles
     int rows, pitch; // padded plane
+    // row slab of a larger grid (single-grid decomposition, pv_slabs.cpp): local array row 0 is row x0 of the whole
+    // grid, whose cell array has NXg = gxg + 1 rows.  A whole grid has x0 = 0, NXg = NX, gxg = gx.
+    int x0, NXg, gxg;
 };
 
 // per-run parameters that change with the listener; lives in device memory so a captured graph can be replayed
@@ -169,6 +172,11 @@ struct AnalyzeArgs {
     float efree;
     float lx, lz;        // listener, metres
     int lcx, lcy;        // listener cell by reciprocal multiply (Analyzer.cpp:200-201)
+    // row slab of a larger grid: result row X of this map is row X + x0 of the whole grid (position arithmetic), and the
+    // pressure history of the row above the slab's first row -- needed by the vx recurrence there -- comes from the
+    // neighbouring slab as a dense [T][histPitch] array (window columns; zeros where nothing was recorded)
+    int x0;
+    const float* histAbove;
     // streaming analysis (sparse-emitter mode): the history is a ring of `ring` planes and the forward sums of
     // every cell are carried in per-cell state planes between passes
     int ring;            // 0 = full history (plane index = t), else plane index = t % ring

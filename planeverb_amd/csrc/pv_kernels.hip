@@ -104,17 +104,18 @@ __global__ void pv_codes_kernel(const uint8_t* __restrict__ mat, uint16_t* __res
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     const int row = blockIdx.y;
     if (col >= g.pitch || row >= g.rows) return;
-    const int x = row - g.G, y = col - g.G;
+    // (x, y) in the WHOLE grid's cell array: a slab's guard rows hold its neighbours' true face codes
+    const int x = row - g.G + g.x0, y = col - g.G;
     unsigned kx = kLutWall, ky = kLutWall;
-    if (x >= 0 && x < g.NX && y >= 0 && y < g.NY) {
-        const bool ghost = (x == g.gx) || (y == g.gy);
+    if (x >= 0 && x < g.NXg && y >= 0 && y < g.NY) {
+        const bool ghost = (x == g.gxg) || (y == g.gy);
         const unsigned mi = mat[(size_t)x * g.NY + y];
         const bool bi = (mi & 1u) && !ghost;
         const unsigned pi = ghost ? 0u : (mi >> 1);
         // x face: neighbour n = (x-1, y)
         if (x == 0) {
             kx = (bi && y < g.gy) ? (unsigned)kLutNegBase : (unsigned)kLutWall;
-        } else if (x == g.gx) {
+        } else if (x == g.gxg) {
             kx = (y < g.gy) ? (unsigned)kLutPosBase : (unsigned)kLutWall;
         } else {
             const unsigned mn = mat[(size_t)(x - 1) * g.NY + y];
@@ -125,13 +126,13 @@ __global__ void pv_codes_kernel(const uint8_t* __restrict__ mat, uint16_t* __res
         }
         // y face: neighbour n = (x, y-1)
         if (y == 0) {
-            ky = (bi && x < g.gx) ? (unsigned)kLutNegBase : (unsigned)kLutWall;
+            ky = (bi && x < g.gxg) ? (unsigned)kLutNegBase : (unsigned)kLutWall;
         } else if (y == g.gy) {
-            ky = (x < g.gx) ? (unsigned)kLutPosBase : (unsigned)kLutWall;
+            ky = (x < g.gxg) ? (unsigned)kLutPosBase : (unsigned)kLutWall;
         } else {
             const unsigned mn = mat[(size_t)x * g.NY + (y - 1)];
-            const bool bn = (mn & 1u) && (x != g.gx);
-            const unsigned pn = (x == g.gx) ? 0u : (mn >> 1);
+            const bool bn = (mn & 1u) && (x != g.gxg);
+            const unsigned pn = (x == g.gxg) ? 0u : (mn >> 1);
             ky = (bi && bn) ? (unsigned)kLutAir
                             : bi ? kLutNegBase + pn : bn ? kLutPosBase + pi : (unsigned)kLutWall;
         }
@@ -2128,6 +2129,10 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
     if (Y > 0 && pcol - 1 >= dyn.histCol0) tFy = a.tileFirst[(X / a.rxi) * a.nty + ((Y - 1) / a.wi)];
     CellHistory hx{a.hist + hoff - a.histPitch, a.histPlane};
     CellHistory hy{a.hist + hoff - 1, a.histPlane};
+    if (X == 0 && a.histAbove) {  // first row of a slab: the row above lives in the neighbouring slab
+        hx = CellHistory{a.histAbove + (pcol - dyn.histCol0), a.histPitch};
+        tFx = 0;
+    }
 
     const uint32_t code = a.codes[(size_t)prow * a.pitch + pcol];
     const float kx = a.lut[code & 0xffu], ky = a.lut[code >> 8];
@@ -2217,7 +2222,7 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
     a.delay[s] = (float)onset;
 
     // obstruction gain + source directivity, Analyzer.cpp:197-220
-    const float EfreePr = efreePerR(a.efree, a.dx, a.lcx, a.lcy, X, Y);
+    const float EfreePr = efreePerR(a.efree, a.dx, a.lcx, a.lcy, X + a.x0, Y);
     const float occ = sqrtf(Edry / EfreePr);
     float norm = sqrtf(fluxX * fluxX + fluxY * fluxY);
     norm = -1.0f / (norm > 0.0f ? norm : 1.0f);
@@ -2376,7 +2381,7 @@ __device__ __forceinline__ void countActiveCells(const AnalyzeArgs& a) {
 }
 
 __global__ __launch_bounds__(256) void pv_far_cells_kernel(const AnalyzeArgs a) {
-    if (blockIdx.x == 0) countActiveCells(a);  // (before any thread leaves: the reduction has barriers)
+    if (blockIdx.x == 0 && a.tileFirst) countActiveCells(a);  // (before any thread leaves: the reduction has barriers)
     const int index = blockIdx.x * blockDim.x + threadIdx.x;
     if (index >= a.gx * a.gy) return;
     a.delay[index] = FLT_MAX;
@@ -2582,6 +2587,65 @@ void launchGatherQueries(const float* res, long long n, const long long* cellsHo
 
 void launchPackResults(const float* res, long long n, float* res8, hipStream_t stream) {
     hipLaunchKernelGGL(pv_pack_results_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, res, n, res8);
+}
+
+// One row of the history window over all T steps as a dense [T][histPitch] array (zeros where the tile had not been
+// reached yet): what the slab BELOW this one needs for the vx recurrence of its first row (AnalyzeArgs::histAbove).
+__global__ void pv_hist_row_kernel(const AnalyzeArgs a, int X, float* __restrict__ out) {
+    const int wc = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
+    if (wc >= a.histPitch || t >= a.T) return;
+    const DynParams dyn = *a.dyn;
+    const int pcol = dyn.histCol0 + wc, prow = X + a.G;
+    float v = 0.f;
+    const int ti = X / a.rxi, tj = (pcol - a.G) / a.wi;
+    const int wti = ti - dyn.histTileX0, wtj = tj - dyn.histTileY0;
+    if (wc < a.winCols && pcol >= a.G && wti >= 0 && wti < dyn.histTilesX && wtj >= 0 && wtj < dyn.histTilesY &&
+        t >= a.tileFirst[ti * a.nty + tj])
+        v = a.hist[(long long)t * a.histPlane + (long long)(prow - dyn.histRow0) * a.histPitch + wc];
+    out[(long long)t * a.histPitch + wc] = v;
+}
+
+void launchHistRow(const AnalyzeArgs& a, int X, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(pv_hist_row_kernel, dim3((a.histPitch + 255) / 256, a.T), dim3(256), 0, stream, a, X, out);
+}
+
+// nplanes planes: the nr x nc block at (sr0, sc0) of src planes (row pitch spitch, plane stride sstride) into the block at
+// (dr0, dc0) of dst planes -- a slab's part of the history window into the whole grid's result / delay maps
+__global__ void pv_copy_block_kernel(const float* __restrict__ src, long long sstride, int spitch, int sr0, int sc0,
+                                     float* __restrict__ dst, long long dstride, int dpitch, int dr0, int dc0, int nr,
+                                     int nc, const int* planes) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y, k = planes ? planes[blockIdx.z] : blockIdx.z;
+    if (c >= nc || r >= nr) return;
+    dst[k * dstride + (long long)(dr0 + r) * dpitch + dc0 + c] = src[k * sstride + (long long)(sr0 + r) * spitch + sc0 + c];
+}
+
+void launchCopyBlock(const float* src, long long sstride, int spitch, int sr0, int sc0, float* dst, long long dstride,
+                     int dpitch, int dr0, int dc0, int nr, int nc, int nplanes, const int* planesDev, hipStream_t stream) {
+    if (nr <= 0 || nc <= 0) return;
+    hipLaunchKernelGGL(pv_copy_block_kernel, dim3((unsigned)((nc + 255) / 256), (unsigned)nr, (unsigned)nplanes), dim3(256),
+                       0, stream, src, sstride, spitch, sr0, sc0, dst, dstride, dpitch, dr0, dc0, nr, nc, planesDev);
+}
+
+// far cells of the whole map (delay = FLT_MAX, default listener direction): the first analysis launch
+void launchFarCells(const AnalyzeArgs& a, hipStream_t stream) {
+    const int n = a.gx * a.gy;
+    hipLaunchKernelGGL(pv_far_cells_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a);
+}
+
+// onset, dry gain, source directivity, lowpass, wet gain, decay time of the window's cells (everything but the listener
+// direction, which needs the delay / occlusion maps of the WHOLE window: launchAnalysisDirection)
+void launchAnalysisCells(const AnalyzeArgs& a, hipStream_t stream) {
+    const dim3 grid = analysisWindowGrid(a);
+    hipLaunchKernelGGL(pv_encode_kernel, grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(pv_rt60_wave_kernel, dim3((a.winCols + 15) / 16, a.winRows), dim3(256), 0, stream, a);
+}
+
+void launchAnalysisDirection(const AnalyzeArgs& a, hipStream_t stream) {
+    const dim3 grid = analysisWindowGrid(a);
+    if (a.dirJump)
+        launchDirectionJump(a, a.dirScratch, stream);
+    else
+        hipLaunchKernelGGL(pv_direction_kernel, grid, dim3(256), 0, stream, a);
 }
 
 void launchAnalysis(const AnalyzeArgs& a, hipStream_t stream) {
@@ -2839,12 +2903,14 @@ __global__ void pv_ir_kernel(const AnalyzeArgs a, int X, int Y, float* out) {
     const uint32_t code = a.codes[(size_t)prow * a.pitch + pcol];
     const float kx = a.lut[code & 0xffu], ky = a.lut[code >> 8];
     const bool airX = kx != kx, airY = ky != ky;
+    const bool above = X == 0 && a.histAbove;  // first row of a slab: the row above lives in the neighbouring slab
     float vx = 0.f, vy = 0.f;
     for (int t = 0; t < a.T; ++t) {
         float p = 0.f;
         if (t >= tFirst) {
             p = a.hist[(long long)t * a.histPlane + hoff];
-            const float pxn = (t >= tFx) ? a.hist[(long long)t * a.histPlane + hoff - a.histPitch] : 0.f;
+            const float pxn = above ? a.histAbove[(long long)t * a.histPitch + (pcol - dyn.histCol0)]
+                                    : (t >= tFx) ? a.hist[(long long)t * a.histPlane + hoff - a.histPitch] : 0.f;
             const float pyn = (t >= tFy) ? a.hist[(long long)t * a.histPlane + hoff - 1] : 0.f;
             const float ax = vx - a.courant * (p - pxn), wx = kx * (p + pxn);
             const float ay = vy - a.courant * (p - pyn), wy = ky * (p + pyn);

@@ -37,6 +37,13 @@ void launchBeginRun(const BeginArgs& a, hipStream_t stream);
 void launchCodes(const uint8_t* mat, uint16_t* codes, const Geometry& g, hipStream_t stream);
 void launchLaneSelfTest(float* out128, hipStream_t stream);
 void launchAnalysis(const AnalyzeArgs& a, hipStream_t stream);
+// the three phases of launchAnalysis separately (slab groups run the middle one per slab, the others on the whole map)
+void launchFarCells(const AnalyzeArgs& a, hipStream_t stream);
+void launchAnalysisCells(const AnalyzeArgs& a, hipStream_t stream);
+void launchAnalysisDirection(const AnalyzeArgs& a, hipStream_t stream);
+void launchHistRow(const AnalyzeArgs& a, int X, float* outTxPitch, hipStream_t stream);
+void launchCopyBlock(const float* src, long long sstride, int spitch, int sr0, int sc0, float* dst, long long dstride,
+                     int dpitch, int dr0, int dc0, int nr, int nc, int nplanes, const int* planesDev, hipStream_t stream);
 void launchGatherQueries(const float* res, long long n, const long long* cellsHost, int nq, float* outHost,
                          hipStream_t stream);  // nq <= 64
 void launchGatherOutput(const float* res, long long n, long long cell, float* out8Host, hipStream_t stream);

@@ -1,0 +1,96 @@
+// pv_slabs.h -- ONE grid split into row slabs (single-grid domain decomposition).
+//
+// The reference has no counterpart: its one loop advances the whole grid (Context/PvContext.cpp:63-94).  Here a grid
+// of ntx tile rows is cut into S slabs of whole tile rows; slab s is a Solver that allocates planes, history and
+// result maps for ITS rows only (HBM per device falls with 1/S) and runs the unchanged step kernels on them.  What
+// couples the slabs:
+//   * per K-step launch: the K rows of pr, vx, vy next to a slab boundary travel into the neighbour's guard band
+//     (3 contiguous blocks of K x pitch floats each way; same device: a copy on the receiver's stream, other device:
+//     a peer copy over xGMI) -- ordered by one event per slab and launch, nothing ever waits for the whole grid;
+//   * per run: the pressure history of each slab's LAST row goes to the slab below (the analysis re-derives vx from the
+//     pressure history, and vx of a slab's first row needs the row above): T x histPitch floats;
+//   * per run: every slab analyses its own cells (onset, gains, decay time, source directivity); the window block of
+//     those maps is gathered into whole-grid maps on the first slab's device, where the listener-direction descent --
+//     a walk over the delay / occlusion maps that crosses slab boundaries -- runs once for the whole window.
+// Results are bit-identical to one Solver on the whole grid (tests/test_gpu_slabs.py).
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "pv_solver.h"
+
+namespace pva {
+
+class SlabGroup {
+public:
+    // devices[s] = HIP device of slab s (all equal: S slabs on one GPU)
+    static SlabGroup* create(const GridSpec& spec, const std::vector<int>& devices, const SolverOptions& opt,
+                             std::string* err);
+    ~SlabGroup();
+
+    const GridSpec& spec() const { return g_; }
+    int numSlabs() const { return (int)slabs_.size(); }
+    const Solver* slab(int s) const { return slabs_[(size_t)s]; }
+    int slabRow0(int s) const { return slabs_[(size_t)s]->x0_; }
+    int slabRows(int s) const { return slabs_[(size_t)s]->lNX_; }
+    float efree() const { return efree_; }
+    int T() const { return T_; }
+    long long deviceBytes() const;
+    const std::string& lastError() const { return err_; }
+    const SolverTimings& timings() const { return tim_; }
+    // bytes of pr / vx / vy halo rows moved between slabs per launch, and of boundary history + result blocks per run
+    long long haloBytesPerLaunch() const;
+    long long exchangeBytesPerRun() const { return exchangePerRun_; }
+
+    int addBox(const Box& b);
+    bool updateBox(int id, const Box& b);
+    bool removeBox(int id);
+    int numBoxes() const { return slabs_[0]->numBoxes(); }
+
+    bool run(float lx, float ly, float lz);
+    bool getOutput(float ex, float ey, float ez, float out8[8], bool* valid);
+    bool copyResults(float* res8, float* delay);
+    bool copyFields(float* pr, float* vx, float* vy);
+    bool copyHistoryPlane(int t, float* pr);
+    bool impulseResponse(int cx, int cy, float* out3T);
+    bool copyMaterial(uint8_t* beta, float* R) { return slabs_[0]->copyMaterial(beta, R); }
+    bool copyPulse(float* out) { return slabs_[0]->copyPulse(out); }
+
+private:
+    SlabGroup() = default;
+    bool init(const GridSpec& spec, const std::vector<int>& devices, const SolverOptions& opt);
+    bool fail(const std::string& what);
+    bool hipOk(hipError_t e, const char* what);
+    bool slabFailed(int s);
+    AnalyzeArgs rootArgs(float lx, float lz) const;
+
+    GridSpec g_;
+    std::vector<Solver*> slabs_;
+    std::vector<int> devices_;
+    std::vector<hipEvent_t> stepEv_;   // 2 per slab (launch parity)
+    std::vector<hipEvent_t> miscEv_;   // 1 per slab: boundary history ready / cell analysis done
+    int K_ = 0, rxi_ = 0, wi_ = 0, T_ = 0;
+    float efree_ = 0.f;
+    std::string err_;
+    SolverTimings tim_;
+    long long exchangePerRun_ = 0;
+
+    // whole-grid maps on devices_[0]
+    int rootDevice_ = 0;
+    hipStream_t rootStream_ = nullptr;
+    hipEvent_t rootEv_[3] = {nullptr, nullptr, nullptr};
+    float* res_ = nullptr;    // 8 planes x gx*gy
+    float* res8_ = nullptr;   // AoS, on demand
+    float* delay_ = nullptr;  // gx*gy
+    int* dirScratch_ = nullptr;
+    int* planesDev_ = nullptr;  // {0, 1, 2, 3, 6, 7}: everything a slab computes (the direction is the root's)
+    DynParams* dynDev_ = nullptr;
+    DynParams* dynHost_ = nullptr;  // pinned
+    float* outHost_ = nullptr;      // pinned, 8 floats
+    int winRows_ = 0, winCols_ = 0;
+    float lastLx_ = 0, lastLz_ = 0;
+    bool ran_ = false;
+};
+
+}  // namespace pva

@@ -101,15 +101,35 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     wi_ = 64 - 2 * K_;
     T_ = opt.numSteps > 0 ? opt.numSteps : g_.T;
 
-    geo_.gx = g_.gx;
+    ntxG_ = ceilDiv(g_.NX, rxi_);
+    if (opt_.slabCount < 1 || opt_.slabIndex < 0 || opt_.slabIndex >= opt_.slabCount) return fail("invalid slab spec");
+    if (isSlab()) {
+        if (opt_.slabCount > ntxG_ / 2) return fail("too many slabs: every slab needs at least two tile rows");
+        if (opt_.streaming || opt_.streamRows > 0 || opt_.edgeTiles || stepConfigStacked(K_, rxi_) || opt_.merged != 1 ||
+            !mergedConfigOk(K_, rxi_))
+            return fail("slabs need the default merged step kernel (no streaming analysis, stacked or edge tiles)");
+        opt_.rowBands = 1;
+        opt_.useGraph = 2;
+        opt_.smallGrid = 2;
+        opt_.withFreeGrid = false;  // the group computes EFree once
+    }
+    tileRow0_ = (int)((long long)ntxG_ * opt_.slabIndex / opt_.slabCount);
+    const int tileRow1 = (int)((long long)ntxG_ * (opt_.slabIndex + 1) / opt_.slabCount);
+    x0_ = tileRow0_ * rxi_;
+    lNX_ = std::min(tileRow1 * rxi_, g_.NX) - x0_;
+    lgx_ = std::max(0, std::min(tileRow1 * rxi_, g_.gx) - x0_);
+    geo_.gx = lgx_;
     geo_.gy = g_.gy;
-    geo_.NX = g_.NX;
+    geo_.NX = lNX_;
     geo_.NY = g_.NY;
+    geo_.x0 = x0_;
+    geo_.NXg = g_.NX;
+    geo_.gxg = g_.gx;
     const int kGuard = std::max(kMinGuard, K_ + stepConfigExtraRows(K_, rxi_));
     geo_.G = kGuard;
     geo_.rxi = rxi_;
     geo_.wi = wi_;
-    geo_.ntx = ceilDiv(g_.NX, rxi_);
+    geo_.ntx = tileRow1 - tileRow0_;
     geo_.nty = ceilDiv(g_.NY, wi_);
     geo_.rows = kGuard + geo_.ntx * rxi_ + kGuard;
     geo_.pitch = roundUp(kGuard + geo_.nty * wi_ + kGuard, 64);
@@ -150,9 +170,9 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     if (!dalloc(&dynDev_, 1, true)) return false;
     if (!dalloc(&errFlag_, 1, true)) return false;
     if (!dalloc(&activeCount_, 1, true)) return false;
-    if (!dalloc(&res_, (size_t)g_.gx * g_.gy * 8, true)) return false;  // zeroed pool: PvContext.cpp:132
-    if (!dalloc(&delay_, (size_t)g_.gx * g_.gy, true)) return false;
-    scratchCount_ = std::max<size_t>({(size_t)3 * std::max(T_, g_.T), (size_t)g_.NX * g_.NY * 3,
+    if (!dalloc(&res_, (size_t)std::max(lgx_, 1) * g_.gy * 8, true)) return false;  // zeroed pool: PvContext.cpp:132
+    if (!dalloc(&delay_, (size_t)std::max(lgx_, 1) * g_.gy, true)) return false;
+    scratchCount_ = std::max<size_t>({(size_t)3 * std::max(T_, g_.T), (size_t)lNX_ * g_.NY * 3,
                                      (size_t)geo_.ntx * rxi_ * geo_.nty * wi_});  // the last: direction scratch
     if (!dalloc(&scratch_, scratchCount_, true)) return false;
 
@@ -162,8 +182,10 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         // + K: a tile counts as active as soon as its K-cell halo is touched
         const int reach = T_ + 2 + K_;
         int wtx = geo_.ntx, wty = geo_.nty;
+        histTilesXG_ = ntxG_;
         if (!opt.denseHistory && !opt.streaming) {
-            wtx = std::min(geo_.ntx, ceilDiv(2 * reach + 1, rxi_) + 1);
+            histTilesXG_ = std::min(ntxG_, ceilDiv(2 * reach + 1, rxi_) + 1);
+            wtx = std::min(geo_.ntx, histTilesXG_);  // (a slab records its part of the whole grid's window)
             wty = std::min(geo_.nty, ceilDiv(2 * reach + 1, wi_) + 1);
         }
         histTilesX_ = wtx;
@@ -183,6 +205,10 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
                         "(PVA_OPT_STREAMING_ANALYSIS + PvAmdSetEmitters), which keeps a 64-step ring instead");
         if (!hipOk(hipMalloc((void**)&hist_, (size_t)bytes), "hipMalloc history")) return false;
         deviceBytes_ += bytes;
+        if (isSlab()) {
+            if (opt_.slabIndex > 0 && !dalloc(&histAbove_, (size_t)T_ * histPitch_, true)) return false;
+            if (opt_.slabIndex + 1 < opt_.slabCount && !dalloc(&histEdge_, (size_t)T_ * histPitch_, true)) return false;
+        }
     }
 
     if (opt.streaming) {
@@ -266,7 +292,8 @@ Solver::~Solver() {
     if (emCells_) hipFree(emCells_);
     if (emTrace_) hipFree(emTrace_);
     void* ptrs[] = {codes_,     matDev_, lutDev_, pulseDev_, hist_,  tileFirst_, tileClass_, generalList_,
-                    generalCount_, dynDev_, errFlag_, res8_,     delay_, scratch_, res_, activeCount_, win8_};
+                    generalCount_, dynDev_, errFlag_, res8_,     delay_, scratch_, res_, activeCount_, win8_,
+                    histAbove_, histEdge_};
     for (void* p : ptrs)
         if (p) hipFree(p);
     for (size_t b = 1; b < bandStream_.size(); ++b)
@@ -499,19 +526,29 @@ bool Solver::computeEfree() {
 // run
 // ----------------------------------------------------------------------------------------------------------------
 
+// first tile row of the WHOLE grid's history window for a listener in cell row lcx
+int Solver::globalWindowTileRow0(int lcx) const {
+    const int reach = T_ + 2 + K_;
+    if (histTilesXG_ >= ntxG_) return 0;
+    return std::min(std::max(floorDiv(std::min(std::max(lcx, 0), g_.gx) - reach, rxi_), 0), ntxG_ - histTilesXG_);
+}
+
 bool Solver::prepareDyn(int lcx, int lcy, bool withPulse, bool banded) {
     bandedRun_ = banded && nb_ > 1;
     DynParams d{};
     const bool inside = withPulse && lcx >= 0 && lcx <= g_.gx && lcy >= 0 && lcy <= g_.gy;
-    d.lrow = inside ? lcx + geo_.G : -100000;
+    d.lrow = inside ? lcx - x0_ + geo_.G : -100000;  // (a slab: possibly far outside its own rows)
     d.lcol = inside ? lcy + geo_.G : -100000;
     // history window in tiles, centred on the listener and clamped to the grid
     // first window tile = the tile holding the lowest reachable row / column (init() sized the window so that
     // histTiles * tile >= 2*reach + tile, i.e. it then also covers listener + reach), clamped into the grid
     int tx0 = 0, ty0 = 0;
     const int reach = T_ + 2 + K_;
-    if (histTilesX_ < geo_.ntx)
-        tx0 = std::min(std::max(floorDiv(std::min(std::max(lcx, 0), g_.gx) - reach, rxi_), 0), geo_.ntx - histTilesX_);
+    {
+        // the WHOLE grid's window first; this solver records its part of it (a slab's own rows always hold everything
+        // of the window that falls into the slab: init() gave it min(own tile rows, window tile rows) planes)
+        tx0 = std::min(std::max(globalWindowTileRow0(lcx) - tileRow0_, 0), geo_.ntx - histTilesX_);
+    }
     if (histTilesY_ < geo_.nty)
         ty0 = std::min(std::max(floorDiv(std::min(std::max(lcy, 0), g_.gy) - reach, wi_), 0), geo_.nty - histTilesY_);
     d.histTileX0 = tx0;
@@ -799,14 +836,16 @@ AnalyzeArgs Solver::analyzeArgs(float lx, float lz) const {
     a.tileFirst = tileFirst_;
     a.dyn = dynDev_;
     a.out = res_;
-    a.resN = (long long)g_.gx * g_.gy;
+    a.resN = (long long)std::max(lgx_, 1) * g_.gy;
     a.delay = delay_;
     a.histPlane = histPlane_;
     a.histPitch = histPitch_;
     a.pitch = geo_.pitch;
     a.G = geo_.G;
-    a.gx = g_.gx;
+    a.gx = lgx_;
     a.gy = g_.gy;
+    a.x0 = x0_;
+    a.histAbove = histAbove_;
     a.rxi = rxi_;
     a.wi = wi_;
     a.nty = geo_.nty;
@@ -1267,7 +1306,7 @@ bool Solver::setEmitters(const float* xyz, int n) {
 
 bool Solver::impulseResponse(int cx, int cy, float* out3T) {
     if (opt_.streaming) return fail("the full pressure history is not kept in streaming-analysis mode");
-    if (cx < 0 || cx > g_.gx || cy < 0 || cy > g_.gy) return fail("cell outside the grid");
+    if (cx < 0 || cx >= lNX_ || cy < 0 || cy > g_.gy) return fail("cell outside the grid");
     if (!dynValid_) return fail("no simulation has run yet");
     if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
     launchIr(analyzeArgs(lastLx_, lastLz_), cx, cy, scratch_, stream_);
@@ -1284,7 +1323,7 @@ bool Solver::impulseResponseCells(int cx, int cy, void* out16T) {
         short b, by;
     };
     static_assert(sizeof(RefCell) == 16, "PvTypes.h:106-121");
-    const size_t i = (size_t)cx * g_.NY + cy;
+    const size_t i = (size_t)(cx + x0_) * g_.NY + cy;
     const short b = (short)(matHost_[i] & 1), by = (short)byHost_[i];
     RefCell* out = static_cast<RefCell*>(out16T);
     for (int t = 0; t < T_; ++t) out[t] = RefCell{f[(size_t)3 * t], f[(size_t)3 * t + 1], f[(size_t)3 * t + 2], b, by};
@@ -1293,7 +1332,7 @@ bool Solver::impulseResponseCells(int cx, int cy, void* out16T) {
 
 bool Solver::copyFields(float* pr, float* vx, float* vy) {
     if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
-    const size_t n = (size_t)g_.NX * g_.NY;
+    const size_t n = (size_t)lNX_ * g_.NY;  // (a slab: its own rows)
     const float* src[3] = {pr_[cur_], vx_[cur_], vy_[cur_]};
     float* dst[3] = {pr, vx, vy};
     for (int i = 0; i < 3; ++i) {
@@ -1306,6 +1345,7 @@ bool Solver::copyFields(float* pr, float* vx, float* vy) {
 }
 
 bool Solver::setFields(const float* pr, const float* vx, const float* vy) {
+    if (isSlab()) return fail("setFields is not available on a slab");
     if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
     const size_t n = (size_t)g_.NX * g_.NY;
     const float* src[3] = {pr, vx, vy};
@@ -1326,8 +1366,8 @@ bool Solver::copyHistoryPlane(int t, float* pr) {
     if (t < 0 || t >= T_) return fail("step outside the recorded range");
     if (!dynValid_) return fail("no simulation has run yet");
     if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
-    launchHistPlane(analyzeArgs(lastLx_, lastLz_), t, scratch_, g_.NX, g_.NY, histRows_, stream_);
-    if (!hipOk(hipMemcpyAsync(pr, scratch_, (size_t)g_.NX * g_.NY * 4, hipMemcpyDeviceToHost, stream_), "plane copy"))
+    launchHistPlane(analyzeArgs(lastLx_, lastLz_), t, scratch_, lNX_, g_.NY, histRows_, stream_);
+    if (!hipOk(hipMemcpyAsync(pr, scratch_, (size_t)lNX_ * g_.NY * 4, hipMemcpyDeviceToHost, stream_), "plane copy"))
         return false;
     return hipOk(hipStreamSynchronize(stream_), "plane sync");
 }

@@ -35,6 +35,11 @@ struct SolverOptions {
                              // batched kernel has that arm, so every run of such a solver goes through it
     int smallGrid = 0;    // 0 = auto: grids that fit one CU's LDS run in the whole-grid-resident kernel; 2 = never
     int timeKernels = 0;  // N > 0: HIP events around every Nth step-kernel launch (bench / roofline)
+    // Row slab of a larger grid (single-grid domain decomposition, pv_slabs.h): this solver owns the tile rows
+    // [ntx * slabIndex / slabCount, ntx * (slabIndex + 1) / slabCount) of the grid, allocates planes for those rows only
+    // and keeps the K rows its neighbours own next to them current in its guard band (SlabGroup exchanges them after
+    // every launch).  slabCount = 1: a whole grid.
+    int slabIndex = 0, slabCount = 1;
     int rowBands = 0;     // B > 1: each sweep = B launches (bands of tile rows, one stream each) with 3-point
                           // dependencies between consecutive sweeps; 0 = auto, 1 = off
 };
@@ -47,7 +52,11 @@ struct SolverTimings {
     int stepLaunches = 0;
 };
 
+class SlabGroup;
+
 class Solver {
+    friend class SlabGroup;
+
 public:
     static Solver* create(const GridSpec& spec, int device, const SolverOptions& opt, std::string* err);
     ~Solver();
@@ -135,7 +144,17 @@ private:
     template <typename Tp>
     bool dalloc(Tp** p, size_t count, bool zero);
 
-    GridSpec g_;
+    GridSpec g_;         // always the WHOLE grid
+    // what this solver owns of it (a whole grid: x0_ = 0, lNX_ = g_.NX, lgx_ = g_.gx)
+    int x0_ = 0;         // first cell-array row
+    int tileRow0_ = 0;   // = x0_ / rxi_
+    int lNX_ = 0;        // cell-array rows owned (the last slab also owns the ghost row)
+    int lgx_ = 0;        // result-map rows owned
+    int ntxG_ = 0, histTilesXG_ = 0;  // the whole grid's tile rows / history-window tile rows
+    bool isSlab() const { return opt_.slabCount > 1; }
+    int globalWindowTileRow0(int lcx) const;
+    float* histAbove_ = nullptr;  // [T][histPitch]: pressure history of the row above this slab (from the neighbour)
+    float* histEdge_ = nullptr;   // [T][histPitch]: this slab's last row, for the neighbour below
     Geometry geo_{};
     SolverOptions opt_;
     int device_ = 0;
