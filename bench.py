@@ -249,8 +249,28 @@ def main():
                 start_group(w, g)
             for sv in solvers:
                 sv.sync()
-    if use_dist:  # first use of the all-gather sets up RCCL's channels: not part of the timed steps
-        pvd.gather_outputs({run_id(0, b): np.zeros((2, 8), np.float32) for b in range(B)}, B * world, dist, dev)
+    # The one collective of the data path: the C++ side's own RCCL communicator (PvAmdComm: ncclCommInitRank /
+    # ncclAllGather inside libplaneverb_amd.so; torch.distributed only carries the 128-byte id to the ranks).  Should
+    # RCCL not bind there, torch.distributed's all_gather does the same job and the JSON line says so.
+    comm, gather_how = None, "single process: no collective"
+    if use_dist:
+        try:
+            comm = pvd.make_comm(dist, local_rank)
+            gather_how = "ncclAllGather in libplaneverb_amd.so (PvAmdCommAllGather), id bootstrapped over torch.distributed"
+        except Exception as e:  # noqa: BLE001
+            gather_how = "torch.distributed.all_gather_into_tensor (C++ RCCL communicator unavailable: %s)" % e
+        ok = torch.tensor([1 if comm is not None else 0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and comm is not None:  # all ranks or none
+            comm.close()
+            comm = None
+            gather_how = "torch.distributed.all_gather_into_tensor (C++ RCCL communicator failed on another rank)"
+        # first use sets up RCCL's channels: not part of the timed steps
+        warm = {run_id(0, b): np.zeros((2, 8), np.float32) for b in range(B)}
+        if comm is not None:
+            pvd.gather_outputs_native(warm, B * world, comm)
+        else:
+            pvd.gather_outputs(warm, B * world, dist, dev)
     n_runs = args.steps * B * world
     local = {}
     fdtd_ms, ana_ms, air_ms, gen_ms, loop_ms = [], [], [], [], []
@@ -281,7 +301,10 @@ def main():
     for b in range(B):
         if pending[b] is not None:
             collect(b)
-    gathered = pvd.gather_outputs(local, n_runs, dist if use_dist else None, dev)  # the one RCCL gather
+    if comm is not None:
+        gathered = pvd.gather_outputs_native(local, n_runs, comm)  # the one RCCL gather, in C++
+    else:
+        gathered = pvd.gather_outputs(local, n_runs, dist if use_dist else None, dev)
     sync()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -345,7 +368,7 @@ def main():
                        "grid": [s.gx, s.gy], "T": T, "res": 275, "mode": "A", "steps_per_launch": K,
                        "tile": [info.tileRows, info.tileCols], "dense_history": bool(args.dense_history),
                        "runs_in_flight_per_gpu": B, "runs_per_batched_launch": NB,
-                       "parallelism": "runs sharded round-robin, 1 all-gather of outputs"},
+                       "parallelism": "runs sharded round-robin, 1 all-gather of outputs", "gather": gather_how},
             "fdtd_cell_updates_per_s": world * B * cells * T / fd,
             "impulse_responses_per_s": world * B * s.gx * s.gy * args.steps / elapsed,
             "fdtd_ms": fd * 1e3, "analysis_ms": float(np.mean(ana_ms)),
@@ -365,13 +388,13 @@ def main():
                                  "overlap, each lasting launch_ms; single_run = the same kernel with one run in "
                                  "flight"},
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
-        else:
-            out["cpu_baseline"] = None
+        # rank 0 only, after the timed region (the other ranks wait at the final barrier)
+        out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline()
         line = json.dumps(out)
     for sv in solvers:
         sv.close()
+    if comm is not None:
+        comm.close()
     if use_dist:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()

@@ -242,6 +242,33 @@ PVA_EXPORT int PvAmdSetFields(PvAmdSolver* s, const float* pr, const float* vx, 
  * linearity / equivalence property tests). */
 PVA_EXPORT int PvAmdRunSteps(PvAmdSolver* s, int nsteps, int withPulse, float lx, float lz);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Part 3 -- independent runs sharded over the GPUs of one node, C++ host side
+ * A "run" = one listener position on one scene (one iteration of the reference's loop, PvContext.cpp:74-93).  Runs share
+ * nothing: run k belongs to rank k mod world (a rank = one process, normally one GPU); inside a rank the runs go round-
+ * robin over the rank's solvers, kept busy through their own HIP streams.  The only exchange is ONE all-gather of the
+ * per-emitter records, RCCL (ncclAllGather over xGMI) when the ranks span processes.  RCCL is bound at run time
+ * (dlopen): a single-GPU user of this library needs no RCCL.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* the plan itself (no device needed): fills runIdx[i] / solverIdx[i] for this rank's i-th run, returns their number
+ * (<= cap entries written) */
+PVA_EXPORT int PvAmdShardPlan(int nRuns, int world, int rank, int nLocalSolvers, int* runIdx, int* solverIdx, int cap);
+typedef struct PvAmdComm PvAmdComm;
+/* rank 0 creates the 128-byte id (ncclGetUniqueId) and hands it to every rank by whatever bootstrap the host has
+ * (a file, MPI, torch.distributed's store); every rank then joins (ncclCommInitRank) with its HIP device */
+PVA_EXPORT int PvAmdCommUniqueId(char id128[128]);
+PVA_EXPORT PvAmdComm* PvAmdCommCreate(const char id128[128], int rank, int world, int device);
+PVA_EXPORT void PvAmdCommDestroy(PvAmdComm* c);
+/* every rank contributes countPerRank floats; all = world * countPerRank floats, rank-major, on every rank */
+PVA_EXPORT int PvAmdCommAllGather(PvAmdComm* c, const float* mine, int countPerRank, float* all);
+/* Simulate nRuns listener positions (listenersXYZ[3k..]) with emittersPerRun emitter positions each
+ * (emittersXYZ[(k*emittersPerRun + e)*3 ..]) on this rank's `solvers` (identically configured, scenes loaded by the
+ * caller; two per GPU keep two runs in flight) and gather all records: out[k*emittersPerRun + e] on every
+ * rank.  world == 1: comm may be NULL.  Returns 0, or -1 with PvAmdLastError. */
+PVA_EXPORT int PvAmdRunSharded(PvAmdSolver* const* solvers, int nSolvers, const float* listenersXYZ, int nRuns,
+                               const float* emittersXYZ, int emittersPerRun, int rank, int world, PvAmdComm* comm,
+                               PlaneverbOutput* out);
+
 /* Host-side pieces of the path that need no device (grid arithmetic, pulse table, rasteriser, .pv parser); the
  * solver uses exactly these internally.  Exposed so that they can be checked without a GPU. */
 /* Grid.cpp:390-396,46-55: fills gx, gy, T, fs, res, dx, dt (other fields 0) */

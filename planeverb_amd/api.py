@@ -134,6 +134,13 @@ SYMBOLS = {
     "PvAmdCopyMaterial": (C.c_int, [_vp, C.POINTER(C.c_ubyte), _fp]),
     "PvAmdSetFields": (C.c_int, [_vp, _fp, _fp, _fp]),
     "PvAmdRunSteps": (C.c_int, [_vp, C.c_int, C.c_int, C.c_float, C.c_float]),
+    "PvAmdShardPlan": (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
+    "PvAmdCommUniqueId": (C.c_int, [C.c_char_p]),
+    "PvAmdCommCreate": (_vp, [C.c_char_p, C.c_int, C.c_int, C.c_int]),
+    "PvAmdCommDestroy": (None, [_vp]),
+    "PvAmdCommAllGather": (C.c_int, [_vp, _fp, C.c_int, _fp]),
+    "PvAmdRunSharded": (C.c_int, [C.POINTER(_vp), C.c_int, _fp, C.c_int, _fp, C.c_int, C.c_int, C.c_int, _vp,
+                                  C.POINTER(PlaneverbOutput)]),
     "PvAmdReverbBusGains": (None, [C.c_float, C.c_float, _fp, _fp, _fp]),
     "PvAmdHostGridInfo": (C.c_int, [C.c_float, C.c_float, C.c_int, C.POINTER(PvAmdInfo)]),
     "PvAmdHostPulse": (C.c_int, [C.c_float, C.c_float, C.c_int, _fp]),
@@ -343,6 +350,60 @@ def batch_solver_options(n):
     if n <= 1536:
         return dict(steps_per_launch=10, tile_rows=36, edge_tiles=1)
     return dict(steps_per_launch=12, tile_rows=36, edge_tiles=1)
+
+
+def shard_plan(n_runs, world, rank, n_local_solvers):
+    """PvAmdShardPlan: [(run index, local solver index), ...] of this rank (run k -> rank k mod world)"""
+    cap = max(1, (n_runs + max(world, 1) - 1) // max(world, 1))
+    r, s = (C.c_int * cap)(), (C.c_int * cap)()
+    n = lib().PvAmdShardPlan(int(n_runs), int(world), int(rank), int(n_local_solvers), r, s, cap)
+    return [(r[i], s[i]) for i in range(min(n, cap))]
+
+
+class Comm:
+    """RCCL communicator of the sharded runs (PvAmdComm*): one per process, bound to the process's HIP device"""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        _check(lib().PvAmdCommUniqueId(buf))
+        return buf.raw
+
+    def __init__(self, unique_id, rank, world, device):
+        assert len(unique_id) == 128
+        self._h = lib().PvAmdCommCreate(unique_id, int(rank), int(world), int(device))
+        if not self._h:
+            raise PlaneverbError(last_error())
+        self.rank, self.world = rank, world
+
+    def all_gather(self, mine):
+        mine = np.ascontiguousarray(mine, np.float32).ravel()
+        out = np.empty(self.world * mine.size, np.float32)
+        _check(lib().PvAmdCommAllGather(self._h, _f(mine), mine.size, _f(out)))
+        return out.reshape(self.world, -1)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().PvAmdCommDestroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def run_sharded(solvers, listeners, emitters, rank=0, world=1, comm=None):
+    """PvAmdRunSharded: listeners [n, 3], emitters [n, E, 3] -> float32 [n, E, 8] on every rank"""
+    L = np.ascontiguousarray(listeners, np.float32).reshape(-1, 3)
+    Em = np.ascontiguousarray(emitters, np.float32).reshape(len(L), -1, 3)
+    n, E = len(L), Em.shape[1]
+    hs = (_vp * len(solvers))(*[sv._h for sv in solvers])
+    out = (PlaneverbOutput * max(1, n * E))()
+    _check(lib().PvAmdRunSharded(hs, len(solvers), _f(L), n, _f(Em), E, int(rank), int(world),
+                                 comm._h if comm is not None else None, out))
+    return np.frombuffer(out, np.float32).reshape(-1, 8)[:n * E].reshape(n, E, 8).copy()
 
 
 def run_batch(solvers, listeners, wait=True):

@@ -8,6 +8,7 @@
 #include "pv_context.h"
 #include "pv_core.h"
 #ifndef PVA_HOST_TEST  // (tests/host/: HIP-less sanitizer build of the live module against a fake Solver)
+#include "pv_shard.h"
 #include "pv_slabs.h"
 #include "pv_solver.h"
 #endif
@@ -503,6 +504,108 @@ int PvAmdSetFields(PvAmdSolver* h, const float* pr, const float* vx, const float
 int PvAmdRunSteps(PvAmdSolver* h, int nsteps, int withPulse, float lx, float lz) {
     if (!ensure(h)) return -1;
     return ret(h, h->s->runSteps(nsteps, withPulse != 0, lx, lz));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Part 3: sharded runs + RCCL gather
+// ---------------------------------------------------------------------------------------------------------------
+
+struct PvAmdComm {
+    Comm* c = nullptr;
+};
+
+int PvAmdShardPlan(int nRuns, int world, int rank, int nLocalSolvers, int* runIdx, int* solverIdx, int cap) {
+    const std::vector<ShardItem> plan = shardPlan(nRuns, world, rank, nLocalSolvers);
+    for (int i = 0; i < (int)plan.size() && i < cap; ++i) {
+        if (runIdx) runIdx[i] = plan[(size_t)i].run;
+        if (solverIdx) solverIdx[i] = plan[(size_t)i].solver;
+    }
+    return (int)plan.size();
+}
+
+int PvAmdCommUniqueId(char id128[128]) {
+    if (!id128) return -1;
+    return Comm::uniqueId(id128, &g_lastError) ? 0 : -1;
+}
+
+PvAmdComm* PvAmdCommCreate(const char id128[128], int rank, int world, int device) {
+    if (!id128) return nullptr;
+    Comm* c = Comm::create(id128, rank, world, device, &g_lastError);
+    if (!c) return nullptr;
+    PvAmdComm* h = new PvAmdComm();
+    h->c = c;
+    return h;
+}
+
+void PvAmdCommDestroy(PvAmdComm* h) {
+    if (!h) return;
+    delete h->c;
+    delete h;
+}
+
+int PvAmdCommAllGather(PvAmdComm* h, const float* mine, int countPerRank, float* all) {
+    if (!h || !h->c || !mine || !all) return -1;
+    return h->c->allGather(mine, countPerRank, all, &g_lastError) ? 0 : -1;
+}
+
+int PvAmdRunSharded(PvAmdSolver* const* hs, int nSolvers, const float* listenersXYZ, int nRuns, const float* emittersXYZ,
+                    int E, int rank, int world, PvAmdComm* comm, PlaneverbOutput* out) {
+    if (!hs || nSolvers < 1 || !listenersXYZ || nRuns < 0 || (E > 0 && !emittersXYZ) || E < 0 || E > Solver::kMaxQueries ||
+        !out || world < 1 || rank < 0 || rank >= world) {
+        g_lastError = "PvAmdRunSharded: invalid arguments";
+        return -1;
+    }
+    if (world > 1 && (!comm || !comm->c || comm->c->world() != world || comm->c->rank() != rank)) {
+        g_lastError = "PvAmdRunSharded: ranks span processes, a matching PvAmdComm is required";
+        return -1;
+    }
+    std::vector<Solver*> sv;
+    for (int i = 0; i < nSolvers; ++i) {
+        if (!ensure(hs[i])) return -1;
+        sv.push_back(hs[i]->s);
+    }
+    const std::vector<ShardItem> plan = shardPlan(nRuns, world, rank, nSolvers);
+    const int perRank = (nRuns + world - 1) / world;
+    const size_t rec = (size_t)E * 8;
+    std::vector<float> mine((size_t)perRank * rec, 0.f);
+    std::vector<int> pending((size_t)nSolvers, -1);
+    auto collect = [&](int s) -> bool {  // wait for solver s's run, take its records (gathered behind the analysis)
+        const int j = pending[(size_t)s];
+        pending[(size_t)s] = -1;
+        float v[Solver::kMaxQueries * 8];
+        unsigned char valid[Solver::kMaxQueries];
+        if (!sv[(size_t)s]->sync() || !sv[(size_t)s]->queriedOutputs(v, valid, E)) return false;
+        for (int e = 0; e < E; ++e) {
+            float* dst = mine.data() + (size_t)j * rec + (size_t)e * 8;
+            if (valid[e]) {
+                std::memcpy(dst, v + 8 * e, 32);
+            } else {  // the reference's sentinel for a position outside the grid (FDTD.cpp:19-47)
+                std::memset(dst, 0, 32);
+                dst[0] = kInvalidDryGain;
+            }
+        }
+        return true;
+    };
+    for (size_t j = 0; j < plan.size(); ++j) {
+        const int s = plan[j].solver, k = plan[j].run;
+        if (pending[(size_t)s] >= 0 && !collect(s)) return ret(hs[s], false);  // the other solvers keep the GPU busy
+        if (!sv[(size_t)s]->setOutputQueries(emittersXYZ + (size_t)k * E * 3, E) ||
+            !sv[(size_t)s]->run(listenersXYZ[3 * k], listenersXYZ[3 * k + 1], listenersXYZ[3 * k + 2], /*wait=*/false))
+            return ret(hs[s], false);
+        pending[(size_t)s] = (int)j;
+    }
+    for (int s = 0; s < nSolvers; ++s)
+        if (pending[(size_t)s] >= 0 && !collect(s)) return ret(hs[s], false);
+    float* o = reinterpret_cast<float*>(out);
+    if (world == 1) {
+        for (int k = 0; k < nRuns; ++k) std::memcpy(o + (size_t)k * rec, mine.data() + (size_t)k * rec, rec * 4);
+        return 0;
+    }
+    std::vector<float> all((size_t)world * perRank * rec);
+    if (rec > 0 && !comm->c->allGather(mine.data(), (int)((size_t)perRank * rec), all.data(), &g_lastError)) return -1;
+    for (int k = 0; k < nRuns; ++k)  // run k = the (k / world)-th run of rank k mod world
+        std::memcpy(o + (size_t)k * rec, all.data() + ((size_t)(k % world) * perRank + (size_t)(k / world)) * rec, rec * 4);
+    return 0;
 }
 
 #endif  // !PVA_HOST_TEST

@@ -44,6 +44,41 @@ def gather_outputs(local, n_runs, dist=None, device=None):
     return out
 
 
+def make_comm(dist, device_index):
+    """The C++ side's RCCL communicator (api.Comm = PvAmdComm: ncclCommInitRank inside libplaneverb_amd.so) for the
+    ranks of an initialised torch.distributed group: rank 0 creates the 128-byte id, torch.distributed only carries
+    it to the other ranks (bootstrap); the data path's one collective then runs in C++ (PvAmdCommAllGather)."""
+    from . import api
+    world, rank = dist.get_world_size(), dist.get_rank()
+    box = [api.Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return api.Comm(box[0], rank, world, device_index)
+
+
+def gather_outputs_native(local, n_runs, comm):
+    """gather_outputs through the C++ RCCL communicator (one ncclAllGather): same result"""
+    n_em = next(iter(local.values())).shape[0] if local else 0
+    world, rank = comm.world, comm.rank
+    per_rank = (n_runs + world - 1) // world
+    send = np.zeros((per_rank, n_em, 8), np.float32)
+    for j, k in enumerate(shard_runs(n_runs, world, rank)):
+        send[j] = local[k]
+    recv = comm.all_gather(send).reshape(world, per_rank, n_em, 8)
+    out = np.zeros((n_runs, n_em, 8), np.float32)
+    for r in range(world):
+        for j, k in enumerate(shard_runs(n_runs, world, r)):
+            out[k] = recv[r, j]
+    return out
+
+
+def run_sharded_native(solvers, listeners, emitters, comm=None):
+    """The whole sharded job in C++ (PvAmdRunSharded): this rank's runs round-robin over `solvers` (two per GPU keep two
+    runs in flight), one RCCL all-gather of the records.  listeners [n, 3], emitters [n, E, 3] -> [n, E, 8]."""
+    from . import api
+    rank, world = (comm.rank, comm.world) if comm is not None else (0, 1)
+    return api.run_sharded(solvers, listeners, emitters, rank, world, comm)
+
+
 def default_inflight(gx, gy):
     """runs a GPU should keep in flight for a gx x gy grid: 2 fill the launch gaps of large grids (a third adds
     1 % at 4096^2); launch-latency-bound grids take 4 (+58 % at 1024^2, +73 % at 512^2)"""

@@ -101,3 +101,32 @@ def test_config5_open_8192_eight_listeners(pvlib, oracle):
             q = s.queried_outputs()
             assert same_bits(q[0], ores[c + 16, c]).all() and same_bits(q[1], ores[c, c + 16]).all()
     w.close()
+
+
+def test_run_sharded_cpp_and_rccl_gather_single_rank(pvlib):
+    """PvAmdRunSharded (C++: this rank's runs round-robin over two solvers kept in flight) + the C++ side's own RCCL
+    communicator at world size 1 (ncclCommInitRank / ncclAllGather bound at run time): the 8 config-4 listeners at
+    1024^2, all 16 records against the reference's closed-room vectors; N > 1 ranks are the driver's scaling run"""
+    g = golden("g71_hugeroom_cfg4")
+    size = mode_a_size(1024)
+    solvers = [pvlib.Solver(size, size, 275) for _ in range(2)]
+    try:
+        for s in solvers:
+            s.load_scene(os.path.join(SCENES, "HugeRoom.pv"))
+        out = pvlib.run_sharded(solvers, g["listeners"], g["emitters"])
+        assert out.shape == (8, 2, 8)
+        assert same_bits(out, g["emitter_out"]).all()
+        comm = pvlib.Comm(pvlib.Comm.unique_id(), 0, 1, 0)
+        try:
+            x = np.arange(24, dtype=np.float32)
+            assert np.array_equal(comm.all_gather(x), x[None])
+            out2 = pvlib.run_sharded(solvers, g["listeners"], g["emitters"], 0, 1, comm)
+            assert same_bits(out2, g["emitter_out"]).all()
+            from planeverb_amd import dist as pvd
+            local = {k: out[k] for k in range(8)}
+            assert same_bits(pvd.gather_outputs_native(local, 8, comm), out).all()
+        finally:
+            comm.close()
+    finally:
+        for s in solvers:
+            s.close()

@@ -233,6 +233,24 @@ def test_cpp_binding_links_against_reference_headers():
         assert re.search(r"\bPlaneverb::%s\(" % fn, defined), fn
 
 
+def test_shard_plan_matches_the_python_layer(pvlib):
+    """PvAmdShardPlan (the C++ side's run -> rank -> solver map) on a fake device list: every run exactly
+    once over the ranks, rank r holds runs r, r + W, ... (what planeverb_amd.dist.shard_runs says), round-robin over the
+    rank's solvers"""
+    from planeverb_amd import dist as pvd
+    for n_runs in (0, 1, 7, 8, 64, 65):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for rank in range(world):
+                for n_local in (1, 2, 4):
+                    plan = pvlib.shard_plan(n_runs, world, rank, n_local)
+                    assert [k for k, _ in plan] == pvd.shard_runs(n_runs, world, rank)
+                    assert [s for _, s in plan] == [j % n_local for j in range(len(plan))]
+                seen += [k for k, _ in pvlib.shard_plan(n_runs, world, rank, 1)]
+            assert sorted(seen) == list(range(n_runs))
+    assert pvlib.shard_plan(5, 2, 2, 1) == [] and pvlib.shard_plan(5, 0, 0, 1) == []
+
+
 def test_batch_policy_helpers():
     """pure host logic: which grids are run in batches, and with which tile"""
     from planeverb_amd import api, dist
