@@ -345,13 +345,53 @@ def main():
             single = {"launch_ms": sl, "achieved": alg_bytes / (sl * 1e-3) / 1e9,
                       "frac": alg_bytes / (sl * 1e-3) / 1e9 / HBM_PEAK_GBS,
                       "from": "the first %d warm-up runs, made one at a time" % len(single_loop_ms)}
-        traffic = None
+        # Counter profile of the dominant kernel (profiles/hbm_traffic.json, written by tools/summarize_profiles.py from
+        # rocprofv3 --pmc passes): quoted only if it was collected on THIS device code (kernel_source_hash) and tile
+        from planeverb_amd.build import kernel_source_hash
+        traffic, traffic_note, prof, sqprof = None, None, None, None
         pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("%d" % args.grid, {}).get("bytes_per_launch")
+                allp = json.load(open(pmc))
+                prof = allp.get("%d" % args.grid)
+                sqprof = allp.get("sq_%d" % args.grid)
             except Exception:
-                traffic = None
+                prof = None
+        for pr in (prof, sqprof):
+            if pr is not None and pr.get("kernel_source_hash") != kernel_source_hash():
+                traffic_note = ("profiles/hbm_traffic.json is stale: collected on kernel sources %s at %s, this build is "
+                                "%s -- counters not quoted" % (pr.get("kernel_source_hash"), pr.get("collected_at_head"),
+                                                               kernel_source_hash()))
+                prof = sqprof = None
+                break
+        if prof is not None and ("<%d, %d," % (K, info.tileRows)) not in prof.get("kernel", ""):
+            traffic_note = "profiles/hbm_traffic.json holds another tile configuration (%s)" % prof.get("kernel")
+            prof = None
+        if prof is not None:
+            traffic = prof.get("bytes_per_launch")
+        # executed vs useful cell-steps of one air tile and launch: step s advances rows [s, ROWS - s - 1) of 64 lanes
+        ROWS = info.tileRows + 2 * K
+        executed = sum((ROWS - 2 * st - 1) * 64 for st in range(K)) if ROWS % 2 == 0 else ROWS * 64 * K
+        useful_lane_fraction = info.tileRows * info.tileCols * K / executed
+        hbm = None
+        if traffic:
+            hbm = {"bytes_per_launch": traffic, "achieved": G * traffic / (air * 1e-3) / 1e9, "unit": "GB/s",
+                   "frac": G * traffic / (air * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   "vs_algorithmic": traffic / (alg_bytes * NB),
+                   "collected_at_head": prof.get("collected_at_head"), "source": "profiles/hbm_traffic.json (rocprofv3 "
+                   "--pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 corrections calibrated on the box)"}
+        valu = None
+        if sqprof and "zero1" in sqprof:
+            z = sqprof["zero1"]
+            q = z["counters"].get("SQ_ACTIVE_INST_VALU")
+            clk = z.get("effective_clock_ghz")
+            if q and clk:
+                valu = {"issue_utilisation": q * 4 / 1024 / ((air / G) * 1e-3 * clk * 1e9),
+                        "issue_utilisation_single_launch_measured": z.get("valu_busy_single_launch"),
+                        "valu_quad_cycles_per_launch": q, "effective_clock_ghz": clk,
+                        "how": "SQ_ACTIVE_INST_VALU (quad-cycles per launch, rocprofv3 --pmc) x 4 / 1024 SIMDs / (live "
+                               "launch_ms / concurrent_launches x effective clock = GRBM_GUI_ACTIVE / 8 / duration)",
+                        "collected_at_head": sqprof.get("collected_at_head"), "source": "profiles/r02_sq_pmc.md"}
         value = world * B * cells * T * args.steps / elapsed
         fd = float(np.mean(fdtd_ms)) * 1e-3
         out = {
@@ -374,8 +414,13 @@ def main():
             "fdtd_ms": fd * 1e3, "analysis_ms": float(np.mean(ana_ms)),
             "hbm_bytes_held": int(info.deviceBytes) * B,
             "verified_runs": verified_runs, "timed_runs": n_runs, "verified_how": verified_how,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                         "basis": "achieved / peak / frac are on SURVEY.md 8d's basis: ALGORITHMIC bytes (24 B per "
+                                  "cell-step) against the 8 TB/s HBM peak.  K-step temporal blocking in registers moves "
+                                  "9-10x fewer bytes than that, so frac > 1 and HBM is NOT what binds: the kernel is bound "
+                                  "by VALU issue (see valu, hbm, useful_lane_fraction)",
+                         "valu": valu, "hbm": hbm, "useful_lane_fraction": useful_lane_fraction,
                          "kernel": "pv_step_merged_kernel<K=%d,rows=%d> (air tiles + general tiles, one launch per K "
                                    "steps)" % (K, info.tileRows),
                          "launch_ms": air, "launch_ms_from": how, "launches_per_run": launches,

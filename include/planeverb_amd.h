@@ -177,6 +177,39 @@ typedef struct PvAmdSlabInfo {
     long long deviceBytes[16];           /* HBM held by slab i (whole-grid result maps: see PvAmdGetInfo) */
 } PvAmdSlabInfo;
 PVA_EXPORT int PvAmdGetSlabInfo(PvAmdSolver* s, PvAmdSlabInfo* out);
+/* The same decomposition with the slabs in DIFFERENT PROCESSES (one rank per GPU): a rank creates ITS slab, the host
+ * language moves the halos between ranks (planeverb_amd/dist_slabs.py: torch.distributed send / recv, RCCL on GPU ranks),
+ * rank 0 additionally holds the whole-grid maps (PvAmdSlabRoot*).  Per run and rank:
+ *   SlabBegin; for li < SlabNumLaunches: { SlabLaunch(li); SlabExportHalo(side) -> neighbour -> SlabImportHalo(side) };
+ *   SlabExportEdgeHistory -> rank below -> SlabImportAboveHistory; SlabAnalyze; SlabWindowBlock -> rank 0 ->
+ *   SlabRootImportBlock; rank 0: SlabRootBegin before the blocks, SlabRootFinish after them, then SlabRootGetOutput.
+ * side 0 = towards the slab above (smaller rows), 1 = towards the slab below.  Buffers are host memory. */
+PVA_EXPORT PvAmdSolver* PvAmdCreateSlabRank(float gridSizeX, float gridSizeY, int gridResolution, int device,
+                                            int slabIndex, int slabCount);
+/* FreeGrid energy (FreeGrid.cpp:71-110) of a config: computed once (rank 0) and given to every slab rank */
+PVA_EXPORT int PvAmdComputeEfree(float gridSizeX, float gridSizeY, int gridResolution, int device, float* efree);
+PVA_EXPORT int PvAmdSlabSetEfree(PvAmdSolver* slab, float efree);
+PVA_EXPORT int PvAmdSlabBegin(PvAmdSolver* slab, float lx, float ly, float lz);
+PVA_EXPORT int PvAmdSlabNumLaunches(PvAmdSolver* slab);
+PVA_EXPORT int PvAmdSlabLaunch(PvAmdSolver* slab, int li);
+PVA_EXPORT int PvAmdSlabHaloFloats(PvAmdSolver* slab);    /* 3 x K x pitch */
+PVA_EXPORT int PvAmdSlabExportHalo(PvAmdSolver* slab, int side, float* host);
+PVA_EXPORT int PvAmdSlabImportHalo(PvAmdSolver* slab, int side, const float* host);
+PVA_EXPORT int PvAmdSlabHistoryFloats(PvAmdSolver* slab); /* T x histPitch */
+PVA_EXPORT int PvAmdSlabExportEdgeHistory(PvAmdSolver* slab, float* host);
+PVA_EXPORT int PvAmdSlabImportAboveHistory(PvAmdSolver* slab, const float* host);
+PVA_EXPORT int PvAmdSlabAnalyze(PvAmdSolver* slab);
+/* info4 = {first whole-grid row, first column, rows, columns} of the block; returns the floats needed (7 planes), and
+ * fills `host` when capacity suffices; < 0 on error */
+PVA_EXPORT long long PvAmdSlabWindowBlock(PvAmdSolver* slab, int* info4, float* host, long long capacityFloats);
+typedef struct PvAmdSlabRoot PvAmdSlabRoot;
+PVA_EXPORT PvAmdSlabRoot* PvAmdSlabRootCreate(PvAmdSolver* anySlab, int device);
+PVA_EXPORT void PvAmdSlabRootDestroy(PvAmdSlabRoot* r);
+PVA_EXPORT int PvAmdSlabRootBegin(PvAmdSlabRoot* r, float lx, float ly, float lz);
+PVA_EXPORT int PvAmdSlabRootImportBlock(PvAmdSlabRoot* r, const int* info4, const float* host);
+PVA_EXPORT int PvAmdSlabRootFinish(PvAmdSlabRoot* r);
+PVA_EXPORT int PvAmdSlabRootGetOutput(PvAmdSlabRoot* r, float ex, float ey, float ez, PlaneverbOutput* out);
+PVA_EXPORT int PvAmdSlabRootCopyResults(PvAmdSlabRoot* r, float* res8, float* delay);
 PVA_EXPORT void PvAmdDestroy(PvAmdSolver* s);
 PVA_EXPORT int PvAmdSetOption(PvAmdSolver* s, int key, long long value);
 PVA_EXPORT int PvAmdGetInfo(PvAmdSolver* s, PvAmdInfo* out);

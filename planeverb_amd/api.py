@@ -108,6 +108,27 @@ SYMBOLS = {
     "PlaneverbCreateGrid": (_vp, [C.c_float, C.c_float, C.c_int, C.c_int]),
     "PvAmdCreateSlabs": (_vp, [C.c_float, C.c_float, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "PvAmdGetSlabInfo": (C.c_int, [_vp, C.POINTER(PvAmdSlabInfo)]),
+    "PvAmdCreateSlabRank": (_vp, [C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "PvAmdComputeEfree": (C.c_int, [C.c_float, C.c_float, C.c_int, C.c_int, _fp]),
+    "PvAmdSlabSetEfree": (C.c_int, [_vp, C.c_float]),
+    "PvAmdSlabBegin": (C.c_int, [_vp] + [C.c_float] * 3),
+    "PvAmdSlabNumLaunches": (C.c_int, [_vp]),
+    "PvAmdSlabLaunch": (C.c_int, [_vp, C.c_int]),
+    "PvAmdSlabHaloFloats": (C.c_int, [_vp]),
+    "PvAmdSlabExportHalo": (C.c_int, [_vp, C.c_int, _fp]),
+    "PvAmdSlabImportHalo": (C.c_int, [_vp, C.c_int, _fp]),
+    "PvAmdSlabHistoryFloats": (C.c_int, [_vp]),
+    "PvAmdSlabExportEdgeHistory": (C.c_int, [_vp, _fp]),
+    "PvAmdSlabImportAboveHistory": (C.c_int, [_vp, _fp]),
+    "PvAmdSlabAnalyze": (C.c_int, [_vp]),
+    "PvAmdSlabWindowBlock": (C.c_longlong, [_vp, C.POINTER(C.c_int), _fp, C.c_longlong]),
+    "PvAmdSlabRootCreate": (_vp, [_vp, C.c_int]),
+    "PvAmdSlabRootDestroy": (None, [_vp]),
+    "PvAmdSlabRootBegin": (C.c_int, [_vp] + [C.c_float] * 3),
+    "PvAmdSlabRootImportBlock": (C.c_int, [_vp, C.POINTER(C.c_int), _fp]),
+    "PvAmdSlabRootFinish": (C.c_int, [_vp]),
+    "PvAmdSlabRootGetOutput": (C.c_int, [_vp] + [C.c_float] * 3 + [C.POINTER(PlaneverbOutput)]),
+    "PvAmdSlabRootCopyResults": (C.c_int, [_vp, _fp, _fp]),
     "PvAmdDestroy": (None, [_vp]),
     "PvAmdSetOption": (C.c_int, [_vp, C.c_int, C.c_longlong]),
     "PvAmdGetInfo": (C.c_int, [_vp, C.POINTER(PvAmdInfo)]),
@@ -406,6 +427,119 @@ def run_sharded(solvers, listeners, emitters, rank=0, world=1, comm=None):
     return np.frombuffer(out, np.float32).reshape(-1, 8)[:n * E].reshape(n, E, 8).copy()
 
 
+def compute_efree(size_x, size_y, res, device=0):
+    """FreeGrid energy of a config (FreeGrid.cpp:71-110): computed once, handed to every slab rank"""
+    e = C.c_float()
+    _check(lib().PvAmdComputeEfree(float(size_x), float(size_y), int(res), int(device), e))
+    return e.value
+
+
+class SlabRank:
+    """ONE slab of a decomposed grid, owned by this process (PvAmdCreateSlabRank + PvAmdSlab*): the per-rank primitives of
+    planeverb_amd.dist_slabs.  Buffers that cross ranks are numpy arrays."""
+
+    def __init__(self, size_x, size_y, res, device, index, count, efree, **options):
+        self.solver = Solver.__new__(Solver)
+        self.solver._h = lib().PvAmdCreateSlabRank(float(size_x), float(size_y), int(res), int(device), int(index), int(count))
+        if not self.solver._h:
+            raise PlaneverbError(last_error())
+        self._h = self.solver._h
+        keys = {"steps_per_launch": PVA_OPT_STEPS_PER_LAUNCH, "tile_rows": PVA_OPT_TILE_ROWS, "num_steps": PVA_OPT_NUM_STEPS}
+        for k, v in options.items():
+            _check(lib().PvAmdSetOption(self._h, keys[k], int(v)))
+        _check(lib().PvAmdSlabSetEfree(self._h, float(efree)))
+        self.index, self.count = index, count
+        self.num_launches = lib().PvAmdSlabNumLaunches(self._h)
+        self.halo_floats = lib().PvAmdSlabHaloFloats(self._h)
+        self.history_floats = lib().PvAmdSlabHistoryFloats(self._h)
+
+    def close(self):
+        self.solver.close()
+        self._h = None
+
+    def add_geometry(self, aabb):
+        return lib().PvAmdAddGeometry(self._h, *[float(v) for v in aabb])
+
+    def begin(self, listener):
+        _check(lib().PvAmdSlabBegin(self._h, *[float(v) for v in listener]))
+
+    def launch(self, li):
+        _check(lib().PvAmdSlabLaunch(self._h, int(li)))
+
+    def export_halo(self, side):
+        out = np.empty(self.halo_floats, np.float32)
+        _check(lib().PvAmdSlabExportHalo(self._h, int(side), _f(out)))
+        return out
+
+    def import_halo(self, side, buf):
+        buf = np.ascontiguousarray(buf, np.float32)
+        assert buf.size == self.halo_floats
+        _check(lib().PvAmdSlabImportHalo(self._h, int(side), _f(buf)))
+
+    def export_edge_history(self):
+        out = np.empty(self.history_floats, np.float32)
+        _check(lib().PvAmdSlabExportEdgeHistory(self._h, _f(out)))
+        return out
+
+    def import_above_history(self, buf):
+        buf = np.ascontiguousarray(buf, np.float32)
+        assert buf.size == self.history_floats
+        _check(lib().PvAmdSlabImportAboveHistory(self._h, _f(buf)))
+
+    def analyze(self):
+        _check(lib().PvAmdSlabAnalyze(self._h))
+
+    def window_block(self):
+        """(info4 int32 [row0 of the whole grid, col0, rows, cols], float32 [7, rows, cols])"""
+        info = (C.c_int * 4)()
+        n = lib().PvAmdSlabWindowBlock(self._h, info, None, 0)
+        if n < 0:
+            raise PlaneverbError(last_error())
+        data = np.empty(max(n, 0), np.float32)
+        if n > 0 and lib().PvAmdSlabWindowBlock(self._h, info, _f(data), n) != n:
+            raise PlaneverbError(last_error())
+        return np.array(list(info), np.int32), data
+
+
+class SlabRoot:
+    """whole-grid result maps of a decomposed grid (rank 0): far cells, the ranks' blocks, the direction descent"""
+
+    def __init__(self, slab_rank, device=0):
+        self._h = lib().PvAmdSlabRootCreate(slab_rank._h, int(device))
+        if not self._h:
+            raise PlaneverbError(last_error())
+        i = PvAmdInfo()
+        _check(lib().PvAmdGetInfo(slab_rank._h, i))
+        self.gx, self.gy = i.gx, i.gy
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().PvAmdSlabRootDestroy(self._h)
+            self._h = None
+
+    def begin(self, listener):
+        _check(lib().PvAmdSlabRootBegin(self._h, *[float(v) for v in listener]))
+
+    def import_block(self, info4, data):
+        info = (C.c_int * 4)(*[int(v) for v in info4])
+        data = np.ascontiguousarray(data, np.float32)
+        _check(lib().PvAmdSlabRootImportBlock(self._h, info, _f(data) if data.size else None))
+
+    def finish(self):
+        _check(lib().PvAmdSlabRootFinish(self._h))
+
+    def get_output(self, emitter):
+        o = PlaneverbOutput()
+        _check(lib().PvAmdSlabRootGetOutput(self._h, *[float(v) for v in emitter], o))
+        return o
+
+    def results(self):
+        res = np.empty((self.gx, self.gy, 8), np.float32)
+        delay = np.empty((self.gx, self.gy), np.float32)
+        _check(lib().PvAmdSlabRootCopyResults(self._h, _f(res), _f(delay)))
+        return res, delay
+
+
 def run_batch(solvers, listeners, wait=True):
     """PvAmdRunBatch: len(solvers) <= 8 independent runs (one listener each) advanced by ONE launch per K steps.
     The solvers must share device, grid and tile configuration; afterwards each holds its own run's results."""
@@ -547,6 +681,16 @@ class Solver:
         pr, vx, vy = (np.empty(shp, np.float32) for _ in range(3))
         _check(lib().PvAmdCopyFields(self._h, _f(pr), _f(vx), _f(vy)))
         return pr, vx, vy
+
+    def fields_local(self):
+        """a slab rank's own rows of the final fields (PvAmdCopyFields on a slab copies the rows it owns)"""
+        i = PvAmdInfo()
+        _check(lib().PvAmdGetInfo(self._h, i))
+        # rows owned = result rows, + the ghost row on the last slab: read generously, trim by what the library wrote
+        bufs = [np.full((i.rows, i.gy + 1), np.nan, np.float32) for _ in range(3)]
+        _check(lib().PvAmdCopyFields(self._h, _f(bufs[0]), _f(bufs[1]), _f(bufs[2])))
+        n = int((~np.isnan(bufs[0][:, 0])).sum())
+        return [b[:n] for b in bufs]
 
     def set_fields(self, pr, vx, vy):
         a = [np.ascontiguousarray(x, np.float32) for x in (pr, vx, vy)]

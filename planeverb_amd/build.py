@@ -8,6 +8,20 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("PLANEVERB_AMD_LIB") or os.path.join(PKG_DIR, "libplaneverb_amd.so")
 
 
+KERNEL_SOURCES = ["pv_kernels.hip", "pv_device.h", "pv_libm.h", "Makefile"]
+
+
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) of the sources that determine the device code: the stamp of profiles/hbm_traffic.json
+    (counter profiles are only quoted by bench.py for the kernels they were collected on)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, jobs=4):
     """Compile every HIP/C++ source of the package for gfx950.  Works without a GPU (cross-compile)."""
     if force:

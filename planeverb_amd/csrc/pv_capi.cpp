@@ -250,6 +250,141 @@ int PvAmdGetSlabInfo(PvAmdSolver* h, PvAmdSlabInfo* out) {
     return 0;
 }
 
+PvAmdSolver* PvAmdCreateSlabRank(float gridSizeX, float gridSizeY, int gridResolution, int device, int slabIndex,
+                                 int slabCount) {
+    PvAmdSolver* h = PvAmdCreate(gridSizeX, gridSizeY, gridResolution, device);
+    if (!h) return nullptr;
+    if (slabCount < 2 || slabIndex < 0 || slabIndex >= slabCount) {
+        g_lastError = "PvAmdCreateSlabRank: 0 <= slabIndex < slabCount, slabCount >= 2";
+        delete h;
+        return nullptr;
+    }
+    h->opt.slabIndex = slabIndex;
+    h->opt.slabCount = slabCount;
+    return h;
+}
+
+int PvAmdComputeEfree(float gridSizeX, float gridSizeY, int gridResolution, int device, float* efree) {
+    if (!efree) return -1;
+    PvAmdSolver* h = PvAmdCreate(gridSizeX, gridSizeY, gridResolution, device);
+    if (!h) return -1;
+    // a throw-away solver of a tiny grid would have another centre cell: the free-field run depends on the grid size
+    // (FreeGrid.cpp:78-84), so the real config is used; its planes are what the windowed FreeGrid run needs anyway
+    const bool ok = ensure(h);
+    if (ok) *efree = h->s->efree();
+    PvAmdDestroy(h);
+    return ok ? 0 : -1;
+}
+
+static Solver* slabOf(PvAmdSolver* h) {
+    if (!ensure(h)) return nullptr;
+    if (h->opt.slabCount < 2) {
+        g_lastError = "not a slab rank handle (PvAmdCreateSlabRank)";
+        return nullptr;
+    }
+    return h->s;
+}
+
+int PvAmdSlabSetEfree(PvAmdSolver* h, float efree) {
+    Solver* s = slabOf(h);
+    if (!s) return -1;
+    s->setEfree(efree);
+    return 0;
+}
+int PvAmdSlabBegin(PvAmdSolver* h, float lx, float ly, float lz) {
+    Solver* s = slabOf(h);
+    return s ? ret(h, SlabRankOps::begin(*s, lx, ly, lz)) : -1;
+}
+int PvAmdSlabNumLaunches(PvAmdSolver* h) {
+    Solver* s = slabOf(h);
+    return s ? SlabRankOps::numLaunches(*s) : -1;
+}
+int PvAmdSlabLaunch(PvAmdSolver* h, int li) {
+    Solver* s = slabOf(h);
+    return s ? ret(h, SlabRankOps::launch(*s, li)) : -1;
+}
+int PvAmdSlabHaloFloats(PvAmdSolver* h) {
+    Solver* s = slabOf(h);
+    return s ? SlabRankOps::haloFloats(*s) : -1;
+}
+int PvAmdSlabExportHalo(PvAmdSolver* h, int side, float* host) {
+    Solver* s = slabOf(h);
+    return (s && host) ? ret(h, SlabRankOps::exportHalo(*s, side, host)) : -1;
+}
+int PvAmdSlabImportHalo(PvAmdSolver* h, int side, const float* host) {
+    Solver* s = slabOf(h);
+    return (s && host) ? ret(h, SlabRankOps::importHalo(*s, side, host)) : -1;
+}
+int PvAmdSlabHistoryFloats(PvAmdSolver* h) {
+    Solver* s = slabOf(h);
+    return s ? SlabRankOps::historyFloats(*s) : -1;
+}
+int PvAmdSlabExportEdgeHistory(PvAmdSolver* h, float* host) {
+    Solver* s = slabOf(h);
+    return (s && host) ? ret(h, SlabRankOps::exportEdgeHistory(*s, host)) : -1;
+}
+int PvAmdSlabImportAboveHistory(PvAmdSolver* h, const float* host) {
+    Solver* s = slabOf(h);
+    return (s && host) ? ret(h, SlabRankOps::importAboveHistory(*s, host)) : -1;
+}
+int PvAmdSlabAnalyze(PvAmdSolver* h) {
+    Solver* s = slabOf(h);
+    return s ? ret(h, SlabRankOps::analyze(*s)) : -1;
+}
+long long PvAmdSlabWindowBlock(PvAmdSolver* h, int* info4, float* host, long long cap) {
+    Solver* s = slabOf(h);
+    if (!s || !info4) return -1;
+    const long long n = SlabRankOps::windowBlock(*s, &info4[0], &info4[1], &info4[2], &info4[3], host, cap);
+    if (n < 0) ret(h, false);
+    return n;
+}
+
+struct PvAmdSlabRoot {
+    SlabRoot* r = nullptr;
+};
+PvAmdSlabRoot* PvAmdSlabRootCreate(PvAmdSolver* anySlab, int device) {
+    Solver* s = slabOf(anySlab);
+    if (!s) return nullptr;
+    SlabRoot* r = SlabRoot::create(*s, device, &g_lastError);
+    if (!r) return nullptr;
+    PvAmdSlabRoot* h = new PvAmdSlabRoot();
+    h->r = r;
+    return h;
+}
+void PvAmdSlabRootDestroy(PvAmdSlabRoot* h) {
+    if (!h) return;
+    delete h->r;
+    delete h;
+}
+static int rootRet(PvAmdSlabRoot* h, bool ok) {
+    if (!ok && h && h->r) g_lastError = h->r->lastError();
+    return ok ? 0 : -1;
+}
+int PvAmdSlabRootBegin(PvAmdSlabRoot* h, float lx, float ly, float lz) {
+    return (h && h->r) ? rootRet(h, h->r->begin(lx, ly, lz)) : -1;
+}
+int PvAmdSlabRootImportBlock(PvAmdSlabRoot* h, const int* info4, const float* host) {
+    return (h && h->r && info4 && (host || info4[2] * info4[3] == 0))
+               ? rootRet(h, h->r->importBlock(info4[0], info4[1], info4[2], info4[3], host))
+               : -1;
+}
+int PvAmdSlabRootFinish(PvAmdSlabRoot* h) { return (h && h->r) ? rootRet(h, h->r->finish()) : -1; }
+int PvAmdSlabRootGetOutput(PvAmdSlabRoot* h, float ex, float ey, float ez, PlaneverbOutput* out) {
+    if (!h || !h->r || !out) return -1;
+    float v[8];
+    bool valid = false;
+    if (!h->r->getOutput(ex, ey, ez, v, &valid)) return rootRet(h, false);
+    std::memset(out, 0, sizeof(*out));
+    if (valid)
+        std::memcpy(out, v, sizeof(*out));
+    else
+        out->occlusion = kInvalidDryGain;
+    return 0;
+}
+int PvAmdSlabRootCopyResults(PvAmdSlabRoot* h, float* res8, float* delay) {
+    return (h && h->r) ? rootRet(h, h->r->copyResults(res8, delay)) : -1;
+}
+
 void PvAmdDestroy(PvAmdSolver* h) {
     if (!h) return;
     delete h->s;

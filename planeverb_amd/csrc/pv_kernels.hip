@@ -2613,17 +2613,20 @@ void launchHistRow(const AnalyzeArgs& a, int X, float* out, hipStream_t stream) 
 // (dr0, dc0) of dst planes -- a slab's part of the history window into the whole grid's result / delay maps
 __global__ void pv_copy_block_kernel(const float* __restrict__ src, long long sstride, int spitch, int sr0, int sc0,
                                      float* __restrict__ dst, long long dstride, int dpitch, int dr0, int dc0, int nr,
-                                     int nc, const int* planes) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y, k = planes ? planes[blockIdx.z] : blockIdx.z;
+                                     int nc, const int* srcPlanes, const int* dstPlanes) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    const int ks = srcPlanes ? srcPlanes[blockIdx.z] : blockIdx.z, kd = dstPlanes ? dstPlanes[blockIdx.z] : blockIdx.z;
     if (c >= nc || r >= nr) return;
-    dst[k * dstride + (long long)(dr0 + r) * dpitch + dc0 + c] = src[k * sstride + (long long)(sr0 + r) * spitch + sc0 + c];
+    dst[kd * dstride + (long long)(dr0 + r) * dpitch + dc0 + c] = src[ks * sstride + (long long)(sr0 + r) * spitch + sc0 + c];
 }
 
 void launchCopyBlock(const float* src, long long sstride, int spitch, int sr0, int sc0, float* dst, long long dstride,
-                     int dpitch, int dr0, int dc0, int nr, int nc, int nplanes, const int* planesDev, hipStream_t stream) {
+                     int dpitch, int dr0, int dc0, int nr, int nc, int nplanes, const int* srcPlanesDev,
+                     const int* dstPlanesDev, hipStream_t stream) {
     if (nr <= 0 || nc <= 0) return;
     hipLaunchKernelGGL(pv_copy_block_kernel, dim3((unsigned)((nc + 255) / 256), (unsigned)nr, (unsigned)nplanes), dim3(256),
-                       0, stream, src, sstride, spitch, sr0, sc0, dst, dstride, dpitch, dr0, dc0, nr, nc, planesDev);
+                       0, stream, src, sstride, spitch, sr0, sc0, dst, dstride, dpitch, dr0, dc0, nr, nc, srcPlanesDev,
+                       dstPlanesDev);
 }
 
 // far cells of the whole map (delay = FLT_MAX, default listener direction): the first analysis launch

@@ -43,7 +43,8 @@ void launchAnalysisCells(const AnalyzeArgs& a, hipStream_t stream);
 void launchAnalysisDirection(const AnalyzeArgs& a, hipStream_t stream);
 void launchHistRow(const AnalyzeArgs& a, int X, float* outTxPitch, hipStream_t stream);
 void launchCopyBlock(const float* src, long long sstride, int spitch, int sr0, int sc0, float* dst, long long dstride,
-                     int dpitch, int dr0, int dc0, int nr, int nc, int nplanes, const int* planesDev, hipStream_t stream);
+                     int dpitch, int dr0, int dc0, int nr, int nc, int nplanes, const int* srcPlanesDev,
+                     const int* dstPlanesDev, hipStream_t stream);  // plane maps: NULL = identity
 void launchGatherQueries(const float* res, long long n, const long long* cellsHost, int nq, float* outHost,
                          hipStream_t stream);  // nq <= 64
 void launchGatherOutput(const float* res, long long n, long long cell, float* out8Host, hipStream_t stream);

@@ -314,8 +314,9 @@ bool SlabGroup::run(float lx, float ly, float lz) {
         const long long lresN = (long long)std::max(v.lgx_, 1) * g_.gy;
         if (v.device_ == rootDevice_) {
             launchCopyBlock(v.res_, lresN, g_.gy, lr0, c0, res_, ra.resN, g_.gy, lr0 + v.x0_, c0, nr, nc, 6, planesDev_,
+                            planesDev_, rootStream_);
+            launchCopyBlock(v.delay_, 0, g_.gy, lr0, c0, delay_, 0, g_.gy, lr0 + v.x0_, c0, nr, nc, 1, nullptr, nullptr,
                             rootStream_);
-            launchCopyBlock(v.delay_, 0, g_.gy, lr0, c0, delay_, 0, g_.gy, lr0 + v.x0_, c0, nr, nc, 1, nullptr, rootStream_);
         } else {
             const int planes[6] = {0, 1, 2, 3, 6, 7};
             for (int k : planes)
@@ -405,6 +406,266 @@ bool SlabGroup::impulseResponse(int cx, int cy, float* out3T) {
         }
     }
     return fail("cell outside the grid");
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// per-rank primitives (slabs in different processes)
+// ----------------------------------------------------------------------------------------------------------------
+
+bool SlabRankOps::begin(Solver& v, float lx, float ly, float lz) {
+    (void)ly;
+    if (!v.isSlab()) return v.fail("not a slab");
+    if (!v.hipOk(hipSetDevice(v.device_), "hipSetDevice")) return false;
+    int lcx, lcy;
+    listenerCell(v.g_, lx, lz, &lcx, &lcy);
+    if (v.pendingTimings_ && !v.sync()) return false;
+    if (!v.applyGeometry() || !v.prepareDyn(lcx, lcy, true, false)) return false;
+    v.lastLx_ = lx;
+    v.lastLz_ = lz;
+    v.tim_.stepLaunches = 0;
+    v.kevUsed_ = 0;
+    v.loopTimed_ = false;
+    v.cur_ = 0;
+    v.launchCap_ = v.numGeneral_;
+    v.enqueueBeginRun(true);
+    return v.hipOk(hipGetLastError(), "begin run");
+}
+
+int SlabRankOps::numLaunches(const Solver& v) { return ceilDiv(v.T_, v.K_); }
+
+bool SlabRankOps::launch(Solver& v, int li) {
+    if (li < 0 || li >= numLaunches(v)) return v.fail("launch index out of range");
+    hipSetDevice(v.device_);
+    return v.enqueueSteps(li * v.K_, std::min(v.K_, v.T_ - li * v.K_), true, true, li == 0);
+}
+
+int SlabRankOps::haloFloats(const Solver& v) { return 3 * v.K_ * v.geo_.pitch; }
+
+bool SlabRankOps::exportHalo(Solver& v, int side, float* host) {
+    hipSetDevice(v.device_);
+    const size_t pitch = (size_t)v.geo_.pitch, n = (size_t)v.K_ * pitch;
+    const size_t row = side == 0 ? (size_t)v.geo_.G : (size_t)v.geo_.G + (size_t)v.geo_.ntx * v.rxi_ - v.K_;
+    const float* src[3] = {v.pr_[v.cur_], v.vx_[v.cur_], v.vy_[v.cur_]};
+    for (int f = 0; f < 3; ++f)
+        if (!v.hipOk(hipMemcpyAsync(host + f * n, src[f] + row * pitch, n * 4, hipMemcpyDeviceToHost, v.stream_), "halo export"))
+            return false;
+    return v.hipOk(hipStreamSynchronize(v.stream_), "halo export sync");
+}
+
+bool SlabRankOps::importHalo(Solver& v, int side, const float* host) {
+    hipSetDevice(v.device_);
+    const size_t pitch = (size_t)v.geo_.pitch, n = (size_t)v.K_ * pitch;
+    const size_t row = side == 0 ? (size_t)v.geo_.G - v.K_ : (size_t)v.geo_.G + (size_t)v.geo_.ntx * v.rxi_;
+    float* dst[3] = {v.pr_[v.cur_], v.vx_[v.cur_], v.vy_[v.cur_]};
+    for (int f = 0; f < 3; ++f)
+        if (!v.hipOk(hipMemcpyAsync(dst[f] + row * pitch, host + f * n, n * 4, hipMemcpyHostToDevice, v.stream_), "halo import"))
+            return false;
+    return v.hipOk(hipStreamSynchronize(v.stream_), "halo import sync");  // (the host buffer may be reused at once)
+}
+
+int SlabRankOps::historyFloats(const Solver& v) { return v.T_ * v.histPitch_; }
+
+bool SlabRankOps::exportEdgeHistory(Solver& v, float* host) {
+    if (!v.histEdge_) return v.fail("the last slab has no slab below it");
+    hipSetDevice(v.device_);
+    launchHistRow(v.analyzeArgs(v.lastLx_, v.lastLz_), v.lNX_ - 1, v.histEdge_, v.stream_);
+    if (!v.hipOk(hipMemcpyAsync(host, v.histEdge_, (size_t)historyFloats(v) * 4, hipMemcpyDeviceToHost, v.stream_), "history export"))
+        return false;
+    return v.hipOk(hipStreamSynchronize(v.stream_), "history export sync");
+}
+
+bool SlabRankOps::importAboveHistory(Solver& v, const float* host) {
+    if (!v.histAbove_) return v.fail("the first slab has no slab above it");
+    hipSetDevice(v.device_);
+    if (!v.hipOk(hipMemcpyAsync(v.histAbove_, host, (size_t)historyFloats(v) * 4, hipMemcpyHostToDevice, v.stream_), "history import"))
+        return false;
+    return v.hipOk(hipStreamSynchronize(v.stream_), "history import sync");
+}
+
+bool SlabRankOps::analyze(Solver& v) {
+    hipSetDevice(v.device_);
+    const AnalyzeArgs a = v.analyzeArgs(v.lastLx_, v.lastLz_);
+    launchFarCells(a, v.stream_);
+    launchAnalysisCells(a, v.stream_);
+    if (!v.hipOk(hipGetLastError(), "slab analysis")) return false;
+    if (!v.hipOk(hipStreamSynchronize(v.stream_), "slab analysis sync")) return false;
+    int flag = 0;
+    if (!v.hipOk(hipMemcpy(&flag, v.errFlag_, sizeof(int), hipMemcpyDeviceToHost), "errFlag copy")) return false;
+    if (flag) return v.fail("pressure history window overflow (a tile outside the window became non-zero)");
+    return true;
+}
+
+long long SlabRankOps::windowBlock(Solver& v, int* r0g, int* c0, int* nr, int* nc, float* host, long long cap) {
+    hipSetDevice(v.device_);
+    const int lr0 = v.dynCur_.histRow0 - v.geo_.G;
+    *r0g = lr0 + v.x0_;
+    *c0 = v.dynCur_.histCol0 - v.geo_.G;
+    *nr = std::max(0, std::min(v.histTilesX_ * v.rxi_, v.lgx_ - lr0));
+    *nc = std::max(0, std::min(v.histTilesY_ * v.wi_, v.g_.gy - *c0));
+    const long long need = 7LL * *nr * *nc;
+    if (!host || cap < need || need == 0) return need;
+    const int planes[6] = {0, 1, 2, 3, 6, 7};
+    const long long lresN = (long long)std::max(v.lgx_, 1) * v.g_.gy;
+    const size_t blk = (size_t)*nr * *nc;
+    for (int k = 0; k < 7; ++k) {
+        const float* src = k < 6 ? v.res_ + planes[k] * lresN : v.delay_;
+        if (!v.hipOk(hipMemcpy2DAsync(host + k * blk, (size_t)*nc * 4, src + (long long)lr0 * v.g_.gy + *c0, (size_t)v.g_.gy * 4,
+                                      (size_t)*nc * 4, (size_t)*nr, hipMemcpyDeviceToHost, v.stream_), "window block"))
+            return -1;
+    }
+    if (!v.hipOk(hipStreamSynchronize(v.stream_), "window block sync")) return -1;
+    return need;
+}
+
+SlabRoot* SlabRoot::create(const Solver& a, int device, std::string* err) {
+    SlabRoot* r = new SlabRoot();
+    r->g_ = a.g_;
+    r->device_ = device;
+    r->G_ = a.geo_.G;
+    r->rxi_ = a.rxi_;
+    r->wi_ = a.wi_;
+    r->nty_ = a.geo_.nty;
+    r->T_ = a.T_;
+    r->K_ = a.K_;
+    r->ntxG_ = a.ntxG_;
+    r->histTilesXG_ = a.histTilesXG_;
+    r->histTilesY_ = a.histTilesY_;
+    r->efree_ = a.efree_;
+    r->winRows_ = a.histTilesXG_ * a.rxi_;
+    r->winCols_ = a.histTilesY_ * a.wi_;
+    const size_t n = (size_t)r->g_.gx * r->g_.gy;
+    const int planes[6] = {0, 1, 2, 3, 6, 7};
+    bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&r->stream_, hipStreamNonBlocking) == hipSuccess &&
+              hipMalloc((void**)&r->res_, n * 32) == hipSuccess && hipMalloc((void**)&r->delay_, n * 4) == hipSuccess &&
+              hipMalloc((void**)&r->dirScratch_, (size_t)r->winRows_ * r->winCols_ * 4) == hipSuccess &&
+              hipMalloc((void**)&r->planesDev_, sizeof(planes)) == hipSuccess &&
+              hipMalloc((void**)&r->dynDev_, sizeof(DynParams)) == hipSuccess &&
+              hipHostMalloc((void**)&r->outHost_, 32) == hipSuccess &&
+              hipMemset(r->res_, 0, n * 32) == hipSuccess && hipMemset(r->delay_, 0, n * 4) == hipSuccess &&
+              hipMemcpy(r->planesDev_, planes, sizeof(planes), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
+        if (err) *err = "slab root: allocation failed";
+        delete r;
+        return nullptr;
+    }
+    return r;
+}
+
+SlabRoot::~SlabRoot() {
+    hipSetDevice(device_);
+    if (stream_) hipStreamSynchronize(stream_);
+    for (void* p : {(void*)res_, (void*)res8_, (void*)delay_, (void*)stage_, (void*)dirScratch_, (void*)planesDev_, (void*)dynDev_})
+        if (p) hipFree(p);
+    if (outHost_) hipHostFree(outHost_);
+    if (stream_) hipStreamDestroy(stream_);
+}
+
+AnalyzeArgs SlabRoot::args() const {
+    AnalyzeArgs a{};
+    a.dyn = dynDev_;
+    a.out = res_;
+    a.resN = (long long)g_.gx * g_.gy;
+    a.delay = delay_;
+    a.G = G_;
+    a.gx = g_.gx;
+    a.gy = g_.gy;
+    a.rxi = rxi_;
+    a.wi = wi_;
+    a.nty = nty_;
+    a.winRows = winRows_;
+    a.winCols = winCols_;
+    a.dirScratch = dirScratch_;
+    a.dirJump = (winRows_ > 256 && winCols_ > 256) ? 1 : 0;
+    a.T = T_;
+    a.fs = g_.fs;
+    a.res = g_.res;
+    a.dx = g_.dx;
+    a.courant = g_.courant;
+    a.efree = efree_;
+    a.lx = lx_;
+    a.lz = lz_;
+    listenerCellRecip(g_, lx_, lz_, &a.lcx, &a.lcy);
+    return a;
+}
+
+bool SlabRoot::begin(float lx, float ly, float lz) {
+    (void)ly;
+    lx_ = lx;
+    lz_ = lz;
+    int lcx, lcy;
+    listenerCell(g_, lx, lz, &lcx, &lcy);
+    // the whole grid's history window: the same placement every slab derives (Solver::prepareDyn)
+    const int reach = T_ + 2 + K_;
+    auto floorDiv = [](int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); };
+    int gtx0 = 0, ty0 = 0;
+    if (histTilesXG_ < ntxG_)
+        gtx0 = std::min(std::max(floorDiv(std::min(std::max(lcx, 0), g_.gx) - reach, rxi_), 0), ntxG_ - histTilesXG_);
+    if (histTilesY_ < nty_)
+        ty0 = std::min(std::max(floorDiv(std::min(std::max(lcy, 0), g_.gy) - reach, wi_), 0), nty_ - histTilesY_);
+    DynParams d{};
+    d.lrow = lcx + G_;
+    d.lcol = lcy + G_;
+    d.histTileX0 = gtx0;
+    d.histTileY0 = ty0;
+    d.histTilesX = histTilesXG_;
+    d.histTilesY = histTilesY_;
+    d.histRow0 = G_ + gtx0 * rxi_;
+    d.histCol0 = G_ + ty0 * wi_;
+    if (hipSetDevice(device_) != hipSuccess || hipMemcpy(dynDev_, &d, sizeof(d), hipMemcpyHostToDevice) != hipSuccess)
+        return fail("slab root: dyn upload failed");
+    launchFarCells(args(), stream_);
+    return hipGetLastError() == hipSuccess ? true : fail("slab root: far cells launch failed");
+}
+
+bool SlabRoot::importBlock(int r0g, int c0, int nr, int nc, const float* host7) {
+    if (nr <= 0 || nc <= 0) return true;
+    if (r0g < 0 || c0 < 0 || r0g + nr > g_.gx || c0 + nc > g_.gy) return fail("slab root: block outside the map");
+    hipSetDevice(device_);
+    const size_t blk = (size_t)nr * nc;
+    if (blk * 7 > stageCap_) {
+        if (stage_) hipFree(stage_);
+        stage_ = nullptr;
+        if (hipMalloc((void**)&stage_, blk * 7 * 4) != hipSuccess) return fail("slab root: staging allocation failed");
+        stageCap_ = blk * 7;
+    }
+    if (hipMemcpyAsync(stage_, host7, blk * 7 * 4, hipMemcpyHostToDevice, stream_) != hipSuccess)
+        return fail("slab root: block upload failed");
+    // staged planes 0..5 -> result planes {0, 1, 2, 3, 6, 7}; staged plane 6 -> the delay map
+    launchCopyBlock(stage_, (long long)blk, nc, 0, 0, res_, (long long)g_.gx * g_.gy, g_.gy, r0g, c0, nr, nc, 6, nullptr,
+                    planesDev_, stream_);
+    launchCopyBlock(stage_ + 6 * blk, 0, nc, 0, 0, delay_, 0, g_.gy, r0g, c0, nr, nc, 1, nullptr, nullptr, stream_);
+    return hipGetLastError() == hipSuccess ? true : fail("slab root: block copy failed");
+}
+
+bool SlabRoot::finish() {
+    hipSetDevice(device_);
+    launchAnalysisDirection(args(), stream_);
+    if (hipGetLastError() != hipSuccess) return fail("slab root: direction launch failed");
+    return hipStreamSynchronize(stream_) == hipSuccess ? true : fail("slab root: sync failed");
+}
+
+bool SlabRoot::getOutput(float ex, float ey, float ez, float out8[8], bool* valid) {
+    (void)ey;
+    int cx, cy;
+    *valid = resultCell(g_, ex, ez, &cx, &cy);
+    if (!*valid) return true;
+    hipSetDevice(device_);
+    launchGatherOutput(res_, (long long)g_.gx * g_.gy, (long long)cx * g_.gy + cy, outHost_, stream_);
+    if (hipStreamSynchronize(stream_) != hipSuccess) return fail("slab root: output sync failed");
+    for (int k = 0; k < 8; ++k) out8[k] = outHost_[k];
+    return true;
+}
+
+bool SlabRoot::copyResults(float* res8, float* delay) {
+    hipSetDevice(device_);
+    const size_t n = (size_t)g_.gx * g_.gy;
+    if (res8) {
+        if (!res8_ && hipMalloc((void**)&res8_, n * 32) != hipSuccess) return fail("slab root: allocation failed");
+        launchPackResults(res_, (long long)n, res8_, stream_);
+        if (hipMemcpyAsync(res8, res8_, n * 32, hipMemcpyDeviceToHost, stream_) != hipSuccess) return fail("results copy");
+    }
+    if (delay && hipMemcpyAsync(delay, delay_, n * 4, hipMemcpyDeviceToHost, stream_) != hipSuccess) return fail("delay copy");
+    return hipStreamSynchronize(stream_) == hipSuccess ? true : fail("slab root: sync failed");
 }
 
 }  // namespace pva

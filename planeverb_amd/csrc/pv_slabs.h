@@ -93,4 +93,65 @@ private:
     bool ran_ = false;
 };
 
+// ---- the same decomposition with the slabs in DIFFERENT PROCESSES (one rank per GPU, torch.distributed / RCCL or any
+// other transport in the host language): the group's steps as per-rank primitives.  A rank owns one slab Solver
+// (SolverOptions::slabIndex / slabCount); what crosses ranks is handed over as plain host buffers, so the transport is
+// the caller's (planeverb_amd/dist_slabs.py: send / recv over torch.distributed).
+struct SlabRankOps {
+    static bool begin(Solver& v, float lx, float ly, float lz);  // per-run set-up (listener, window, begin-run kernel)
+    static bool launch(Solver& v, int li);                        // K-step launch li of this slab's rows
+    static int numLaunches(const Solver& v);
+    static int haloFloats(const Solver& v);                       // 3 planes x K rows x pitch
+    // side 0 = towards the slab ABOVE (smaller rows), 1 = towards the slab BELOW
+    static bool exportHalo(Solver& v, int side, float* host);       // my K boundary rows of the set just written
+    static bool importHalo(Solver& v, int side, const float* host); // the neighbour's rows into my guard band
+    static int historyFloats(const Solver& v);                    // T x histPitch
+    static bool exportEdgeHistory(Solver& v, float* host);        // my last row's pressure history (for the slab below)
+    static bool importAboveHistory(Solver& v, const float* host);
+    static bool analyze(Solver& v);                               // far cells + cell analysis of my rows
+    // the window block of my maps: whole-grid row of its first row, first column, extent; 7 planes (result planes
+    // 0,1,2,3,6,7 + delay) of nr x nc floats into host (capacity in floats; returns the floats needed, < 0 on error)
+    static long long windowBlock(Solver& v, int* r0g, int* c0, int* nr, int* nc, float* host, long long cap);
+};
+
+// whole-grid result / delay maps of a decomposed grid whose slabs live in other processes: far cells, the slabs' blocks,
+// then the listener-direction descent (what SlabGroup does on its first device)
+class SlabRoot {
+public:
+    static SlabRoot* create(const Solver& anySlab, int device, std::string* err);  // geometry taken from a slab
+    ~SlabRoot();
+    bool begin(float lx, float ly, float lz);
+    bool importBlock(int r0g, int c0, int nr, int nc, const float* host7);
+    bool finish();
+    bool getOutput(float ex, float ey, float ez, float out8[8], bool* valid);
+    bool copyResults(float* res8, float* delay);
+    const std::string& lastError() const { return err_; }
+    const GridSpec& spec() const { return g_; }
+
+private:
+    SlabRoot() = default;
+    bool fail(const std::string& w) {
+        err_ = w;
+        return false;
+    }
+    GridSpec g_;
+    int device_ = 0, G_ = 0, rxi_ = 0, wi_ = 0, nty_ = 0, T_ = 0, K_ = 0;
+    int ntxG_ = 0, histTilesXG_ = 0, histTilesY_ = 0;
+    float efree_ = 0;
+    hipStream_t stream_ = nullptr;
+    float* res_ = nullptr;
+    float* res8_ = nullptr;
+    float* delay_ = nullptr;
+    float* stage_ = nullptr;  // one block, 7 planes
+    size_t stageCap_ = 0;
+    int* dirScratch_ = nullptr;
+    int* planesDev_ = nullptr;
+    DynParams* dynDev_ = nullptr;
+    float* outHost_ = nullptr;
+    int winRows_ = 0, winCols_ = 0;
+    float lx_ = 0, lz_ = 0;
+    std::string err_;
+    AnalyzeArgs args() const;
+};
+
 }  // namespace pva

@@ -53,9 +53,13 @@ struct SolverTimings {
 };
 
 class SlabGroup;
+class SlabRoot;
+struct SlabRankOps;
 
 class Solver {
     friend class SlabGroup;
+    friend class SlabRoot;
+    friend struct SlabRankOps;
 
 public:
     static Solver* create(const GridSpec& spec, int device, const SolverOptions& opt, std::string* err);
@@ -66,6 +70,7 @@ public:
     int device() const { return device_; }
     int K() const { return K_; }
     float efree() const { return efree_; }
+    void setEfree(float e) { efree_ = e; }  // slab ranks: computed once for the whole grid
     int T() const { return T_; }
     long long deviceBytes() const { return deviceBytes_; }
     int histRows() const { return histRows_; }

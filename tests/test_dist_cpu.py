@@ -50,3 +50,44 @@ def test_single_process_gather():
     local = {0: np.ones((2, 8), np.float32), 1: np.full((2, 8), 2, np.float32)}
     out = pvd.gather_outputs(local, 2, None)
     assert out.shape == (2, 2, 8) and out[1, 0, 0] == 2
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_exchange_schedule_gloo(world, tmp_path):
+    """SURVEY.md 8f N4 across processes: planeverb_amd.dist_slabs.run_rank (per launch: K boundary rows both ways between
+    neighbouring ranks; per run: the last row's history to the rank below, the window blocks to rank 0) over gloo, on a toy
+    slab with exact integer arithmetic (tests/_slab_toy.py): final fields and gathered maps EQUAL the undivided domain's"""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _slab_toy import analysis, whole_domain
+    port = str(_free_port())
+    worker = os.path.join(ROOT, "tests", "_slab_worker.py")
+    outs = [str(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), port, outs[r]]) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=180) == 0
+    NX, cols, T, K = 60, 17, 23, 4
+    data = [np.load(o) for o in outs]
+    for i, src in enumerate([(NX // world, 5), (NX // world - 1, 9), (3, 2)]):
+        final, hist = whole_domain(NX, cols, T, K, src)
+        got = np.concatenate([d["f%d" % i] for d in data])
+        assert np.array_equal(got, final), "final field, source %s" % (src,)
+        want = analysis(hist, np.zeros((T, cols)))
+        assert np.array_equal(data[0]["m%d" % i], want), "gathered maps, source %s" % (src,)
+    assert final.any() and want.any()
+
+
+def test_slab_schedule_local_equals_undivided():
+    """the lock-step form (dist_slabs.run_local: all ranks in one process, how a one-GPU box runs the decomposition)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from planeverb_amd import dist_slabs
+    from _slab_toy import ToyRoot, ToySlab, analysis, whole_domain
+    NX, cols, T, K = 60, 17, 23, 4
+    for world in (2, 4):
+        src = (NX // world, 5)
+        slabs = [ToySlab(NX, cols, T, K, r, world, src) for r in range(world)]
+        root = ToyRoot(NX, cols)
+        dist_slabs.run_local(slabs, root, (0, 0, 0))
+        final, hist = whole_domain(NX, cols, T, K, src)
+        assert np.array_equal(np.concatenate([s.u[K:K + s.n] for s in slabs]), final)
+        assert np.array_equal(root.maps, analysis(hist, np.zeros((T, cols)))) and root.finished

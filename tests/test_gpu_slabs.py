@@ -142,3 +142,47 @@ def test_slabs_open_field_4096_matches_single_solver(pvlib):
         for k in range(8):
             assert same_bits(ra[..., k], rb[..., k]).all(), k
         assert (da < 1e30).sum() > 200000
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_ranks_with_host_exchange_match_single_solver_1024(pvlib, world):
+    """the decomposition with one slab per RANK (PvAmdCreateSlabRank + PvAmdSlab* primitives, whole-grid maps in
+    PvAmdSlabRoot*): the exchange schedule of planeverb_amd.dist_slabs (the one that runs over torch.distributed / RCCL with
+    one process per GPU; tests/test_dist_cpu.py runs it over gloo) driven in lock-step inside this process, halos, boundary
+    histories and result blocks passing through host buffers.  Bit-identical to one solver on the whole grid."""
+    from planeverb_amd import dist_slabs
+    n = 1024
+    opts = dict(steps_per_launch=8, tile_rows=24)
+    size = size_of(n)
+    efree = pvlib.compute_efree(size, size, 275)
+    slabs = [pvlib.SlabRank(size, size, 275, 0, r, world, efree, **opts) for r in range(world)]
+    root = pvlib.SlabRoot(slabs[0], 0)
+    try:
+        with pvlib.Solver(size, size, 275, **opts) as a:
+            assert np.float32(a.efree) == np.float32(efree)
+            edge = (-(-(n + 1) // 24) * 1 // world) * 24
+            Ls = [cell(edge, 400), cell(edge - 1, 640)]
+            boxes = [[Ls[0][0] + 1.0, Ls[0][2] + 9.0, 40.0, 1.0, 0.85], [Ls[0][0] - 20.0, Ls[0][2] - 4.0, 1.2, 55.0, 0.5]]
+            for box in boxes:
+                a.add_geometry(box)
+                for s in slabs:
+                    s.add_geometry(box)
+            for L in Ls:
+                a.run(L)
+                dist_slabs.run_local(slabs, root, L)
+                ra, da = a.results()
+                rb, db = root.results()
+                assert same_bits(da, db).all(), "delay map"
+                for k in range(8):
+                    assert same_bits(ra[..., k], rb[..., k]).all(), "result plane %d" % k
+                assert (da < 1e30).sum() > 100000
+                e = (L[0] + 3.0, 0.0, L[2] + 2.0)
+                assert same_bits(a.get_output(e).as_array(), root.get_output(e).as_array()).all()
+                fa = a.fields()
+                fb = [np.concatenate(p) for p in zip(*[s.solver.fields_local() for s in slabs])]
+                for x, y in zip(fa, fb):
+                    assert same_bits(x, y).all(), "final fields"
+    finally:
+        root.close()
+        for s in slabs:
+            s.close()

@@ -35,6 +35,8 @@ def steady(v):
 
 
 shutil.copy(os.path.join(SRC, "trace", "bench_kernel_stats.csv"), os.path.join(DST, R + "_kernel_stats.csv"))
+if os.path.exists(os.path.join(ROOT, "gpurun_out", "r02_sq", "summary.md")):
+    shutil.copy(os.path.join(ROOT, "gpurun_out", "r02_sq", "summary.md"), os.path.join(DST, R + "_sq_pmc.md"))
 for f in ("bench.json", "bench_8192.json", "bench_8192_open.json", "bench_2048.json", "bench_512.json", "bench_dense.json",
           "bench_inflight1.json", "bench_512_batch8.json", "bench_1024_batch8.json", "sizes.txt", "concurrent.txt",
           "batch.txt",
@@ -91,6 +93,43 @@ for tag, fd, wd in (("4096", "pmc_fetch", "pmc_write"), ("8192", "pmc_fetch8k", 
             traffic[tag] = {"bytes_per_launch": rb + wb, "read_bytes": rb, "write_bytes": wb, "kernel": short}
     out["grids"][tag] = g
     lines.append("")
+# stamp: which device code these counters belong to (bench.py quotes them only for the same kernel sources)
+sys.path.insert(0, ROOT)
+from planeverb_amd.build import kernel_source_hash  # noqa: E402
+import subprocess  # noqa: E402
+try:
+    head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:
+    head = None
+stamp = {"kernel_source_hash": kernel_source_hash(), "collected_at_head": head, "round": R,
+         "box_note": "one MI355X box of the pool; boxes differ by up to 10 %"}
+# SQ / GRBM counters of the dominant kernel (tools/pmc_r02.sh -> gpurun_out/r02_sq), single launches
+sq_dir = os.path.join(ROOT, "gpurun_out", "r02_sq")
+sq = {}
+for w in ("zero1", "random1"):
+    acc = collections.defaultdict(list)
+    import glob
+    for f in glob.glob(os.path.join(sq_dir, w, "p*", "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "pv_step_merged_kernel" in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    durs = []
+    for f in glob.glob(os.path.join(sq_dir, w, "p1", "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "pv_step_merged_kernel" in r["Kernel_Name"]:
+                durs.append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    if acc and durs:
+        m = {k: med(v) for k, v in acc.items()}
+        d = med(durs)
+        sq[w] = {"counters": m, "launch_ns_under_pmc": d,
+                 # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+                 "effective_clock_ghz": m.get("GRBM_GUI_ACTIVE", 0) / 8.0 / d,
+                 "valu_busy_single_launch": m.get("SQ_ACTIVE_INST_VALU", 0) * 4.0 / 1024.0 / (m.get("GRBM_GUI_ACTIVE", 1) / 8.0)}
+for t in traffic.values():
+    t.update(stamp)
+if sq:
+    traffic["sq_4096"] = dict(sq, **stamp)
+out["stamp"] = stamp
 json.dump(out, open(os.path.join(DST, R + "_hbm_pmc.json"), "w"), indent=1)
 open(os.path.join(DST, R + "_hbm_pmc.md"), "w").write("\n".join(lines) + "\n")
 json.dump(traffic, open(os.path.join(DST, "hbm_traffic.json"), "w"), indent=1)

@@ -54,9 +54,9 @@ print("# SQ / GRBM / TCC counters of `pv_step_merged_kernel<12,36>` -- raw stenc
 print()
 print("Collected by `tools/pmc_r02.sh` (rocprofv3 `--pmc` in separate passes with `--kernel-trace` only).  Medians over "
       "the full 12-step launches of one pass.  Units: `SQ_*_CYCLES` / `SQ_ACTIVE_INST_*` / `SQ_WAIT_*` count "
-      "quad-cycles summed over waves (MI355X_MICROARCH.md); `VALUBusy` = SQ_ACTIVE_INST_VALU / CU_NUM / GRBM_GUI_ACTIVE "
-      "(rocprofiler-sdk's gfx950 formula, CU_NUM = 256); effective clock = GRBM_GUI_ACTIVE / launch duration of the same "
-      "pass.  Under `--pmc` the profiler serialises dispatches, so counters exist for single launches only; the "
+      "quad-cycles summed over waves (MI355X_MICROARCH.md); GRBM_GUI_ACTIVE is summed over the 8 XCDs (it reads 8 x "
+      "clock x duration), so per-XCD cycles = GRBM_GUI_ACTIVE / 8 and effective clock = that / launch duration of the same "
+      "pass (the guide's DVFS recipe); VALU issue utilisation = VALU quad-cycles x 4 / 1024 SIMDs / per-XCD cycles.  Under `--pmc` the profiler serialises dispatches, so counters exist for single launches only; the "
       "`2 in flight` rows come from the counter-free kernel trace and the wall rate.")
 print()
 rows = {}
@@ -91,8 +91,14 @@ def derived(w):
     g = m.get("GRBM_GUI_ACTIVE", float("nan"))
     d = collections.OrderedDict()
     d["launch duration under --pmc (us)"] = dur / 1e3
-    d["effective clock = GRBM_GUI_ACTIVE / duration (GHz)"] = g / dur
-    d["VALUBusy = SQ_ACTIVE_INST_VALU / 256 / GRBM_GUI_ACTIVE"] = m.get("SQ_ACTIVE_INST_VALU", float("nan")) / CU_NUM / g
+    # GRBM_GUI_ACTIVE comes back SUMMED over the 8 XCDs (8 x 2.4 GHz x duration): per-XCD cycles = / 8
+    d["effective clock = GRBM_GUI_ACTIVE / 8 / duration (GHz)"] = g / 8 / dur
+    d["VALU issue utilisation = SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8)"] = (
+        m.get("SQ_ACTIVE_INST_VALU", float("nan")) * 4 / SIMDS / (g / 8))
+    d["any-instruction issue utilisation = SQ_ACTIVE_INST_ANY x 4 / 1024 / (GRBM / 8)"] = (
+        m.get("SQ_ACTIVE_INST_ANY", float("nan")) * 4 / SIMDS / (g / 8))
+    d["mean resident waves per SIMD = SQ_WAVE_CYCLES x 4 / 1024 / (GRBM / 8)"] = (
+        m.get("SQ_WAVE_CYCLES", float("nan")) * 4 / SIMDS / (g / 8))
     d["VALU instructions per wave"] = m.get("SQ_INSTS_VALU", float("nan")) / m.get("SQ_WAVES", float("nan"))
     d["active lanes per VALU instruction (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 64... of 64)"] = (
         m.get("SQ_THREAD_CYCLES_VALU", float("nan")) / m.get("SQ_ACTIVE_INST_VALU", float("nan")))
