@@ -3,7 +3,7 @@
 # HBM PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs, as MI355X_MICROARCH.md prescribes), and the counter
 # calibration.  Everything lands in gpurun_out/; tools/summarize_profiles.py turns it into profiles/.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-R=${1:-r01}
+R=${1:-r02}
 O=gpurun_out/$R
 rm -rf $O && mkdir -p $O
 # (--steps 20: the kernel average below then is dominated by the timed, overlapped launches -- 2 of the 42 runs of the
@@ -37,3 +37,7 @@ python tools/gpu_batch.py 512,1024,2048 "1x1 4x1 1x8 2x8" Shoebox.pv > $O/batch.
 python tools/gpu_batch.py 4096 "2x1 1x2 3x1" >> $O/batch.txt 2>&1
 rm -f $O/trace/bench_kernel_trace.csv.bak
 ls -la $O
+# SQ / GRBM counters of the dominant kernel, zero vs random fields (-> gpurun_out/r02_sq, summarised into profiles/<round>_sq_pmc.md)
+bash tools/pmc_r02.sh > $O/pmc_r02.log 2>&1
+python tools/gpu_live_rate.py --out $O/live_rate.txt > /dev/null 2>&1
+python tools/gpu_slabs.py 4096 2048 > $O/slabs_one_device.txt 2>&1
