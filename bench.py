@@ -253,7 +253,10 @@ def main():
     # ncclAllGather inside libplaneverb_amd.so; torch.distributed only carries the 128-byte id to the ranks).  Should
     # RCCL not bind there, torch.distributed's all_gather does the same job and the JSON line says so.
     comm, gather_how = None, "single process: no collective"
-    if use_dist:
+    if use_dist and os.environ.get("PV_BENCH_GATHER") == "torch":
+        gather_how = "torch.distributed.all_gather_into_tensor (PV_BENCH_GATHER=torch)"
+        pvd.gather_outputs({run_id(0, b): np.zeros((2, 8), np.float32) for b in range(B)}, B * world, dist, dev)
+    elif use_dist:
         try:
             comm = pvd.make_comm(dist, local_rank)
             gather_how = "ncclAllGather in libplaneverb_amd.so (PvAmdCommAllGather), id bootstrapped over torch.distributed"

@@ -50,8 +50,15 @@ def make_comm(dist, device_index):
     it to the other ranks (bootstrap); the data path's one collective then runs in C++ (PvAmdCommAllGather)."""
     from . import api
     world, rank = dist.get_world_size(), dist.get_rank()
-    box = [api.Comm.unique_id() if rank == 0 else None]
+    box = [None]
+    if rank == 0:
+        try:
+            box = [api.Comm.unique_id()]
+        except Exception as e:  # noqa: BLE001 -- every rank must still leave the broadcast below
+            box = [RuntimeError("PvAmdCommUniqueId failed: %s" % e)]
     dist.broadcast_object_list(box, src=0)
+    if not isinstance(box[0], (bytes, bytearray)):
+        raise RuntimeError(str(box[0]))
     return api.Comm(box[0], rank, world, device_index)
 
 
