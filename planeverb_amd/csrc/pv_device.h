@@ -62,6 +62,9 @@ struct StepArgs {
     float* hist;           // window base, plane stride histPlane
     int* tileFirst;        // per tile: first step block in which the tile was non-zero (INT_MAX = never)
     const uint8_t* tileClass;   // per tile: 0 = all faces air|air (air kernel), 1 = general kernel
+    const uint8_t* tileDead;    // per tile (NULL = feature off): 1 = every interior cell is wall with wall|wall faces, so
+                                // its pr, vx, vy are identically zero in a run that starts from zero fields: the general
+                                // arm skips it (thick walls of a 25 m scene at fine resolution: 17 % of all tiles)
     const int* generalList;     // tiles for the general kernel: class-1 tiles + tiles holding the listener
     int numGeneral;             // capacity of generalList used to size the grid; live count is dyn->numGeneral
     const DynParams* dyn;

@@ -1495,9 +1495,10 @@ __global__ __launch_bounds__(256, WPS) void pv_step_merged_kernel(const StepArgs
     const int gblocks = a.numGeneral;  // one block per general tile
     if ((int)blockIdx.x < gblocks) {
         if ((int)blockIdx.x >= a.dyn->numGeneral) return;
+        const int tile = __builtin_amdgcn_readfirstlane(a.generalList[blockIdx.x]);
+        if (deadTileSkippable<K, RXI>(a, tile)) return;  // (block-uniform)
         lut[threadIdx.x] = a.lut[threadIdx.x];
         __syncthreads();
-        const int tile = __builtin_amdgcn_readfirstlane(a.generalList[blockIdx.x]);
         stepTileGeneral4<K, RXI>(a, tile, wave, lane, lut, gsh);
         return;
     }
@@ -1534,9 +1535,10 @@ __global__ __launch_bounds__(256, WPS) void pv_step_batch_kernel(const BatchArgs
     const int gblocks = ba.gblocks;
     if ((int)blockIdx.x < gblocks) {
         if ((int)blockIdx.x >= a.dyn->numGeneral) return;
+        const int tile = __builtin_amdgcn_readfirstlane(a.generalList[blockIdx.x]);
+        if (deadTileSkippable<K, RXI>(a, tile)) return;  // (block-uniform)
         lut[threadIdx.x] = a.lut[threadIdx.x];
         __syncthreads();
-        const int tile = __builtin_amdgcn_readfirstlane(a.generalList[blockIdx.x]);
         stepTileGeneral4<K, RXI>(a, tile, wave, lane, lut, gsh);
         return;
     }
@@ -1640,6 +1642,42 @@ __global__ __launch_bounds__(256) void pv_tileclass_kernel(const uint16_t* codes
         tileClass[tile] = air ? 0 : edge ? 2 : 1;
         if (!air && !edge) generalList[atomicAdd(generalCount, 1)] = tile;
     }
+}
+
+// Dead tiles: every interior cell is a wall cell whose x and y faces are wall|wall (code 0x8080).  Then pr = beta * (...)
+// = 0 (FDTD.cpp:139) and both velocities are 0 (FDTD.cpp:165-168 with beta = beta_n = 0) whatever the halo holds, so a
+// run that starts from zero fields never has to touch the tile: both buffer sets keep their zeros there.  One wave per tile.
+__global__ __launch_bounds__(256) void pv_tiledead_kernel(const uint16_t* codes, uint8_t* dead, int* count, Geometry g,
+                                                          int K) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= g.ntx * g.nty) return;
+    const int WI = 64 - 2 * K;
+    const int ti = tile / g.nty, tj = tile - ti * g.nty;
+    const size_t base = (size_t)(g.G + ti * g.rxi) * g.pitch + (g.G + tj * WI - K + lane);
+    bool ok = true;
+    if (lane >= K && lane < 64 - K)
+        for (int r = 0; r < g.rxi; ++r) ok = ok && codes[base + (size_t)r * g.pitch] == (uint16_t)(kLutWall | (kLutWall << 8));
+    const bool d = __ballot(!ok) == 0ull;
+    if (lane == 0) {
+        dead[tile] = d ? 1 : 0;
+        if (d) atomicAdd(count, 1);
+    }
+}
+
+void launchTileDead(const uint16_t* codes, uint8_t* dead, int* count, const Geometry& g, int K, hipStream_t stream) {
+    hipLaunchKernelGGL(pv_tiledead_kernel, dim3((g.ntx * g.nty + 3) / 4), dim3(256), 0, stream, codes, dead, count, g, K);
+}
+
+// general arm: may this block leave at once?  (a dead tile, unless the listener sits in its loaded region: the pulse is
+// injected into the wall cell and swallowed there, but the final field still shows its last sample, FDTD.cpp:234)
+template <int K, int RXI>
+__device__ __forceinline__ bool deadTileSkippable(const StepArgs& a, int tile) {
+    if (!a.tileDead || !a.tileDead[tile]) return false;
+    if (!a.withPulse) return true;
+    const int ti = tile / a.nty, tj = tile - ti * a.nty;
+    const int lr = a.dyn->lrow - (a.G - K + ti * RXI), lc = a.dyn->lcol - (a.G - K + tj * (64 - 2 * K));
+    return !(lr >= 0 && lr < RXI + 2 * K + 8 && lc >= 0 && lc < 64);
 }
 
 // positions an XCD's band needs under the chosen order (sub-bands are padded to whole multiples of H rows)

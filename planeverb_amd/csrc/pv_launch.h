@@ -29,6 +29,8 @@ void launchBatch(int K, int rxi, const BatchArgs& ba, hipStream_t stream);
 // has the mirror-pair air tile)
 void launchTileClass(int K, int rxi, const uint16_t* codes, uint8_t* tileClass, int* list, int* count,
                      const Geometry& g, hipStream_t stream, bool allowEdge);
+// dead tiles (all-wall interior): dead[tile] = 1, *count += number of them
+void launchTileDead(const uint16_t* codes, uint8_t* dead, int* count, const Geometry& g, int K, hipStream_t stream);
 // cells = NX*NY must satisfy smallGridFits()
 bool smallGridFits(int NX, int NY);
 void launchSmallGrid(const SmallArgs& a, hipStream_t stream);

@@ -201,7 +201,7 @@ bool SlabGroup::run(float lx, float ly, float lz) {
         Solver& v = *slabs_[(size_t)s];
         if (!hipOk(hipSetDevice(v.device_), "hipSetDevice")) return false;
         if (v.pendingTimings_ && !v.sync()) return slabFailed(s);
-        if (!v.applyGeometry() || !v.prepareDyn(lcx, lcy, true, false)) return slabFailed(s);
+        if (!v.applyGeometry() || !v.prepareDyn(lcx, lcy, true, false) || !v.zeroPlanesIfNeeded()) return slabFailed(s);
         v.lastLx_ = lx;
         v.lastLz_ = lz;
         v.tim_.stepLaunches = 0;
@@ -419,7 +419,7 @@ bool SlabRankOps::begin(Solver& v, float lx, float ly, float lz) {
     int lcx, lcy;
     listenerCell(v.g_, lx, lz, &lcx, &lcy);
     if (v.pendingTimings_ && !v.sync()) return false;
-    if (!v.applyGeometry() || !v.prepareDyn(lcx, lcy, true, false)) return false;
+    if (!v.applyGeometry() || !v.prepareDyn(lcx, lcy, true, false) || !v.zeroPlanesIfNeeded()) return false;
     v.lastLx_ = lx;
     v.lastLz_ = lz;
     v.tim_.stepLaunches = 0;

@@ -163,6 +163,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     if (!dalloc(&pulseDev_, (size_t)std::max(T_, g_.T), true)) return false;
     if (!dalloc(&tileFirst_, (size_t)ntiles, true)) return false;
     if (!dalloc(&tileClass_, (size_t)ntiles, true)) return false;
+    if (!dalloc(&tileDead_, (size_t)ntiles, true) || !dalloc(&deadCount_, 1, true)) return false;
     if (!dalloc(&nz_[0], (size_t)ntiles, true) || !dalloc(&nz_[1], (size_t)ntiles, true)) return false;
     listCap_ = ntiles;
     if (!dalloc(&generalList_, (size_t)listCap_, true)) return false;
@@ -194,7 +195,10 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         histPitch_ = roundUp(wty * wi_, 64);
         histPlane_ = (long long)histRows_ * histPitch_;
         // streaming mode keeps a ring of 8 launches' worth of planes instead of all T
-        ring_ = opt.streaming ? std::min(roundUp(T_, K_), 8 * K_) : T_;
+        // streaming: TWO half rings of 8 launches' planes -- the forward sums of one half advance on a second stream while
+        // the step kernels fill the other (the accumulate pass is latency / bandwidth work, the stencil VALU work)
+        halfRing_ = std::min(roundUp(T_, K_), 8 * K_);
+        ring_ = opt.streaming ? 2 * halfRing_ : T_;
         const long long bytes = histPlane_ * 4 * (long long)ring_;
         if (histPlane_ * 4 > (long long)INT_MAX) return fail("history plane too large for 32-bit offsets");
         size_t freeB = 0, totalB = 0;
@@ -293,7 +297,7 @@ Solver::~Solver() {
     if (emTrace_) hipFree(emTrace_);
     void* ptrs[] = {codes_,     matDev_, lutDev_, pulseDev_, hist_,  tileFirst_, tileClass_, generalList_,
                     generalCount_, dynDev_, errFlag_, res8_,     delay_, scratch_, res_, activeCount_, win8_,
-                    histAbove_, histEdge_};
+                    histAbove_, histEdge_, tileDead_, deadCount_};
     for (void* p : ptrs)
         if (p) hipFree(p);
     for (size_t b = 1; b < bandStream_.size(); ++b)
@@ -302,6 +306,8 @@ Solver::~Solver() {
             hipStreamDestroy(bandStream_[b]);
         }
     for (auto& e : bandEv_)
+        if (e) hipEventDestroy(e);
+    for (auto& e : streamEv_)
         if (e) hipEventDestroy(e);
     if (dynBandsDev_) hipFree(dynBandsDev_);
     if (dynBandsHost_) hipHostFree(dynBandsHost_);
@@ -440,7 +446,11 @@ bool Solver::applyGeometry() {
     if (!hipOk(hipMemsetAsync(generalCount_, 0, sizeof(int), stream_), "memset")) return false;
     launchTileClass(K_, rxi_, codes_, tileClass_, generalList_, generalCount_, geo_, stream_,
                     opt_.edgeTiles);
+    if (!hipOk(hipMemsetAsync(deadCount_, 0, sizeof(int), stream_), "memset")) return false;
+    launchTileDead(codes_, tileDead_, deadCount_, geo_, K_, stream_);
     int count = 0;
+    if (!hipOk(hipMemcpyAsync(&numDead_, deadCount_, sizeof(int), hipMemcpyDeviceToHost, stream_), "count copy"))
+        return false;
     if (!hipOk(hipMemcpyAsync(&count, generalCount_, sizeof(int), hipMemcpyDeviceToHost, stream_), "count copy"))
         return false;
     if (!hipOk(hipStreamSynchronize(stream_), "geometry sync")) return false;
@@ -456,6 +466,7 @@ bool Solver::applyGeometry() {
         return false;
     mat_.clearDirty();
     geometryDirty_ = false;
+    planesDirty_ = true;  // a tile that is dead now may hold an earlier scene's fields
     dynValid_ = false;
     dropGraph();  // tile classes / list capacity may have changed
     tim_.geometryMs =
@@ -610,6 +621,20 @@ bool Solver::prepareDyn(int lcx, int lcy, bool withPulse, bool banded) {
 
 // prepareDyn() left the run's parameters in pinned host memory; this launch moves them to HBM and resets the
 // per-tile bookkeeping (see pv_begin_run_kernel).  It is captured into the run graph with the step launches.
+// Dead tiles are never written by a run, so both buffer sets must hold zeros there: re-established here whenever the
+// planes may hold anything else (new geometry, setFields / raw stepping).  Scenes without dead tiles pay nothing.
+bool Solver::zeroPlanesIfNeeded() {
+    if (numDead_ == 0 || !planesDirty_) return true;
+    const size_t bytes = (size_t)geo_.rows * geo_.pitch * 4;
+    for (int i = 0; i < 2; ++i)
+        if (!hipOk(hipMemsetAsync(pr_[i], 0, bytes, stream_), "plane clear") ||
+            !hipOk(hipMemsetAsync(vx_[i], 0, bytes, stream_), "plane clear") ||
+            !hipOk(hipMemsetAsync(vy_[i], 0, bytes, stream_), "plane clear"))
+            return false;
+    planesDirty_ = false;
+    return true;
+}
+
 void Solver::enqueueBeginRun(bool resetTiles) {
     BeginArgs b{};
     b.dynHost = dynHost_;
@@ -639,6 +664,9 @@ StepArgs Solver::baseStepArgs(bool withPulse, bool record) const {
     a.hist = hist_;
     a.tileFirst = tileFirst_;
     a.tileClass = tileClass_;
+    // dead tiles are skipped only by runs that start from zero fields (record = a run; raw stepping starts from the
+    // caller's fields, which may be anything inside a wall)
+    a.tileDead = (record && numDead_ > 0) ? tileDead_ : nullptr;
     a.generalList = generalList_;
     a.numGeneral = launchCap_;
     a.dyn = dynDev_;
@@ -697,6 +725,7 @@ StepArgs Solver::bandStepArgs(const StepArgs& a, int b) const {
     v.codes += off;
     v.tileFirst += (long long)r0 * geo_.nty;
     v.tileClass += (long long)r0 * geo_.nty;
+    if (v.tileDead) v.tileDead += (long long)r0 * geo_.nty;
     if (v.tileOpen) v.tileOpen += (long long)r0 * geo_.nty;
     v.nzIn += (long long)r0 * geo_.nty;
     v.nzOut += (long long)r0 * geo_.nty;
@@ -891,6 +920,7 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
     const bool graph = !opt_.timeKernels && !opt_.streaming &&
                        (opt_.useGraph == 1 || (opt_.useGraph == 0 && ntiles <= 4096));
     if (!prepareDyn(lcx, lcy, true, /*banded=*/!graph)) return false;
+    if (!zeroPlanesIfNeeded()) return false;
     lastLx_ = lx;
     lastLz_ = lz;
     tim_.stepLaunches = 0;
@@ -914,13 +944,27 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
         launchCap_ = numGeneral_;
         enqueueBeginRun(true);
         AnalyzeArgs aa = analyzeArgs(lx, lz);
-        for (int tA = 0; tA < T_; tA += ring_) {
-            const int n = std::min(ring_, T_ - tA);
+        if (streamEv_[0] == nullptr)
+            for (auto& e : streamEv_)
+                if (!hipOk(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate")) return false;
+        // Half h of the ring: [steps fill it on stream_] -> stepDone[h] -> [accumulate pass on stream2_] -> accDone[h] ->
+        // [steps may overwrite it].  The passes stay in order on stream2_ (they carry per-cell state from one to the next);
+        // the per-tile "history still wanted" flags they produce reach the step kernels half a ring later than in a serial
+        // schedule, which only means a tile may record a few planes nobody reads.
+        int pass = 0;
+        for (int tA = 0; tA < T_; tA += halfRing_, ++pass) {
+            const int n = std::min(halfRing_, T_ - tA), h = pass & 1;
+            if (pass >= 2) hipStreamWaitEvent(stream_, streamEv_[2 + h], 0);
             if (!enqueueSteps(tA, n, true, true, tA == 0)) return false;
+            hipEventRecord(streamEv_[h], stream_);
+            hipStreamWaitEvent(stream2_, streamEv_[h], 0);
             aa.tA = tA;
             aa.tB = tA + n;
-            launchStreamAccum(aa, tileEmit_, tileOpen_, ntiles, stream_);
+            launchStreamAccum(aa, tileEmit_, tileOpen_, ntiles, stream2_);
+            hipEventRecord(streamEv_[2 + h], stream2_);
         }
+        hipStreamWaitEvent(stream_, streamEv_[2], 0);
+        if (pass >= 2) hipStreamWaitEvent(stream_, streamEv_[3], 0);
         hipEventRecord(ev_[1], stream_);
         launchStreamFinalize(aa, stream_);
         hipEventRecord(ev_[2], stream_);
@@ -1048,7 +1092,8 @@ bool Solver::runBatch(Solver* const* s, int n, const float* lxyz, bool wait, std
         const float lx = lxyz[3 * i], lz = lxyz[3 * i + 2];
         int lcx, lcy;
         listenerCell(v.g_, lx, lz, &lcx, &lcy);
-        if ((v.pendingTimings_ && !v.sync()) || !v.applyGeometry() || !v.prepareDyn(lcx, lcy, true, false)) {
+        if ((v.pendingTimings_ && !v.sync()) || !v.applyGeometry() || !v.prepareDyn(lcx, lcy, true, false) ||
+            !v.zeroPlanesIfNeeded()) {
             if (err) *err = v.err_;
             return false;
         }
@@ -1163,6 +1208,7 @@ bool Solver::runSteps(int nsteps, bool withPulse, float lx, float lz) {
     kevUsed_ = 0;
     loopTimed_ = false;
     launchCap_ = numGeneral_;
+    planesDirty_ = true;
     enqueueBeginRun(false);
     hipEventRecord(ev_[0], stream_);
     if (!enqueueSteps(0, nsteps, withPulse, false)) return false;
@@ -1346,6 +1392,7 @@ bool Solver::copyFields(float* pr, float* vx, float* vy) {
 
 bool Solver::setFields(const float* pr, const float* vx, const float* vy) {
     if (isSlab()) return fail("setFields is not available on a slab");
+    planesDirty_ = true;
     if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
     const size_t n = (size_t)g_.NX * g_.NY;
     const float* src[3] = {pr, vx, vy};

@@ -143,6 +143,7 @@ private:
     void setLaunchArgs(StepArgs& a, int t0, int k, bool firstOfRun, int li) const;
     bool prepareDyn(int lcx, int lcy, bool withPulse, bool banded);
     void enqueueBeginRun(bool resetTiles);
+    bool zeroPlanesIfNeeded();
     AnalyzeArgs analyzeArgs(float lx, float lz) const;
     bool fail(const std::string& what);
     bool hipOk(hipError_t e, const char* what);
@@ -195,6 +196,10 @@ private:
     uint8_t* nz_[2] = {nullptr, nullptr};  // per-tile non-zero flags, ping-pong per launch
     int* tileFirst_ = nullptr;
     uint8_t* tileClass_ = nullptr;
+    uint8_t* tileDead_ = nullptr;   // per tile: all-wall interior (skipped by runs that start from zero fields)
+    int* deadCount_ = nullptr;
+    int numDead_ = 0;
+    bool planesDirty_ = false;      // the field planes may hold non-zero values inside dead tiles
     int* generalList_ = nullptr;
     int* generalCount_ = nullptr;
     DynParams* dynDev_ = nullptr;
@@ -207,6 +212,8 @@ private:
     float* delay_ = nullptr;
     // streaming analysis state
     int ring_ = 0;             // history planes allocated (T_ when not streaming)
+    int halfRing_ = 0;         // streaming: steps per accumulate pass (the ring holds two such halves)
+    hipEvent_t streamEv_[4] = {nullptr, nullptr, nullptr, nullptr};  // stepDone[2], accDone[2]
     int* sOnset_ = nullptr;
     float* sState_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // Edry, fluxX, fluxY, vx, vy
     uint8_t* tileOpen_ = nullptr;   // per tile: history still wanted (streaming mode)

@@ -370,6 +370,63 @@ def test_palette_is_rebuilt_when_values_come_and_go(pvlib, oracle):
     compare_maps(res, delay, rres, rdelay, 435, 1443, "after 300 absorption changes")
 
 
+def test_dead_tiles_thick_walls_vs_oracle(pvlib, oracle):
+    """Tiles whose interior is solid wall (thick walls: a 25 m scene at fine resolution, Mode B) are skipped by runs that
+    start from zero fields -- their pr, vx, vy are identically zero.  A 256^2 grid with a 40 m solid block and a thick
+    bar (several all-wall tiles), against the oracle: listener beside the block, listener INSIDE the block (the pulse is
+    swallowed, the final field still shows its last sample), then the geometry changes on the same solver (block removed:
+    sound enters where dead tiles were; a new block where sound was) -- whole maps, recorded planes and final fields."""
+    dx = np.float32(343.21) / np.float32(275) / np.float32(3.5)
+    size = float((256 + 0.5) * dx)
+    block = [30.0, 40.0, 40.0, 44.0, 0.9]
+    bar = [70.0, 45.0, 12.0, 60.0, 0.5]
+    late = [62.0, 18.0, 30.0, 26.0, 0.7]
+    ef = oracle.free_energy(size, size, 275)
+
+    def check(s, boxes, L):
+        s.run(L)
+        o = oracle.OracleGrid(size, size, 275, np.array(boxes, np.float32) if boxes else None)
+        f = o.fdtd(L, want_fields=True)
+        hp, _, _ = o.history()
+        for t in (0, 30, 200, 434):
+            assert same_bits(s.history_plane(t), hp[t]).all(), "recorded pr, step %d" % t
+        for mine, ref in zip(s.fields(), f):
+            assert same_bits(mine, ref).all(), "final fields"
+        rres, rdelay, _ = o.analyze(ef, L)
+        res, delay = s.results()
+        o.close()
+        # the solver is re-used: cells WITHOUT an onset keep the previous run's values (SURVEY Q8) and the direction walk
+        # of such a cell looks at them, while the oracle call starts from a zeroed pool -- compare what a run defines
+        assert same_bits(delay, rdelay).all(), "delay map"
+        valid, onset = valid_mask(rdelay, 435, 1443), rdelay < 1e30
+        for k, nm in enumerate(NAMES):
+            m = onset if k in (4, 5) else valid
+            assert same_bits(res[..., k][m], rres[..., k][m]).all(), "%s %s" % (L, nm)
+        return int(valid.sum())
+
+    with pvlib.Solver(size, size, 275, steps_per_launch=8, tile_rows=24) as s:
+        assert np.float32(s.efree) == np.float32(ef)
+        ids = [s.add_geometry(block), s.add_geometry(bar)]
+        assert check(s, [block, bar], (55.0, 0.0, 30.0)) > 5000
+        assert check(s, [block, bar], (30.0, 0.0, 40.0)) >= 0          # listener in the middle of the block
+        s.remove_geometry(ids[0])
+        assert check(s, [bar], (30.0, 0.0, 40.0)) > 5000              # the block's tiles are alive again
+        s.add_geometry(late)
+        assert check(s, [bar, late], (30.0, 0.0, 40.0)) > 5000        # a block lands where the field was non-zero
+        # raw stepping from arbitrary fields does NOT skip (wall cells may hold anything): same bits as the two-kernel form
+        rng = np.random.default_rng(4)
+        f0 = [(rng.random((257, 257), np.float32) - np.float32(0.5)) for _ in range(3)]
+        with pvlib.Solver(size, size, 275, steps_per_launch=8, tile_rows=24, merged_launch=0) as t:
+            t.add_geometry(bar)
+            t.add_geometry(late)
+            for v in (s, t):
+                v.set_fields(*f0)
+                v.run_steps(24)
+            for a, b in zip(s.fields(), t.fields()):
+                assert same_bits(a, b).all()
+        assert check(s, [bar, late], (30.0, 0.0, 70.0)) > 5000        # and a run after that starts clean again
+
+
 def test_step_composition_and_zero_fixed_point(pvlib):
     """raw stencil properties: 2n steps == n steps twice (any K), and an all-zero field stays all-zero"""
     rng = np.random.default_rng(11)
