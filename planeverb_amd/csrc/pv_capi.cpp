@@ -209,6 +209,14 @@ PvAmdSolver* PvAmdCreate(float gridSizeX, float gridSizeY, int gridResolution, i
     PvAmdSolver* h = new PvAmdSolver();
     h->spec = makeGridSpec(gridSizeX, gridSizeY, gridResolution);
     h->device = device;
+    if (h->spec.gx != h->spec.gy) {
+        static bool warned = false;
+        if (!warned)
+            std::fprintf(stderr, "[planeverb_amd] warning: %d x %d grid -- the reference indexes non-square grids "
+                                 "inconsistently (SURVEY.md Q1); results there are defined by this library (cell array stride "
+                                 "gy+1 throughout), not by the reference\n", h->spec.gx, h->spec.gy);
+        warned = true;
+    }
     return h;
 }
 

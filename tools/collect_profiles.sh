@@ -41,3 +41,4 @@ ls -la $O
 bash tools/pmc_r02.sh > $O/pmc_r02.log 2>&1
 python tools/gpu_live_rate.py --out $O/live_rate.txt > /dev/null 2>&1
 python tools/gpu_slabs.py 4096 2048 > $O/slabs_one_device.txt 2>&1
+python tools/modeb_probe.py 2009 8034 16067 > $O/modeB_streaming.txt 2>&1

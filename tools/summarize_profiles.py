@@ -40,7 +40,7 @@ if os.path.exists(os.path.join(ROOT, "gpurun_out", "r02_sq", "summary.md")):
 for f in ("bench.json", "bench_8192.json", "bench_8192_open.json", "bench_2048.json", "bench_512.json", "bench_dense.json",
           "bench_inflight1.json", "bench_512_batch8.json", "bench_1024_batch8.json", "sizes.txt", "concurrent.txt",
           "batch.txt",
-          "bench_under_rocprof.json", "hbm_calib.txt"):
+          "bench_under_rocprof.json", "hbm_calib.txt", "live_rate.txt", "modeB_streaming.txt", "slabs_one_device.txt"):
     p = os.path.join(SRC, f)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(DST, R + "_" + f))
