@@ -7,8 +7,9 @@
 //   pr/vx/vy : float32, ping-pong pair (a fused K-step launch reads one set and writes the other)
 //   codes    : uint16 per cell = kxIdx | kyIdx << 8, indices into a 256-entry float LUT that folds beta,
 //              wall admittance Y=(1-R)/(1+R) and the absorbing grid edges into one per-face coefficient
-//   hist     : float32 pr[t][row][col] over a tile-aligned window around the listener (cells that the pulse
-//              cannot have reached are exactly zero and are not stored)
+//   hist     : float32 pr[t][window tile][row in tile][col in tile] over a tile-aligned window around the listener
+//              (tile-major: a tile's block of one step is one contiguous chunk; cells that the pulse cannot have
+//              reached are exactly zero and are not stored)
 // The guard band (G cells on every side, plus tile overhang) holds zeros / wall codes and is never written
 // with anything else, so no kernel needs a bounds check.
 #pragma once
@@ -69,9 +70,9 @@ struct StepArgs {
     int numGeneral;             // capacity of generalList used to size the grid; live count is dyn->numGeneral
     const DynParams* dyn;
     int* errFlag;
-    long long histPlane;   // floats per recorded step
+    long long histPlane;   // floats per recorded step (= window tiles x RXI x WI: tile-major, no padding)
     long long planeBytes;  // bytes of one padded float plane
-    int histPitch;
+    int histPitch;         // pitch of the slabs' boundary-row history arrays only ([T][histPitch]); planes are tile-major
     int pitch;
     int G;
     int ntx, nty, ntiles;
@@ -144,6 +145,7 @@ struct SmallArgs {
     int T;
     int record;
     float courant;
+    int rxi, wi;  // tile interior (the history planes are tile-major: histOffset)
 };
 
 struct AnalyzeArgs {

@@ -39,6 +39,16 @@ namespace pva {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// The pressure history is TILE-MAJOR: plane[t][window tile][row in tile][column in tile], RXI x WI floats per tile, no
+// padding.  A step kernel records a tile's RXI x WI block of one sub-step as ONE contiguous chunk (5.76 KB for the 36 x 40
+// tile) instead of RXI segments of 160 B that sit a whole plane row apart: 5.2 instead of 3.2 TB/s of history writes on
+// MI355X (tools/hist_write_probe.hip), which is what the dense-history and the sparse-emitter (ring) modes are bound by.
+// Offset (floats) of window cell (hr, hc) -- window row / column, both >= 0 -- inside one plane:
+__device__ __forceinline__ long long histOffset(int hr, int hc, int rxi, int wi, int tilesY) {
+    const int ti = hr / rxi, tj = hc / wi;
+    return ((long long)(ti * tilesY + tj) * rxi + (hr - ti * rxi)) * wi + (hc - tj * wi);
+}
+
 // value held by lane+1 (lane 63 receives an unspecified value; it is always a halo lane)
 __device__ __forceinline__ float laneNext(float v) {
 #if PV_USE_DPP
@@ -336,10 +346,11 @@ __device__ __forceinline__ void stepTile(const StepArgs& a, const int tile, cons
     const float C = a.courant;
     const bool inCols = lane >= K && lane < 64 - K;
     const float* hplane = a.hist + (long long)a.histSlot * a.histPlane;
-    // history window addressing: soffset = row part (>= 0 for every stored row), voffset = column part
-    const int hpitchB = a.histPitch * 4;
-    const int hsoff0 = (hti * RXI + part * SUB - K) * hpitchB;  // + r*hpitchB with r >= K
-    const int hvoff = (htj * WI - K + lane) * 4;        // >= 0 for the stored lanes (lane >= K)
+    // history window addressing (tile-major, see histOffset): soffset = tile + row part (>= 0 for every stored row),
+    // voffset = column part
+    const int hpitchB = WI * 4;
+    const int hsoff0 = ((hti * a.dyn->histTilesY + htj) * RXI + part * SUB - K) * hpitchB;  // + r*hpitchB with r >= K
+    const int hvoff = (lane - K) * 4;                   // >= 0 for the stored lanes (lane >= K)
 
 #pragma unroll 1
     for (int s = 0; s < a.nsteps; ++s) {
@@ -547,9 +558,9 @@ __device__ __forceinline__ void stepTileAirPacked(const StepArgs& a, const int t
     const float C = a.courant;
     const bool inCols = lane >= K && lane < 64 - K;
     const float* hplane = a.hist + (long long)a.histSlot * a.histPlane;
-    const int hpitchB = a.histPitch * 4;
-    const int hsoff0 = (hti * RXI - K) * hpitchB;
-    const int hvoff = (htj * WI - K + lane) * 4;
+    const int hpitchB = WI * 4;
+    const int hsoff0 = ((hti * a.dyn->histTilesY + htj) * RXI - K) * hpitchB;
+    const int hvoff = (lane - K) * 4;
 
     PackedSteps<K, RXI, 0>::run(pr, vx, vy, C, a, rec && inCols, hplane, hvoff, hsoff0, hpitchB);
 
@@ -814,9 +825,9 @@ __device__ __forceinline__ void stepTileAirMirror(const StepArgs& a, const int t
     const float C = a.courant;
     const bool inCols = lane >= K && lane < 64 - K;
     const float* hplane = a.hist + (long long)a.histSlot * a.histPlane;
-    const int hpitchB = a.histPitch * 4;
-    const int hsoff0 = (hti * RXI - K) * hpitchB;
-    const int hvoff = (htj * WI - K + lane) * 4;
+    const int hpitchB = WI * 4;
+    const int hsoff0 = ((hti * a.dyn->histTilesY + htj) * RXI - K) * hpitchB;
+    const int hvoff = (lane - K) * 4;
 
     if constexpr (EDGE) {
         const bool recLane = rec && inCols;
@@ -973,9 +984,9 @@ __device__ __forceinline__ void stepTileGeneral4(const StepArgs& a, const int ti
     const float C = a.courant;
     const bool inCols = lane >= K && lane < 64 - K;
     const float* hplane = a.hist + (long long)a.histSlot * a.histPlane;
-    const int hpitchB = a.histPitch * 4;
-    const int hsoff0 = (hti * RXI - K + ws) * hpitchB;
-    const int hvoff = (htj * WI - K + lane) * 4;
+    const int hpitchB = WI * 4;
+    const int hsoff0 = ((hti * a.dyn->histTilesY + htj) * RXI - K + ws) * hpitchB;
+    const int hvoff = (lane - K) * 4;
 
 #pragma unroll 1
     for (int s = 0; s < a.nsteps; ++s) {
@@ -1167,9 +1178,9 @@ __device__ __forceinline__ void stepTileStack(const StepArgs& a, const int tile,
     const bool inCols = lane >= K && lane < 64 - K;
     const bool recLane = rec && inCols;
     const float* hplane = a.hist + (long long)a.histSlot * a.histPlane;
-    const int hpitchB = a.histPitch * 4;
-    const int hsoffW = (hti * X - K + ws) * hpitchB;  // + r*hpitchB; stored rows have -K + ws + r >= 0
-    const int hvoff = (htj * WI - K + lane) * 4;
+    const int hpitchB = WI * 4;
+    const int hsoffW = ((hti * a.dyn->histTilesY + htj) * X - K + ws) * hpitchB;  // + r*hpitchB; stored rows have -K + ws + r >= 0
+    const int hvoff = (lane - K) * 4;
 
 #pragma unroll 1
     for (int s = 0; s < a.nsteps; ++s) {
@@ -1288,9 +1299,9 @@ __global__ __launch_bounds__(256, WPS) void pv_step_stream_kernel(const StepArgs
     }
     const float C = a.courant;
     const bool inCols = lane >= K && lane < 64 - K;
-    const int hpitchB = a.histPitch * 4;
-    const int hvoff = ((tj - dyn.histTileY0) * WI - K + lane) * 4;
-    const int hrow0 = (ti0 - dyn.histTileX0) * RXI - K;  // history row of relative row 0
+    const int hpitchB = WI * 4;
+    const int hvoff = (lane - K) * 4;
+    const int htile0 = (ti0 - dyn.histTileX0) * dyn.histTilesY + (tj - dyn.histTileY0);  // window tile of the chunk's first tile
 
     // S[par][level]: the two newest rows of every time level; in an iteration of parity par, [par] is the older row
     float Sp[2][K + 1], Sx[2][K + 1], Sy[2][K + 1];
@@ -1343,7 +1354,7 @@ __global__ __launch_bounds__(256, WPS) void pv_step_stream_kernel(const StepArgs
                     const int ql = q - K;
                     if (ql >= 0 && ql < CH && ((recMask >> (ql / RXI)) & 1u) && inCols) {
                         const rsrc_t rH = makeRsrc(a.hist + (long long)(a.histSlot + s) * a.histPlane, a.histPlane * 4);
-                        bufStoreF(pn, rH, hvoff, (hrow0 + q) * hpitchB);
+                        bufStoreF(pn, rH, hvoff, ((htile0 + (ql / RXI) * dyn.histTilesY) * RXI + ql % RXI) * hpitchB);
                     }
                 }
                 if (s + 1 == K) {
@@ -1929,7 +1940,7 @@ __global__ __launch_bounds__(kSmallThreads) void pv_small_grid_kernel(const Smal
             kx[j] = a.lut[code & 0xffu];
             ky[j] = a.lut[code >> 8];
             if ((code & 0xffu) < (unsigned)kLutWall) beta |= 1u << j;
-            hoff[j] = (x + a.G - dyn.histRow0) * a.histPitch + (y + a.G - dyn.histCol0);
+            hoff[j] = (int)histOffset(x + a.G - dyn.histRow0, y + a.G - dyn.histCol0, a.rxi, a.wi, dyn.histTilesY);
         }
     }
     __syncthreads();
@@ -2060,7 +2071,7 @@ __device__ __forceinline__ Rt60Cell rt60Cell(const AnalyzeArgs& a, const DynPara
     const float d = a.delay[s];
     if (d == FLT_MAX) return c;
     c.s = s;
-    c.hc = CellHistory{a.hist + (long long)(X + a.G - dyn.histRow0) * a.histPitch + (Y + a.G - dyn.histCol0),
+    c.hc = CellHistory{a.hist + histOffset(X + a.G - dyn.histRow0, Y + a.G - dyn.histCol0, a.rxi, a.wi, dyn.histTilesY),
                        a.histPlane};
     c.startingPoint = (int)d + a.nDry + 1;
     return c;
@@ -2158,15 +2169,17 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
         return;
     }
     const int T = a.T;
-    const long long hoff = (long long)(prow - dyn.histRow0) * a.histPitch + (pcol - dyn.histCol0);
+    const int hr = prow - dyn.histRow0, hcol = pcol - dyn.histCol0;
+    const long long hoff = histOffset(hr, hcol, a.rxi, a.wi, dyn.histTilesY);
     CellHistory hc{a.hist + hoff, a.histPlane};
     // neighbours for the velocity recurrence; a neighbour tile that became active later (or never) has
     // unwritten history that is exactly zero by causality
     int tFx = INT_MAX, tFy = INT_MAX;
     if (X > 0 && prow - 1 >= dyn.histRow0) tFx = a.tileFirst[((X - 1) / a.rxi) * a.nty + (Y / a.wi)];
     if (Y > 0 && pcol - 1 >= dyn.histCol0) tFy = a.tileFirst[(X / a.rxi) * a.nty + ((Y - 1) / a.wi)];
-    CellHistory hx{a.hist + hoff - a.histPitch, a.histPlane};
-    CellHistory hy{a.hist + hoff - 1, a.histPlane};
+    // (the neighbours' offsets are only formed where they are read: tFx / tFy stay INT_MAX otherwise)
+    CellHistory hx{a.hist + (tFx != INT_MAX ? histOffset(hr - 1, hcol, a.rxi, a.wi, dyn.histTilesY) : hoff), a.histPlane};
+    CellHistory hy{a.hist + (tFy != INT_MAX ? histOffset(hr, hcol - 1, a.rxi, a.wi, dyn.histTilesY) : hoff), a.histPlane};
     if (X == 0 && a.histAbove) {  // first row of a slab: the row above lives in the neighbouring slab
         hx = CellHistory{a.histAbove + (pcol - dyn.histCol0), a.histPitch};
         tFx = 0;
@@ -2639,7 +2652,7 @@ __global__ void pv_hist_row_kernel(const AnalyzeArgs a, int X, float* __restrict
     const int wti = ti - dyn.histTileX0, wtj = tj - dyn.histTileY0;
     if (wc < a.winCols && pcol >= a.G && wti >= 0 && wti < dyn.histTilesX && wtj >= 0 && wtj < dyn.histTilesY &&
         t >= a.tileFirst[ti * a.nty + tj])
-        v = a.hist[(long long)t * a.histPlane + (long long)(prow - dyn.histRow0) * a.histPitch + wc];
+        v = a.hist[(long long)t * a.histPlane + histOffset(prow - dyn.histRow0, wc, a.rxi, a.wi, dyn.histTilesY)];
     out[(long long)t * a.histPitch + wc] = v;
 }
 
@@ -2731,13 +2744,14 @@ __global__ __launch_bounds__(256) void pv_stream_accum_kernel(const AnalyzeArgs 
     if ((a.codes[(size_t)(X + a.G) * a.pitch + (Y + a.G)] & 0xffu) >= (unsigned)kLutWall) return;
 
     const int prow = X + a.G, pcol = Y + a.G;
-    const long long hoff = (long long)(prow - dyn.histRow0) * a.histPitch + (pcol - dyn.histCol0);
+    const int hr = prow - dyn.histRow0, hcol = pcol - dyn.histCol0;
+    const long long hoff = histOffset(hr, hcol, a.rxi, a.wi, dyn.histTilesY);
     int tFx = INT_MAX, tFy = INT_MAX;
     if (X > 0 && prow - 1 >= dyn.histRow0) tFx = a.tileFirst[((X - 1) / a.rxi) * a.nty + (Y / a.wi)];
     if (Y > 0 && pcol - 1 >= dyn.histCol0) tFy = a.tileFirst[(X / a.rxi) * a.nty + ((Y - 1) / a.wi)];
     const float* hc = a.hist + hoff;
-    const float* hx = hc - a.histPitch;
-    const float* hy = hc - 1;
+    const float* hx = a.hist + (tFx != INT_MAX ? histOffset(hr - 1, hcol, a.rxi, a.wi, dyn.histTilesY) : hoff);
+    const float* hy = a.hist + (tFy != INT_MAX ? histOffset(hr, hcol - 1, a.rxi, a.wi, dyn.histTilesY) : hoff);
     const uint32_t code = a.codes[(size_t)prow * a.pitch + pcol];
     const float kx = a.lut[code & 0xffu], ky = a.lut[code >> 8];
     const bool airX = kx != kx, airY = ky != ky;
@@ -2813,7 +2827,7 @@ __global__ void pv_stream_trace_kernel(const AnalyzeArgs a) {
     float v = 0.f;
     if (t >= tFirst)
         v = a.hist[(long long)(t % a.ring) * a.histPlane +
-                   (long long)(X + a.G - dyn.histRow0) * a.histPitch + (Y + a.G - dyn.histCol0)];
+                   histOffset(X + a.G - dyn.histRow0, Y + a.G - dyn.histCol0, a.rxi, a.wi, dyn.histTilesY)];
     a.emTrace[(size_t)e * a.T + t] = v;
 }
 
@@ -2937,10 +2951,12 @@ __global__ void pv_ir_kernel(const AnalyzeArgs a, int X, int Y, float* out) {
     const int wti = ti - dyn.histTileX0, wtj = tj - dyn.histTileY0;
     const bool inWin = wti >= 0 && wti < dyn.histTilesX && wtj >= 0 && wtj < dyn.histTilesY;
     const int tFirst = inWin ? a.tileFirst[ti * a.nty + tj] : INT_MAX;
-    const long long hoff = (long long)(prow - dyn.histRow0) * a.histPitch + (pcol - dyn.histCol0);
+    const long long hoff = inWin ? histOffset(prow - dyn.histRow0, pcol - dyn.histCol0, a.rxi, a.wi, dyn.histTilesY) : 0;
     int tFx = INT_MAX, tFy = INT_MAX;
     if (X > 0 && prow - 1 >= dyn.histRow0) tFx = a.tileFirst[((X - 1) / a.rxi) * a.nty + tj];
     if (Y > 0 && pcol - 1 >= dyn.histCol0) tFy = a.tileFirst[ti * a.nty + ((Y - 1) / a.wi)];
+    const long long hoffX = tFx != INT_MAX ? histOffset(prow - 1 - dyn.histRow0, pcol - dyn.histCol0, a.rxi, a.wi, dyn.histTilesY) : 0;
+    const long long hoffY = tFy != INT_MAX ? histOffset(prow - dyn.histRow0, pcol - 1 - dyn.histCol0, a.rxi, a.wi, dyn.histTilesY) : 0;
     const uint32_t code = a.codes[(size_t)prow * a.pitch + pcol];
     const float kx = a.lut[code & 0xffu], ky = a.lut[code >> 8];
     const bool airX = kx != kx, airY = ky != ky;
@@ -2951,8 +2967,8 @@ __global__ void pv_ir_kernel(const AnalyzeArgs a, int X, int Y, float* out) {
         if (t >= tFirst) {
             p = a.hist[(long long)t * a.histPlane + hoff];
             const float pxn = above ? a.histAbove[(long long)t * a.histPitch + (pcol - dyn.histCol0)]
-                                    : (t >= tFx) ? a.hist[(long long)t * a.histPlane + hoff - a.histPitch] : 0.f;
-            const float pyn = (t >= tFy) ? a.hist[(long long)t * a.histPlane + hoff - 1] : 0.f;
+                                    : (t >= tFx) ? a.hist[(long long)t * a.histPlane + hoffX] : 0.f;
+            const float pyn = (t >= tFy) ? a.hist[(long long)t * a.histPlane + hoffY] : 0.f;
             const float ax = vx - a.courant * (p - pxn), wx = kx * (p + pxn);
             const float ay = vy - a.courant * (p - pyn), wy = ky * (p + pyn);
             vx = airX ? ax : wx;
@@ -2987,9 +3003,9 @@ __global__ void pv_histplane_kernel(const AnalyzeArgs a, int t, float* dense, in
     const DynParams dyn = *a.dyn;
     const int hr = x + a.G - dyn.histRow0, hcn = y + a.G - dyn.histCol0;
     float v = 0.f;
-    if (hr >= 0 && hr < histRows && hcn >= 0 && hcn < a.histPitch) {
+    if (hr >= 0 && hr < histRows && hcn >= 0 && hcn < dyn.histTilesY * a.wi) {
         const int tF = a.tileFirst[(x / a.rxi) * a.nty + (y / a.wi)];
-        if (t >= tF) v = a.hist[(long long)t * a.histPlane + (long long)hr * a.histPitch + hcn];
+        if (t >= tF) v = a.hist[(long long)t * a.histPlane + histOffset(hr, hcn, a.rxi, a.wi, dyn.histTilesY)];
     }
     dense[(size_t)x * NY + y] = v;
 }

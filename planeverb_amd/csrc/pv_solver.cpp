@@ -193,7 +193,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         histTilesY_ = wty;
         histRows_ = wtx * rxi_;
         histPitch_ = roundUp(wty * wi_, 64);
-        histPlane_ = (long long)histRows_ * histPitch_;
+        histPlane_ = (long long)wtx * wty * rxi_ * wi_;  // tile-major planes: [tile][row][col], no padding
         // streaming mode keeps a ring of 8 launches' worth of planes instead of all T
         // streaming: TWO half rings of 8 launches' planes -- the forward sums of one half advance on a second stream while
         // the step kernels fill the other (the accumulate pass is latency / bandwidth work, the stencil VALU work)
@@ -479,8 +479,9 @@ bool Solver::applyGeometry() {
 // ----------------------------------------------------------------------------------------------------------------
 
 bool Solver::freeFieldEnergyAt(int cellX, int cellY, int n, float r, float* out) {
-    const long long off = (long long)(cellX + geo_.G - dynCur_.histRow0) * histPitch_ +
-                          (cellY + geo_.G - dynCur_.histCol0);
+    const int hr = cellX + geo_.G - dynCur_.histRow0, hc = cellY + geo_.G - dynCur_.histCol0;
+    const int hti = hr / rxi_, htj = hc / wi_;  // tile-major history planes (pv_kernels.hip: histOffset)
+    const long long off = ((long long)(hti * histTilesY_ + htj) * rxi_ + (hr - hti * rxi_)) * wi_ + (hc - htj * wi_);
     launchEfree(hist_, histPlane_, off, n, r, scratch_, stream_);
     if (!hipOk(hipMemcpyAsync(out, scratch_, 4, hipMemcpyDeviceToHost, stream_), "efree copy")) return false;
     return hipOk(hipStreamSynchronize(stream_), "efree sync");
@@ -994,6 +995,8 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
         sa.T = T_;
         sa.record = 1;
         sa.courant = g_.courant;
+        sa.rxi = rxi_;
+        sa.wi = wi_;
         launchSmallGrid(sa, stream_);
         tim_.stepLaunches = 1;
     } else if (graph) {
