@@ -26,7 +26,12 @@ CONFIGS = [dict(), dict(), dict(steps_per_launch=12, tile_rows=36), dict(steps_p
            dict(streaming_analysis=1), dict(streaming_analysis=1, steps_per_launch=12, tile_rows=36),
            dict(streaming_analysis=1, steps_per_launch=4, tile_rows=32),
            dict(steps_per_launch=8, tile_rows=40, edge_tiles=1), dict(steps_per_launch=10, tile_rows=36, edge_tiles=1),
-           dict(steps_per_launch=12, tile_rows=36, edge_tiles=1)]
+           dict(steps_per_launch=12, tile_rows=36, edge_tiles=1),
+           # round 2: row bands, single-grid decomposition into slabs (falls back to a plain solver where the grid has
+           # fewer than 4 tile rows), thick walls (dead tiles) come from random_scene's larger boxes
+           dict(row_bands=2), dict(steps_per_launch=8, tile_rows=24, row_bands=3),
+           dict(steps_per_launch=8, tile_rows=24, slabs=[0, 0]), dict(steps_per_launch=8, tile_rows=24, slabs=[0, 0, 0]),
+           dict(steps_per_launch=8, tile_rows=24, slabs=[0, 0])]
 
 
 def one(seed):
@@ -46,6 +51,11 @@ def one(seed):
     flat = hp.reshape(o.T, -1)
     finite = np.isfinite(flat).all(1) & (np.abs(np.nan_to_num(flat, nan=np.inf)).max(1) < 1e30)
     tmax = o.T - 1 if finite.all() else int(np.argmin(finite)) - 1
+    if "slabs" in opts:
+        try:
+            pv.Solver(size, size, res, **opts).close()
+        except pv.PlaneverbError:  # too few tile rows for that many slabs
+            opts = {k: v for k, v in opts.items() if k != "slabs"}
     with pv.Solver(size, size, res, **opts) as s:
         assert (s.gx, s.gy, s.T) == (o.gx, o.gy, o.T)
         assert np.float32(s.efree) == np.float32(ef), "EFree"
