@@ -48,12 +48,23 @@ def same_bits(a, b):
     return (a.view(np.uint32) == b.view(np.uint32)) | ((a == 0) & (b == 0)) | (np.isnan(a) & np.isnan(b))
 
 
-def verify_records(gathered, scene, open_field, listener_index):
+def verify_records(gathered, scene, open_field, listener_index, grid=4096):
     """Compare EVERY gathered per-emitter record of the timed runs with the reference, bit for bit.
     HugeRoom.pv is a closed room: at any Mode A grid size the records equal the reference's 71^2 (25 m) run of the same
     listener / emitters (closed-room isolation); tests/golden/g71_hugeroom_cfg4.npz holds those 8 x 2
     records, generated from the compiled reference (tests/golden/make_golden.py cfg4).  Returns (verified_runs, how);
     raises if any record differs -- a fast run with wrong results is not a result."""
+    if open_field and grid == 8192:
+        # BASELINE config 5: records of the 64 seeded listener cells from the pinned oracle's 513^2 window analysed with the
+        # 8192^2 grid's position arithmetic (tests/golden/make_golden.py cfg5; the open field is translation-invariant)
+        g = np.load(os.path.join(ROOT, "tests", "golden", "g8192_open_cfg5.npz"))
+        want = g["emitter_out"]
+        bad = [k for k in range(gathered.shape[0]) if not same_bits(gathered[k], want[k % len(want)]).all()]
+        if bad:
+            raise AssertionError("bench: %d of %d timed runs differ from the reference records, first run %d: got %r "
+                                 "want %r" % (len(bad), gathered.shape[0], bad[0], gathered[bad[0]], want[bad[0] % len(want)]))
+        return int(gathered.shape[0]), ("every timed run's 2 emitter records bit-identical to the pinned oracle's (513^2 "
+                                        "window, 8192^2 position arithmetic: tests/golden/g8192_open_cfg5.npz)")
     if open_field or scene != "HugeRoom.pv":
         return None, "no reference records for this workload (tests/test_gpu_configs.py covers configs 3 and 5)"
     g = np.load(os.path.join(ROOT, "tests", "golden", "g71_hugeroom_cfg4.npz"))
@@ -318,7 +329,8 @@ def main():
     if rank == 0:
         assert gathered.shape == (n_runs, 2, 8)
         # run k of the gathered array = global run index k (gather_outputs orders by run index) = listener k mod 8
-        verified_runs, verified_how = verify_records(gathered, args.scene, args.open_field, lambda k: k % len(LISTENERS))
+        verified_runs, verified_how = verify_records(gathered, args.scene, args.open_field, lambda k: k % len(LISTENERS),
+                                                     args.grid)
         info = s.info
         K = info.stepsPerLaunch
         launches = s.timings().stepLaunches

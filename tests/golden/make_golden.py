@@ -10,6 +10,7 @@ IR traces, result / delay maps).  No reference source text is stored.
     python tests/golden/make_golden.py modeB512   # Shoebox, 25 m at res 2009  (~3 min, 27 GB)
     python tests/golden/make_golden.py cfg4       # HugeRoom, the 8 listeners of BASELINE config 4 (seconds)
     python tests/golden/make_golden.py open_offset  # open 640^2 field, listener off-centre (~1 min, 3 GB)
+    python tests/golden/make_golden.py cfg5       # 8192^2 open field: records of the 64 seeded listener cells (pinned oracle, ~5 min)
     python tests/golden/make_golden.py cells      # raw reference Cells of a few IRs (GetImpulseResponse layout)
     python tests/golden/make_golden.py findgain   # FindGainA/B/C table from PlaneverbDSP's compiled context file
 """
@@ -165,6 +166,29 @@ def run_cells():
     print("cells ->", path, "%.1f kB" % (os.path.getsize(path) / 1e3))
 
 
+def run_cfg5():
+    """BASELINE config 5 (8192^2 open field, Mode A): the two emitter records (listener + (16, 0) and + (0, 16) cells) of
+    all 64 seeded listener cells.  No CPU run can hold an 8192^2 grid; the open field is translation-invariant, so the
+    pinned C restatement runs ONE 513^2 window and analyses it with the large grid's position arithmetic
+    (pvo_analyze_at, itself pinned against the compiled reference by g640_open_offset.npz).  bench.py --open-field
+    --grid 8192 compares its timed runs with these."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import pvoracle
+    from test_oracle_golden import OpenFieldWindowOracle
+    w = OpenFieldWindowOracle(pvoracle)
+    cells = np.random.default_rng(0).integers(1024, 7168, size=(64, 2))
+    out = np.zeros((64, 2, 8), np.float32)
+    for i, (lx, ly) in enumerate(cells):
+        res, _ = w.analyze((int(lx), int(ly)))
+        out[i, 0] = res[w.c + 16, w.c]
+        out[i, 1] = res[w.c, w.c + 16]
+        print(i, out[i, 0, :4], flush=True)
+    w.close()
+    path = os.path.join(OUT, "g8192_open_cfg5.npz")
+    np.savez_compressed(path, cells=cells.astype(np.int32), emitter_out=out, efree=np.float32(0.0447895788))
+    print("cfg5 ->", path)
+
+
 def findgain_inputs():
     """(rt60, wet) sweep for SURVEY.md 8a row 24: dense in rt60 incl. the 0.5 / 1.0 / 3.0 s bucket edges and their
     float neighbours, the analysis' degenerate values (0, negative, inf, NaN), a few wet gains"""
@@ -191,6 +215,8 @@ def main():
         return run_findgain()
     if what == "cells":
         return run_cells()
+    if what == "cfg5":
+        return run_cfg5()
     if what == "cfg4":
         return run_cfg4()
     if what == "open_offset":

@@ -150,3 +150,16 @@ def test_window_oracle_with_offset_reproduces_reference(oracle):
     for k in range(8):
         m = valid if k not in (4, 5) else np.ones_like(valid)
         assert same_bits(res[sl][..., k][m], g["results"][..., k][m]).all(), k
+
+
+def test_config5_records_fixture_matches_the_window_oracle(oracle):
+    """tests/golden/g8192_open_cfg5.npz (what bench.py --open-field --grid 8192 verifies its runs against) is what the
+    pinned window oracle gives: re-derived here for three of the 64 listener cells"""
+    g = golden("g8192_open_cfg5")
+    assert np.array_equal(g["cells"], np.random.default_rng(0).integers(1024, 7168, size=(64, 2)))
+    w = OpenFieldWindowOracle(oracle)
+    for i in (0, 17, 63):
+        res, _ = w.analyze(tuple(int(v) for v in g["cells"][i]), g["efree"])
+        assert same_bits(res[w.c + 16, w.c], g["emitter_out"][i, 0]).all()
+        assert same_bits(res[w.c, w.c + 16], g["emitter_out"][i, 1]).all()
+    w.close()
