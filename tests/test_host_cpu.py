@@ -277,3 +277,15 @@ def test_live_module_host_side_under_sanitizers(san, tmp_path):
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     assert "Sanitizer" not in r.stderr, r.stderr[-4000:]
     assert " 0 bad, phase3 flags 0" in r.stdout, r.stdout
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/planeverb_amd.h is a C header (the drop-in boundary: extern "C", plain pointers and sizes): it must compile
+    as C99 on its own, and PlaneverbOutput / PlaneverbCell must have the reference's sizes (8 floats; 16 bytes)"""
+    src = tmp_path / "abi.c"
+    src.write_text('#include "planeverb_amd.h"\n'
+                   'typedef char out_is_32_bytes[sizeof(PlaneverbOutput) == 32 ? 1 : -1];\n'
+                   'typedef char cell_is_16_bytes[sizeof(PlaneverbCell) == 16 ? 1 : -1];\n'
+                   'int main(void) { PvAmdSlabInfo i; PvAmdInfo j; (void)i; (void)j; return 0; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I",
+                           os.path.join(ROOT, "include"), str(src)])
