@@ -145,7 +145,7 @@ enum {
     PVA_OPT_SMALL_GRID_KERNEL = 10, /* 0 = auto (grids that fit one CU's LDS run in one resident kernel), 2 = never */
     PVA_OPT_PACKED_MATH = 11,  /* air-tile kernel arithmetic: 1 = packed f32 (default), 0 = scalar f32 */
     PVA_OPT_STREAMING_ANALYSIS = 12, /* 1 = sparse-emitter mode: ring history + incremental analysis (see PvAmdSetEmitters) */
-    PVA_OPT_STREAM_ROWS = 13,  /* M > 0: all-air chunks of M stacked tiles run in the row-streaming stencil kernel */
+    PVA_OPT_STREAM_ROWS = 13,  /* N > 0: the air part of the grid is advanced by about N row-streaming segments per sweep (a wave streams down a 256-column strip, K time levels in flight) instead of one wave per air tile; tile configurations (8, 40) and (12, 36) only, ignored elsewhere and with slabs / row bands / graphs / streaming analysis.  Bit-identical; experimental: slower than the tile kernels at 4096^2.  Default 0 = off */
     PVA_OPT_MERGED_LAUNCH = 14, /* 1 (default) = general + air tiles in one launch per K steps; 0 = two kernels, two streams */
     PVA_OPT_ROW_BANDS = 16,    /* B > 1: every K-step sweep is launched as B bands of tile rows on B HIP streams; band b of sweep n+1 waits only for bands b-1, b, b+1 of sweep n, so consecutive sweeps of ONE run overlap (no chip-wide drain between launches) -- what gives a single run most of the two-runs-in-flight rate.  0 = auto by grid size, 1 = one launch per sweep.  Large grids with the merged kernel only; ignored elsewhere (streaming analysis, graphs, batched runs) */
     PVA_OPT_EDGE_TILES = 15    /* 1 = tiles whose only non-air faces are the grid's absorbing edges run the air-tile code + edge overrides (tile class 2) instead of the general path.  Only the batched kernels of the mirror-pair tiles (K, rows = (8,40), (10,36), (12,36)) have that arm -- inside the merged kernel it slows the air tiles by 25-40 %, DESIGN.md 8.4 -- so every run of such a solver goes through PvAmdRunBatch's kernel (PvAmdRun = a batch of one) and PvAmdRunSteps is refused; ignored for other configurations.  Default 0 */

@@ -419,7 +419,7 @@ int PvAmdSetOption(PvAmdSolver* h, int key, long long value) {
         case PVA_OPT_SMALL_GRID_KERNEL: h->opt.smallGrid = (int)value; break;
         case PVA_OPT_PACKED_MATH: h->opt.packed = value != 0; break;
         case PVA_OPT_STREAMING_ANALYSIS: h->opt.streaming = value != 0; break;
-        case PVA_OPT_STREAM_ROWS: h->opt.streamRows = (int)value; break;
+        case PVA_OPT_STREAM_ROWS: h->opt.segments = (int)value; break;
         case PVA_OPT_MERGED_LAUNCH: h->opt.merged = (int)value; break;
         case PVA_OPT_EDGE_TILES: h->opt.edgeTiles = value != 0; break;
         case PVA_OPT_ROW_BANDS: h->opt.rowBands = (int)value; break;

@@ -48,6 +48,13 @@ struct DynParams {
     int histRow0, histCol0;  // padded coordinates of the history window origin (tile aligned)
     int histTileX0, histTileY0, histTilesX, histTilesY;
     int numGeneral;          // live entries of generalList (the launch grid is sized for its capacity)
+    int numSeg;              // live entries of segList (row-streaming air segments, pv_seg.h)
+};
+
+// A row-streaming air segment (pv_seg.h): interior rows [row0, row0 + nrows) of the array x tile columns
+// [tj0, tj0 + w); every face in its loaded region (K cells around) is air|air and the listener is not inside.
+struct SegDesc {
+    int row0, nrows, tj0, w;
 };
 
 struct StepArgs {
@@ -68,6 +75,8 @@ struct StepArgs {
                                 // arm skips it (thick walls of a 25 m scene at fine resolution: 17 % of all tiles)
     const int* generalList;     // tiles for the general kernel: class-1 tiles + tiles holding the listener
     int numGeneral;             // capacity of generalList used to size the grid; live count is dyn->numGeneral
+    const SegDesc* segList;     // row-streaming air segments of this run (pv_step_seg_kernel; NULL = tile kernels)
+    int numSeg;                 // capacity used to size the grid; live count is dyn->numSeg
     const DynParams* dyn;
     int* errFlag;
     long long histPlane;   // floats per recorded step (= window tiles x RXI x WI: tile-major, no padding)
@@ -79,7 +88,6 @@ struct StepArgs {
     int gx, gy;            // the reference's grid size (cells are 0..gx x 0..gy): edge tiles locate the ghost column
     int bandRows;          // tile rows per XCD band = ceil(ntx / 8)
     int packed;            // air kernel: packed-f32 (v_pk_*) arithmetic variant
-    int streamM;           // > 0: all-air chunks of streamM vertically adjacent tiles go to the row-streaming kernel
     const uint8_t* tileOpen;    // streaming analysis only (else NULL): per tile, 1 while any of its cells still has an
                                 // open forward-analysis window, or the tile holds a registered emitter
     const uint8_t* nzIn;   // per tile: non-zero at the end of the previous launch (conservative)
@@ -113,6 +121,9 @@ struct BeginArgs {
     DynParams* dyn;
     const int* listHost;       // pinned, dynHost->numGeneral live entries
     int* list;
+    const SegDesc* segHost;    // pinned, dynHost->numSeg live entries (NULL = no segments)
+    SegDesc* seg;
+    int segCap;
     int* tileFirst;            // NULL = leave the per-tile state alone (stencil-only stepping)
     uint8_t* nz0;
     uint8_t* nz1;

@@ -396,9 +396,11 @@ __device__ __forceinline__ void stepTile(const StepArgs& a, const int tile, cons
 // air tile with packed-f32 arithmetic
 // ---------------------------------------------------------------------------------------------------------------
 // PMC on the scalar form (SQ_ACTIVE_INST_VALU ~ 92 % of the SIMD issue slots at K = 8) shows the air kernel is bound
-// by VALU ISSUE, not by HBM: a CU issues one VALU instruction per SIMD every 4 cycles, and a plain wave64 f32 op
-// uses only half of the SIMD-32's lanes-per-slot; only packed ops (v_pk_add_f32 / v_pk_mul_f32, two floats per lane)
-// reach the full f32 rate.  Here two ADJACENT ROWS of a lane's column live in one 64-bit register pair, so every
+// by VALU ISSUE, not by HBM.  Packed ops (v_pk_add_f32 / v_pk_mul_f32, two floats per lane) halve the instruction
+// count; measured later (tools/valu_probe.hip): a packed op takes 4.4-4.9 cycles per wave and SIMD against 2.75 for a
+// plain two-source f32 op, so packing is worth 1.13-1.25x in VALU time (and a DPP read costs as much as a packed op),
+// not the 2x this was written for.  (Original text: "only packed ops
+// reach the full f32 rate.")  Here two ADJACENT ROWS of a lane's column live in one 64-bit register pair, so every
 // y-direction difference and every multiply / subtract is one packed op per two cells; x-direction differences need
 // the row-shifted pair (p[r-1], p[r]), built with one v_pk_mov-style shuffle per pair.  Per-element arithmetic and
 // its order are unchanged (packed ops are IEEE per half), so the fields stay bit-identical.
@@ -962,8 +964,7 @@ __device__ __forceinline__ void stepTileGeneral4(const StepArgs& a, const int ti
     const bool hasL = a.withPulse && lr >= 0 && lr <= R - 2 && lc >= 0 && lc < 64;
     const int lrT = dyn.lrow - (row0 - ws);  // listener row in loaded-tile rows: is it anywhere in the block?
     const bool tileHasL = a.withPulse && lrT >= 0 && lrT < Gm::L && lc >= 0 && lc < 64;
-    // general tiles always count as non-zero and are recorded on every step
-    if (first && lane == 0) a.nzOut[tile] = 1;
+    // general tiles are recorded on every step
     const int hti = ti - dyn.histTileX0, htj = tj - dyn.histTileY0;
     const bool inWin = hti >= 0 && hti < dyn.histTilesX && htj >= 0 && htj < dyn.histTilesY;
     const bool rec = a.record && inWin && historyWanted(a, ti, tj);
@@ -1037,6 +1038,16 @@ __device__ __forceinline__ void stepTileGeneral4(const StepArgs& a, const int ti
         }
     }
 
+    // per-tile non-zero flag of the state this launch leaves behind (halo included: conservative), for the row-streaming
+    // segments' recording decision in the next launch.  Monotone within a run: written, never cleared
+    // (pv_begin_run_kernel zeroes both flag planes).
+    if (a.record) {
+        uint32_t nzE = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            nzE |= (__float_as_uint(pr[r]) | __float_as_uint(vx[r]) | __float_as_uint(vy[r])) & 0x7fffffffu;
+        if ((__ballot(nzE != 0u) != 0ull || a.nzIn[tile]) && lane == 0) a.nzOut[tile] = 1;
+    }
     const rsrc_t rPrOut = makeRsrc(a.prOut, a.planeBytes), rVxOut = makeRsrc(a.vxOut, a.planeBytes),
                  rVyOut = makeRsrc(a.vyOut, a.planeBytes);
     if (inCols) {
@@ -1218,177 +1229,6 @@ __device__ __forceinline__ void stepTileStack(const StepArgs& a, const int tile,
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// row-streaming air kernel
-// ---------------------------------------------------------------------------------------------------------------
-// The tile kernels sit on their load/store floor: a (RXI+2K) x 64 tile re-reads a K-row halo above and below its RXI
-// interior rows, so the CUs move 2.2x the unique state at K = 8.  Here a wave owns a 64-lane column strip and STREAMS
-// down a chunk of M tiles: every iteration loads one new row (time level 0) and advances all K time levels by one
-// row each -- level s+1 row q needs level s rows q, q+1 and level s+1 row q-1 -- keeping only the two newest rows of
-// every level in registers (6*(K+1) VGPRs, independent of the chunk height).  The x halo is paid once per chunk
-// ((CH+2K)/CH instead of (RXI+2K)/RXI) and every level's update inside an iteration uses the previous iteration's
-// rows, so the K updates are independent instruction streams.  Same arithmetic per cell as the tile kernels.
-
-// does the stream kernel own chunk `ci` of tile column `tj`?  (all its tiles air, listener not in its loaded region)
-template <int K, int RXI>
-__device__ __forceinline__ bool streamOwnsChunk(const StepArgs& a, int ci, int tj) {
-    const int M = a.streamM;
-    const int ti0 = ci * M, ti1 = min(ti0 + M, a.ntx);
-    for (int ti = ti0; ti < ti1; ++ti)
-        if (a.tileClass[ti * a.nty + tj] != 0) return false;
-    if (a.withPulse) {
-        const int lr = a.dyn->lrow - (a.G - K + ti0 * RXI), lc = a.dyn->lcol - (a.G - K + tj * (64 - 2 * K));
-        if (lr >= 0 && lr < (ti1 - ti0) * RXI + 2 * K && lc >= 0 && lc < 64) return false;
-    }
-    return true;
-}
-
-template <int K, int RXI, int WPS>
-__global__ __launch_bounds__(256, WPS) void pv_step_stream_kernel(const StepArgs a) {
-    constexpr int WI = 64 - 2 * K;
-    constexpr int PF = 4;  // input rows in flight (ring of PF register rows, loop unrolled by PF)
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int unit = blockIdx.x * 4 + wave;
-    const int nchunks = (a.ntx + a.streamM - 1) / a.streamM;
-    if (unit >= nchunks * a.nty) return;
-    // consecutive units walk down a tile column band by band is not needed: chunks of one column are far apart in
-    // memory anyway; neighbouring columns share their y halo, so units are ordered column-fastest
-    const int ci = unit / a.nty;
-    const int tj = unit - ci * a.nty;
-    if (!streamOwnsChunk<K, RXI>(a, ci, tj)) return;
-    const int ti0 = ci * a.streamM;
-    const int ntile = min(a.streamM, a.ntx - ti0);
-    const int CH = ntile * RXI;            // interior rows of this chunk
-    const int nin = CH + 2 * K;            // input rows
-    const int row0 = a.G - K + ti0 * RXI;  // first loaded row / column, padded coordinates
-    const int col0 = a.G - K + tj * WI;
-    const int voff = lane * 4;
-    const int pitchB = a.pitch * 4;
-    const int soff0 = (row0 * a.pitch + col0) * 4;
-    const rsrc_t rPrIn = makeRsrc(a.prIn, a.inBytes), rVxIn = makeRsrc(a.vxIn, a.inBytes),
-                 rVyIn = makeRsrc(a.vyIn, a.inBytes);
-    const rsrc_t rPrOut = makeRsrc(a.prOut, a.planeBytes), rVxOut = makeRsrc(a.vxOut, a.planeBytes),
-                 rVyOut = makeRsrc(a.vyOut, a.planeBytes);
-
-    const DynParams dyn = *a.dyn;
-    // recording decision per tile of the chunk, from the previous launch's non-zero flags of the tile and its 8
-    // neighbours: one launch moves the field by at most K < tile cells, so a tile whose 3x3 block was zero stays zero
-    unsigned recMask = 0;  // bit i: tile ti0+i is recorded in this launch
-    unsigned winMask = 0;  // bit i: tile ti0+i lies inside the history window
-    if (a.record) {
-        for (int i = 0; i < ntile; ++i) {
-            const int ti = ti0 + i;
-            const int tile = ti * a.nty + tj;
-            const int hti = ti - dyn.histTileX0, htj = tj - dyn.histTileY0;
-            const bool inWin = hti >= 0 && hti < dyn.histTilesX && htj >= 0 && htj < dyn.histTilesY;
-            bool on = a.dense || a.tileFirst[tile] != INT_MAX;
-            if (!on) {
-                for (int di = -1; di <= 1 && !on; ++di)
-                    for (int dj = -1; dj <= 1; ++dj) {
-                        const int u = ti + di, v = tj + dj;
-                        if (u >= 0 && u < a.ntx && v >= 0 && v < a.nty && a.nzIn[u * a.nty + v]) on = true;
-                    }
-            }
-            if (inWin) winMask |= 1u << i;
-            if (on && inWin) {
-                recMask |= 1u << i;
-                if (lane == 0 && !a.dense) atomicMin(&a.tileFirst[tile], a.t0);
-            }
-        }
-    }
-    const float C = a.courant;
-    const bool inCols = lane >= K && lane < 64 - K;
-    const int hpitchB = WI * 4;
-    const int hvoff = (lane - K) * 4;
-    const int htile0 = (ti0 - dyn.histTileX0) * dyn.histTilesY + (tj - dyn.histTileY0);  // window tile of the chunk's first tile
-
-    // S[par][level]: the two newest rows of every time level; in an iteration of parity par, [par] is the older row
-    float Sp[2][K + 1], Sx[2][K + 1], Sy[2][K + 1];
-#pragma unroll
-    for (int s = 0; s <= K; ++s) {
-        Sp[0][s] = Sp[1][s] = 0.f;
-        Sx[0][s] = Sx[1][s] = 0.f;
-        Sy[0][s] = Sy[1][s] = 0.f;
-    }
-    float inP[PF], inX[PF], inY[PF];
-#pragma unroll
-    for (int k = 0; k < PF; ++k) {
-        const int so = soff0 + min(k, nin - 1) * pitchB;
-        inP[k] = bufLoadF(rPrIn, voff, so);
-        inX[k] = bufLoadF(rVxIn, voff, so);
-        inY[k] = bufLoadF(rVyIn, voff, so);
-    }
-    unsigned nzAcc = 0;     // OR of the final-level outputs of the current tile
-    unsigned nzMask = 0;    // bit i: tile ti0+i has a non-zero output
-    const int niter = nin + 2 * K;  // level K row o leaves at iteration o + 2K
-#pragma unroll 1
-    for (int n0 = 0; n0 < niter; n0 += PF) {
-#pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            const int n = n0 + k;
-            constexpr int dummy = 0;
-            (void)dummy;
-            const int par = k & 1;  // PF is even, so the parity of n is the parity of k
-            // take this iteration's input row and refill its slot with row n + PF
-            const float p0 = (n < nin) ? inP[k] : 0.f;
-            const float x0 = (n < nin) ? inX[k] : 0.f;
-            const float y0 = (n < nin) ? inY[k] : 0.f;
-            if (n + PF < nin) {
-                const int so = soff0 + (n + PF) * pitchB;
-                inP[k] = bufLoadF(rPrIn, voff, so);
-                inX[k] = bufLoadF(rVxIn, voff, so);
-                inY[k] = bufLoadF(rVyIn, voff, so);
-            }
-            // advance every level by one row, highest level first (each uses the rows of the previous iteration)
-#pragma unroll
-            for (int s = K - 1; s >= 0; --s) {
-                const float ap = Sp[par][s], ax = Sx[par][s], ay = Sy[par][s];  // level s, row q
-                const float bx = Sx[par ^ 1][s];                                // level s, row q+1
-                const float div = (bx - ax) + (laneNext(ay) - ay);
-                const float pn = ap - C * div;                                  // FDTD.cpp:124-141
-                const float xn = ax - C * (pn - Sp[par ^ 1][s + 1]);            // FDTD.cpp:143-170
-                const float yn = ay - C * (pn - lanePrev(pn));                  // FDTD.cpp:172-199
-                const int q = n - 2 * (s + 1);                                  // relative row of the new row
-                if (recMask) {  // pressure after step t0+s, before any pulse (none in an air chunk)
-                    const int ql = q - K;
-                    if (ql >= 0 && ql < CH && ((recMask >> (ql / RXI)) & 1u) && inCols) {
-                        const rsrc_t rH = makeRsrc(a.hist + (long long)(a.histSlot + s) * a.histPlane, a.histPlane * 4);
-                        bufStoreF(pn, rH, hvoff, ((htile0 + (ql / RXI) * dyn.histTilesY) * RXI + ql % RXI) * hpitchB);
-                    }
-                }
-                if (s + 1 == K) {
-                    const int ql = q - K;
-                    if (ql >= 0 && ql < CH) {
-                        if (inCols) {
-                            const int so = soff0 + q * pitchB;
-                            bufStoreF(pn, rPrOut, voff, so);
-                            bufStoreF(xn, rVxOut, voff, so);
-                            bufStoreF(yn, rVyOut, voff, so);
-                            nzAcc |= (__float_as_uint(pn) | __float_as_uint(xn) | __float_as_uint(yn)) & 0x7fffffffu;
-                        }
-                        if ((ql + 1) % RXI == 0) {  // last row of a tile
-                            if (__ballot(nzAcc != 0u) != 0ull) nzMask |= 1u << (ql / RXI);
-                            nzAcc = 0;
-                        }
-                    }
-                }
-                Sp[par][s + 1] = pn;
-                Sx[par][s + 1] = xn;
-                Sy[par][s + 1] = yn;
-            }
-            Sp[par][0] = p0;
-            Sx[par][0] = x0;
-            Sy[par][0] = y0;
-        }
-    }
-    if (lane == 0) {
-        for (int i = 0; i < ntile; ++i) a.nzOut[(ti0 + i) * a.nty + tj] = (nzMask >> i) & 1u;
-        // a tile outside the history window must never become non-zero (the window covers the pulse's reach)
-        if (a.record && (nzMask & ~winMask)) atomicExch(a.errFlag, 1);
-    }
-}
-
 // Position q inside an XCD's band of `bandRows` tile rows -> (row in band, tile column).
 //   order 1      : row-major over the whole band
 //   order 2      : column-major over the whole band
@@ -1463,7 +1303,6 @@ __global__ __launch_bounds__(256, WPS) void pv_step_air_kernel(const StepArgs a)
     const int tile = ti * a.nty + tj;
     const int cls = a.tileClass[tile];
     if (cls == 1) return;
-    if (a.streamM > 0 && streamOwnsChunk<K, RXI>(a, ti / a.streamM, tj)) return;  // row-streaming kernel's
     if (a.withPulse) {  // the tile(s) holding the listener are on the general kernel's list
         const int lr = a.dyn->lrow - (a.G - K + ti * RXI), lc = a.dyn->lcol - (a.G - K + tj * (64 - 2 * K));
         if (lr >= 0 && lr < RXI + 2 * K && lc >= 0 && lc < 64) return;
@@ -1691,6 +1530,76 @@ __device__ __forceinline__ bool deadTileSkippable(const StepArgs& a, int tile) {
     return !(lr >= 0 && lr < RXI + 2 * K + 8 && lc >= 0 && lc < 64);
 }
 
+}  // namespace pva
+#include "pv_seg.h"
+namespace pva {
+
+// Segment form of the merged launch: the first blocks advance one general tile each (stepTileGeneral4, as in
+// pv_step_merged_kernel), every other block four row-streaming air segments, one per wave (pv_seg.h).  XCD x = block % 8
+// takes a contiguous eighth of the segment list, which the host sorts by (first row, tile column): segments that share
+// y-halo columns stream down side by side on the same L2.
+template <int K, int RXI, int NC, int WPS>
+__global__ __launch_bounds__(256, WPS) void pv_step_seg_kernel(const StepArgs a) {
+    __shared__ float lut[256];
+    __shared__ GenShared gsh;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int gblocks = a.numGeneral;  // one block per general tile
+    if ((int)blockIdx.x < gblocks) {
+        if ((int)blockIdx.x >= a.dyn->numGeneral) return;
+        const int tile = __builtin_amdgcn_readfirstlane(a.generalList[blockIdx.x]);
+        if (deadTileSkippable<K, RXI>(a, tile)) return;  // (block-uniform)
+        lut[threadIdx.x] = a.lut[threadIdx.x];
+        __syncthreads();
+        stepTileGeneral4<K, RXI>(a, tile, wave, lane, lut, gsh);
+        return;
+    }
+    const int b = blockIdx.x - gblocks;
+    const int nseg = a.dyn->numSeg;
+    const int per = (nseg + 7) >> 3;
+    const int q = (b >> 3) * 4 + wave;
+    const int idx = (b & 7) * per + q;
+    if (q >= per || idx >= nseg) return;
+    SegDesc sd = a.segList[idx];
+    sd.row0 = __builtin_amdgcn_readfirstlane(sd.row0);
+    sd.nrows = __builtin_amdgcn_readfirstlane(sd.nrows);
+    sd.tj0 = __builtin_amdgcn_readfirstlane(sd.tj0);
+    sd.w = __builtin_amdgcn_readfirstlane(sd.w);
+    stepSegment<K, RXI, NC>(a, sd, lane);
+}
+
+// configurations with a segment kernel: (K, tile rows, columns per lane, waves per SIMD).  K = 8: 11 ring slots, 199
+// VGPRs, two waves per SIMD.  K = 12: 16 ring slots need ~290 registers -- one wave per SIMD (256 VGPRs + AGPRs).
+#define PV_SEG_CONFIGS(X) X(8, 40, 4, 2) X(12, 36, 4, 1)
+
+int segConfigColumns(int K, int rxi) {
+#define X(k, r, nc, w) \
+    if (K == k && rxi == r) return nc;
+    PV_SEG_CONFIGS(X)
+#undef X
+    return 0;
+}
+
+int segConfigMaxTileColumns(int K, int rxi) {
+#define X(k, r, nc, w) \
+    if (K == k && rxi == r) return SegGeom<k, nc>::WMAX;
+    PV_SEG_CONFIGS(X)
+#undef X
+    return 0;
+}
+
+void launchStepSeg(int K, int rxi, const StepArgs& a, hipStream_t stream) {
+    const int per = (a.numSeg + 7) / 8;
+    const int blocks = a.numGeneral + 8 * ((per + 3) / 4);
+#define X(k, r, nc, w) \
+    if (K == k && rxi == r) { \
+        hipLaunchKernelGGL((pv_step_seg_kernel<k, r, nc, w>), dim3(blocks), dim3(256), 0, stream, a); \
+        return; \
+    }
+    PV_SEG_CONFIGS(X)
+#undef X
+}
+
 // positions an XCD's band needs under the chosen order (sub-bands are padded to whole multiples of H rows)
 static int bandPositions(const StepArgs& a) {
     if (a.tileOrder <= 1) return (a.ntiles + 7) / 8;
@@ -1705,10 +1614,6 @@ static void launchStepT(const StepArgs& a, hipStream_t stream, int which, hipStr
         const int blocks = a.numGeneral + 8 * ((bandPositions(a) + 3) / 4);
         hipLaunchKernelGGL((pv_step_merged_kernel<K, RXI, WPS, SUB>), dim3(blocks), dim3(256), 0, stream, a);
         return;
-    }
-    if ((which & 1) && a.streamM > 0) {
-        const int units = ((a.ntx + a.streamM - 1) / a.streamM) * a.nty;
-        hipLaunchKernelGGL((pv_step_stream_kernel<K, RXI, 4>), dim3((units + 3) / 4), dim3(256), 0, stream, a);
     }
     if (which & 1) {
         const int blocks = a.tileOrder == 0 ? (a.ntiles + 3) / 4 : 8 * ((bandPositions(a) + 3) / 4);
@@ -1746,6 +1651,11 @@ static void launchStackT(const StepArgs& a, hipStream_t stream) {
 }
 
 // (K steps per launch, interior rows per tile, waves/SIMD bound of the air kernel, rows per general-tile slice)
+#ifdef PV_DEV_FAST  // development builds: two configurations only (make EXTRA=-DPV_DEV_FAST)
+#define PV_STEP_CONFIGS(X) X(8, 24, 3, 12) X(12, 36, 2, 9) X(8, 40, 2, 10)
+#define PV_STACK_CONFIGS(X)
+#define PV_BATCH_CONFIGS(X) X(8, 24, 3, 12) X(12, 36, 2, 9) X(8, 40, 2, 10)
+#else
 #define PV_STEP_CONFIGS(X) \
     X(4, 32, 3, 8) X(4, 24, 4, 6) X(2, 28, 4, 7) X(1, 30, 4, 15) X(8, 24, 3, 12) X(6, 28, 3, 14) X(3, 26, 4, 13) \
     X(8, 48, 2, 12) X(12, 40, 2, 10) X(8, 40, 2, 10) X(12, 32, 2, 8) X(10, 36, 2, 9) X(8, 44, 2, 11) X(10, 40, 2, 10) X(12, 36, 2, 9) \
@@ -1755,6 +1665,7 @@ static void launchStackT(const StepArgs& a, hipStream_t stream) {
 // tile's interior height doubles as the configuration's `rxi`
 #define PV_STACK_CONFIGS(X) \
     X(12, 28, 196, 7) X(12, 30, 210, 10)
+#endif
 
 void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream, int which, hipStream_t stream2) {
 #define X(k, np, x, sub) \
@@ -1769,7 +1680,9 @@ void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream, int which
 
 // configurations with a batched kernel: the defaults of every grid-size class (pv_solver.cpp) and the other
 // merged-launch tiles of the tuning sweeps
+#ifndef PV_DEV_FAST
 #define PV_BATCH_CONFIGS(X) X(8, 24, 3, 12) X(6, 28, 3, 14) X(10, 36, 2, 9) X(12, 36, 2, 9) X(8, 40, 2, 10)
+#endif
 
 bool batchConfigOk(int K, int rxi) {
 #define X(k, r, w, sub) \
@@ -1855,6 +1768,7 @@ __global__ void pv_begin_run_kernel(BeginArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = min(a.dynHost->numGeneral, a.listCap);
     if (i < n) a.list[i] = a.listHost[i];
+    if (a.segHost && i < min(a.dynHost->numSeg, a.segCap)) a.seg[i] = a.segHost[i];
     if (i == 0) {
         *a.dyn = *a.dynHost;
         *a.errFlag = 0;
@@ -1878,7 +1792,8 @@ void launchZero(float* p, long long n, hipStream_t stream) {
 }
 
 void launchBeginRun(const BeginArgs& a, hipStream_t stream) {
-    const int n = a.ntiles > a.listCap ? a.ntiles : a.listCap;
+    int n = a.ntiles > a.listCap ? a.ntiles : a.listCap;
+    if (a.segHost && a.segCap > n) n = a.segCap;
     hipLaunchKernelGGL(pv_begin_run_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a);
 }
 

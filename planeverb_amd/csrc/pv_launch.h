@@ -20,6 +20,11 @@ int stepConfigExtraRows(int K, int rxi);
 // 4 = both in ONE merged launch (one block per general tile first, then the air tiles)
 // The general kernel goes to stream2 when given (the caller orders the two streams with events).
 void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream, int which = 3, hipStream_t stream2 = nullptr);
+// row-streaming air segments (pv_seg.h): columns per lane of the configuration's segment kernel (0 = it has none), the
+// tile columns a segment can span, and the launch (general tiles + a.numSeg segments in one grid)
+int segConfigColumns(int K, int rxi);
+int segConfigMaxTileColumns(int K, int rxi);
+void launchStepSeg(int K, int rxi, const StepArgs& a, hipStream_t stream);
 // batched merged launch: ba.n runs (blockIdx.y) of identically configured solvers in one grid; only for
 // batchConfigOk() configurations
 bool batchConfigOk(int K, int rxi);

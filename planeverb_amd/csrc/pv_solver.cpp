@@ -96,7 +96,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     if (!stepConfigSupported(K_, rxi_)) return fail("unsupported (stepsPerLaunch, tileRows) configuration");
     // edge tiles are an "allow": only the batched kernels of the mirror-pair tiles have that arm
     if (opt_.edgeTiles && !(edgeConfigOk(K_, rxi_) && opt_.packed && opt_.merged == 1 && !opt_.streaming &&
-                            opt_.streamRows == 0 && opt_.timeKernels == 0))
+                            opt_.timeKernels == 0))
         opt_.edgeTiles = false;
     wi_ = 64 - 2 * K_;
     T_ = opt.numSteps > 0 ? opt.numSteps : g_.T;
@@ -105,7 +105,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     if (opt_.slabCount < 1 || opt_.slabIndex < 0 || opt_.slabIndex >= opt_.slabCount) return fail("invalid slab spec");
     if (isSlab()) {
         if (opt_.slabCount > ntxG_ / 2) return fail("too many slabs: every slab needs at least two tile rows");
-        if (opt_.streaming || opt_.streamRows > 0 || opt_.edgeTiles || stepConfigStacked(K_, rxi_) || opt_.merged != 1 ||
+        if (opt_.streaming || opt_.edgeTiles || stepConfigStacked(K_, rxi_) || opt_.merged != 1 ||
             !mergedConfigOk(K_, rxi_))
             return fail("slabs need the default merged step kernel (no streaming analysis, stacked or edge tiles)");
         opt_.rowBands = 1;
@@ -153,9 +153,12 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
             if (h[64 + i] != (float)(i - 1)) return fail("DPP wave_shr self-test failed");
     }
 
+    // pr, vx, vy of a buffer set are ONE allocation: the segment kernel reaches the three planes of a set through a
+    // single buffer descriptor (pv_seg.h)
     for (int i = 0; i < 2; ++i) {
-        if (!dalloc(&pr_[i], plane, true) || !dalloc(&vx_[i], plane, true) || !dalloc(&vy_[i], plane, true))
-            return false;
+        if (!dalloc(&pr_[i], 3 * plane, true)) return false;
+        vx_[i] = pr_[i] + plane;
+        vy_[i] = pr_[i] + 2 * plane;
     }
     if (!dalloc(&codes_, plane, true)) return false;
     if (!dalloc(&matDev_, (size_t)g_.NX * g_.NY, true)) return false;
@@ -229,13 +232,25 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     if (!hipOk(hipHostMalloc((void**)&qCellsHost_, kMaxQueries * sizeof(long long)), "hipHostMalloc")) return false;
     if (!hipOk(hipHostMalloc((void**)&qOutHost_, kMaxQueries * 8 * sizeof(float)), "hipHostMalloc")) return false;
     if (!hipOk(hipHostMalloc((void**)&listHost_, sizeof(int) * (size_t)listCap_), "hipHostMalloc")) return false;
+    // row-streaming air segments (opt-in: measured slower than the tile kernels at 4096^2): grids whose
+    // configuration has a segment kernel; not with the modes whose launches are cut differently (slabs, row bands,
+    // batched / edge-tile kernel, graphs) or record every tile (sparse-emitter ring)
+    segWMax_ = segConfigMaxTileColumns(K_, rxi_);
+    useSeg_ = segWMax_ > 0 && opt_.segments > 0 && !opt_.streaming && !isSlab() && !opt_.edgeTiles && opt_.merged == 1 &&
+              opt_.timeKernels == 0 && opt_.useGraph != 1 && (opt_.useGraph == 2 || ntiles > 4096) &&
+              plane * 12 <= (size_t)INT_MAX;
+    if (useSeg_) {
+        segCap_ = 2 * ntiles + 8;
+        if (!dalloc(&segList_, (size_t)segCap_, true)) return false;
+        if (!hipOk(hipHostMalloc((void**)&segHost_, sizeof(SegDesc) * (size_t)segCap_), "hipHostMalloc")) return false;
+    }
 
     // Row bands (see enqueueSteps): worth it where a sweep is thousands of tiles; measured on MI355X at 4096^2 / 8192^2
     {
         const bool mergedLaunch = !stepConfigStacked(K_, rxi_) && opt_.merged == 1 && mergedConfigOk(K_, rxi_);
         int want = opt_.rowBands;
         if (want == 0) want = kAutoRowBands;
-        if (!mergedLaunch || opt_.streaming || opt_.streamRows > 0 || opt_.edgeTiles || opt_.timeKernels > 0) want = 1;
+        if (!mergedLaunch || opt_.streaming || opt_.edgeTiles || opt_.timeKernels > 0) want = 1;
         // a band must be tall enough that only ADJACENT bands share halos: >= 2 tile rows each
         want = std::max(1, std::min(want, geo_.ntx / 2));
         nb_ = want;
@@ -281,9 +296,7 @@ Solver::~Solver() {
     if (stream_) hipStreamSynchronize(stream_);
     if (stream2_) hipStreamSynchronize(stream2_);
     for (int i = 0; i < 2; ++i) {
-        if (pr_[i]) hipFree(pr_[i]);
-        if (vx_[i]) hipFree(vx_[i]);
-        if (vy_[i]) hipFree(vy_[i]);
+        if (pr_[i]) hipFree(pr_[i]);  // (vx, vy live in the same allocation)
     }
     for (uint8_t* p : nz_)
         if (p) hipFree(p);
@@ -316,6 +329,8 @@ Solver::~Solver() {
     if (qCellsHost_) hipHostFree(qCellsHost_);
     if (qOutHost_) hipHostFree(qOutHost_);
     if (listHost_) hipHostFree(listHost_);
+    if (segHost_) hipHostFree(segHost_);
+    if (segList_) hipFree(segList_);
     for (auto& e : ev_)
         if (e) hipEventDestroy(e);
     dropGraph();
@@ -589,6 +604,12 @@ bool Solver::prepareDyn(int lcx, int lcy, bool withPulse, bool banded) {
     numGeneral_ = n;
     dynCur_.numGeneral = n;
     dynHost_->numGeneral = n;
+    segActive_ = useSeg_ && !bandedRun_;
+    numSeg_ = 0;
+    if (segActive_) buildSegments(n);
+    segActive_ = segActive_ && numSeg_ > 0;
+    dynCur_.numSeg = numSeg_;
+    dynHost_->numSeg = numSeg_;
     if (bandedRun_) {
         // the list, band by band, as LOCAL tile ids of each band's own tile-row range; each band gets its own view of
         // the run parameters (the kernels then see a grid that starts at the band's first tile row)
@@ -618,6 +639,68 @@ bool Solver::prepareDyn(int lcx, int lcy, bool withPulse, bool banded) {
     }
     dynValid_ = true;
     return true;
+}
+
+// Row-streaming air segments of this run (pv_seg.h): every air tile that is not on the general list (walls, edges, the
+// tiles around the listener: listHost_[0, listed)) is covered by exactly one segment.  Tile rows are cut into maximal
+// runs of air tiles and those into chunks of <= segWMax_ tile columns; identical chunks of consecutive tile rows form a
+// rectangle, and rectangles are cut into pieces of about equal height -- row-granular, not tile-granular -- so that a
+// sweep is `target` segments of about equal work.  Sorted by (first row, tile column): pv_step_seg_kernel gives each XCD
+// a contiguous eighth of the list.
+void Solver::buildSegments(int listed) {
+    const int ntx = geo_.ntx, nty = geo_.nty;
+    std::vector<uint8_t> air((size_t)ntx * nty);
+    for (size_t t = 0; t < air.size(); ++t) air[t] = tileClassHost_[t] == 0;
+    for (int i = 0; i < listed; ++i) air[(size_t)listHost_[i]] = 0;
+    struct Rect {
+        int ti0, nt, tj0, w;
+    };
+    std::vector<Rect> rects;
+    std::vector<int> open((size_t)nty * 8, -1), next((size_t)nty * 8, -1);
+    for (int ti = 0; ti < ntx; ++ti) {
+        std::fill(next.begin(), next.end(), -1);
+        const uint8_t* row = air.data() + (size_t)ti * nty;
+        for (int tj = 0; tj < nty;) {
+            if (!row[tj]) {
+                ++tj;
+                continue;
+            }
+            int e = tj;
+            while (e < nty && row[e]) ++e;
+            for (int c = tj; c < e; c += segWMax_) {
+                const int w = std::min(segWMax_, e - c);
+                const size_t key = (size_t)c * 8 + (size_t)w;
+                int r = open[key];
+                if (r >= 0 && rects[(size_t)r].ti0 + rects[(size_t)r].nt == ti) {
+                    ++rects[(size_t)r].nt;
+                } else {
+                    r = (int)rects.size();
+                    rects.push_back({ti, 1, c, w});
+                }
+                next[key] = r;
+            }
+            tj = e;
+        }
+        open.swap(next);
+    }
+    long long totalRows = 0;
+    for (const Rect& r : rects) totalRows += (long long)r.nt * rxi_;
+    const int target = opt_.segments > 0 ? opt_.segments : 1024;
+    const int maxX = 7 * rxi_;  // a segment touches at most 8 tile rows (pv_seg.h: SegGeom::MAXTR)
+    const int Xt = (int)std::min<long long>(maxX, std::max<long long>(rxi_ / 2 + 1, ceilDiv((int)std::min<long long>(totalRows, INT_MAX / 2), target)));
+    int n = 0;
+    for (const Rect& r : rects) {
+        const int rows = r.nt * rxi_;
+        const int m = ceilDiv(rows, Xt);
+        for (int k = 0; k < m && n < segCap_; ++k) {
+            const int r0 = (int)((long long)rows * k / m), r1 = (int)((long long)rows * (k + 1) / m);
+            segHost_[n++] = SegDesc{r.ti0 * rxi_ + r0, r1 - r0, r.tj0, r.w};
+        }
+    }
+    std::sort(segHost_, segHost_ + n, [](const SegDesc& x, const SegDesc& y) {
+        return x.row0 != y.row0 ? x.row0 < y.row0 : x.tj0 < y.tj0;
+    });
+    numSeg_ = n;
 }
 
 // prepareDyn() left the run's parameters in pinned host memory; this launch moves them to HBM and resets the
@@ -650,6 +733,9 @@ void Solver::enqueueBeginRun(bool resetTiles) {
     b.ntiles = geo_.ntx * geo_.nty;
     b.tileFirstInit = opt_.denseHistory ? 0 : INT_MAX;
     b.listCap = listCap_;
+    b.segHost = segActive_ ? segHost_ : nullptr;
+    b.seg = segList_;
+    b.segCap = segCap_;
     b.dynBandsHost = bandedRun_ ? dynBandsHost_ : nullptr;
     b.dynBands = dynBandsDev_;
     b.nbands = bandedRun_ ? nb_ : 0;
@@ -670,6 +756,8 @@ StepArgs Solver::baseStepArgs(bool withPulse, bool record) const {
     a.tileDead = (record && numDead_ > 0) ? tileDead_ : nullptr;
     a.generalList = generalList_;
     a.numGeneral = launchCap_;
+    a.segList = segActive_ ? segList_ : nullptr;
+    a.numSeg = segActive_ ? numSeg_ : 0;
     a.dyn = dynDev_;
     a.tileOpen = opt_.streaming ? tileOpen_ : nullptr;
     a.errFlag = errFlag_;
@@ -704,8 +792,7 @@ void Solver::setLaunchArgs(StepArgs& a, int t0, int k, bool firstOfRun, int li) 
     a.t0 = t0;
     a.histSlot = opt_.streaming ? t0 % ring_ : t0;
     a.nsteps = k;
-    a.inBytes = (firstOfRun && opt_.streamRows == 0) ? 0 : (int)a.planeBytes;
-    a.streamM = (k == K_) ? opt_.streamRows : 0;  // the streaming kernel always advances exactly K levels
+    a.inBytes = firstOfRun ? 0 : (int)a.planeBytes;
     a.nzIn = nz_[li & 1];
     a.nzOut = nz_[(li & 1) ^ 1];
 }
@@ -749,7 +836,7 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
     // reads, WAR on the tiles it overwrites): one event per kernel per launch.
     // merged: one launch per K steps on one stream (no cross-stream hand-shake); not with the streaming kernel
     const bool mergedLaunch =
-        stepConfigStacked(K_, rxi_) || (opt_.merged == 1 && mergedConfigOk(K_, rxi_) && opt_.streamRows == 0);
+        stepConfigStacked(K_, rxi_) || (opt_.merged == 1 && mergedConfigOk(K_, rxi_));
     const bool two = launchCap_ > 0 && !mergedLaunch;
     const int nl = ceilDiv(nsteps, K_);
     if (two) {
@@ -766,15 +853,10 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
         hipStreamWaitEvent(stream2_, forkEv_, 0);
     }
     // A run starts from zero fields.  The first launch gets zero-extent input descriptors (its loads return 0) and
-    // overwrites the other buffer set completely, so no reset pass over the planes exists; only the experimental
-    // row-streaming kernel still wants real zeros.  (No hipMemsetAsync here on purpose: as nodes of a replayed graph the three large plane
-    // memsets were observed to be skipped after a hipDeviceSynchronize on ROCm 7.0's runtime.)
-    if (fromZero && opt_.streamRows > 0) {
-        const long long n = (long long)geo_.rows * geo_.pitch;
-        launchZero(pr_[cur_], n, stream_);
-        launchZero(vx_[cur_], n, stream_);
-        launchZero(vy_[cur_], n, stream_);
-    }
+    // overwrites the other buffer set completely, so no reset pass over the planes exists.  (No hipMemsetAsync here on
+    // purpose: as nodes of a replayed graph the three large plane memsets were observed to be skipped after a
+    // hipDeviceSynchronize on ROCm 7.0's runtime.)
+    (void)fromZero;
     if (mergedLaunch && bandsActive()) {
         // Row bands: sweep n of band b reads buffer set A (its own rows + K halo rows of bands b-1, b+1) and writes its
         // rows of set B.  So sweep n+1 of band b -- which reads set B around band b and overwrites set A's rows of band b
@@ -819,7 +901,11 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
         hipEvent_t* te = (opt_.timeKernels > 0 && k == K_ && li % opt_.timeKernels == 0) ? &kev_[(size_t)kevUsed_] : nullptr;
         if (mergedLaunch) {
             if (te) hipEventRecord(te[0], stream_);
-            launchStep(K_, rxi_, a, stream_, 4);
+            // the segment kernel always advances exactly K levels; a run's short last launch takes the tile kernel
+            if (a.segList && k == K_)
+                launchStepSeg(K_, rxi_, a, stream_);
+            else
+                launchStep(K_, rxi_, a, stream_, 4);
             if (te) {
                 hipEventRecord(te[1], stream_);
                 hipEventRecord(te[2], stream_);
@@ -1083,7 +1169,7 @@ bool Solver::runBatch(Solver* const* s, int n, const float* lxyz, bool wait, std
             v.geo_.nty != lead.geo_.nty || v.g_.gx != lead.g_.gx || v.g_.gy != lead.g_.gy ||
             v.opt_.tileOrder != lead.opt_.tileOrder)
             return bad("batched solvers must share device, grid and tile configuration");
-        if (v.opt_.streaming || v.opt_.streamRows > 0 || v.opt_.timeKernels > 0 || v.opt_.merged != 1 ||
+        if (v.opt_.streaming || v.opt_.timeKernels > 0 || v.opt_.merged != 1 ||
             !v.opt_.packed || !batchConfigOk(v.K_, v.rxi_))
             return bad("batched runs need the default merged packed-math kernel of a batch configuration, without "
                        "streaming analysis or kernel timing");

@@ -28,7 +28,8 @@ struct SolverOptions {
     bool withFreeGrid = true;
     int tileOrder = 1;    // air-kernel block->tile map: 1 = XCD-band row-major (1-5 % faster than 0 = linear, measured)
     int merged = 1;       // 1 = general + air tiles in one launch per K steps (where it compiles spill-free), 0 = two kernels on two streams
-    int streamRows = 0;   // M > 0: all-air chunks of M stacked tiles run in the row-streaming kernel
+    int segments = 0;     // N > 0: row-streaming air segments (pv_seg.h) instead of one wave per air tile, about N per
+                          // sweep; only the (K, rows) = (8, 40) and (12, 36) configurations have the kernel.  0 = off
     bool streaming = false;  // sparse-emitter mode: ring history + incremental forward analysis
     bool packed = true;   // packed-f32 arithmetic in the air-tile kernel (VALU-issue bound otherwise)
     bool edgeTiles = false;  // grid-edge tiles of empty regions on the air path + overrides (tile class 2): only the
@@ -234,6 +235,14 @@ private:
     void enqueueQueries();
     int* listHost_ = nullptr;
     int listCap_ = 0;
+    // row-streaming air segments (pv_seg.h): rebuilt for every run (they avoid the tiles around the listener)
+    bool useSeg_ = false;      // this solver's configuration and options allow them
+    bool segActive_ = false;   // the run being enqueued uses them
+    int segWMax_ = 0;          // tile columns a segment can span
+    SegDesc* segHost_ = nullptr;  // pinned
+    SegDesc* segList_ = nullptr;  // device
+    int segCap_ = 0, numSeg_ = 0;
+    void buildSegments(int listed);
 
     // host state
     MaterialPlane mat_;

@@ -744,34 +744,39 @@ def test_listener_outside_grid_and_api_misc(pvlib):
     assert L.PvAmdCreate(25.0, 25.0, 275, 99) is None and "device" in pvlib.last_error()
 
 
-@pytest.mark.parametrize("M", [1, 3, 4])
-def test_row_streaming_kernel_equivalence(pvlib, M):
-    """PVA_OPT_STREAM_ROWS (experimental row-streaming stencil for all-air chunks): same bits as the tile kernels,
-    raw stencil from dense random fields and a full run (history, activity flags, analysis)"""
+@pytest.mark.parametrize("K,rows,nseg", [(8, 40, 40), (8, 40, 300), (12, 36, 64), (12, 36, 1000)])
+def test_row_streaming_segments_equivalence(pvlib, K, rows, nseg):
+    """PVA_OPT_STREAM_ROWS (row-streaming air segments, pv_seg.h): same bits as the tile kernels -- the raw stencil from
+    dense random fields with walls, a closed-room run and an open-field run whose pulse crosses many segments (history
+    planes, activity flags, every result member)"""
     dx = np.float32(343.21) / np.float32(275) / np.float32(3.5)
-    n = 600
+    n = 900
     size = float((n + 0.5) * dx)
     rng = np.random.default_rng(0)
     init = [rng.standard_normal((n + 1, n + 1)).astype(np.float32) for _ in range(3)]
     walls = [[60, 70, 20, 1, 0.9], [120, 40, 1, 30, 0.7]]
+    cfg = dict(steps_per_launch=K, tile_rows=rows, use_graph=2)
     outs = []
-    for m in (0, M):
-        with pvlib.Solver(size, size, 275, no_free_grid=1, stream_rows=m) as s:
+    for m in (0, nseg):
+        with pvlib.Solver(size, size, 275, no_free_grid=1, stream_rows=m, **cfg) as s:
             for w in walls:
                 s.add_geometry(w)
             s.set_fields(*init)
-            s.run_steps(37)
+            s.run_steps(3 * K + 1)  # (the short last launch takes the tile kernel)
             outs.append(s.fields())
     assert all(same_bits(a, b).all() for a, b in zip(*outs))
-    res = []
-    for m in (0, M):
-        with pvlib.Solver(size, size, 275, stream_rows=m) as s:
-            s.load_scene(os.path.join(SCENES, "HugeRoom.pv"))
-            s.run((100.0, 0.0, 90.0))
-            res.append((s.results(), [s.history_plane(t) for t in (3, 100, 434)]))
-    (r0, h0), (r1, h1) = res
-    assert same_bits(r0[0], r1[0]).all() and same_bits(r0[1], r1[1]).all()
-    assert all(same_bits(a, b).all() for a, b in zip(h0, h1))
+    for scene, listener in (("HugeRoom.pv", (100.0, 0.0, 90.0)), (None, (150.0, 0.0, 170.0))):
+        res = []
+        for m in (0, nseg):
+            with pvlib.Solver(size, size, 275, stream_rows=m, **cfg) as s:
+                if scene:
+                    s.load_scene(os.path.join(SCENES, scene))
+                s.run(listener)
+                s.run(listener)  # twice: the per-tile flags of the first run must not leak into the second
+                res.append((s.results(), [s.history_plane(t) for t in (3, 100, 300, 434)]))
+        (r0, h0), (r1, h1) = res
+        assert same_bits(r0[0], r1[0]).all() and same_bits(r0[1], r1[1]).all()
+        assert all(same_bits(a, b).all() for a, b in zip(h0, h1))
 
 
 def test_history_that_cannot_fit_fails_loudly(pvlib):
