@@ -31,7 +31,14 @@ CONFIGS = [dict(), dict(), dict(steps_per_launch=12, tile_rows=36), dict(steps_p
            # fewer than 4 tile rows), thick walls (dead tiles) come from random_scene's larger boxes
            dict(row_bands=2), dict(steps_per_launch=8, tile_rows=24, row_bands=3),
            dict(steps_per_launch=8, tile_rows=24, slabs=[0, 0]), dict(steps_per_launch=8, tile_rows=24, slabs=[0, 0, 0]),
-           dict(steps_per_launch=8, tile_rows=24, slabs=[0, 0])]
+           dict(steps_per_launch=8, tile_rows=24, slabs=[0, 0]),
+           # row-streaming air segments (pv_seg.h)
+           dict(steps_per_launch=8, tile_rows=40, stream_rows=6, use_graph=2),
+           dict(steps_per_launch=12, tile_rows=36, stream_rows=30, use_graph=2)]
+SEG_CONFIGS = [dict(steps_per_launch=k, tile_rows=r, stream_rows=n, use_graph=2)
+               for k, r in ((8, 40), (12, 36)) for n in (1, 7, 40, 400)]
+if os.environ.get("PV_FUZZ_SEG"):  # a campaign on the segment kernels only
+    CONFIGS = SEG_CONFIGS
 
 
 def one(seed):
