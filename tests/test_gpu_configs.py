@@ -52,6 +52,27 @@ def test_config4_hugeroom_4096_all_listeners(pvlib):
             assert (delay[80:, :] > 1e30).all() and (delay[:, 80:] > 1e30).all()  # nothing leaves the closed room
 
 
+@pytest.mark.parametrize("K,rows,nseg", [(8, 40, 2048), (12, 36, 1024)])
+def test_config4_hugeroom_4096_row_streaming_segments(pvlib, K, rows, nseg):
+    """BASELINE config 4 at full size through the row-streaming segment kernels (PVA_OPT_STREAM_ROWS, pv_seg.h): three of
+    the listeners, both emitters each and the 25 m block of every map against the reference's vectors"""
+    g = golden("g71_hugeroom_cfg4")
+    with pvlib.Solver(mode_a_size(4096), mode_a_size(4096), 275, steps_per_launch=K, tile_rows=rows,
+                      stream_rows=nseg) as s:
+        s.load_scene(os.path.join(SCENES, "HugeRoom.pv"))
+        for i in (0, 3, 7):
+            s.set_output_queries(g["emitters"][i])
+            s.run(g["listeners"][i])
+            q = s.queried_outputs()
+            for j in range(2):
+                assert same_bits(q[j], g["emitter_out"][i, j]).all(), (i, j)
+            res, delay = s.results()
+            n = compare_maps(res[:70, :70], delay[:70, :70], g["results"][i], g["delay"][i], 435, 1443,
+                             "listener %d, 25 m block" % i)
+            assert n > 3500
+            assert (delay[80:, :] > 1e30).all() and (delay[:, 80:] > 1e30).all()
+
+
 def test_config3_bigroom_2048(pvlib):
     """BASELINE config 3: BigRoom.pv (closed 10 m room) at 2048^2 Mode A (730.458 m), L (5,0,4), E (5,0,6) + two
     emitters outside the room (no onset: untouched zero records), and the whole 25 m block of the maps"""
