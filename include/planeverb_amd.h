@@ -286,6 +286,11 @@ PVA_EXPORT int PvAmdRunSteps(PvAmdSolver* s, int nsteps, int withPulse, float lx
 /* the plan itself (no device needed): fills runIdx[i] / solverIdx[i] for this rank's i-th run, returns their number
  * (<= cap entries written) */
 PVA_EXPORT int PvAmdShardPlan(int nRuns, int world, int rank, int nLocalSolvers, int* runIdx, int* solverIdx, int cap);
+/* the segment plan of PVA_OPT_STREAM_ROWS (no device needed; test hook): air[ti * nty + tj] != 0 marks the air tiles;
+ * fills seg4[4 i .. 4 i + 3] = {first array row, rows, first tile column, tile columns} for up to cap segments, returns
+ * their number.  Every air tile is covered by exactly one segment. */
+PVA_EXPORT int PvAmdPlanSegments(const unsigned char* air, int ntx, int nty, int tileRows, int maxTileColumns, int target,
+                                 int* seg4, int cap);
 typedef struct PvAmdComm PvAmdComm;
 /* rank 0 creates the 128-byte id (ncclGetUniqueId) and hands it to every rank by whatever bootstrap the host has
  * (a file, MPI, torch.distributed's store); every rank then joins (ncclCommInitRank) with its HIP device */

@@ -156,6 +156,7 @@ SYMBOLS = {
     "PvAmdSetFields": (C.c_int, [_vp, _fp, _fp, _fp]),
     "PvAmdRunSteps": (C.c_int, [_vp, C.c_int, C.c_int, C.c_float, C.c_float]),
     "PvAmdShardPlan": (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
+    "PvAmdPlanSegments": (C.c_int, [C.POINTER(C.c_ubyte)] + [C.c_int] * 5 + [C.POINTER(C.c_int), C.c_int]),
     "PvAmdCommUniqueId": (C.c_int, [C.c_char_p]),
     "PvAmdCommCreate": (_vp, [C.c_char_p, C.c_int, C.c_int, C.c_int]),
     "PvAmdCommDestroy": (None, [_vp]),
@@ -413,6 +414,18 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+
+def plan_segments(air, tile_rows, max_tile_columns, target):
+    """PvAmdPlanSegments: the row-streaming segments (PVA_OPT_STREAM_ROWS) covering the air tiles of a [ntx, nty] 0/1
+    array: int array [n, 4] of (first array row, rows, first tile column, tile columns)"""
+    a = np.ascontiguousarray(air, np.uint8)
+    ntx, nty = a.shape
+    cap = 2 * a.size + 8
+    out = np.zeros((cap, 4), np.int32)
+    n = lib().PvAmdPlanSegments(a.ctypes.data_as(C.POINTER(C.c_ubyte)), ntx, nty, int(tile_rows), int(max_tile_columns),
+                                int(target), out.ctypes.data_as(C.POINTER(C.c_int)), cap)
+    return out[:min(n, cap)].copy()
 
 
 def run_sharded(solvers, listeners, emitters, rank=0, world=1, comm=None):

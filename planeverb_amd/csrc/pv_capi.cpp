@@ -666,6 +666,19 @@ int PvAmdShardPlan(int nRuns, int world, int rank, int nLocalSolvers, int* runId
     return (int)plan.size();
 }
 
+int PvAmdPlanSegments(const unsigned char* air, int ntx, int nty, int tileRows, int maxTileColumns, int target, int* seg4,
+                      int cap) {
+    if (!air || ntx < 1 || nty < 1) return 0;
+    const std::vector<SegRect> segs = planSegments(air, ntx, nty, tileRows, maxTileColumns, target);
+    for (int i = 0; i < (int)segs.size() && i < cap && seg4; ++i) {
+        seg4[4 * i] = segs[(size_t)i].row0;
+        seg4[4 * i + 1] = segs[(size_t)i].nrows;
+        seg4[4 * i + 2] = segs[(size_t)i].tj0;
+        seg4[4 * i + 3] = segs[(size_t)i].w;
+    }
+    return (int)segs.size();
+}
+
 int PvAmdCommUniqueId(char id128[128]) {
     if (!id128) return -1;
     return Comm::uniqueId(id128, &g_lastError) ? 0 : -1;

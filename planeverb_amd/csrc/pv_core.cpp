@@ -223,4 +223,57 @@ void reverbBusGains(float rt60, float wet, float* a, float* b, float* c) {
     else *c = wet - wet * (g(t3) - g(rt60)) / (g(t3) - g(t2));
 }
 
+std::vector<SegRect> planSegments(const uint8_t* air, int ntx, int nty, int rxi, int wmax, int target) {
+    struct Rect {
+        int ti0, nt, tj0, w;
+    };
+    std::vector<Rect> rects;
+    std::vector<SegRect> out;
+    if (ntx <= 0 || nty <= 0 || rxi <= 0 || wmax <= 0) return out;
+    wmax = std::min(wmax, 7);  // (the chunk key below has 3 bits for the width)
+    std::vector<int> open((size_t)nty * 8, -1), next((size_t)nty * 8, -1);
+    for (int ti = 0; ti < ntx; ++ti) {
+        std::fill(next.begin(), next.end(), -1);
+        const uint8_t* row = air + (size_t)ti * nty;
+        for (int tj = 0; tj < nty;) {
+            if (!row[tj]) {
+                ++tj;
+                continue;
+            }
+            int e = tj;
+            while (e < nty && row[e]) ++e;
+            for (int c = tj; c < e; c += wmax) {
+                const int w = std::min(wmax, e - c);
+                const size_t key = (size_t)c * 8 + (size_t)w;
+                int r = open[key];
+                if (r >= 0 && rects[(size_t)r].ti0 + rects[(size_t)r].nt == ti) {
+                    ++rects[(size_t)r].nt;
+                } else {
+                    r = (int)rects.size();
+                    rects.push_back({ti, 1, c, w});
+                }
+                next[key] = r;
+            }
+            tj = e;
+        }
+        open.swap(next);
+    }
+    long long totalRows = 0;
+    for (const Rect& r : rects) totalRows += (long long)r.nt * rxi;
+    const long long want = (totalRows + std::max(target, 1) - 1) / std::max(target, 1);
+    const int Xt = (int)std::min<long long>(7LL * rxi, std::max<long long>(rxi / 2 + 1, want));
+    for (const Rect& r : rects) {
+        const int rows = r.nt * rxi;
+        const int m = (rows + Xt - 1) / Xt;
+        for (int k = 0; k < m; ++k) {
+            const int r0 = (int)((long long)rows * k / m), r1 = (int)((long long)rows * (k + 1) / m);
+            out.push_back(SegRect{r.ti0 * rxi + r0, r1 - r0, r.tj0, r.w});
+        }
+    }
+    std::sort(out.begin(), out.end(), [](const SegRect& x, const SegRect& y) {
+        return x.row0 != y.row0 ? x.row0 < y.row0 : x.tj0 < y.tj0;
+    });
+    return out;
+}
+
 }  // namespace pva

@@ -87,4 +87,14 @@ bool savePv(const std::string& path, const std::vector<std::pair<int, Box>>& box
 // PlaneverbDSP/src/PvDSPContext.cpp:165-228
 void reverbBusGains(float rt60, float wet, float* a, float* b, float* c);
 
+// Row-streaming air segments (pv_seg.h, PVA_OPT_STREAM_ROWS): cover every tile with air[ti * nty + tj] != 0 by exactly
+// one segment.  Tile rows are cut into maximal runs of air tiles and those into chunks of <= wmax tile columns; identical
+// chunks of consecutive tile rows form a rectangle; rectangles are cut into pieces of about equal height -- ROW-granular,
+// not tile-granular -- of about (total rows / target) rows, at most 7 * rxi (a segment may touch 8 tile rows).  Sorted by
+// (first row, tile column).  Pure index arithmetic (no reference counterpart).
+struct SegRect {
+    int row0, nrows, tj0, w;  // array rows [row0, row0 + nrows) x tile columns [tj0, tj0 + w)
+};
+std::vector<SegRect> planSegments(const uint8_t* air, int ntx, int nty, int rxi, int wmax, int target);
+
 }  // namespace pva

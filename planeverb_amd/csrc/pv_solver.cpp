@@ -642,64 +642,19 @@ bool Solver::prepareDyn(int lcx, int lcy, bool withPulse, bool banded) {
 }
 
 // Row-streaming air segments of this run (pv_seg.h): every air tile that is not on the general list (walls, edges, the
-// tiles around the listener: listHost_[0, listed)) is covered by exactly one segment.  Tile rows are cut into maximal
-// runs of air tiles and those into chunks of <= segWMax_ tile columns; identical chunks of consecutive tile rows form a
-// rectangle, and rectangles are cut into pieces of about equal height -- row-granular, not tile-granular -- so that a
-// sweep is `target` segments of about equal work.  Sorted by (first row, tile column): pv_step_seg_kernel gives each XCD
-// a contiguous eighth of the list.
+// tiles around the listener: listHost_[0, listed)) is covered by exactly one segment (planSegments, pv_core.cpp);
+// pv_step_seg_kernel gives each XCD a contiguous eighth of the sorted list.
 void Solver::buildSegments(int listed) {
     const int ntx = geo_.ntx, nty = geo_.nty;
     std::vector<uint8_t> air((size_t)ntx * nty);
     for (size_t t = 0; t < air.size(); ++t) air[t] = tileClassHost_[t] == 0;
     for (int i = 0; i < listed; ++i) air[(size_t)listHost_[i]] = 0;
-    struct Rect {
-        int ti0, nt, tj0, w;
-    };
-    std::vector<Rect> rects;
-    std::vector<int> open((size_t)nty * 8, -1), next((size_t)nty * 8, -1);
-    for (int ti = 0; ti < ntx; ++ti) {
-        std::fill(next.begin(), next.end(), -1);
-        const uint8_t* row = air.data() + (size_t)ti * nty;
-        for (int tj = 0; tj < nty;) {
-            if (!row[tj]) {
-                ++tj;
-                continue;
-            }
-            int e = tj;
-            while (e < nty && row[e]) ++e;
-            for (int c = tj; c < e; c += segWMax_) {
-                const int w = std::min(segWMax_, e - c);
-                const size_t key = (size_t)c * 8 + (size_t)w;
-                int r = open[key];
-                if (r >= 0 && rects[(size_t)r].ti0 + rects[(size_t)r].nt == ti) {
-                    ++rects[(size_t)r].nt;
-                } else {
-                    r = (int)rects.size();
-                    rects.push_back({ti, 1, c, w});
-                }
-                next[key] = r;
-            }
-            tj = e;
-        }
-        open.swap(next);
-    }
-    long long totalRows = 0;
-    for (const Rect& r : rects) totalRows += (long long)r.nt * rxi_;
-    const int target = opt_.segments > 0 ? opt_.segments : 1024;
-    const int maxX = 7 * rxi_;  // a segment touches at most 8 tile rows (pv_seg.h: SegGeom::MAXTR)
-    const int Xt = (int)std::min<long long>(maxX, std::max<long long>(rxi_ / 2 + 1, ceilDiv((int)std::min<long long>(totalRows, INT_MAX / 2), target)));
+    const std::vector<SegRect> segs = planSegments(air.data(), ntx, nty, rxi_, segWMax_, opt_.segments > 0 ? opt_.segments : 1024);
     int n = 0;
-    for (const Rect& r : rects) {
-        const int rows = r.nt * rxi_;
-        const int m = ceilDiv(rows, Xt);
-        for (int k = 0; k < m && n < segCap_; ++k) {
-            const int r0 = (int)((long long)rows * k / m), r1 = (int)((long long)rows * (k + 1) / m);
-            segHost_[n++] = SegDesc{r.ti0 * rxi_ + r0, r1 - r0, r.tj0, r.w};
-        }
+    for (const SegRect& r : segs) {
+        if (n >= segCap_) break;
+        segHost_[n++] = SegDesc{r.row0, r.nrows, r.tj0, r.w};
     }
-    std::sort(segHost_, segHost_ + n, [](const SegDesc& x, const SegDesc& y) {
-        return x.row0 != y.row0 ? x.row0 < y.row0 : x.tj0 < y.tj0;
-    });
     numSeg_ = n;
 }
 

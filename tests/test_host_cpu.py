@@ -251,6 +251,36 @@ def test_shard_plan_matches_the_python_layer(pvlib):
     assert pvlib.shard_plan(5, 2, 2, 1) == [] and pvlib.shard_plan(5, 0, 0, 1) == []
 
 
+def test_segment_plan_covers_every_air_tile_once(pvlib):
+    """PvAmdPlanSegments (the host plan of the row-streaming air segments, PVA_OPT_STREAM_ROWS): on random tile maps every
+    air tile row is covered by exactly one segment, no segment touches a non-air tile, widths and heights stay inside what
+    the kernel's bookkeeping can hold, the list is sorted, and the target steers the segment count"""
+    rng = np.random.default_rng(5)
+    for trial in range(60):
+        ntx, nty = int(rng.integers(1, 40)), int(rng.integers(1, 30))
+        rows, wmax = int(rng.choice([24, 36, 40])), int(rng.choice([2, 5]))
+        air = (rng.random((ntx, nty)) < rng.choice([0.3, 0.8, 0.97, 1.0])).astype(np.uint8)
+        target = int(rng.choice([1, 7, 64, 1024]))
+        seg = pvlib.plan_segments(air, rows, wmax, target)
+        cover = np.zeros((ntx * rows, nty), np.int32)
+        for r0, n, tj0, w in seg:
+            assert 1 <= w <= wmax and 1 <= n <= 7 * rows and r0 >= 0 and r0 + n <= ntx * rows and tj0 + w <= nty
+            assert (r0 % rows + n + rows - 1) // rows <= 8  # tile rows a segment touches
+            cover[r0:r0 + n, tj0:tj0 + w] += 1
+        want = np.repeat(air.astype(np.int32), rows, axis=0)
+        assert np.array_equal(cover, want), trial
+        keys = [(int(a), int(c)) for a, _, c, _ in seg]
+        assert keys == sorted(keys)
+    # an open 114 x 103 tile grid (4096^2 at 36 x 40 tiles) with its border tiles general, 1024 segments wanted
+    air = np.ones((114, 103), np.uint8)
+    air[0, :] = air[-1, :] = 0
+    air[:, 0] = air[:, -1] = 0
+    seg = pvlib.plan_segments(air, 36, 5, 1024)
+    assert 900 <= len(seg) <= 1300 and seg[:, 3].max() == 5 and (seg[:, 1] <= 7 * 36).all()
+    assert len(pvlib.plan_segments(air, 36, 5, 64)) < len(seg) < len(pvlib.plan_segments(air, 36, 5, 4096))
+    assert len(pvlib.plan_segments(np.zeros((3, 3), np.uint8), 36, 5, 10)) == 0
+
+
 def test_batch_policy_helpers():
     """pure host logic: which grids are run in batches, and with which tile"""
     from planeverb_amd import api, dist
