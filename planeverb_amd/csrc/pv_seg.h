@@ -14,9 +14,14 @@
 //     (the latter was advanced a moment ago in this iteration) and pr of row i-1 at level s+1 (advanced in the
 //     previous iteration, not yet in this one): the update is IN PLACE.  A row is loaded once, lives in one ring slot
 //     for K+1 iterations and leaves at level K: no x halo is recomputed except K rows at either end of the segment
-//     (K*X + K^2 row updates for K*X useful ones), and only K+2 rows + the prefetched ones are in registers
-//     ((K+2+PF) * 3 * NC = 192 VGPRs), whatever the segment's length.
+//     (K * roundup(X + 2K, RS) row updates for K*X useful ones: the loop is branch-free, see `iteration`), and only
+//     K+2 rows + the prefetched ones are in registers ((K+2+PF) * 3 * NC: 132 at K = 8, 192 at K = 12), whatever the
+//     segment's length.
 //   * loads (row j+PF) and stores (row j-K) are spread evenly through the wave's life: no load phase, no store phase.
+//
+// Measured: the loop runs at the VALU rate (3.6 cycles per instruction and SIMD at K = 8, two waves per
+// SIMD) and executes 11-40 % fewer VALU instructions than the tile kernel, but at the segment lengths a 4096^2 or 8192^2
+// grid allows it re-reads too much x halo from HBM: slower than the tile kernels there, off by default.
 //
 // The ring is indexed statically: the loop is unrolled RS = K+2+PF times (row i lives in slot i mod RS).
 // Same arithmetic per cell, in the same order, as leapfrogStep<FAST> (FDTD.cpp:124-199 for air|air faces).
@@ -286,15 +291,15 @@ __device__ __forceinline__ void stepSegment(const StepArgs& a, const SegDesc sd,
         ++trSt;
     };
 
-    // ---- the stream, for segments that record nothing in this launch (all but those around the pulse) -------------
-    // NO branch around a memory operation and none per level: the s_waitcnt pass merges the outstanding-operation
+    // ---- one iteration of the stream; U = j mod RS is a compile-time constant --------------------------------------
+    // NO branch around a load or a final store and none per level: the s_waitcnt pass merges the outstanding-operation
     // counts of all paths into a branch target conservatively, and one skipped load turns every wait into vmcnt(0) --
     // no prefetch (measured: waves parked on s_waitcnt 47 % of their cycles).  So loads past the last row and stores
-    // before the first finished row are issued with an out-of-range lane offset (no memory access), and all K
-    // level-steps run from the first iteration on: what they compute before their rows exist is garbage in slots
-    // nothing valid ever reads (a level-step only touches the slots of rows j-K-1 .. j, the loads fill those of rows
-    // j+1 .. j+PF: disjoint mod RS) -- K^2 wasted row updates per segment.  The loop runs whole chunks of RS
-    // iterations; the host makes X + 2K a multiple of RS where it can.
+    // before the first finished row go through a descriptor of extent 0 (no memory access), and all K level-steps run
+    // from the first iteration on: what they compute before their rows exist is garbage in slots nothing valid ever
+    // reads (a level-step only touches the slots of rows j-K-1 .. j, the loads fill those of rows j+1 .. j+PF: disjoint
+    // mod RS) -- K^2 wasted row updates per segment.  The loop runs whole chunks of RS iterations (up to RS-1 more
+    // wasted iterations at the end).
     auto iteration = [&](auto uc, const int j) __attribute__((always_inline)) {
         constexpr int U = decltype(uc)::value;
         {
@@ -309,7 +314,7 @@ __device__ __forceinline__ void stepSegment(const StepArgs& a, const SegDesc sd,
 #pragma unroll
         for (int s = 0; s < K; ++s) {
             levelStep(((U - s - 1) % RS + RS) % RS, ((U - s) % RS + RS) % RS, ((U - s - 2) % RS + RS) % RS);
-            // (one level-step = one scheduling region: across level-steps the scheduler only adds register pressure)
+            // (PV_SEG_SCHEDBAR: one level-step = one scheduling region; measured slower at K = 8: 6.6 vs 5.6 ms per run)
 #if PV_SEG_SCHEDBAR
             __builtin_amdgcn_sched_barrier(0);
 #endif
