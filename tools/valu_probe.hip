@@ -77,6 +77,36 @@ __global__ __launch_bounds__(256) void probe(unsigned long long* cyc, float* sin
 #define X(i) asm volatile("v_pk_mul_f32 %0, %0, %1\n\tv_pk_add_f32 %0, %0, %1" : "+v"(p[0]) : "v"(c2));
                 REP16(X)
 #undef X
+            } else if (KIND == 13) {  // three-address v_pk_add_f32 with neg modifiers (the stencil's form), sources from two other streams
+#define X(i) asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(p[i]) : "v"(p[(i + 5) & 15]), "v"(p[(i + 10) & 15]));
+                REP16(X)
+#undef X
+            } else if (KIND == 14) {  // v_pk_mul_f32 with an SGPR-pair source (the stencil's C * x)
+#define X(i) asm volatile("v_pk_mul_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(p[i]) : "s"(c2), "v"(p[(i + 5) & 15]));
+                REP16(X)
+#undef X
+            } else if (KIND == 15) {  // explicit registers: both source pairs in the same VGPR bank pair (v[100:101], v[104:105])
+                asm volatile(
+                    "v_pk_add_f32 v[108:109], v[100:101], v[104:105]\n\tv_pk_add_f32 v[112:113], v[100:101], v[104:105]\n\t"
+                    "v_pk_add_f32 v[116:117], v[100:101], v[104:105]\n\tv_pk_add_f32 v[120:121], v[100:101], v[104:105]\n\t"
+                    "v_pk_add_f32 v[108:109], v[100:101], v[104:105]\n\tv_pk_add_f32 v[112:113], v[100:101], v[104:105]\n\t"
+                    "v_pk_add_f32 v[116:117], v[100:101], v[104:105]\n\tv_pk_add_f32 v[120:121], v[100:101], v[104:105]\n\t"
+                    "v_pk_add_f32 v[108:109], v[100:101], v[104:105]\n\tv_pk_add_f32 v[112:113], v[100:101], v[104:105]\n\t"
+                    "v_pk_add_f32 v[116:117], v[100:101], v[104:105]\n\tv_pk_add_f32 v[120:121], v[100:101], v[104:105]\n\t"
+                    "v_pk_add_f32 v[108:109], v[100:101], v[104:105]\n\tv_pk_add_f32 v[112:113], v[100:101], v[104:105]\n\t"
+                    "v_pk_add_f32 v[116:117], v[100:101], v[104:105]\n\tv_pk_add_f32 v[120:121], v[100:101], v[104:105]"
+                    ::: "v100", "v101", "v104", "v105", "v108", "v109", "v112", "v113", "v116", "v117", "v120", "v121");
+            } else if (KIND == 16) {  // explicit registers: source pairs in different banks (v[100:101], v[106:107])
+                asm volatile(
+                    "v_pk_add_f32 v[108:109], v[100:101], v[106:107]\n\tv_pk_add_f32 v[112:113], v[100:101], v[106:107]\n\t"
+                    "v_pk_add_f32 v[116:117], v[100:101], v[106:107]\n\tv_pk_add_f32 v[120:121], v[100:101], v[106:107]\n\t"
+                    "v_pk_add_f32 v[108:109], v[100:101], v[106:107]\n\tv_pk_add_f32 v[112:113], v[100:101], v[106:107]\n\t"
+                    "v_pk_add_f32 v[116:117], v[100:101], v[106:107]\n\tv_pk_add_f32 v[120:121], v[100:101], v[106:107]\n\t"
+                    "v_pk_add_f32 v[108:109], v[100:101], v[106:107]\n\tv_pk_add_f32 v[112:113], v[100:101], v[106:107]\n\t"
+                    "v_pk_add_f32 v[116:117], v[100:101], v[106:107]\n\tv_pk_add_f32 v[120:121], v[100:101], v[106:107]\n\t"
+                    "v_pk_add_f32 v[108:109], v[100:101], v[106:107]\n\tv_pk_add_f32 v[112:113], v[100:101], v[106:107]\n\t"
+                    "v_pk_add_f32 v[116:117], v[100:101], v[106:107]\n\tv_pk_add_f32 v[120:121], v[100:101], v[106:107]"
+                    ::: "v100", "v101", "v106", "v107", "v108", "v109", "v112", "v113", "v116", "v117", "v120", "v121");
             } else if (KIND == 12) {  // row_shr:1 dpp sub (row-local shift) for comparison with the wave shift
 #define X(i) asm volatile("v_sub_f32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a[i]) : "v"(a[(i + 8) & 15]));
                 REP16(X)
@@ -142,5 +172,9 @@ int main() {
     run<7>("v_mul_f32 dependent chain", 16);
     run<6>("v_pk_mul_f32 dependent chain", 16);
     run<11>("pk_mul -> pk_add dependent chain", 32);
+    run<13>("v_pk_add_f32 three-address, neg modifiers", 16);
+    run<14>("v_pk_mul_f32 with SGPR-pair source", 16);
+    run<15>("v_pk_add_f32 sources v[100:101], v[104:105] (same banks)", 16);
+    run<16>("v_pk_add_f32 sources v[100:101], v[106:107] (other banks)", 16);
     return 0;
 }
