@@ -141,7 +141,7 @@ enum {
     PVA_OPT_TILE_ROWS = 6,     /* interior rows of a wave tile (tuning; must pair with a compiled K) */
     PVA_OPT_NO_FREE_GRID = 7,  /* 1 = skip the free-field run (efree = 0; stencil-only use) */
     PVA_OPT_TIME_KERNELS = 8,  /* N > 0: HIP events around every Nth step-kernel launch (per-kernel durations) */
-    PVA_OPT_TILE_ORDER = 9,    /* air-kernel workgroup->tile map: 0 linear, 1 XCD band row-major, 2 band col-major */
+    PVA_OPT_TILE_ORDER = 9,    /* air-kernel workgroup->tile map: 0 linear, 1 XCD band of tile rows walked row-major, 2 the band column-major, 3 XCD strip of tile columns walked row-major (vertical halo neighbours stay in the XCD's L2), >= 4 sub-bands of that many tile rows; default: 3 for grids of >= 4500 tiles (3072^2 and up), else 1 */
     PVA_OPT_SMALL_GRID_KERNEL = 10, /* 0 = auto (grids that fit one CU's LDS run in one resident kernel), 2 = never */
     PVA_OPT_PACKED_MATH = 11,  /* air-tile kernel arithmetic: 1 = packed f32 (default), 0 = scalar f32 */
     PVA_OPT_STREAMING_ANALYSIS = 12, /* 1 = sparse-emitter mode: ring history + incremental analysis (see PvAmdSetEmitters) */

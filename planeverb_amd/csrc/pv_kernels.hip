@@ -1262,6 +1262,17 @@ __device__ __forceinline__ bool bandPosition(const StepArgs& a, int q, int bandR
 // block b (of the air part of a launch), wave w -> tile.  XCD x = b % 8 owns a contiguous span of the row-major tile
 // sequence: ntiles/8 tiles each (order 1, balanced to one tile), or a band of whole tile rows (orders 2, >= 4).
 __device__ __forceinline__ bool xcdTileAt(const StepArgs& a, int xcd, int q, int* ti, int* tj) {
+    if (a.tileOrder == 3) {  // column strips: XCD x owns tile columns [x*cw, (x+1)*cw) and walks its strip row-major, so
+                             // that a tile's vertical neighbours are cw tiles -- not a whole tile row of the grid -- away
+        const int cw = (a.nty + 7) >> 3;
+        const int c0 = xcd * cw, w = min(cw, a.nty - c0);
+        if (w <= 0) return false;
+        const int r = q / w;
+        if (r >= a.ntx) return false;
+        *ti = r;
+        *tj = c0 + (q - r * w);
+        return true;
+    }
     if (a.tileOrder <= 1) {
         const int per = (a.ntiles + 7) >> 3;
         const int t = xcd * per + q;
@@ -1603,6 +1614,7 @@ void launchStepSeg(int K, int rxi, const StepArgs& a, hipStream_t stream) {
 // positions an XCD's band needs under the chosen order (sub-bands are padded to whole multiples of H rows)
 static int bandPositions(const StepArgs& a) {
     if (a.tileOrder <= 1) return (a.ntiles + 7) / 8;
+    if (a.tileOrder == 3) return a.ntx * ((a.nty + 7) / 8);
     if (a.tileOrder < 4) return a.bandRows * a.nty;
     const int H = a.tileOrder;
     return ((a.bandRows + H - 1) / H) * H * a.nty;

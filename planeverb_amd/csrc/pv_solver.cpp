@@ -94,6 +94,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         rxi_ = 24;
     }
     if (!stepConfigSupported(K_, rxi_)) return fail("unsupported (stepsPerLaunch, tileRows) configuration");
+    if (opt_.tileOrder < 0) opt_.tileOrder = tiles36 >= 4500 ? 3 : 1;  // (measured: profiles/r02_tile_order.txt)
     // edge tiles are an "allow": only the batched kernels of the mirror-pair tiles have that arm
     if (opt_.edgeTiles && !(edgeConfigOk(K_, rxi_) && opt_.packed && opt_.merged == 1 && !opt_.streaming &&
                             opt_.timeKernels == 0))

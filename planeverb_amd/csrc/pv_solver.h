@@ -26,7 +26,11 @@ struct SolverOptions {
     bool skipAnalysis = false;
     int useGraph = 0;     // 0 = auto (small grids), 1 = always, 2 = never: replay the run from a captured hipGraph
     bool withFreeGrid = true;
-    int tileOrder = 1;    // air-kernel block->tile map: 1 = XCD-band row-major (1-5 % faster than 0 = linear, measured)
+    int tileOrder = -1;   // air-kernel block->tile map: 0 = linear, 1 = XCD band of tile rows, row-major (1-5 % faster than 0),
+                          // 2 / >= 4 = compact variants of it (fewer bytes, slower), 3 = XCD strip of tile COLUMNS, row-major:
+                          // a tile's vertical halo neighbours are nty/8 tiles away instead of nty, so they are still in the
+                          // 4 MiB L2 (HBM reads 316 -> 268 MB per launch at 4096^2, 1400 -> 948 MB at 8192^2; +2.5 % / +4 %
+                          // cell-updates/s; -3 % at 2048^2 and below).  -1 = by grid size: 3 for the large-grid tile, else 1
     int merged = 1;       // 1 = general + air tiles in one launch per K steps (where it compiles spill-free), 0 = two kernels on two streams
     int segments = 0;     // N > 0: row-streaming air segments (pv_seg.h) instead of one wave per air tile, about N per
                           // sweep; only the (K, rows) = (8, 40) and (12, 36) configurations have the kernel.  0 = off

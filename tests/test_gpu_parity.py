@@ -779,6 +779,29 @@ def test_row_streaming_segments_equivalence(pvlib, K, rows, nseg):
         assert all(same_bits(a, b).all() for a, b in zip(h0, h1))
 
 
+def test_tile_orders_cover_every_tile(pvlib):
+    """PVA_OPT_TILE_ORDER only changes which workgroup advances which air tile: linear, XCD bands of tile rows (row- /
+    column-major / sub-bands) and XCD strips of tile columns must give the same fields, on a grid whose tile counts are
+    not multiples of 8 in either direction"""
+    dx = np.float32(343.21) / np.float32(275) / np.float32(3.5)
+    n = 1250
+    size = float((n + 0.5) * dx)
+    rng = np.random.default_rng(3)
+    init = [rng.standard_normal((n + 1, n + 1)).astype(np.float32) for _ in range(3)]
+    ref = None
+    for order in (1, 0, 2, 3, 5):
+        with pvlib.Solver(size, size, 275, no_free_grid=1, steps_per_launch=12, tile_rows=36, use_graph=2,
+                          tile_order=order) as s:
+            s.add_geometry([200, 170, 30, 2, 0.8])
+            s.set_fields(*init)
+            s.run_steps(25)
+            f = s.fields()
+        if ref is None:
+            ref = f
+        else:
+            assert all(same_bits(a, b).all() for a, b in zip(f, ref)), order
+
+
 def test_history_that_cannot_fit_fails_loudly(pvlib):
     """a 25 m scene at 4096^2 needs T = 25 432 history planes (1.7 TB): refused with a pointer to the streaming mode"""
     with pytest.raises(pvlib.PlaneverbError, match="sparse-emitter mode"):

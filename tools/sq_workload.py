@@ -23,6 +23,7 @@ ap.add_argument("--launches", type=int, default=6)
 ap.add_argument("--inflight", type=int, default=1)
 ap.add_argument("--scene", default="HugeRoom.pv")
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--tile-order", type=int, default=-1)
 ap.add_argument("--k", type=int, default=0)
 ap.add_argument("--rows", type=int, default=0)
 ap.add_argument("--segments", type=int, default=0)  # PVA_OPT_STREAM_ROWS: row-streaming air segments (-1 = tile kernels)
@@ -31,6 +32,8 @@ a = ap.parse_args()
 dx = np.float32(343.21) / np.float32(275) / np.float32(3.5)
 size = float((a.grid + 0.5) * dx)
 kw = dict(steps_per_launch=a.k, tile_rows=a.rows) if a.k else {}
+if a.tile_order >= 0:
+    kw["tile_order"] = a.tile_order
 solvers = [pv.Solver(size, size, 275, no_free_grid=1, stream_rows=a.segments, **kw) for _ in range(a.inflight)]
 rng = np.random.default_rng(1)
 for s in solvers:
