@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <cstdlib>
 #include <climits>
 #include <cstdint>
 
@@ -505,7 +506,9 @@ struct PackedSteps {
                     for (int r = K; r < ROWS - K; ++r)
                         bufStoreF((r & 1) ? pr[r >> 1].y : pr[r >> 1].x, rH, hvoff, hsoff0 + r * hpitchB);
                 }
+#if PV_STEP_SCHEDBAR
                 __builtin_amdgcn_sched_barrier(0);  // keep the steps apart: interleaving them only costs registers
+#endif
                 PackedSteps<K, RXI, S + 1>::run(pr, vx, vy, C, a, recLane, hplane + a.histPlane, hvoff, hsoff0,
                                                 hpitchB);
             }
@@ -691,6 +694,15 @@ __device__ __forceinline__ void leapfrogStepMirror(v2f (&pr)[NP], v2f (&vx)[NP],
 #ifndef PV_LOAD_FENCE
 #define PV_LOAD_FENCE 0
 #endif
+#ifndef PV_PROBE_NOMEM
+#define PV_PROBE_NOMEM 0
+#endif
+#ifndef PV_MIRROR_G
+#define PV_MIRROR_G 4  // row pairs per interleaved group of the mirror sweeps
+#endif
+#ifndef PV_STEP_SCHEDBAR
+#define PV_STEP_SCHEDBAR 1  // scheduling barrier between the steps of an air tile
+#endif
 #ifndef PV_LATE_ARGS
 #define PV_LATE_ARGS 0
 #endif
@@ -751,14 +763,16 @@ struct MirrorSteps {
                                                const int hpitchB) {
         if constexpr (S < K) {
             if (S < a.nsteps) {
-                leapfrogStepMirror<NP, 4, S>(pr, vx, vy, vxS, C);
+                leapfrogStepMirror<NP, PV_MIRROR_G, S>(pr, vx, vy, vxS, C);
                 if (recLane) {  // pressure of this step, interior rows (air tiles never hold the listener)
                     const rsrc_t rH = makeRsrc(hplane, a.histPlane * 4);
 #pragma unroll
                     for (int r = K; r < ROWS - K; ++r)
                         bufStoreF(r < NP ? pr[r].x : pr[ROWS - 1 - r].y, rH, hvoff, hsoff0 + r * hpitchB);
                 }
+#if PV_STEP_SCHEDBAR
                 __builtin_amdgcn_sched_barrier(0);  // keep the steps apart: interleaving them only costs registers
+#endif
                 MirrorSteps<K, RXI, S + 1>::run(pr, vx, vy, vxS, C, a, recLane, hplane + a.histPlane, hvoff,
                                                 hsoff0, hpitchB);
             }
@@ -790,6 +804,15 @@ __device__ __forceinline__ void stepTileAirMirror(const StepArgs& a, const int t
     const rsrc_t rPrIn = makeRsrc(a.prIn, a.inBytes), rVxIn = makeRsrc(a.vxIn, a.inBytes),
                  rVyIn = makeRsrc(a.vyIn, a.inBytes);
     v2f pr[NP], vx[NP], vy[NP];
+#if PV_PROBE_NOMEM  // measurement builds only: the arithmetic of an air tile without its loads and stores
+    float vxS = (float)lane * 1e-6f;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        pr[i] = v2f{vxS + i, vxS - i};
+        vy[i] = v2f{vxS * 2.f + i, vxS * 3.f - i};
+        vx[i] = v2f{vxS * 5.f + i, vxS * 7.f - i};
+    }
+#else
     float vxS = bufLoadF(rVxIn, voff, soff0 + NP * pitchB);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -801,6 +824,7 @@ __device__ __forceinline__ void stepTileAirMirror(const StepArgs& a, const int t
         vx[i].x = bufLoadF(rVxIn, voff, soT);
         vx[i].y = (i > 0) ? -bufLoadF(rVxIn, voff, soB + pitchB) : 0.f;  // face ROWS-i; face ROWS is not in the tile
     }
+#endif
     // All 3*ROWS loads are in flight before anything consumes one.  Without this fence the schedule depends on what
     // ELSE is in the kernel: with more code (an extra tile variant, even one that never runs) the scheduler feeds the
     // non-zero test below a few loads at a time, s_waitcnt vmcnt(5) after every group -- ten memory round trips per
@@ -859,7 +883,11 @@ __device__ __forceinline__ void stepTileAirMirror(const StepArgs& a, const int t
     // cells past the ghost column are outside the grid: stored as the zeros they are in memory; the ghost column's
     // own vx is zero (wall|wall face)
     const bool outP = EDGE && e.eR >= 0 && lane > e.eR, outX = EDGE && e.eR >= 0 && lane >= e.eR;
+#if PV_PROBE_NOMEM
+    if (inCols && pr[3].x == 12345.678f) {  // (never true: keeps the arithmetic alive without the stores)
+#else
     if (inCols) {
+#endif
 #pragma unroll
         for (int r = K; r < ROWS - K; ++r) {
             const int so = soff0 + r * pitchB;
@@ -925,7 +953,7 @@ struct GenShared {
 };
 
 template <int K, int RXI>
-__device__ __forceinline__ void stepTileGeneral4(const StepArgs& a, const int tile, const int wave, const int lane,
+__device__ __forceinline__ void stepTileGeneral4Scalar(const StepArgs& a, const int tile, const int wave, const int lane,
                                                  const float* lut, GenShared& sh) {
     using Gm = GenStackGeom<K, RXI>;
     constexpr int R = Gm::R;
@@ -1061,6 +1089,206 @@ __device__ __forceinline__ void stepTileGeneral4(const StepArgs& a, const int ti
             }
         }
     }
+}
+
+// PV_GENERAL_PACKED (round 2): the same block, the same windows, the same exchange -- with two ADJACENT rows of a lane's
+// column per 64-bit register pair and v_pk_* arithmetic, as in stepTileAirPacked.  The x-differences need the row-shifted
+// pair (one v_pk_mov-style shuffle per pair and sweep); the air / wall choice of a face is a bit select (v_bfi_b32) with
+// a mask made once per launch from the face coefficient (NaN = air|air) instead of a compare + v_cndmask per face and
+// step: 12.5 instead of 21 VALU instructions per row and step.  Same operations per cell in the same order (packed ops
+// are IEEE per half; the wall value of an air face is computed and discarded, as before): same bits.
+#ifndef PV_GENERAL_PACKED
+#define PV_GENERAL_PACKED 1  // 1 = where it pays (K < 12), 2 = everywhere, 0 = nowhere
+#endif
+typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+
+template <int K, int RXI>
+__device__ __forceinline__ void stepTileGeneral4Packed(const StepArgs& a, const int tile, const int wave, const int lane,
+                                                       const float* lut, GenShared& sh) {
+    using Gm = GenStackGeom<K, RXI>;
+    constexpr int R = Gm::R;
+    constexpr int NP = (R + 1) / 2;  // row pairs (R odd: the last pair's second row is a spare row below the window)
+    constexpr int WI = 64 - 2 * K;
+    const int ti = tile / a.nty;
+    const int tj = tile - ti * a.nty;
+    const int ws = wave * (R - 2);                   // first row of this wave's window, in loaded-tile rows
+    const int row0 = a.G - K + ti * RXI + ws;
+    const int col0 = a.G - K + tj * WI;
+    const int voff = lane * 4;
+    const int pitchB = a.pitch * 4;
+    const int soff0 = (row0 * a.pitch + col0) * 4;
+    const bool first = wave == 0, last = wave == 3;
+
+    const rsrc_t rPrIn = makeRsrc(a.prIn, a.inBytes), rVxIn = makeRsrc(a.vxIn, a.inBytes),
+                 rVyIn = makeRsrc(a.vyIn, a.inBytes);
+    const rsrc_t rCodes = makeRsrc(a.codes, a.planeBytes / 2);
+    // row r of the window lives in pair r / 2, component r % 2
+    v2f pr[NP], vx[NP], vy[NP], kx[NP], ky[NP], bt[NP];
+    u2 mx[NP], my[NP];  // all-ones where the face is air|air
+    auto getc = [](const v2f& v, int r) { return (r & 1) ? v.y : v.x; };
+    auto setc = [](v2f& v, int r, float val) {
+        if (r & 1) v.y = val; else v.x = val;
+    };
+#pragma unroll
+    for (int r = 0; r < 2 * NP; ++r) {
+        if (r < R) {
+            const int so = soff0 + r * pitchB;
+            setc(pr[r / 2], r, bufLoadF(rPrIn, voff, so));
+            setc(vx[r / 2], r, bufLoadF(rVxIn, voff, so));
+            setc(vy[r / 2], r, bufLoadF(rVyIn, voff, so));
+            const uint32_t c = __builtin_amdgcn_raw_buffer_load_b16(rCodes, lane * 2, so >> 1, 0);
+            const float kxv = lut[c & 0xffu], kyv = lut[(c >> 8) & 0xffu];
+            setc(kx[r / 2], r, kxv);
+            setc(ky[r / 2], r, kyv);
+            setc(bt[r / 2], r, (c & 0xffu) < (uint32_t)kLutWall ? 1.f : 0.f);
+            if (r & 1) {
+                mx[r / 2].y = (kxv != kxv) ? 0xffffffffu : 0u;
+                my[r / 2].y = (kyv != kyv) ? 0xffffffffu : 0u;
+            } else {
+                mx[r / 2].x = (kxv != kxv) ? 0xffffffffu : 0u;
+                my[r / 2].x = (kyv != kyv) ? 0xffffffffu : 0u;
+            }
+        } else {  // the spare row: zeros, wall|wall faces (never read by a live row)
+            setc(pr[r / 2], r, 0.f);
+            setc(vx[r / 2], r, 0.f);
+            setc(vy[r / 2], r, 0.f);
+            setc(kx[r / 2], r, 0.f);
+            setc(ky[r / 2], r, 0.f);
+            setc(bt[r / 2], r, 0.f);
+            if (r & 1) mx[r / 2].y = my[r / 2].y = 0u; else mx[r / 2].x = my[r / 2].x = 0u;
+        }
+    }
+
+    const DynParams dyn = *a.dyn;
+    // listener row inside this wave's window: rows 0..R-2 hold a live pressure (row 0 = the copy of the previous
+    // wave's last row), row R-1 does not
+    const int lr = dyn.lrow - row0;
+    const int lc = dyn.lcol - col0;
+    const bool hasL = a.withPulse && lr >= 0 && lr <= R - 2 && lc >= 0 && lc < 64;
+    const int lrT = dyn.lrow - (row0 - ws);  // listener row in loaded-tile rows: is it anywhere in the block?
+    const bool tileHasL = a.withPulse && lrT >= 0 && lrT < Gm::L && lc >= 0 && lc < 64;
+    // general tiles are recorded on every step
+    const int hti = ti - dyn.histTileX0, htj = tj - dyn.histTileY0;
+    const bool inWin = hti >= 0 && hti < dyn.histTilesX && htj >= 0 && htj < dyn.histTilesY;
+    const bool rec = a.record && inWin && historyWanted(a, ti, tj);
+    if (a.record) {
+        uint32_t nz = 0;
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            nz |= (__float_as_uint(pr[i].x) | __float_as_uint(pr[i].y) | __float_as_uint(vx[i].x) |
+                   __float_as_uint(vx[i].y) | __float_as_uint(vy[i].x) | __float_as_uint(vy[i].y)) & 0x7fffffffu;
+        const bool active = tileHasL || __ballot(nz != 0u) != 0ull;
+        if (active && lane == 0) {
+            atomicMin(&a.tileFirst[tile], a.t0);
+            if (!inWin) atomicExch(a.errFlag, 1);
+        }
+    }
+
+    // rows this wave stores: its own rows 1..R-2 that lie in the tile's interior
+    const int rLo = max(1, K - ws), rHi = min(R - 1, K + RXI - ws);
+    const float C = a.courant;
+    const v2f c2 = {C, C};
+    const bool inCols = lane >= K && lane < 64 - K;
+    const float* hplane = a.hist + (long long)a.histSlot * a.histPlane;
+    const int hpitchB = WI * 4;
+    const int hsoff0 = ((hti * a.dyn->histTilesY + htj) * RXI - K + ws) * hpitchB;
+    const int hvoff = (lane - K) * 4;
+    auto sel = [](const u2 m, const v2f airv, const v2f wallv) {  // air where the mask is set, else wall: v_bfi_b32 x 2
+        const u2 ua = __builtin_bit_cast(u2, airv), uw = __builtin_bit_cast(u2, wallv);
+        return __builtin_bit_cast(v2f, (ua & m) | (uw & ~m));
+    };
+
+#pragma unroll 1
+    for (int s = 0; s < a.nsteps; ++s) {
+        // pressure sweep, FDTD.cpp:124-141 (row R-1 holds no live pressure; what is computed there is never read)
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const v2f vxn = (i + 1 < NP) ? v2f{vx[i].y, vx[i + 1].x} : v2f{vx[i].y, 0.f};  // vx of rows r+1
+            const v2f dyv = v2f{laneNext(vy[i].x) - vy[i].x, laneNext(vy[i].y) - vy[i].y};
+            const v2f div = (vxn - vx[i]) + dyv;
+            pr[i] = bt[i] * (pr[i] - c2 * div);
+        }
+        // vx sweep, FDTD.cpp:143-170 (+ edges :201-223 through the coefficients): own rows only (1 .. R-2); row 0's
+        // and row R-1's faces come from the neighbouring waves below, and whatever is computed for them here is
+        // overwritten
+        const float vx0keep = vx[0].x, vxLkeep = getc(vx[(R - 1) / 2], R - 1);
+#pragma unroll
+        for (int i = NP - 1; i >= 0; --i) {
+            const v2f pnv = (i > 0) ? v2f{pr[i - 1].y, pr[i].x} : v2f{pr[0].x, pr[0].x};  // pressure of rows r-1
+            const v2f airv = vx[i] - c2 * (pr[i] - pnv);
+            const v2f wallv = kx[i] * (pr[i] + pnv);
+            vx[i] = sel(mx[i], airv, wallv);
+        }
+        vx[0].x = vx0keep;
+        setc(vx[(R - 1) / 2], R - 1, vxLkeep);
+        sh.xch[s & 1][wave][0][lane] = vx[0].y;                          // vx[1]
+        sh.xch[s & 1][wave][1][lane] = getc(vx[(R - 2) / 2], R - 2);      // vx[R-2]
+        // vy sweep, FDTD.cpp:172-199
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const v2f pnv = v2f{lanePrev(pr[i].x), lanePrev(pr[i].y)};
+            const v2f airv = vy[i] - c2 * (pr[i] - pnv);
+            const v2f wallv = ky[i] * (pr[i] + pnv);
+            vy[i] = sel(my[i], airv, wallv);
+        }
+        // LDS only: the history stores of earlier steps stay in flight across the barrier
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (!first) vx[0].x = sh.xch[s & 1][wave - 1][1][lane];
+        if (!last) setc(vx[(R - 1) / 2], R - 1, sh.xch[s & 1][wave + 1][0][lane]);
+
+        // record the pressure of this step before the pulse is injected (FDTD.cpp:226-234)
+        if (rec && inCols) {
+            const rsrc_t rH = makeRsrc(hplane, a.histPlane * 4);
+#pragma unroll
+            for (int r = 1; r < R - 1; ++r)
+                if (r >= rLo && r < rHi) bufStoreF(getc(pr[r / 2], r), rH, hvoff, hsoff0 + r * hpitchB);
+        }
+        hplane += a.histPlane;
+
+        if (hasL) {  // soft source: p[listener] += pulse[t], FDTD.cpp:234
+            const float pv = (lane == lc) ? a.pulse[a.t0 + s] : 0.f;
+#pragma unroll
+            for (int r = 0; r < R - 1; ++r) setc(pr[r / 2], r, getc(pr[r / 2], r) + ((r == lr) ? pv : 0.f));
+        }
+    }
+
+    // per-tile non-zero flag of the state this launch leaves behind (halo included: conservative), for the row-streaming
+    // segments' recording decision in the next launch.  Monotone within a run: written, never cleared
+    // (pv_begin_run_kernel zeroes both flag planes).
+    if (a.record) {
+        uint32_t nzE = 0;
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            nzE |= (__float_as_uint(pr[i].x) | __float_as_uint(pr[i].y) | __float_as_uint(vx[i].x) |
+                    __float_as_uint(vx[i].y) | __float_as_uint(vy[i].x) | __float_as_uint(vy[i].y)) & 0x7fffffffu;
+        if ((__ballot(nzE != 0u) != 0ull || a.nzIn[tile]) && lane == 0) a.nzOut[tile] = 1;
+    }
+    const rsrc_t rPrOut = makeRsrc(a.prOut, a.planeBytes), rVxOut = makeRsrc(a.vxOut, a.planeBytes),
+                 rVyOut = makeRsrc(a.vyOut, a.planeBytes);
+    if (inCols) {
+#pragma unroll
+        for (int r = 1; r < R - 1; ++r) {
+            if (r >= rLo && r < rHi) {
+                const int so = soff0 + r * pitchB;
+                bufStoreF(getc(pr[r / 2], r), rPrOut, voff, so);
+                bufStoreF(getc(vx[r / 2], r), rVxOut, voff, so);
+                bufStoreF(getc(vy[r / 2], r), rVyOut, voff, so);
+            }
+        }
+    }
+}
+
+template <int K, int RXI>
+__device__ __forceinline__ void stepTileGeneral4(const StepArgs& a, const int tile, const int wave, const int lane,
+                                                 const float* lut, GenShared& sh) {
+    // Measured (profiles/r02_ab_general_packed.txt): +9-10 % at 512^2 (4 runs in flight, K = 8 tiles: a quarter of all
+    // tiles are general), +1.5 % at 2048^2 (K = 10) -- and 3 % SLOWER at 4096^2 / 8192^2, where 4 % of the tiles are
+    // general and the changed arm disturbs the register allocation of the air arm that shares its kernel (DESIGN.md 8.4
+    // has two more cases of that).  So the large-grid tile (K = 12) keeps the scalar form.
+    if constexpr (PV_GENERAL_PACKED == 1 ? K < 12 : PV_GENERAL_PACKED != 0)
+        stepTileGeneral4Packed<K, RXI>(a, tile, wave, lane, lut, sh);
+    else
+        stepTileGeneral4Scalar<K, RXI>(a, tile, wave, lane, lut, sh);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1355,6 +1583,9 @@ __global__ __launch_bounds__(256, WPS) void pv_step_merged_kernel(const StepArgs
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int gblocks = a.numGeneral;  // one block per general tile
     if ((int)blockIdx.x < gblocks) {
+#if PV_PROBE_NOMEM == 2  // (measurement builds: air tiles only)
+        return;
+#endif
         if ((int)blockIdx.x >= a.dyn->numGeneral) return;
         const int tile = __builtin_amdgcn_readfirstlane(a.generalList[blockIdx.x]);
         if (deadTileSkippable<K, RXI>(a, tile)) return;  // (block-uniform)
@@ -1624,7 +1855,9 @@ template <int K, int RXI, int WPS, int SUB>
 static void launchStepT(const StepArgs& a, hipStream_t stream, int which, hipStream_t stream2) {
     if (which == 4) {  // merged single launch: one block per general tile, then 4 air tiles per block
         const int blocks = a.numGeneral + 8 * ((bandPositions(a) + 3) / 4);
-        hipLaunchKernelGGL((pv_step_merged_kernel<K, RXI, WPS, SUB>), dim3(blocks), dim3(256), 0, stream, a);
+        // (PV_PROBE_LDS = bytes of dynamic LDS per block: measurement aid, limits the blocks resident per CU)
+        static const int probeLds = getenv("PV_PROBE_LDS") ? atoi(getenv("PV_PROBE_LDS")) : 0;
+        hipLaunchKernelGGL((pv_step_merged_kernel<K, RXI, WPS, SUB>), dim3(blocks), dim3(256), probeLds, stream, a);
         return;
     }
     if (which & 1) {
