@@ -804,7 +804,7 @@ __device__ __forceinline__ void stepTileAirMirror(const StepArgs& a, const int t
     const rsrc_t rPrIn = makeRsrc(a.prIn, a.inBytes), rVxIn = makeRsrc(a.vxIn, a.inBytes),
                  rVyIn = makeRsrc(a.vyIn, a.inBytes);
     v2f pr[NP], vx[NP], vy[NP];
-#if PV_PROBE_NOMEM  // measurement builds only: the arithmetic of an air tile without its loads and stores
+#if PV_PROBE_NOMEM == 1 || PV_PROBE_NOMEM == 2  // measurement builds only: the arithmetic of an air tile without its loads and stores
     float vxS = (float)lane * 1e-6f;
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
@@ -883,7 +883,7 @@ __device__ __forceinline__ void stepTileAirMirror(const StepArgs& a, const int t
     // cells past the ghost column are outside the grid: stored as the zeros they are in memory; the ghost column's
     // own vx is zero (wall|wall face)
     const bool outP = EDGE && e.eR >= 0 && lane > e.eR, outX = EDGE && e.eR >= 0 && lane >= e.eR;
-#if PV_PROBE_NOMEM
+#if PV_PROBE_NOMEM == 1 || PV_PROBE_NOMEM == 2
     if (inCols && pr[3].x == 12345.678f) {  // (never true: keeps the arithmetic alive without the stores)
 #else
     if (inCols) {
@@ -1583,7 +1583,7 @@ __global__ __launch_bounds__(256, WPS) void pv_step_merged_kernel(const StepArgs
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int gblocks = a.numGeneral;  // one block per general tile
     if ((int)blockIdx.x < gblocks) {
-#if PV_PROBE_NOMEM == 2  // (measurement builds: air tiles only)
+#if PV_PROBE_NOMEM >= 2  // (measurement builds: air tiles only; 3 = with their loads and stores)
         return;
 #endif
         if ((int)blockIdx.x >= a.dyn->numGeneral) return;
