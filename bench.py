@@ -17,6 +17,10 @@ at 2048^2).  A step is then one batch of B listener positions per GPU; --infligh
 N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL); runs are sharded round-robin
 with no data-path collective and one all-gather of the per-emitter outputs at the end ("scaling": "weak").
 Prints ONE JSON line on rank 0.
+
+PV_BENCH_BACKEND (default "nccl" = RCCL) names the torch.distributed backend.  tests/test_dist_cpu.py runs this file's
+N = 2 orchestration on CPU with PV_BENCH_BACKEND=gloo and a stand-in solver (main(argv, hooks=...)): process group,
+communicator fail-over on every rank at once, barriers, max-over-ranks timing, the JSON line on rank 0 only.
 """
 import argparse
 import json
@@ -133,7 +137,53 @@ def cpu_baseline(grid_cells=1025, scene="HugeRoom.pv"):
     return out
 
 
-def main():
+class GpuHooks:
+    """what main() needs from the machine: the real thing.  (tests/_bench_worker.py substitutes a CPU stand-in to run the
+    multi-rank orchestration under gloo.)"""
+    backend_default = "nccl"
+
+    def __init__(self, local_rank):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("bench.py needs a HIP device (no CPU path)")
+        torch.cuda.set_device(local_rank)
+        self.torch = torch
+        self.local_rank = local_rank
+        self.device = torch.device("cuda", local_rank)
+
+    def init_process_group(self, dist, backend, rank, world):
+        if backend == "nccl":
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=self.device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    def make_solver(self, size, res, **opts):
+        from planeverb_amd import api
+        return api.Solver(size, size, res, device=self.local_rank, **opts)
+
+    def batch_solver_options(self, grid):
+        from planeverb_amd import api
+        return api.batch_solver_options(grid)
+
+    def run_batch(self, solvers, listeners, wait):
+        from planeverb_amd import api
+        return api.run_batch(solvers, listeners, wait=wait)
+
+    def make_comm(self, dist):
+        from planeverb_amd import dist as pvd
+        return pvd.make_comm(dist, self.local_rank)
+
+    def device_sync(self):
+        self.torch.cuda.synchronize()
+
+    def barrier(self, dist, backend):
+        if backend == "nccl":
+            dist.barrier(device_ids=[self.local_rank])
+        else:
+            dist.barrier()
+
+
+def main(argv=None, hooks=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
@@ -151,6 +201,8 @@ def main():
                          "batched kernel, also with --batch 1)")
     ap.add_argument("--tile-order", type=int, default=-1, help="PVA_OPT_TILE_ORDER (development: block -> tile map)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-cells", type=int, default=1025,
+                    help="side of the cell array of the bounded CPU-baseline sample (same scene, dx and T)")
     ap.add_argument("--inflight", type=int, default=2,
                     help="independent runs a GPU works on concurrently (one solver instance + stream each); a step "
                          "is one batch of this many listener positions per GPU")
@@ -162,29 +214,29 @@ def main():
     ap.add_argument("--time-kernels", type=int, default=0,
                     help="N > 0: HIP events around every Nth step-kernel launch instead of around the whole launch loop "
                          "(the extra events cost 0.2-0.5 ms per run)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     import torch  # first: libplaneverb_amd.so then binds to the HIP runtime torch already loaded
     import torch.distributed as dist
-    from planeverb_amd import api, dist as pvd
+    from planeverb_amd import dist as pvd
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise RuntimeError("bench.py needs a HIP device (no CPU path)")
+    if hooks is None:
+        hooks = GpuHooks(local_rank)
     if args.gpus > 1 and world == 1:
         raise SystemExit("--gpus %d needs one rank per GPU: python -m torch.distributed.run --nnodes=1 "
                          "--nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d ..." % (
                              args.gpus, args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev = hooks.device
+    backend = os.environ.get("PV_BENCH_BACKEND", hooks.backend_default)
     use_dist = world > 1 or os.environ.get("PV_BENCH_FORCE_DIST") == "1"  # the latter: 1-rank RCCL self-test
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        hooks.init_process_group(dist, backend, rank, world)
 
     size = mode_a_size(args.grid)
     # roofline launch duration: HIP events on the solver's stream around the back-to-back step launches of every timed
@@ -204,10 +256,10 @@ def main():
         args.batch = 8 if args.grid <= 1536 else 1
     NB = max(1, min(args.batch, 8))  # runs per batched launch
     if NB > 1 and not args.steps_per_launch and not args.tile_rows:
-        opts.update(api.batch_solver_options(args.grid))  # mirror-pair tile + edge tiles (batched kernel only)
+        opts.update(hooks.batch_solver_options(args.grid))  # mirror-pair tile + edge tiles (batched kernel only)
     G = max(1, args.inflight)         # groups in flight (one stream each)
     B = G * NB                        # runs per step and GPU
-    solvers = [api.Solver(size, size, 275, device=local_rank, **opts) for _ in range(B)]
+    solvers = [hooks.make_solver(size, 275, **opts) for _ in range(B)]
     if args.open_field:
         args.scene = "none"
     for sv in solvers:
@@ -240,12 +292,12 @@ def main():
         if NB == 1:
             solvers[g].run_async(listener(step, g))
         else:
-            api.run_batch(solvers[g * NB:(g + 1) * NB], [listener(step, g * NB + j) for j in range(NB)], wait=False)
+            hooks.run_batch(solvers[g * NB:(g + 1) * NB], [listener(step, g * NB + j) for j in range(NB)], False)
 
     def sync():
-        torch.cuda.synchronize()
+        hooks.device_sync()
         if use_dist:
-            dist.barrier(device_ids=[local_rank])
+            hooks.barrier(dist, backend)
 
     # warm-up: the first round one run at a time, which also gives the step kernel's duration with a single run in
     # flight; further rounds in flight together like the timed steps
@@ -269,7 +321,7 @@ def main():
         pvd.gather_outputs({run_id(0, b): np.zeros((2, 8), np.float32) for b in range(B)}, B * world, dist, dev)
     elif use_dist:
         try:
-            comm = pvd.make_comm(dist, local_rank)
+            comm = hooks.make_comm(dist)
             gather_how = "ncclAllGather in libplaneverb_amd.so (PvAmdCommAllGather), id bootstrapped over torch.distributed"
         except Exception as e:  # noqa: BLE001
             gather_how = "torch.distributed.all_gather_into_tensor (C++ RCCL communicator unavailable: %s)" % e
@@ -282,7 +334,7 @@ def main():
         # first use sets up RCCL's channels: not part of the timed steps
         warm = {run_id(0, b): np.zeros((2, 8), np.float32) for b in range(B)}
         if comm is not None:
-            pvd.gather_outputs_native(warm, B * world, comm)
+            pvd.gather_outputs_native(warm, B * world, comm, n_em=2)
         else:
             pvd.gather_outputs(warm, B * world, dist, dev)
     n_runs = args.steps * B * world
@@ -316,7 +368,7 @@ def main():
         if pending[b] is not None:
             collect(b)
     if comm is not None:
-        gathered = pvd.gather_outputs_native(local, n_runs, comm)  # the one RCCL gather, in C++
+        gathered = pvd.gather_outputs_native(local, n_runs, comm, n_em=2)  # the one RCCL gather, in C++
     else:
         gathered = pvd.gather_outputs(local, n_runs, dist if use_dist else None, dev)
     sync()
@@ -423,7 +475,8 @@ def main():
                        "grid": [s.gx, s.gy], "T": T, "res": 275, "mode": "A", "steps_per_launch": K,
                        "tile": [info.tileRows, info.tileCols], "dense_history": bool(args.dense_history),
                        "runs_in_flight_per_gpu": B, "runs_per_batched_launch": NB,
-                       "parallelism": "runs sharded round-robin, 1 all-gather of outputs", "gather": gather_how},
+                       "parallelism": "runs sharded round-robin, 1 all-gather of outputs", "gather": gather_how,
+                       "backend": backend if use_dist else None},
             "fdtd_cell_updates_per_s": world * B * cells * T / fd,
             "impulse_responses_per_s": world * B * s.gx * s.gy * args.steps / elapsed,
             "fdtd_ms": fd * 1e3, "analysis_ms": float(np.mean(ana_ms)),
@@ -449,14 +502,14 @@ def main():
                                  "flight"},
         }
         # rank 0 only, after the timed region (the other ranks wait at the final barrier)
-        out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline()
+        out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(args.cpu_baseline_cells)
         line = json.dumps(out)
     for sv in solvers:
         sv.close()
     if comm is not None:
         comm.close()
     if use_dist:
-        dist.barrier(device_ids=[local_rank])
+        hooks.barrier(dist, backend)
         dist.destroy_process_group()
     if rank == 0:
         # RCCL prints its version banner (NCCL_DEBUG=VERSION in this image) through C stdio, which is flushed at

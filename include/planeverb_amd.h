@@ -3,9 +3,9 @@
  * Part 1 is the reference's own flat C-ABI, symbol for symbol -- the functions Unity P/Invokes from
  * ProjectPlaneverbUnityPlugin (reference: ProjectPlaneverb/PlaneverbUnityPluginAPI/PlaneverbUnity.cpp:12-135,
  * C# mirror PlaneverbContext.cs:25-60).  A build of the Acoustics module that loads this library instead of
- * ProjectPlaneverbUnityPlugin.dll needs no source change; pass threadExecutionType = 1 (pv_GPU, the value the
- * C# enum already defines, PlaneverbConfig.cs:23-29) -- this library has no CPU path and fails loudly without a
- * HIP device.
+ * ProjectPlaneverbUnityPlugin.dll needs no source change.  threadExecutionType 0 (pv_CPU) and 1 (pv_GPU, the value
+ * the C# enum already defines, PlaneverbConfig.cs:23-29) are accepted alike and BOTH run on the HIP device: this
+ * library has no CPU path and fails loudly without a HIP device.
  *
  * Part 2 (PvAmd*) is an extension: a handle-based, synchronous batch interface to the same solver, used by the
  * benchmarks, the parity tests and the multi-GPU sharding layer.  It replaces nothing in the reference; it exposes
@@ -62,7 +62,12 @@ PVA_EXPORT int PlaneverbEmit(float x, float y, float z);
 PVA_EXPORT void PlaneverbUpdateEmission(int id, float x, float y, float z);
 /* PlaneverbUnity.cpp:60-64 */
 PVA_EXPORT void PlaneverbEndEmission(int id);
-/* PlaneverbUnity.cpp:78-92 -> Planeverb::GetOutput (FDTD.cpp:16-58); wait-free, O(1) */
+/* PlaneverbUnity.cpp:78-92 -> Planeverb::GetOutput (FDTD.cpp:16-58); O(1), no lock, no device access (lock-free: a
+ * reader repeats its 32-byte copy only if the once-per-iteration publish step ran meanwhile).
+ * Sparse-emitter mode (configurations whose T-step pressure history does not fit the device, e.g. 25 m at 16 kHz; chosen
+ * by PlaneverbInit by itself, forced by the environment variable PLANEVERB_AMD_LIVE_STREAMING=1): occlusion, lowpass and
+ * both directions are valid for every cell as usual; wetGain and rt60 are computed for the cells of the emitters that
+ * existed when the iteration started (an emitter added or moved to another cell gets them one iteration later). */
 PVA_EXPORT PlaneverbOutput PlaneverbGetOutput(int emissionID);
 /* PlaneverbUnity.cpp:94-107 ; -1 when not initialised (GeometryManager.cpp:20) */
 PVA_EXPORT int PlaneverbAddGeometry(float posX, float posY, float width, float height, float absorption);
@@ -95,6 +100,10 @@ PVA_EXPORT long long PlaneverbIterationCount(void);
 PVA_EXPORT long long PlaneverbWaitIterations(long long count, int timeoutMs);
 /* 1 if the module is initialised and its simulation worker is alive (0 after a worker error: PvAmdLastError) */
 PVA_EXPORT int PlaneverbIsRunning(void);
+/* why the simulation worker stopped ("" while it runs / when the module is down); valid until this thread's next call */
+PVA_EXPORT const char* PlaneverbWorkerError(void);
+/* 1 if the live module runs in the sparse-emitter mode (see PlaneverbGetOutput), else 0 */
+PVA_EXPORT int PlaneverbIsStreaming(void);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Part 2 -- batch solver handle (extension)
@@ -313,6 +322,10 @@ PVA_EXPORT int PvAmdRunSharded(PvAmdSolver* const* solvers, int nSolvers, const 
 PVA_EXPORT int PvAmdHostGridInfo(float gridSizeX, float gridSizeY, int gridResolution, PvAmdInfo* out);
 /* Grid.cpp:12-27: T floats */
 PVA_EXPORT int PvAmdHostPulse(float gridSizeX, float gridSizeY, int gridResolution, float* out);
+/* 1 if this host's expf reproduces five samples of the reference's 275 Hz pulse table bit for bit (the pulse is made
+ * with the host libm, as in the reference: Grid.cpp:12-27), else 0.  The solver checks this once per process by itself
+ * and warns on stderr. */
+PVA_EXPORT int PvAmdHostPulseSelfCheck(void);
 /* Grid::AddAABB / RemoveAABB on a fresh grid: ops[i] = +1 add / -1 remove of boxes5[5*i..]; beta, R are
  * (gx+1)*(gy+1) */
 PVA_EXPORT int PvAmdHostRasterize(float gridSizeX, float gridSizeY, int gridResolution, const float* boxes5,

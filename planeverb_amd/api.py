@@ -100,6 +100,8 @@ SYMBOLS = {
     "PlaneverbIterationCount": (C.c_longlong, []),
     "PlaneverbWaitIterations": (C.c_longlong, [C.c_longlong, C.c_int]),
     "PlaneverbIsRunning": (C.c_int, []),
+    "PlaneverbWorkerError": (C.c_char_p, []),
+    "PlaneverbIsStreaming": (C.c_int, []),
     "PlaneverbGetImpulseResponse": (C.c_int, [C.c_float] * 3 + [C.POINTER(PlaneverbCell), C.c_int]),
     "PvAmdDeviceCount": (C.c_int, []),
     "PvAmdLastError": (C.c_char_p, []),
@@ -166,6 +168,7 @@ SYMBOLS = {
     "PvAmdReverbBusGains": (None, [C.c_float, C.c_float, _fp, _fp, _fp]),
     "PvAmdHostGridInfo": (C.c_int, [C.c_float, C.c_float, C.c_int, C.POINTER(PvAmdInfo)]),
     "PvAmdHostPulse": (C.c_int, [C.c_float, C.c_float, C.c_int, _fp]),
+    "PvAmdHostPulseSelfCheck": (C.c_int, []),
     "PvAmdHostRasterize": (C.c_int, [C.c_float, C.c_float, C.c_int, _fp, C.POINTER(C.c_int), C.c_int,
                                      C.POINTER(C.c_ubyte), _fp]),
     "PvAmdHostLoadPv": (C.c_int, [C.c_char_p, _fp, C.c_int]),

@@ -46,6 +46,16 @@ static bool ensure(PvAmdSolver* h, bool slabsOk = false) {
     return h->s != nullptr;
 }
 
+// A handle from PvAmdCreateSlabRank holds ONE slab of the grid (no FreeGrid, no halo exchange of its own): the whole-grid
+// entry points (run / outputs / result maps) would silently work on a partial grid, so they refuse it.
+static bool wholeGrid(PvAmdSolver* h) {
+    if (h && h->opt.slabCount > 1) {
+        g_lastError = "slab rank handle: use the PvAmdSlab* / PvAmdSlabRoot* primitives (PvAmdCreateSlabRank)";
+        return false;
+    }
+    return true;
+}
+
 static int ret(PvAmdSolver* h, bool ok) {
     if (ok) return 0;
     if (h && h->s && !h->s->lastError().empty()) g_lastError = h->s->lastError();
@@ -164,6 +174,11 @@ int PlaneverbIsRunning(void) {
     return (c && !c->failed()) ? 1 : 0;
 }
 
+int PlaneverbIsStreaming(void) {
+    Context::Ref c;
+    return (c && c->streaming()) ? 1 : 0;
+}
+
 int PlaneverbGetImpulseResponse(float x, float y, float z, PlaneverbCell* out, int capacity) {
     Context::Ref c;
     if (!c || capacity < 0) return -1;
@@ -177,11 +192,24 @@ int PlaneverbGetImpulseResponse(float x, float y, float z, PlaneverbCell* out, i
 // ---------------------------------------------------------------------------------------------------------------
 
 const char* PvAmdLastError(void) {
-    {  // a live module whose worker died reports that before anything else
+    // A live module whose worker died reports that -- ONCE per failed context and thread, so that the errors of later,
+    // unrelated calls on this thread (batch solver, slabs, communicator) stay readable.  PlaneverbWorkerError() always
+    // has the worker's reason.
+    {
+        static thread_local const void* reported = nullptr;
         Context::Ref c;
-        if (c && c->failed()) g_lastError = "simulation worker stopped: " + c->workerError();
+        if (c && c->failed() && reported != (const void*)c.get()) {
+            reported = c.get();
+            g_lastError = "simulation worker stopped: " + c->workerError();
+        }
     }
     return g_lastError.c_str();
+}
+const char* PlaneverbWorkerError(void) {
+    static thread_local std::string w;
+    Context::Ref c;
+    w = (c && c->failed()) ? c->workerError() : std::string();
+    return w.c_str();
 }
 const char* PvAmdVersion(void) { return "planeverb_amd 0.2 (gfx950)"; }
 
@@ -516,13 +544,13 @@ int PvAmdSaveScene(PvAmdSolver* h, const char* pvPath) {
 }
 
 int PvAmdRun(PvAmdSolver* h, float lx, float ly, float lz) {
-    if (!ensure(h, true)) return -1;
+    if (!wholeGrid(h) || !ensure(h, true)) return -1;
     if (h->g) return ret(h, h->g->run(lx, ly, lz));
     return ret(h, h->s->run(lx, ly, lz, true));
 }
 
 int PvAmdRunAsync(PvAmdSolver* h, float lx, float ly, float lz) {
-    if (!ensure(h)) return -1;
+    if (!wholeGrid(h) || !ensure(h)) return -1;
     return ret(h, h->s->run(lx, ly, lz, false));
 }
 
@@ -533,7 +561,7 @@ int PvAmdRunBatch(PvAmdSolver* const* hs, int n, const float* listenersXYZ, int 
     }
     Solver* s[kBatchMax];
     for (int i = 0; i < n; ++i) {
-        if (!ensure(hs[i])) return -1;
+        if (!wholeGrid(hs[i]) || !ensure(hs[i])) return -1;
         s[i] = hs[i]->s;
     }
     std::string err;
@@ -543,7 +571,7 @@ int PvAmdRunBatch(PvAmdSolver* const* hs, int n, const float* listenersXYZ, int 
 }
 
 int PvAmdSync(PvAmdSolver* h) {
-    if (!ensure(h)) return -1;
+    if (!wholeGrid(h) || !ensure(h)) return -1;
     return ret(h, h->s->sync());
 }
 
@@ -564,12 +592,12 @@ int PvAmdGetTimings(PvAmdSolver* h, PvAmdTimings* out) {
 }
 
 int PvAmdSetEmitters(PvAmdSolver* h, const float* xyz, int n) {
-    if (!ensure(h) || (n > 0 && !xyz)) return -1;
+    if (!wholeGrid(h) || !ensure(h) || (n > 0 && !xyz)) return -1;
     return ret(h, h->s->setEmitters(xyz, n));
 }
 
 int PvAmdGetOutput(PvAmdSolver* h, float ex, float ey, float ez, PlaneverbOutput* out) {
-    if (!out || !ensure(h, true)) return -1;
+    if (!wholeGrid(h) || !out || !ensure(h, true)) return -1;
     float v[8];
     bool valid = false;
     if (!(h->g ? h->g->getOutput(ex, ey, ez, v, &valid) : h->s->getOutput(ex, ey, ez, v, &valid))) return ret(h, false);
@@ -583,12 +611,12 @@ int PvAmdGetOutput(PvAmdSolver* h, float ex, float ey, float ez, PlaneverbOutput
 }
 
 int PvAmdSetOutputQueries(PvAmdSolver* h, const float* xyz, int n) {
-    if ((n > 0 && !xyz) || !ensure(h)) return -1;
+    if (!wholeGrid(h) || (n > 0 && !xyz) || !ensure(h)) return -1;
     return ret(h, h->s->setOutputQueries(xyz, n));
 }
 
 int PvAmdGetQueriedOutputs(PvAmdSolver* h, PlaneverbOutput* out, int n) {
-    if (n < 0 || n > Solver::kMaxQueries || (n > 0 && !out) || !ensure(h)) return -1;
+    if (n < 0 || n > Solver::kMaxQueries || (n > 0 && !out) || !wholeGrid(h) || !ensure(h)) return -1;
     float v[Solver::kMaxQueries * 8];
     unsigned char valid[Solver::kMaxQueries];
     if (!h->s->queriedOutputs(v, valid, n)) return ret(h, false);
@@ -604,7 +632,7 @@ int PvAmdGetQueriedOutputs(PvAmdSolver* h, PlaneverbOutput* out, int n) {
 }
 
 int PvAmdCopyResults(PvAmdSolver* h, float* res8, float* delay) {
-    if (!ensure(h, true)) return -1;
+    if (!wholeGrid(h) || !ensure(h, true)) return -1;
     return ret(h, h->g ? h->g->copyResults(res8, delay) : h->s->copyResults(res8, delay));
 }
 
@@ -645,7 +673,7 @@ int PvAmdSetFields(PvAmdSolver* h, const float* pr, const float* vx, const float
 }
 
 int PvAmdRunSteps(PvAmdSolver* h, int nsteps, int withPulse, float lx, float lz) {
-    if (!ensure(h)) return -1;
+    if (!wholeGrid(h) || !ensure(h)) return -1;
     return ret(h, h->s->runSteps(nsteps, withPulse != 0, lx, lz));
 }
 
@@ -717,7 +745,7 @@ int PvAmdRunSharded(PvAmdSolver* const* hs, int nSolvers, const float* listeners
     }
     std::vector<Solver*> sv;
     for (int i = 0; i < nSolvers; ++i) {
-        if (!ensure(hs[i])) return -1;
+        if (!wholeGrid(hs[i]) || !ensure(hs[i])) return -1;
         sv.push_back(hs[i]->s);
     }
     const std::vector<ShardItem> plan = shardPlan(nRuns, world, rank, nSolvers);
@@ -779,6 +807,8 @@ int PvAmdHostGridInfo(float sx, float sy, int res, PvAmdInfo* out) {
     out->dt = g.dt;
     return 0;
 }
+
+int PvAmdHostPulseSelfCheck(void) { return pulseMatchesReferenceLibm() ? 1 : 0; }
 
 int PvAmdHostPulse(float sx, float sy, int res, float* out) {
     if (!out || res < kLowResolution) return -1;

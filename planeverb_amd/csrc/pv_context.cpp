@@ -37,16 +37,42 @@ Context::Ref::~Ref() {
     if (c_) g_pinned.fetch_sub(1, std::memory_order_seq_cst);
 }
 
-static void retireContext(Context* c, void (*destroy)(Context*)) {
+void retireContext(Context* c) {
     if (!c) return;
-    while (g_pinned.load(std::memory_order_seq_cst) != 0) std::this_thread::yield();  // callers still inside
-    destroy(c);
+    // wake the callers that block INSIDE the context (WaitIterations) and let the worker finish its iteration, so that
+    // the pins drain at once instead of after the callers' own timeouts.  The wake-up is repeated while pins remain: a
+    // waiter that tested its predicate just before retiring_ was set and blocks just after the first notify is caught by
+    // the next one (no mutex is taken here, so nothing of the context is held when it is deleted).
+    c->beginRetire();
+    while (g_pinned.load(std::memory_order_seq_cst) != 0) {  // callers still inside
+        c->iterCv_.notify_all();
+        std::this_thread::yield();
+    }
+    delete c;
+}
+
+void Context::beginRetire() {
+    running_.store(false);
+    retiring_.store(true, std::memory_order_seq_cst);
+    iterCv_.notify_all();
+}
+
+uint64_t Context::packXZ(float x, float z) {
+    uint32_t a, b;
+    std::memcpy(&a, &x, 4);
+    std::memcpy(&b, &z, 4);
+    return ((uint64_t)a << 32) | b;
+}
+void Context::unpackXZ(uint64_t v, float* x, float* z) {
+    const uint32_t a = (uint32_t)(v >> 32), b = (uint32_t)v;
+    std::memcpy(x, &a, 4);
+    std::memcpy(z, &b, 4);
 }
 
 bool Context::init(const LiveConfig& cfg, std::string* err) {
     std::lock_guard<std::mutex> lock(g_lifeMutex);
     // Init while running = Exit + Init, PvContext.cpp:27-31
-    retireContext(g_context.exchange(nullptr, std::memory_order_seq_cst), [](Context* c) { delete c; });
+    retireContext(g_context.exchange(nullptr, std::memory_order_seq_cst));
     // PvContext.cpp:101-107
     if (cfg.res < kLowResolution || cfg.sizeX == 0.f || cfg.sizeY == 0.f || cfg.tempDir == nullptr ||
         cfg.maxThreads < 0) {
@@ -60,13 +86,22 @@ bool Context::init(const LiveConfig& cfg, std::string* err) {
         std::fprintf(stderr, "[planeverb_amd] warning: %d x %d grid -- the reference indexes non-square grids "
                              "inconsistently (SURVEY.md Q1); results there are defined by this library (cell array "
                              "stride gy+1 throughout), not by the reference\n", spec.gx, spec.gy);
+    // Planeverb::Init takes any resolution >= 275 (PvContext.cpp:101-107).  Where the T-step pressure history does not fit
+    // the device (25 m at 16 kHz: T = 25 432 on a 4096^2 grid) the solver falls back to the sparse-emitter mode by itself;
+    // PLANEVERB_AMD_LIVE_STREAMING=1 forces that mode (tests, memory-tight hosts).
     SolverOptions opt;
+    opt.autoStreaming = true;
+    if (const char* e = std::getenv("PLANEVERB_AMD_LIVE_STREAMING")) opt.streaming = std::atoi(e) != 0;
     Context* c = new Context();
     c->solver_ = Solver::create(spec, device, opt, err);
     if (!c->solver_) {
         delete c;
         return false;
     }
+    c->streaming_ = c->solver_->options().streaming;
+    if (c->streaming_)
+        std::fprintf(stderr, "[planeverb_amd] %d x %d grid, T = %d: sparse-emitter mode (wet gain / RT60 for the cells of the "
+                             "emitters registered at the start of an iteration)\n", spec.gx, spec.gy, c->solver_->T());
     const size_t bytes = c->solver_->windowCapacity() * 32;
     for (Slot& s : c->slots_) {
         s.data = static_cast<float*>(Solver::hostAlloc(bytes));
@@ -84,7 +119,7 @@ bool Context::init(const LiveConfig& cfg, std::string* err) {
 
 void Context::exit() {
     std::lock_guard<std::mutex> lock(g_lifeMutex);
-    retireContext(g_context.exchange(nullptr, std::memory_order_seq_cst), [](Context* c) { delete c; });
+    retireContext(g_context.exchange(nullptr, std::memory_order_seq_cst));
 }
 
 Context::~Context() {
@@ -103,11 +138,34 @@ Context::~Context() {
 // worker: PvContext.cpp:63-94
 // ----------------------------------------------------------------------------------------------------------------
 
+// sparse-emitter mode: the emitters alive now are the cells whose wet gain / RT60 this iteration computes
+// (EmissionManager.cpp:37-54 keeps the same table; ended ids are skipped)
+bool Context::registerEmitters() {
+    std::vector<float> xyz;
+    {
+        std::lock_guard<std::mutex> lock(emitMutex_);
+        const int n = emitterCount_.load(std::memory_order_acquire);
+        std::vector<uint8_t> ended((size_t)n, 0);
+        for (int id : emitterFree_)
+            if (id >= 0 && id < n) ended[(size_t)id] = 1;
+        for (int id = 0; id < n; ++id) {
+            if (ended[(size_t)id]) continue;
+            Emitter* e = emitterAt(id);
+            if (!e) continue;
+            xyz.push_back(e->x.load());
+            xyz.push_back(e->y.load());
+            xyz.push_back(e->z.load());
+        }
+    }
+    return solver_->setEmitters(xyz.data(), (int)(xyz.size() / 3));
+}
+
 void Context::workerLoop() {
-    float lx = lx_.load(), ly = ly_.load(), lz = lz_.load();
+    float lx, lz, ly = ly_.load();
+    unpackXZ(lxz_.load(), &lx, &lz);
     std::unique_lock<std::mutex> solverLock(solverMutex_);
     while (running_.load(std::memory_order_acquire)) {
-        const bool ok = solver_->run(lx, ly, lz, /*wait=*/false) && publish();
+        const bool ok = (!streaming_ || registerEmitters()) && solver_->run(lx, ly, lz, /*wait=*/false) && publish();
         if (!ok) {
             // The worker stops; the host can see it: IsRunning reports 0, PvAmdLastError carries the reason, GetOutput
             // keeps serving the last published iteration.
@@ -127,9 +185,8 @@ void Context::workerLoop() {
         }
         iterCv_.notify_all();
         pushGeometryChanges();  // PvContext.cpp:86
-        lx = lx_.load();        // PvContext.cpp:89
+        unpackXZ(lxz_.load(), &lx, &lz);  // PvContext.cpp:89
         ly = ly_.load();
-        lz = lz_.load();
         if (solverWaiters_.load(std::memory_order_acquire) > 0) {  // a GetImpulseResponse call wants the solver
             solverLock.unlock();
             while (solverWaiters_.load(std::memory_order_acquire) > 0) std::this_thread::yield();
@@ -147,15 +204,15 @@ std::string Context::workerError() {
 
 long long Context::waitIterations(long long count, int timeoutMs) {
     std::unique_lock<std::mutex> lock(iterMutex_);
-    iterCv_.wait_for(lock, std::chrono::milliseconds(timeoutMs),
-                     [&] { return iterations_.load() >= count || !running_.load(); });
+    // (system_clock: pthread_cond_timedwait, which ThreadSanitizer models; wait_for's pthread_cond_clockwait it does not)
+    iterCv_.wait_until(lock, std::chrono::system_clock::now() + std::chrono::milliseconds(timeoutMs),
+                     [&] { return iterations_.load() >= count || !running_.load() || retiring_.load(); });
     return iterations_.load();
 }
 
 void Context::setListener(float x, float y, float z) {
-    lx_.store(x);
+    lxz_.store(packXZ(x, z));
     ly_.store(y);
-    lz_.store(z);
 }
 
 // ----------------------------------------------------------------------------------------------------------------

@@ -12,9 +12,12 @@
 // file and pv_core.cpp against a fake Solver):
 //   * any API function may be called from any thread at any time, including concurrently with Exit / re-Init:
 //     entry points pin the context with Context::Ref (one fetch_add + one load, wait-free); Exit unpublishes the
-//     pointer and waits for the pinned callers to leave before it deletes anything;
-//   * GetOutput reads one consistent iteration through a sequence lock around the publish step (a few stores),
-//     so a reader repeats only if a publish happened while it copied its 32 bytes.
+//     pointer, marks the context as retiring (which wakes the callers that block inside it: WaitIterations) and waits
+//     for the pinned callers to leave before it deletes anything;
+//   * GetOutput never takes a lock and never touches the device.  It reads one consistent iteration through a
+//     sequence lock around the publish step (a few stores): a reader repeats only if a publish happened while it
+//     copied its 32 bytes -- LOCK-FREE, not wait-free (a reader can in principle lose against every publish; publishes
+//     are one per iteration, milliseconds apart).
 #pragma once
 
 #include <atomic>
@@ -63,6 +66,7 @@ public:
         Ref& operator=(const Ref&) = delete;
         explicit operator bool() const { return c_ != nullptr; }
         Context* operator->() const { return c_; }
+        Context* get() const { return c_; }
 
     private:
         Context* c_;
@@ -94,6 +98,9 @@ public:
     // the worker stops for good on a solver error: then this is true, workerError() says why and IsRunning reports 0
     bool failed() const { return failed_.load(std::memory_order_acquire); }
     std::string workerError();
+    // true when the solver runs in the sparse-emitter mode (the T-step history did not fit, or PLANEVERB_AMD_LIVE_STREAMING=1):
+    // the worker registers the emitters alive at the start of every iteration, wet gain / RT60 exist for their cells
+    bool streaming() const { return streaming_; }
 
 private:
     Context() = default;
@@ -101,11 +108,16 @@ private:
     void workerLoop();
     void pushGeometryChanges();
     bool publish();
+    void beginRetire();
+    bool registerEmitters();
+    friend void retireContext(Context*);
 
     Solver* solver_ = nullptr;
     std::thread worker_;
     std::atomic<bool> running_{false};
+    std::atomic<bool> retiring_{false};
     std::atomic<bool> failed_{false};
+    bool streaming_ = false;
     std::atomic<long long> iterations_{0};
     std::mutex iterMutex_;
     std::condition_variable iterCv_;
@@ -115,8 +127,13 @@ private:
     std::mutex solverMutex_;
     std::atomic<int> solverWaiters_{0};
 
-    // listener (plain fields in the reference, PvContext.h:40)
-    std::atomic<float> lx_{0.f}, ly_{0.f}, lz_{0.f};
+    // listener (a plain vec3 in the reference, PvContext.h:40, where a reader can see x of one SetListenerPosition and
+    // z of the next).  The simulation uses x and z only (world y is ignored, FDTD.cpp:97-98): both live in ONE 64-bit
+    // atomic, so the worker always latches a position some caller actually set.
+    std::atomic<uint64_t> lxz_{0};
+    std::atomic<float> ly_{0.f};
+    static uint64_t packXZ(float x, float z);
+    static void unpackXZ(uint64_t v, float* x, float* z);
 
     // emitters: fixed-capacity chunks so readers never race a reallocation
     struct Emitter {

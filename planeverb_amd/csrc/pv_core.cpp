@@ -1,6 +1,9 @@
 // pv_core.cpp -- see pv_core.h.  Host-side float32 index arithmetic; no fast-math.
 #include "pv_core.h"
 
+#include <cstdio>
+#include <cstring>
+
 #include <algorithm>
 #include <cmath>
 #include <fstream>
@@ -73,6 +76,35 @@ std::vector<float> gaussianPulse(const GridSpec& g) {
         out[(size_t)i] = std::exp(-(t - delay) * (t - delay) / (sigma * sigma));
     }
     return out;
+}
+
+// Bit parity of the pulse rides on the HOST libm's expf (glibc 2.35 in the reference build): a libm whose
+// expf rounds differently would shift every field by an ulp and no test on that host would say why.  Checked once per
+// process against five samples of the reference's own 275 Hz table (tests/golden/g71_*.npz `pulse`), incl. a denormal.
+bool pulseMatchesReferenceLibm() {
+    static const struct {
+        int i;
+        uint32_t bits;
+    } kRef[] = {{0, 0x3c960aaeu}, {10, 0x3ebecae4u}, {20, 0x3405f3a0u}, {30, 0x1c4fb297u}, {40, 0x0000002cu}};
+    const std::vector<float> p = gaussianPulse(makeGridSpec(25.f, 25.f, 275));
+    for (const auto& r : kRef) {
+        uint32_t b;
+        std::memcpy(&b, &p[(size_t)r.i], 4);
+        if (b != r.bits) return false;
+    }
+    return true;
+}
+
+void warnIfPulseDiffers() {
+    static const bool ok = [] {
+        const bool m = pulseMatchesReferenceLibm();
+        if (!m)
+            std::fprintf(stderr, "[planeverb_amd] warning: this host's expf does not reproduce the reference's Gaussian pulse "
+                                 "table bit for bit (glibc 2.35 expected): fields and outputs may differ from the reference "
+                                 "in the last place\n");
+        return m;
+    }();
+    (void)ok;
 }
 
 void listenerCell(const GridSpec& g, float lx, float lz, int* cx, int* cy) {

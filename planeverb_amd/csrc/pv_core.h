@@ -45,6 +45,9 @@ GridSpec makeGridSpec(float sizeX, float sizeY, int res);
 GridSpec makeGridSpecCells(int gx, int gy, int res);
 // Grid.cpp:12-27
 std::vector<float> gaussianPulse(const GridSpec& g);
+// does the host's expf reproduce the reference's pulse table?  (checked once per process, a warning on stderr if not)
+bool pulseMatchesReferenceLibm();
+void warnIfPulseDiffers();
 // FDTD.cpp:97-98 : (int)((pos + offset) / dx)
 void listenerCell(const GridSpec& g, float lx, float lz, int* cx, int* cy);
 // Analyzer.cpp:200-201 : (int)(pos * (1/dx))

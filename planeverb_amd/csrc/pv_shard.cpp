@@ -62,12 +62,21 @@ Rccl& rccl() {
                 std::fclose(f);
             }
         }
-        if (!path.empty()) r.lib = dlopen(path.c_str(), RTLD_NOW | RTLD_GLOBAL);
+        // dlerror() hands out its message ONCE and clears it: read it right after each failed dlopen, keep the last
+        std::string lastErr;
+        auto tryOpen = [&](const char* name) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (!r.lib) {
+                const char* e = dlerror();
+                lastErr = e ? e : "?";
+            }
+        };
+        if (!path.empty()) tryOpen(path.c_str());
         // 2. the system's
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-            if (!r.lib) r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (!r.lib) tryOpen(name);
         if (!r.lib) {
-            r.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?");
+            r.why = std::string("librccl not found: ") + (lastErr.empty() ? "?" : lastErr);
             return;
         }
         r.getUniqueId = reinterpret_cast<decltype(r.getUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
@@ -140,11 +149,14 @@ Comm::~Comm() {
 }
 
 bool Comm::allGather(const float* mine, int countPerRank, float* all, std::string* err) {
-    if (countPerRank <= 0) return true;
     auto bad = [&](const char* what) {
         if (err) *err = what;
         return false;
     };
+    // a collective: every rank must enter it with the same count.  A rank that skipped it for "nothing to send" would
+    // leave the others blocked inside ncclAllGather, so an empty contribution is an error here and the callers pad
+    // (dist.gather_outputs_native, PvAmdRunSharded: per_rank * n_emitters * 8 floats on every rank, zero-filled).
+    if (countPerRank <= 0) return bad("PvAmdCommAllGather: countPerRank must be > 0 and equal on every rank");
     if (hipSetDevice(device_) != hipSuccess) return bad("hipSetDevice failed");
     const size_t n = (size_t)countPerRank;
     if (n > cap_) {

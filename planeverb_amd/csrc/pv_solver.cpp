@@ -101,6 +101,21 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         opt_.edgeTiles = false;
     wi_ = 64 - 2 * K_;
     T_ = opt.numSteps > 0 ? opt.numSteps : g_.T;
+    // The live module must come up at any resolution the reference accepts (PvContext.cpp:101-107): where the T-step
+    // history window does not fit beside the planes, fall back to the sparse-emitter mode (a 2 x 8-launch ring; the
+    // caller then registers its emitters before every run: Context::workerLoop).
+    if (opt_.autoStreaming && !opt_.streaming && !opt_.denseHistory && opt_.slabCount == 1) {
+        const int reach = T_ + 2 + K_;
+        const long long wtx = std::min(ceilDiv(g_.NX, rxi_), ceilDiv(2 * reach + 1, rxi_) + 1);
+        const long long wty = std::min(ceilDiv(g_.NY, wi_), ceilDiv(2 * reach + 1, wi_) + 1);
+        const long long histBytes = wtx * wty * rxi_ * wi_ * 4 * (long long)T_;
+        const long long planeBytes = (long long)(g_.NX + 64) * (g_.NY + 128) * (24 + 2 + 36 + 12);  // fields, codes, maps, scratch
+        size_t freeB = 0, totalB = 0;
+        hipMemGetInfo(&freeB, &totalB);
+        if ((unsigned long long)(histBytes + planeBytes) + (2ull << 30) > freeB || wtx * wty * rxi_ * wi_ * 4 > (long long)INT_MAX)
+            opt_.streaming = true;
+    }
+    if (opt_.streaming && opt_.edgeTiles) opt_.edgeTiles = false;
 
     ntxG_ = ceilDiv(g_.NX, rxi_);
     if (opt_.slabCount < 1 || opt_.slabIndex < 0 || opt_.slabIndex >= opt_.slabCount) return fail("invalid slab spec");
@@ -188,7 +203,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         const int reach = T_ + 2 + K_;
         int wtx = geo_.ntx, wty = geo_.nty;
         histTilesXG_ = ntxG_;
-        if (!opt.denseHistory && !opt.streaming) {
+        if (!opt_.denseHistory && !opt_.streaming) {
             histTilesXG_ = std::min(ntxG_, ceilDiv(2 * reach + 1, rxi_) + 1);
             wtx = std::min(geo_.ntx, histTilesXG_);  // (a slab records its part of the whole grid's window)
             wty = std::min(geo_.nty, ceilDiv(2 * reach + 1, wi_) + 1);
@@ -202,7 +217,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         // streaming: TWO half rings of 8 launches' planes -- the forward sums of one half advance on a second stream while
         // the step kernels fill the other (the accumulate pass is latency / bandwidth work, the stencil VALU work)
         halfRing_ = std::min(roundUp(T_, K_), 8 * K_);
-        ring_ = opt.streaming ? 2 * halfRing_ : T_;
+        ring_ = opt_.streaming ? 2 * halfRing_ : T_;
         const long long bytes = histPlane_ * 4 * (long long)ring_;
         if (histPlane_ * 4 > (long long)INT_MAX) return fail("history plane too large for 32-bit offsets");
         size_t freeB = 0, totalB = 0;
@@ -219,7 +234,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         }
     }
 
-    if (opt.streaming) {
+    if (opt_.streaming) {
         const size_t nres = (size_t)g_.gx * g_.gy;
         if (!dalloc(&sOnset_, nres, true)) return false;
         for (auto& p : sState_)
@@ -270,6 +285,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         if (!hipOk(hipHostMalloc((void**)&dynBandsHost_, sizeof(DynParams) * (size_t)nb_), "hipHostMalloc")) return false;
     }
 
+    warnIfPulseDiffers();
     pulse_ = gaussianPulse(g_);
     pulse_.resize((size_t)std::max(T_, g_.T), 0.f);  // an extended run (numSteps > T) injects nothing after T
     if (!hipOk(hipMemcpyAsync(pulseDev_, pulse_.data(), pulse_.size() * 4, hipMemcpyHostToDevice, stream_),

@@ -35,6 +35,8 @@ struct SolverOptions {
     int segments = 0;     // N > 0: row-streaming air segments (pv_seg.h) instead of one wave per air tile, about N per
                           // sweep; only the (K, rows) = (8, 40) and (12, 36) configurations have the kernel.  0 = off
     bool streaming = false;  // sparse-emitter mode: ring history + incremental forward analysis
+    bool autoStreaming = false;  // switch to the sparse-emitter mode when the T-step pressure history does not fit the
+                                 // device (the live module: Planeverb::Init accepts any resolution, PvContext.cpp:101-107)
     bool packed = true;   // packed-f32 arithmetic in the air-tile kernel (VALU-issue bound otherwise)
     bool edgeTiles = false;  // grid-edge tiles of empty regions on the air path + overrides (tile class 2): only the
                              // batched kernel has that arm, so every run of such a solver goes through it

@@ -62,11 +62,18 @@ def make_comm(dist, device_index):
     return api.Comm(box[0], rank, world, device_index)
 
 
-def gather_outputs_native(local, n_runs, comm):
-    """gather_outputs through the C++ RCCL communicator (one ncclAllGather): same result"""
-    n_em = next(iter(local.values())).shape[0] if local else 0
+def gather_outputs_native(local, n_runs, comm, n_em=None):
+    """gather_outputs through the C++ RCCL communicator (one ncclAllGather): same result.
+    Every rank enters the collective with the same count, also a rank that owns no run (n_runs < world): pass the
+    number of emitters per run as `n_em`, or leave it None and the ranks agree on it first (one extra 4-byte gather,
+    the counterpart of gather_outputs' all_reduce(MAX))."""
     world, rank = comm.world, comm.rank
+    if n_em is None:
+        mine = next(iter(local.values())).shape[0] if local else 0
+        n_em = int(comm.all_gather(np.array([mine], np.float32)).max())
     per_rank = (n_runs + world - 1) // world
+    if per_rank * n_em == 0:
+        return np.zeros((n_runs, n_em, 8), np.float32)  # nothing to exchange, on every rank alike
     send = np.zeros((per_rank, n_em, 8), np.float32)
     for j, k in enumerate(shard_runs(n_runs, world, rank)):
         send[j] = local[k]

@@ -20,7 +20,9 @@
 
 namespace pva {
 
-struct SolverOptions {};
+struct SolverOptions {
+    bool streaming = false, autoStreaming = false;
+};
 
 class Solver {
 public:
@@ -35,17 +37,22 @@ public:
         static std::atomic<int> v{-1};
         return v;
     }
+    static std::atomic<int>& lastEmitters() {
+        static std::atomic<int> v{-1};
+        return v;
+    }
     static std::atomic<long long>& liveInstances() {
         static std::atomic<long long> v{0};
         return v;
     }
 
-    static Solver* create(const GridSpec& spec, int, const SolverOptions&, std::string* err) {
+    static Solver* create(const GridSpec& spec, int, const SolverOptions& o, std::string* err) {
         if (spec.gx < 1 || spec.gy < 1) {
             if (err) *err = "grid has no cells";
             return nullptr;
         }
         Solver* s = new Solver();
+        s->opt_ = o;
         s->g_ = spec;
         s->mat_.init(spec);
         liveInstances().fetch_add(1);
@@ -56,6 +63,12 @@ public:
     const GridSpec& spec() const { return g_; }
     int T() const { return g_.T; }
     const std::string& lastError() const { return err_; }
+    SolverOptions& options() { return opt_; }
+    bool setEmitters(const float*, int n) {
+        emitters_ = n;
+        lastEmitters().store(n);
+        return true;
+    }
     void rasterAdd(const Box& b) { mat_.add(b); }
     void rasterRemove(const Box& b) { mat_.remove(b); }
 
@@ -140,6 +153,8 @@ public:
 private:
     Solver() = default;
     GridSpec g_;
+    SolverOptions opt_;
+    int emitters_ = 0;
     MaterialPlane mat_;
     std::string err_;
     long long runs_ = 0;

@@ -189,10 +189,58 @@ int main(int argc, char** argv) {
     if (PlaneverbIsRunning()) bad3 |= 1;
     if (!std::strstr(PvAmdLastError(), "injected failure")) bad3 |= 2;
     if (PlaneverbIterationCount() != 5) bad3 |= 4;
+    if (!std::strstr(PlaneverbWorkerError(), "injected failure")) bad3 |= 16;
+    // the worker's failure is reported once per thread: a later, unrelated error on this thread stays readable
+    if (PvAmdHostLoadPv("/nonexistent/scene.pv", nullptr, 0) >= 0) bad3 |= 32;
+    if (std::strstr(PvAmdLastError(), "injected failure") || !PvAmdLastError()[0]) bad3 |= 64;
     (void)PlaneverbGetOutput(e);
     PlaneverbExit();
+    if (PlaneverbWorkerError()[0]) bad3 |= 128;
     pva::Solver::failAfterRuns().store(-1);
     if (pva::Solver::liveInstances().load() != 0) bad3 |= 8;
+
+    // phase 4: Exit must not wait for a caller's own timeout -- a thread blocked in WaitIterations(far future, 30 s) holds a
+    // pin; retiring the context wakes it
+    int bad4 = 0;
+    {
+        PlaneverbInit(kSize, kSize, kRes, 0, dir, 0, 1);
+        std::atomic<bool> entered{false};
+        std::thread waiter([&] {
+            entered.store(true);
+            (void)PlaneverbWaitIterations(1LL << 40, 30000);
+        });
+        while (!entered.load()) std::this_thread::yield();
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        const auto a = std::chrono::steady_clock::now();
+        PlaneverbExit();
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+        waiter.join();
+        if (ms > 5000.0) bad4 |= 1;
+        if (pva::Solver::liveInstances().load() != 0) bad4 |= 2;
+    }
+
+    // phase 5: sparse-emitter mode of the live module (forced through the environment, as on the GPU): the worker registers
+    // the emitters alive at the start of each iteration -- ended ids are left out
+    int bad5 = 0;
+    {
+        setenv("PLANEVERB_AMD_LIVE_STREAMING", "1", 1);
+        PlaneverbInit(kSize, kSize, kRes, 0, dir, 0, 1);
+        if (PlaneverbIsStreaming() != 1) bad5 |= 1;
+        const int a = PlaneverbEmit(5.f, 0.f, 6.f), b = PlaneverbEmit(7.f, 0.f, 6.f), c = PlaneverbEmit(9.f, 0.f, 6.f);
+        (void)a;
+        (void)c;
+        PlaneverbWaitIterations(PlaneverbIterationCount() + 2, 5000);
+        if (pva::Solver::lastEmitters().load() != 3) bad5 |= 2;
+        PlaneverbEndEmission(b);
+        PlaneverbWaitIterations(PlaneverbIterationCount() + 2, 5000);
+        if (pva::Solver::lastEmitters().load() != 2) bad5 |= 4;
+        PlaneverbExit();
+        unsetenv("PLANEVERB_AMD_LIVE_STREAMING");
+        PlaneverbInit(kSize, kSize, kRes, 0, dir, 0, 1);
+        if (PlaneverbIsStreaming() != 0) bad5 |= 8;
+        PlaneverbExit();
+    }
+    bad3 |= (bad4 << 8) | (bad5 << 12);
 
     std::printf("hammer: %lld reads (%lld in-window, %lld out-of-window, %lld sentinel), %d init/exit cycles, %lld bad, "
                 "phase3 flags %d\n", g_reads.load(), g_window.load(), g_stale.load(), g_sentinel.load(), cycles,

@@ -91,3 +91,36 @@ def test_slab_schedule_local_equals_undivided():
         final, hist = whole_domain(NX, cols, T, K, src)
         assert np.array_equal(np.concatenate([s.u[K:K + s.n] for s in slabs]), final)
         assert np.array_equal(root.maps, analysis(hist, np.zeros((T, cols)))) and root.finished
+
+
+@pytest.mark.parametrize("comm_mode", ["fail", "fail-rank1"])
+def test_bench_orchestration_gloo_world2(comm_mode, tmp_path):
+    """bench.py's own N = 2 orchestration on CPU (PV_BENCH_BACKEND=gloo, stand-in solver, tests/_bench_worker.py): the
+    first multi-rank contact of the process group, the communicator fail-over (all ranks or none), the barriers, the
+    max-over-ranks timing and the rank-0-only JSON line happens here, not on the driver's 8-GPU node."""
+    import json
+    import subprocess
+    port = str(_free_port())
+    worker = os.path.join(ROOT, "tests", "_bench_worker.py")
+    outs = [str(tmp_path / ("rank%d.txt" % r)) for r in range(2)]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, WORLD_SIZE="2", RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   PV_BENCH_BACKEND="gloo")
+        env.pop("PV_BENCH_FORCE_DIST", None)
+        env.pop("PV_BENCH_GATHER", None)
+        procs.append(subprocess.Popen([sys.executable, worker, comm_mode, outs[r]], env=env))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    lines0 = [l for l in open(outs[0]).read().splitlines() if l.strip()]
+    assert open(outs[1]).read().strip() == "", "only rank 0 prints"
+    assert len(lines0) == 1, lines0
+    j = json.loads(lines0[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 2 and j["scaling"] == "weak"
+    assert j["metric"] == "grid_cell_updates_per_s" and j["higher_is_better"] is True
+    assert j["timed_runs"] == 3 * 2 * 2 and j["verified_runs"] == j["timed_runs"]  # steps x in flight x ranks
+    assert "torch.distributed.all_gather_into_tensor" in j["config"]["gather"]
+    assert j["config"]["backend"] == "gloo"
+    assert j["value"] == pytest.approx(2 * 2 * 4097 * 4097 * 435 * 3 / (j["ms_per_step"] * 3e-3), rel=1e-9)
+    assert j["cpu_baseline"] is not None and j["cpu_baseline"]["cores"] == 1 and j["cpu_baseline"]["value"] > 0
+    assert j["roofline"]["frac"] > 0

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import SCENES, golden, same_cells
+from conftest import SCENES, golden, same_cells, valid_mask
 from test_gpu_parity import compare_output
 
 pytestmark = pytest.mark.gpu
@@ -214,3 +214,75 @@ def test_headless_cli(pvlib):
         assert abs(e["rt60"] - ro[2]) <= 1e-4 * abs(ro[2])
         assert np.float32(e["direction"][0]) == ro[4] and np.float32(e["sourceDirectivity"][1]) == ro[7]
         assert len(e["reverbBusGains"]) == 3
+
+
+def test_live_module_sparse_emitter_mode_512_mode_b(pvlib, monkeypatch):
+    """The live module in the sparse-emitter mode, through the UNCHANGED flat ABI: BASELINE config 2 /
+    Mode B (25 m at res 2009: 512^2, T = 3179) with the mode forced by PLANEVERB_AMD_LIVE_STREAMING=1.  The worker registers
+    the emitters alive at the start of every iteration (PlaneverbEmit / UpdateEmission / EndEmission -> setEmitters before
+    run, EmissionManager.cpp:37-75): records bit-equal to the reference's vectors, an emitter added between iterations is
+    picked up by the next one, an ended one is dropped."""
+    g = golden("g512B_shoebox")
+    monkeypatch.setenv("PLANEVERB_AMD_LIVE_STREAMING", "1")
+    pvlib.Init(pvlib.Config((25.0, 25.0), 2009, 0, ".", 0, pvlib.pv_GPU))
+    try:
+        assert pvlib.lib().PlaneverbIsStreaming() == 1
+        pvlib.SetListenerPosition(g["listener"])
+        for b in g["boxes"]:
+            pvlib.AddGeometry(b)
+        e0 = pvlib.Emit(g["emitters"][0])
+        settle(pvlib, 3)
+        compare_output(pvlib.GetOutput(e0), g["emitter_out"][0], "emitter present from the start")
+        # a second emitter, added between iterations, on one of the reference's sampled cells
+        c = g["cells"]
+        dx = np.float32(343.21) / np.float32(2009) / np.float32(3.5)
+        gx, gy, T, fs = (int(v) for v in g["dims"])
+        valid = np.flatnonzero(valid_mask(g["cell_delay"], T, fs) & (g["cell_results"][:, 1] > 0))
+        k = int(valid[len(valid) // 2])
+        pos = ((c[k, 0] + 0.5) * float(dx), 0.0, (c[k, 1] + 0.5) * float(dx))
+        e1 = pvlib.Emit(pos)
+        settle(pvlib, 2)
+        compare_output(pvlib.GetOutput(e1), g["cell_results"][k], "emitter added between iterations")
+        compare_output(pvlib.GetOutput(e0), g["emitter_out"][0], "first emitter, later iteration")
+        # moving an emitter: the forward quantities of the new cell are there at once, wet gain / RT60 one iteration later
+        k2 = int(valid[len(valid) // 3])
+        pos2 = ((c[k2, 0] + 0.5) * float(dx), 0.0, (c[k2, 1] + 0.5) * float(dx))
+        pvlib.UpdateEmission(e1, pos2)
+        o = pvlib.GetOutput(e1).as_array()
+        for idx in (0, 4, 5, 6, 7):
+            assert np.float32(o[idx]).view(np.uint32) == np.float32(g["cell_results"][k2][idx]).view(np.uint32) or \
+                (o[idx] == 0 and g["cell_results"][k2][idx] == 0)
+        settle(pvlib, 2)
+        compare_output(pvlib.GetOutput(e1), g["cell_results"][k2], "moved emitter, next iteration")
+        pvlib.EndEmission(e1)
+        settle(pvlib, 2)
+        compare_output(pvlib.GetOutput(e0), g["emitter_out"][0], "after EndEmission of the other one")
+        # the IR cube does not exist in this mode: the call fails cleanly
+        with pytest.raises(pvlib.PlaneverbError):
+            pvlib.GetImpulseResponse(g["emitters"][0])
+    finally:
+        pvlib.Exit()
+
+
+def test_live_module_falls_back_to_sparse_emitter_mode_by_itself(pvlib, monkeypatch):
+    """PlaneverbInit(25, 25, 16067, ...) -- a 4096^2 grid with T = 25 432, whose history window would take 1.7 TB --
+    comes up by itself in the sparse-emitter mode (Planeverb::Init accepts any resolution >= 275, PvContext.cpp:101-107).
+    Only initialisation, an emitter and the Exit racing the first 0.5 s iteration are exercised here."""
+    monkeypatch.delenv("PLANEVERB_AMD_LIVE_STREAMING", raising=False)
+    pvlib.Init(pvlib.Config((25.0, 25.0), 16067, 0, ".", 0, pvlib.pv_GPU))
+    try:
+        assert pvlib.IsRunning()
+        assert pvlib.lib().PlaneverbIsStreaming() == 1
+        pvlib.SetListenerPosition((5.0, 0.0, 4.0))
+        e = pvlib.Emit((5.0, 0.0, 6.0))
+        assert e == 0
+        assert pvlib.WaitIterations(1, 120000) >= 1
+        assert pvlib.IsRunning(), pvlib.last_error()
+    finally:
+        pvlib.Exit()
+    # a config whose history fits stays in the full-history mode
+    pvlib.Init(pvlib.Config((25.0, 25.0), 275, 0, ".", 0, pvlib.pv_GPU))
+    try:
+        assert pvlib.lib().PlaneverbIsStreaming() == 0
+    finally:
+        pvlib.Exit()

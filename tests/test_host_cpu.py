@@ -319,3 +319,14 @@ def test_header_is_plain_c(tmp_path):
                    'int main(void) { PvAmdSlabInfo i; PvAmdInfo j; (void)i; (void)j; return 0; }\n')
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I",
                            os.path.join(ROOT, "include"), str(src)])
+
+
+def test_host_libm_reproduces_the_reference_pulse(pvlib):
+    """the Gaussian pulse is made with the HOST's expf (Grid.cpp:12-27): the library checks five samples of the reference's
+    275 Hz table once per process and warns; here the check itself must hold (glibc 2.35 in this image and on the GPU box)"""
+    assert pvlib.lib().PvAmdHostPulseSelfCheck() == 1
+
+
+def test_worker_error_accessor_without_module(pvlib):
+    assert pvlib.lib().PlaneverbWorkerError() == b""
+    assert pvlib.lib().PlaneverbIsStreaming() == 0
