@@ -157,6 +157,8 @@ enum {
     PVA_OPT_STREAM_ROWS = 13,  /* N > 0: the air part of the grid is advanced by about N row-streaming segments per sweep (a wave streams down a 256-column strip, K time levels in flight) instead of one wave per air tile; tile configurations (8, 40) and (12, 36) only, ignored elsewhere and with slabs / row bands / graphs / streaming analysis.  Bit-identical; experimental: slower than the tile kernels at 4096^2.  Default 0 = off */
     PVA_OPT_MERGED_LAUNCH = 14, /* 1 (default) = general + air tiles in one launch per K steps; 0 = two kernels, two streams */
     PVA_OPT_ROW_BANDS = 16,    /* B > 1: every K-step sweep is launched as B bands of tile rows on B HIP streams; band b of sweep n+1 waits only for bands b-1, b, b+1 of sweep n, so consecutive sweeps of ONE run overlap (no chip-wide drain between launches) -- what gives a single run most of the two-runs-in-flight rate.  0 = auto by grid size, 1 = one launch per sweep.  Large grids with the merged kernel only; ignored elsewhere (streaming analysis, graphs, batched runs) */
+    PVA_OPT_PATCH_KERNEL = 17, /* air tiles by the persistent per-CU kernel with LDS-DMA run-ahead (csrc/pv_patch.h: one 512-thread workgroup per CU, the next 4-tile patch lands in LDS while the current one computes) instead of one wave per tile; general tiles in a launch of their own.  Only the large-grid tile (steps per launch 12, tile rows 36) has the kernel; ignored elsewhere and with streaming analysis, slabs, edge tiles, kernel timing.  -1 = default for the configuration, 0 = off, 1 = on */
+    PVA_OPT_PATCH_STRIP = 18,  /* patch columns per strip of the patch kernel's walk over the grid (development; default 3) */
     PVA_OPT_EDGE_TILES = 15    /* 1 = tiles whose only non-air faces are the grid's absorbing edges run the air-tile code + edge overrides (tile class 2) instead of the general path.  Only the batched kernels of the mirror-pair tiles (K, rows = (8,40), (10,36), (12,36)) have that arm -- inside the merged kernel it slows the air tiles by 25-40 %, DESIGN.md 8.4 -- so every run of such a solver goes through PvAmdRunBatch's kernel (PvAmdRun = a batch of one) and PvAmdRunSteps is refused; ignored for other configurations.  Default 0 */
 };
 

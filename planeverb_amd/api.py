@@ -39,6 +39,8 @@ PVA_OPT_STREAM_ROWS = 13
 PVA_OPT_MERGED_LAUNCH = 14
 PVA_OPT_EDGE_TILES = 15
 PVA_OPT_ROW_BANDS = 16
+PVA_OPT_PATCH_KERNEL = 17
+PVA_OPT_PATCH_STRIP = 18
 
 
 class PlaneverbOutput(C.Structure):
@@ -587,7 +589,8 @@ class Solver:
                 "tile_order": PVA_OPT_TILE_ORDER, "small_grid_kernel": PVA_OPT_SMALL_GRID_KERNEL,
                 "packed_math": PVA_OPT_PACKED_MATH, "streaming_analysis": PVA_OPT_STREAMING_ANALYSIS,
                 "stream_rows": PVA_OPT_STREAM_ROWS, "merged_launch": PVA_OPT_MERGED_LAUNCH,
-                "edge_tiles": PVA_OPT_EDGE_TILES, "row_bands": PVA_OPT_ROW_BANDS}
+                "edge_tiles": PVA_OPT_EDGE_TILES, "row_bands": PVA_OPT_ROW_BANDS,
+                "patch_kernel": PVA_OPT_PATCH_KERNEL, "patch_strip": PVA_OPT_PATCH_STRIP}
         for k, v in options.items():
             _check(lib().PvAmdSetOption(self._h, keys[k], int(v)))
         self.info = PvAmdInfo()

@@ -1774,7 +1774,30 @@ __device__ __forceinline__ bool deadTileSkippable(const StepArgs& a, int tile) {
 
 }  // namespace pva
 #include "pv_seg.h"
+#include "pv_patch.h"
 namespace pva {
+
+// configurations with a persistent patch kernel (pv_patch.h): the large-grid tile
+#define PV_PATCH_CONFIGS(X) X(12, 36)
+
+bool patchConfigOk(int K, int rxi) {
+#define X(k, r) \
+    if (K == k && rxi == r) return true;
+    PV_PATCH_CONFIGS(X)
+#undef X
+    return false;
+}
+
+// the air tiles of one K-step sweep: `blocks` resident 512-thread workgroups (one per CU, a multiple of 8)
+void launchStepPatch(int K, int rxi, const StepArgs& a, int blocks, hipStream_t stream) {
+#define X(k, r) \
+    if (K == k && rxi == r) { \
+        hipLaunchKernelGGL((pv_step_patch_kernel<k, r>), dim3(blocks), dim3(512), 0, stream, a); \
+        return; \
+    }
+    PV_PATCH_CONFIGS(X)
+#undef X
+}
 
 // Segment form of the merged launch: the first blocks advance one general tile each (stepTileGeneral4, as in
 // pv_step_merged_kernel), every other block four row-streaming air segments, one per wave (pv_seg.h).  XCD x = block % 8
@@ -1853,6 +1876,11 @@ static int bandPositions(const StepArgs& a) {
 
 template <int K, int RXI, int WPS, int SUB>
 static void launchStepT(const StepArgs& a, hipStream_t stream, int which, hipStream_t stream2) {
+    if (which == 16) {  // the general tiles of the merged launch alone (the air tiles go through pv_step_patch_kernel)
+        if (a.numGeneral > 0)
+            hipLaunchKernelGGL((pv_step_merged_kernel<K, RXI, WPS, SUB>), dim3(a.numGeneral), dim3(256), 0, stream, a);
+        return;
+    }
     if (which == 4) {  // merged single launch: one block per general tile, then 4 air tiles per block
         const int blocks = a.numGeneral + 8 * ((bandPositions(a) + 3) / 4);
         // (PV_PROBE_LDS = bytes of dynamic LDS per block: measurement aid, limits the blocks resident per CU)

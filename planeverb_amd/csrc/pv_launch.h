@@ -20,6 +20,10 @@ int stepConfigExtraRows(int K, int rxi);
 // 4 = both in ONE merged launch (one block per general tile first, then the air tiles)
 // The general kernel goes to stream2 when given (the caller orders the two streams with events).
 void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream, int which = 3, hipStream_t stream2 = nullptr);
+// persistent patch kernel (pv_patch.h): the AIR tiles of one sweep by `blocks` resident workgroups (one per CU, multiple
+// of 8); the general tiles of the sweep are launched with launchStep(..., which = 16)
+bool patchConfigOk(int K, int rxi);
+void launchStepPatch(int K, int rxi, const StepArgs& a, int blocks, hipStream_t stream);
 // row-streaming air segments (pv_seg.h): columns per lane of the configuration's segment kernel (0 = it has none), the
 // tile columns a segment can span, and the launch (general tiles + a.numSeg segments in one grid)
 int segConfigColumns(int K, int rxi);

@@ -18,6 +18,7 @@ namespace {
 // banded sweeps are bit-exact but 6-35 % SLOWER than one launch per sweep at 4096^2 and 8192^2 for every band count --
 // two cross-stream event waits per band and sweep cost more than the chip-wide drain they remove.
 constexpr int kAutoRowBands = 1;
+constexpr int kDefaultPatch = 0;  // persistent patch kernel for the (12, 36) tile: off until measured faster (PVA_OPT_PATCH_KERNEL)
 constexpr int kMinGuard = 8;  // guard width = max(this, K): a tile's halo never leaves the allocation
 inline int roundUp(int v, int m) { return (v + m - 1) / m * m; }
 inline int ceilDiv(int a, int b) { return (a + b - 1) / b; }
@@ -259,6 +260,23 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         segCap_ = 2 * ntiles + 8;
         if (!dalloc(&segList_, (size_t)segCap_, true)) return false;
         if (!hipOk(hipHostMalloc((void**)&segHost_, sizeof(SegDesc) * (size_t)segCap_), "hipHostMalloc")) return false;
+    }
+
+    // Persistent patch kernel for the air tiles (pv_patch.h): the large-grid tile only; one descriptor spans a buffer
+    // set's three planes, so they must fit 31 bits
+    {
+        const bool mergedLaunch = !stepConfigStacked(K_, rxi_) && opt_.merged == 1 && mergedConfigOk(K_, rxi_);
+        int want = opt_.patch;
+        if (want < 0) want = kDefaultPatch;
+        usePatch_ = want > 0 && patchConfigOk(K_, rxi_) && mergedLaunch && opt_.packed && !opt_.streaming && !isSlab() &&
+                    !opt_.edgeTiles && opt_.timeKernels == 0 && !useSeg_ && plane * 12 <= (size_t)INT_MAX;
+        if (usePatch_) {
+            hipDeviceProp_t prop;
+            if (!hipOk(hipGetDeviceProperties(&prop, device_), "hipGetDeviceProperties")) return false;
+            patchBlocks_ = std::max(8, prop.multiProcessorCount / 8 * 8);
+            if ((opt_.patchStrip & 0xff) < 1) opt_.patchStrip |= 1;
+            opt_.rowBands = 1;
+        }
     }
 
     // Row bands (see enqueueSteps): worth it where a sweep is thousands of tiles; measured on MI355X at 4096^2 / 8192^2
@@ -745,6 +763,7 @@ StepArgs Solver::baseStepArgs(bool withPulse, bool record) const {
     a.gy = g_.gy;
     a.bandRows = ceilDiv(geo_.ntx, 8);
     a.tileOrder = opt_.tileOrder;
+    a.patchStrip = opt_.patchStrip;
     a.packed = opt_.packed ? 1 : 0;
     a.withPulse = withPulse ? 1 : 0;
     a.record = record ? 1 : 0;
@@ -874,10 +893,16 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
         if (mergedLaunch) {
             if (te) hipEventRecord(te[0], stream_);
             // the segment kernel always advances exactly K levels; a run's short last launch takes the tile kernel
-            if (a.segList && k == K_)
+            if (a.segList && k == K_) {
                 launchStepSeg(K_, rxi_, a, stream_);
-            else
+            } else if (usePatch_) {
+                // general tiles in their 4-wave blocks, then the air tiles by the resident workgroups (disjoint tiles of
+                // the same output set; neither reads what the other writes)
+                launchStep(K_, rxi_, a, stream_, 16);
+                launchStepPatch(K_, rxi_, a, patchBlocks_, stream_);
+            } else {
                 launchStep(K_, rxi_, a, stream_, 4);
+            }
             if (te) {
                 hipEventRecord(te[1], stream_);
                 hipEventRecord(te[2], stream_);

@@ -47,6 +47,8 @@ struct SolverOptions {
     // and keeps the K rows its neighbours own next to them current in its guard band (SlabGroup exchanges them after
     // every launch).  slabCount = 1: a whole grid.
     int slabIndex = 0, slabCount = 1;
+    int patch = -1;       // air tiles by the persistent patch kernel (pv_patch.h): -1 = default of the configuration, 0 off, 1 on
+    int patchStrip = 3;   // patch columns per strip of its walk
     int rowBands = 0;     // B > 1: each sweep = B launches (bands of tile rows, one stream each) with 3-point
                           // dependencies between consecutive sweeps; 0 = auto, 1 = off
 };
@@ -242,6 +244,8 @@ private:
     int* listHost_ = nullptr;
     int listCap_ = 0;
     // row-streaming air segments (pv_seg.h): rebuilt for every run (they avoid the tiles around the listener)
+    bool usePatch_ = false;    // air tiles go through the persistent patch kernel (pv_patch.h)
+    int patchBlocks_ = 0;      // its grid: one workgroup per CU, a multiple of 8
     bool useSeg_ = false;      // this solver's configuration and options allow them
     bool segActive_ = false;   // the run being enqueued uses them
     int segWMax_ = 0;          // tile columns a segment can span

@@ -779,6 +779,43 @@ def test_row_streaming_segments_equivalence(pvlib, K, rows, nseg):
         assert all(same_bits(a, b).all() for a, b in zip(h0, h1))
 
 
+@pytest.mark.parametrize("n,strip", [(900, 3), (1250, 1), (1250, 5)])
+def test_patch_kernel_equivalence(pvlib, n, strip):
+    """PVA_OPT_PATCH_KERNEL (persistent per-CU air-tile kernel with LDS-DMA run-ahead, pv_patch.h): same bits as the
+    one-wave-per-tile kernel -- the raw stencil from dense random fields with walls (every tile non-zero, ragged last
+    patch: tile columns not a multiple of 4), a closed-room run and an open-field run (history planes, activity flags,
+    every result member), two runs in a row (the zero-extent input descriptors of a run's first launch go through the
+    DMA path too)"""
+    dx = np.float32(343.21) / np.float32(275) / np.float32(3.5)
+    size = float((n + 0.5) * dx)
+    rng = np.random.default_rng(n)
+    init = [rng.standard_normal((n + 1, n + 1)).astype(np.float32) for _ in range(3)]
+    walls = [[60, 70, 20, 1, 0.9], [120, 40, 1, 30, 0.7]]
+    cfg = dict(steps_per_launch=12, tile_rows=36, use_graph=2)
+    outs = []
+    for m in (0, 1):
+        with pvlib.Solver(size, size, 275, no_free_grid=1, patch_kernel=m, patch_strip=strip, **cfg) as s:
+            for w in walls:
+                s.add_geometry(w)
+            s.set_fields(*init)
+            s.run_steps(3 * 12 + 5)  # three full launches and a short one
+            outs.append(s.fields())
+    assert all(same_bits(a, b).all() for a, b in zip(*outs))
+    for scene, listener in (("HugeRoom.pv", (100.0, 0.0, 90.0)), (None, (150.0, 0.0, 170.0))):
+        res = []
+        for m in (0, 1):
+            with pvlib.Solver(size, size, 275, patch_kernel=m, patch_strip=strip, **cfg) as s:
+                if scene:
+                    s.load_scene(os.path.join(SCENES, scene))
+                s.run(listener)
+                s.run(listener)  # twice: the per-tile flags of the first run must not leak into the second
+                res.append((s.results(), [s.history_plane(t) for t in (3, 100, 300, 434)], s.fields()))
+        (r0, h0, f0), (r1, h1, f1) = res
+        assert same_bits(r0[0], r1[0]).all() and same_bits(r0[1], r1[1]).all()
+        assert all(same_bits(a, b).all() for a, b in zip(h0, h1))
+        assert all(same_bits(a, b).all() for a, b in zip(f0, f1))
+
+
 def test_tile_orders_cover_every_tile(pvlib):
     """PVA_OPT_TILE_ORDER only changes which workgroup advances which air tile: linear, XCD bands of tile rows (row- /
     column-major / sub-bands) and XCD strips of tile columns must give the same fields, on a grid whose tile counts are
