@@ -93,7 +93,8 @@ struct StepArgs {
     const uint8_t* nzIn;   // per tile: non-zero at the end of the previous launch (conservative)
     uint8_t* nzOut;        // per tile: non-zero at the end of this launch
     int tileOrder;         // air-kernel block -> tile mapping (0 linear, 1 XCD band row-major, 2 band column-major)
-    int patchStrip;        // persistent patch kernel (pv_patch.h): patch columns per strip of its walk
+    int patchStrip;        // persistent patch kernel (pv_patch.h): bits 8.. = measurement switches (0 in real runs)
+    long long* patchTrace; // development aid (PV_PATCH_TRACE=1): s_memtime stamps of the phases of block 0's waves, or NULL
     int t0;                // first global step of this launch
     int histSlot;          // history plane index of step t0 (= t0, or t0 % ring length in streaming mode)
     int nsteps;            // steps in this launch (<= K)

@@ -113,43 +113,34 @@ struct PatchSteps {
     }
 };
 
-// position s of the strip-major patch sequence -> (tile row, patch column).  Strips are SW patch columns wide and walked
-// row-major, so a patch's vertical neighbours are SW positions away (cf. tile order 3 of the tile kernel).
-__device__ __forceinline__ void patchAt(int s, int ntx, int npy, int SW, int* ti, int* pj) {
-    const int nStrips = (npy + SW - 1) / SW;
-    const int perStrip = ntx * SW;
-    const int k = min(s / perStrip, nStrips - 1);
-    const int rem = s - k * perStrip;
-    const int w = (k == nStrips - 1) ? npy - k * SW : SW;
-    *ti = rem / w;
-    *pj = k * SW + (rem - *ti * w);
-}
-
 template <int K, int RXI>
 __global__ __launch_bounds__(512, 2) void pv_step_patch_kernel(const StepArgs a) {
     using Gm = PatchGeom<K, RXI>;
     constexpr int ROWS = Gm::ROWS, NP = Gm::NP, WI = Gm::WI, PW = Gm::PW, PLANE = Gm::PLANE;
+    constexpr int SLOTG = ROWS / 12;  // the ring of row slots advances by RXI = 36 rows per patch: everything moves in 12-row groups
+    static_assert(ROWS % 12 == 0 && RXI % 12 == 0 && (2 * K) % 12 == 0, "ring arithmetic in groups of 12 rows");
     __shared__ __attribute__((aligned(1024))) float zone[Gm::ZONE];
+    __shared__ int counters[2];  // [0] DMA shares landed, [1] tile reads done: 4 per patch each (one per wave of its group)
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int g = wave >> 2, w = wave & 3;
+    if (threadIdx.x == 0) counters[0] = counters[1] = 0;
+    __syncthreads();
 
-    // this group's share of the patch sequence: XCD x = block % 8 owns a contiguous eighth, its groups stride through it
+    // this block's share of the patches: a contiguous range of the COLUMN-major sequence (patch c = pj * ntx + ti), so that
+    // consecutive patches are vertically adjacent; blocks of one XCD (block % 8, observed) take neighbouring ranges
     const int npy = (a.nty + Gm::TPP - 1) / Gm::TPP;
     const int npatch = a.ntx * npy;
-    const int per = (npatch + 7) >> 3;
-    const int xcd = blockIdx.x & 7;
-    const int sBeg = xcd * per, sEnd = min(sBeg + per, npatch);
-    const int GX = (int)(gridDim.x >> 3) * 2;              // groups per XCD
-    const int gl = (int)(blockIdx.x >> 3) * 2 + g;         // this group's index within the XCD
-    const int nIt = (max(sEnd - sBeg, 0) - ((int)(blockIdx.x >> 3) * 2) + GX - 1) / GX;  // iterations of the BLOCK (its first group's count)
+    const int nb = (int)gridDim.x;
+    const int q = (int)(blockIdx.x & 7) * (nb >> 3) + (int)(blockIdx.x >> 3);
+    const int c0 = (int)((long long)npatch * q / nb), c1 = (int)((long long)npatch * (q + 1) / nb);
+    const int n = c1 - c0;  // patch m of the block (0 <= m < n) belongs to group m & 1 and sits in the zone after patch m - 1
 
     const int pitchB = a.pitch * 4;
-    // measurement aid (tools/gpu_patch.py): bits 8.. of patchStrip switch parts of the kernel off -- 1 steps, 2 DMA, 4 result
+    // measurement aid (tools/patch_decomp.sh): bits 8.. of patchStrip switch parts of the kernel off -- 1 steps, 2 DMA, 4 result
     // stores, 8 zone reads.  0 in every real run.
     const int dbg = a.patchStrip >> 8;
-    const int SW = a.patchStrip & 0xff;
     // per-lane offsets are re-made from the lane index where they are used (opaque copies, so that they are not hoisted):
     // every value kept live across the unrolled steps is a VGPR the 180-register tile does not have
     auto laneCopy = [&]() {
@@ -163,19 +154,28 @@ __global__ __launch_bounds__(512, 2) void pv_step_patch_kernel(const StepArgs a)
     const int planeB = (int)a.planeBytes;
     const rsrc_t rIn = makeRsrc(a.prIn, a.inBytes ? 3 * planeB : 0);
 
-    auto issueDma = [&](int s) {  // patch at sequence position s (wave-uniform); this wave's share: 4-row blocks w, w+4, ...
-        if (s >= sEnd || (dbg & 2)) return;
-        int ti, pj;
-        patchAt(s, a.ntx, npy, SW, &ti, &pj);
+    volatile int* const cnt = counters;
+    auto bump = [&](int which) {  // one count per wave
+        if (lane == 0) __hip_atomic_fetch_add(&counters[which], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto reached = [&](int which, int target) { return __builtin_amdgcn_readfirstlane(cnt[which]) >= target; };
+    auto waitFor = [&](int which, int target) {
+        while (!reached(which, target)) __builtin_amdgcn_s_sleep(2);
+        asm volatile("" ::: "memory");
+    };
+
+    // DMA of patch m's NEW rows into the ring: all ROWS rows for the first patch of the block or of a grid column, else the
+    // RXI rows below the 2K rows it shares with patch m - 1 (already in the zone: slots are never moved).  Row r of patch m
+    // lives in slot (m * RXI + r) mod ROWS.  This wave's share: 4-row blocks w, w + 4, ... of the new rows.  The caller has
+    // made sure that patch m - 1 has been read (counters[1] >= 4 m).
+    auto issueDma = [&](int m) {
+        if (dbg & 2) return;
+        const int c = c0 + m;
+        const int pj = c / a.ntx, ti = c - pj * a.ntx;
+        const int r0 = (m > 0 && ti != 0) ? 2 * K : 0;
         const int row0 = a.G - K + ti * RXI, col0 = a.G - K + pj * Gm::TPP * WI;
-        // running scalar offsets with an opaque pitch: written as soff0 + r * pitchB (+ p * planeB) the 180 row offsets are
-        // loop-invariant sums that the optimiser hoists out of the tile loop into 100+ SGPRs -- and spills
-        int pB = pitchB, plB = planeB;
+        int pB = pitchB, plB = planeB;  // (opaque: no loop-invariant offset tables in SGPRs)
         asm volatile("" : "+s"(pB), "+s"(plB));
-        int so = (row0 * a.pitch + col0) * 4 + w * 4 * pB;  // 4-row block w of every plane first
-        const int so16 = 16 * pB;
-        unsigned lw = zoneB + (unsigned)(w * 4 * PW * 4);  // (opaque as well: 135 loop-invariant LDS addresses otherwise)
-        asm volatile("" : "+s"(lw));
         int dvoff[3];
         {
             const int l = laneCopy();
@@ -185,32 +185,40 @@ __global__ __launch_bounds__(512, 2) void pv_step_patch_kernel(const StepArgs a)
                 dvoff[j] = (u / 48) * pB + (u % 48) * 16;
             }
         }
+        const int slot0 = (m * (RXI / 4)) % (ROWS / 4);  // first 4-row slot block of the patch
+#pragma unroll 1
+        for (int rb = r0 / 4 + w; rb < ROWS / 4; rb += 4) {
+            int sb = slot0 + rb;
+            if (sb >= ROWS / 4) sb -= ROWS / 4;
+            const int so = ((row0 + 4 * rb) * a.pitch + col0) * 4;
+            const unsigned l0 = zoneB + (unsigned)(sb * 4 * PW * 4);
 #pragma unroll
-        for (int q = 0; q < (Gm::RB + 3) / 4; ++q) {
-            const int rb = w + 4 * q;
-            if (rb < Gm::RB) {
-                const unsigned l0 = lw + (unsigned)(4 * q * 4 * PW * 4);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    patchDma16(rIn, dvoff[j], so, l0 + (unsigned)(j * 1024));
-                    patchDma16(rIn, dvoff[j], so + plB, l0 + (unsigned)(PLANE * 4 + j * 1024));
-                    patchDma16(rIn, dvoff[j], so + 2 * plB, l0 + (unsigned)(2 * PLANE * 4 + j * 1024));
-                }
-                so += so16;
+            for (int j = 0; j < 3; ++j) {
+                patchDma16(rIn, dvoff[j], so, l0 + (unsigned)(j * 1024));
+                patchDma16(rIn, dvoff[j], so + plB, l0 + (unsigned)(PLANE * 4 + j * 1024));
+                patchDma16(rIn, dvoff[j], so + 2 * plB, l0 + (unsigned)(2 * PLANE * 4 + j * 1024));
             }
         }
     };
 
-    // prologue: group 0 fetches its first patch at once; group 1 runs half a period behind (see the header)
-    if (g == 1) {
-        asm volatile("s_barrier" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");
+    // prologue: the group's first patch.  Group 1's (m = 1) may only overwrite the zone once group 0 has read patch 0.
+    if (g < n) {
+        if (g == 1) waitFor(1, 4);
+        issueDma(g);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bump(0);
     }
-    issueDma(sBeg + gl);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     const float C = a.courant;
     const bool inCols = lane >= K && lane < 64 - K;
+    // development aid: stamp `id` of this wave's tile number `it` (block 0 only, 16 stamps x 16 tiles x 8 waves)
+    const bool tracing = a.patchTrace != nullptr && blockIdx.x == 0 && a.nsteps == K;
+    auto stamp = [&](int it, int id) {
+        if (tracing && it < 16) {
+            const long long t = (long long)__builtin_amdgcn_s_memtime();
+            if (lane == 0) a.patchTrace[(wave * 16 + it) * 16 + id] = t;
+        }
+    };
 
     v2f pr[NP], vx[NP], vy[NP];
     float vxS = 0.f;
@@ -218,12 +226,11 @@ __global__ __launch_bounds__(512, 2) void pv_step_patch_kernel(const StepArgs a)
     for (int i = 0; i < NP; ++i) pr[i] = vx[i] = vy[i] = v2f{0.f, 0.f};
 
 #pragma unroll 1
-    for (int it = 0; it < nIt; ++it) {
-        const int s = sBeg + gl + it * GX;
-        int ti = 0, pj = 0;
-        if (s < sEnd) patchAt(s, a.ntx, npy, SW, &ti, &pj);
+    for (int m = g; m < n; m += 2) {
+        const int c = c0 + m;
+        const int pj = c / a.ntx, ti = c - pj * a.ntx;
         const int tj = pj * Gm::TPP + w;
-        bool mine = s < sEnd && tj < a.nty;
+        bool mine = tj < a.nty;
         const int tile = ti * a.nty + tj;
         const DynParams dyn = patchSLoad(a.dyn);  // (per tile: a copy kept live across the loop costs 10 SGPRs)
         if (mine) {
@@ -235,8 +242,10 @@ __global__ __launch_bounds__(512, 2) void pv_step_patch_kernel(const StepArgs a)
         }
         mine = __builtin_amdgcn_readfirstlane((int)mine) != 0;
 
-        // ---- first half: take the tile out of the zone, steps [0, K/2)
-        asm volatile("s_barrier" ::: "memory");  // every wave of the group has waited for its DMA pieces
+        // ---- take the tile out of the zone (all four DMA shares of the patch have landed), steps [0, K/2)
+        stamp(m >> 1, 0);
+        waitFor(0, 4 * (m + 1));
+        stamp(m >> 1, 1);
         bool recLane = false;
         long long hstride = a.histPlane;
         int ns = a.nsteps;
@@ -246,19 +255,31 @@ __global__ __launch_bounds__(512, 2) void pv_step_patch_kernel(const StepArgs a)
         int hsoff0 = 0;
         const int hvoff = (laneCopy() - K) * 4, hpitchB = WI * 4;
         if (mine && !(dbg & 8)) {
-            const float* zl = zone + w * WI + laneCopy();  // this lane's column of this wave's tile, row 0 of the pr plane
-            vxS = zl[PLANE + NP * PW];
+            // row r of the patch sits in slot group (bq + r / 12) mod 5, row r % 12 of it
+            const int bq = (m * (RXI / 12)) % SLOTG;
+            const float* zl = zone + w * WI + laneCopy();
+            const float* gp[SLOTG];
+#pragma unroll
+            for (int k = 0; k < SLOTG; ++k) {
+                int sg = bq + k;
+                if (sg >= SLOTG) sg -= SLOTG;
+                gp[k] = zl + sg * 12 * PW;
+            }
+            auto at = [&](int plane, int r) { return gp[r / 12][plane * PLANE + (r % 12) * PW]; };
+            vxS = at(1, NP);
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                pr[i].x = zl[i * PW];
-                pr[i].y = zl[(ROWS - 1 - i) * PW];
-                vy[i].x = zl[2 * PLANE + i * PW];
-                vy[i].y = zl[2 * PLANE + (ROWS - 1 - i) * PW];
-                vx[i].x = zl[PLANE + i * PW];
-                vx[i].y = (i > 0) ? -zl[PLANE + (ROWS - i) * PW] : 0.f;  // face ROWS-i; face ROWS is not in the tile
+                pr[i].x = at(0, i);
+                pr[i].y = at(0, ROWS - 1 - i);
+                vy[i].x = at(2, i);
+                vy[i].y = at(2, ROWS - 1 - i);
+                vx[i].x = at(1, i);
+                vx[i].y = (i > 0) ? -at(1, ROWS - i) : 0.f;  // face ROWS-i; face ROWS is not in the tile
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // zone free: the other group may refill it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bump(1);  // this wave is done with the zone
+        stamp(m >> 1, 2);
         if (mine) {
             uint32_t nz = __float_as_uint(vxS);
 #pragma unroll
@@ -276,18 +297,40 @@ __global__ __launch_bounds__(512, 2) void pv_step_patch_kernel(const StepArgs a)
             if (a.record && active && !inWin && lane == 0) atomicExch(a.errFlag, 1);
             recLane = rec && inCols;
             hsoff0 = ((hti * dyn.histTilesY + htj) * RXI - K) * hpitchB;
-            if (!(dbg & 1)) PatchSteps<K, RXI, 0, K / 2>::run(pr, vx, vy, vxS, C, ns, recLane, hplane, hstride, hvoff, hsoff0, hpitchB);
+            if (!(dbg & 1))
+                PatchSteps<K, RXI, 0, K / 2>::run(pr, vx, vy, vxS, C, ns, recLane, hplane, hstride, hvoff, hsoff0, hpitchB);
         }
 
-        // ---- second half: one step while the other group reads the zone, then prefetch and finish
-        asm volatile("s_barrier" ::: "memory");
-        if (mine && !(dbg & 1)) PatchSteps<K, RXI, K / 2, K / 2 + 1>::run(pr, vx, vy, vxS, C, ns, recLane, hplane, hstride, hvoff, hsoff0, hpitchB);
-        asm volatile("s_barrier" ::: "memory");
-        issueDma(s + GX);
-        if (mine && !(dbg & 1)) PatchSteps<K, RXI, K / 2 + 1, K>::run(pr, vx, vy, vxS, C, ns, recLane, hplane, hstride, hvoff, hsoff0, hpitchB);
-        // the next patch must have landed before this wave passes the next barrier -- and waiting BEFORE the result stores
-        // are issued keeps them out of the wait (vmcnt counts loads and stores in issue order)
+        // ---- second half: fetch the group's next patch as soon as the other group has read ITS current one (asked after
+        // every step, forced before the result stores), steps [K/2, K)
+        stamp(m >> 1, 3);
+        const bool more = m + 2 < n;
+        bool issued = !more;
+        auto tryIssue = [&](bool force) {
+            if (issued) return;
+            if (force)
+                waitFor(1, 4 * (m + 2));
+            else if (!reached(1, 4 * (m + 2)))
+                return;
+            issueDma(m + 2);
+            issued = true;
+        };
+        tryIssue(false);
+        if (mine && !(dbg & 1)) {
+            PatchSteps<K, RXI, K / 2, K / 2 + 2>::run(pr, vx, vy, vxS, C, ns, recLane, hplane, hstride, hvoff, hsoff0, hpitchB);
+            tryIssue(false);
+            PatchSteps<K, RXI, K / 2 + 2, K / 2 + 4>::run(pr, vx, vy, vxS, C, ns, recLane, hplane, hstride, hvoff, hsoff0, hpitchB);
+            tryIssue(false);
+            PatchSteps<K, RXI, K / 2 + 4, K>::run(pr, vx, vy, vxS, C, ns, recLane, hplane, hstride, hvoff, hsoff0, hpitchB);
+        }
+        stamp(m >> 1, 4);
+        tryIssue(true);
+        stamp(m >> 1, 5);
+        // the next patch's shares must have landed before this wave says so -- and waiting BEFORE the result stores are issued
+        // keeps them out of the wait (vmcnt counts loads and stores in issue order)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (more) bump(0);
+        stamp(m >> 1, 6);
         if (mine && inCols && !(dbg & 4)) {
             const int row0 = a.G - K + ti * RXI, col0 = a.G - K + tj * WI;
             int pB = pitchB, plB = planeB;  // (opaque: see issueDma)
@@ -303,10 +346,7 @@ __global__ __launch_bounds__(512, 2) void pv_step_patch_kernel(const StepArgs a)
                 so += pB;
             }
         }
-    }
-    if (g == 0) {  // pairs with the last half of group 1
-        asm volatile("s_barrier" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");
+        stamp(m >> 1, 7);
     }
 }
 

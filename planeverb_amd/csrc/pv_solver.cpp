@@ -275,6 +275,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
             if (!hipOk(hipGetDeviceProperties(&prop, device_), "hipGetDeviceProperties")) return false;
             patchBlocks_ = std::max(8, prop.multiProcessorCount / 8 * 8);
             if ((opt_.patchStrip & 0xff) < 1) opt_.patchStrip |= 1;
+            if (std::getenv("PV_PATCH_TRACE") && !dalloc(&patchTrace_, (size_t)8 * 16 * 16, true)) return false;
             opt_.rowBands = 1;
         }
     }
@@ -329,6 +330,22 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
 
 Solver::~Solver() {
     if (stream_) hipStreamSynchronize(stream_);
+    if (patchTrace_) {  // development aid: phase stamps of the LAST launch (block 0), cycles relative to the first stamp
+        std::vector<long long> t((size_t)8 * 16 * 16);
+        hipMemcpy(t.data(), patchTrace_, t.size() * 8, hipMemcpyDeviceToHost);
+        long long t0 = 0;
+        for (long long v : t)
+            if (v && (!t0 || v < t0)) t0 = v;
+        for (int w = 0; w < 8; ++w)
+            for (int it = 0; it < 16; ++it) {
+                const long long* r = &t[(size_t)(w * 16 + it) * 16];
+                if (!r[0]) continue;
+                std::fprintf(stderr, "trace wave %d tile %2d:", w, it);
+                for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %8lld", r[k] ? r[k] - t0 : -1);
+                std::fprintf(stderr, "\n");
+            }
+        hipFree(patchTrace_);
+    }
     if (stream2_) hipStreamSynchronize(stream2_);
     for (int i = 0; i < 2; ++i) {
         if (pr_[i]) hipFree(pr_[i]);  // (vx, vy live in the same allocation)
@@ -764,6 +781,7 @@ StepArgs Solver::baseStepArgs(bool withPulse, bool record) const {
     a.bandRows = ceilDiv(geo_.ntx, 8);
     a.tileOrder = opt_.tileOrder;
     a.patchStrip = opt_.patchStrip;
+    a.patchTrace = patchTrace_;
     a.packed = opt_.packed ? 1 : 0;
     a.withPulse = withPulse ? 1 : 0;
     a.record = record ? 1 : 0;

@@ -246,6 +246,7 @@ private:
     // row-streaming air segments (pv_seg.h): rebuilt for every run (they avoid the tiles around the listener)
     bool usePatch_ = false;    // air tiles go through the persistent patch kernel (pv_patch.h)
     int patchBlocks_ = 0;      // its grid: one workgroup per CU, a multiple of 8
+    long long* patchTrace_ = nullptr;  // development aid (PV_PATCH_TRACE)
     bool useSeg_ = false;      // this solver's configuration and options allow them
     bool segActive_ = false;   // the run being enqueued uses them
     int segWMax_ = 0;          // tile columns a segment can span

@@ -1,7 +1,7 @@
 #!/bin/bash
 # runs ON THE GPU BOX: HBM-side bytes per launch of the patch kernel / the tile kernel (separate --pmc passes)
 cd /tmp && export TMPDIR=/tmp
-for cfg in "1 4096 3" "1 4096 1" "1 4096 2" "1 4096 5" "0 4096 3"; do
+for cfg in "1 4096 3" "0 4096 3"; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pp; timeout 120 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pp -o p -- python /root/repo/tools/gpu_patch_prof.py $cfg > /tmp/p.log 2>&1 </dev/null
     python3 - "$cfg" $c <<'PY'
