@@ -267,6 +267,8 @@ PVA_EXPORT int PvAmdSetOutputQueries(PvAmdSolver* s, const float* xyz, int n);
 PVA_EXPORT int PvAmdGetQueriedOutputs(PvAmdSolver* s, PlaneverbOutput* out, int n);
 /* Whole result map: res8 = gx*gy*8 floats in AnalyzerResult order (Analyzer.h:13-21), delay = gx*gy */
 PVA_EXPORT int PvAmdCopyResults(PvAmdSolver* s, float* res8, float* delay);
+/* the same for the block of result cells [r0, r0 + nr) x [c0, c0 + nc): nr x nc records / onsets, row-major (either may be NULL) */
+PVA_EXPORT int PvAmdCopyResultsBlock(PvAmdSolver* s, int r0, int c0, int nr, int nc, float* res8, float* delay);
 /* Planeverb::GetImpulseResponse (FDTD.cpp:60-70): T x {pr, vx, vy} at array cell (cx, cy) */
 PVA_EXPORT int PvAmdGetImpulseResponse(PvAmdSolver* s, int cx, int cy, float* out3T);
 /* the same as T reference Cells (pr, vx, vy + the cell's b / by), the layout Planeverb::GetImpulseResponse hands out */

@@ -151,6 +151,7 @@ SYMBOLS = {
     "PvAmdSetOutputQueries": (C.c_int, [_vp, _fp, C.c_int]),
     "PvAmdGetQueriedOutputs": (C.c_int, [_vp, C.POINTER(PlaneverbOutput), C.c_int]),
     "PvAmdCopyResults": (C.c_int, [_vp, _fp, _fp]),
+    "PvAmdCopyResultsBlock": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "PvAmdGetImpulseResponse": (C.c_int, [_vp, C.c_int, C.c_int, _fp]),
     "PvAmdGetImpulseResponseCells": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(PlaneverbCell)]),
     "PvAmdCopyFields": (C.c_int, [_vp, _fp, _fp, _fp]),
@@ -682,6 +683,13 @@ class Solver:
         res = np.empty((self.gx, self.gy, 8), np.float32)
         delay = np.empty((self.gx, self.gy), np.float32)
         _check(lib().PvAmdCopyResults(self._h, _f(res), _f(delay)))
+        return res, delay
+
+    def results_block(self, r0, c0, nr, nc):
+        """(records [nr, nc, 8], onsets [nr, nc]) of result cells [r0, r0 + nr) x [c0, c0 + nc)"""
+        res = np.empty((nr, nc, 8), np.float32)
+        delay = np.empty((nr, nc), np.float32)
+        _check(lib().PvAmdCopyResultsBlock(self._h, int(r0), int(c0), int(nr), int(nc), _f(res), _f(delay)))
         return res, delay
 
     def impulse_response(self, cx, cy):

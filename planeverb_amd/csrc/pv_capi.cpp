@@ -638,6 +638,11 @@ int PvAmdCopyResults(PvAmdSolver* h, float* res8, float* delay) {
     return ret(h, h->g ? h->g->copyResults(res8, delay) : h->s->copyResults(res8, delay));
 }
 
+int PvAmdCopyResultsBlock(PvAmdSolver* h, int r0, int c0, int nr, int nc, float* res8, float* delay) {
+    if (!wholeGrid(h) || !ensure(h)) return -1;
+    return ret(h, h->s->copyResultsBlock(r0, c0, nr, nc, res8, delay));
+}
+
 int PvAmdGetImpulseResponse(PvAmdSolver* h, int cx, int cy, float* out3T) {
     if (!out3T || !ensure(h, true)) return -1;
     return ret(h, h->g ? h->g->impulseResponse(cx, cy, out3T) : h->s->impulseResponse(cx, cy, out3T));

@@ -1390,6 +1390,26 @@ bool Solver::copyResults(float* res8, float* delay) {
     return hipOk(hipStreamSynchronize(stream_), "results sync");
 }
 
+bool Solver::copyResultsBlock(int r0, int c0, int nr, int nc, float* res8, float* delay) {
+    if (r0 < 0 || c0 < 0 || nr < 1 || nc < 1 || r0 + nr > g_.gx || c0 + nc > g_.gy) return fail("result block outside the map");
+    if (isSlab()) return fail("copyResultsBlock is not available on a slab");
+    if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
+    const size_t cells = (size_t)nr * nc;
+    if (res8) {
+        float* tmp = nullptr;
+        if (!hipOk(hipMalloc((void**)&tmp, cells * 32), "hipMalloc result block")) return false;
+        launchPackWindow(res_, (long long)g_.gx * g_.gy, g_.gy, r0, c0, nr, nc, tmp, stream_);
+        const bool ok = hipOk(hipMemcpyAsync(res8, tmp, cells * 32, hipMemcpyDeviceToHost, stream_), "block copy") &&
+                        hipOk(hipStreamSynchronize(stream_), "block sync");
+        hipFree(tmp);
+        if (!ok) return false;
+    }
+    if (delay && !hipOk(hipMemcpy2DAsync(delay, (size_t)nc * 4, delay_ + (size_t)r0 * g_.gy + c0, (size_t)g_.gy * 4,
+                                          (size_t)nc * 4, (size_t)nr, hipMemcpyDeviceToHost, stream_), "delay block copy"))
+        return false;
+    return hipOk(hipStreamSynchronize(stream_), "block sync");
+}
+
 bool Solver::copyResultsAsync(float* res8Host) {
     const size_t n = (size_t)g_.gx * g_.gy;
     if (!packResults()) return false;

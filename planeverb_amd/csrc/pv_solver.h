@@ -113,6 +113,8 @@ public:
     bool setOutputQueries(const float* xyz, int n);
     bool queriedOutputs(float* out8n, unsigned char* valid, int n);
     bool copyResults(float* res8, float* delay);
+    // the block [r0, r0 + nr) x [c0, c0 + nc) of the result map (AoS records) and of the onset map, row-major nr x nc
+    bool copyResultsBlock(int r0, int c0, int nr, int nc, float* res8, float* delay);
     // device -> caller-provided (pinned) host buffers, asynchronously on the solver's stream
     bool copyResultsAsync(float* res8Host);
     // The block of the result map the LAST run could have changed: the history window, clipped to the map (everything

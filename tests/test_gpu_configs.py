@@ -93,34 +93,43 @@ def test_config3_bigroom_2048(pvlib):
             assert same_bits(s.impulse_response(cx, cy), ir).all(), "IR at %d,%d" % (cx, cy)
 
 
-def test_config5_open_8192_eight_listeners(pvlib, oracle):
-    """BASELINE config 5: 8 of the 64 seeded listener cells (the first 8 of SURVEY.md 8d's list, which are the runs
-    bench.py --open-field makes first).  Pressure history, onset map and ALL EIGHT result members of the 141 x 141
-    cells around the listener -- which hold both emitters, listener + (16, 0) and + (0, 16) cells -- bit for bit."""
+def test_config5_open_8192_all_64_listeners(pvlib, oracle):
+    """BASELINE config 5: ALL 64 seeded listener cells of SURVEY.md 8d.  For every one: onset map and ALL EIGHT result members
+    of the 141 x 141 cells around the listener -- which hold both emitters, listener + (16, 0) and + (0, 16) cells -- bit for
+    bit against the pinned oracle's window analysis, and the two emitter records against the committed vectors
+    (tests/golden/g8192_open_cfg5.npz, what bench.py --open-field --grid 8192 verifies its timed runs with); for the first 8
+    (the runs that bench makes first) also four planes of the pressure history."""
     from test_oracle_golden import OpenFieldWindowOracle
     w = OpenFieldWindowOracle(oracle)
     c, R = w.c, w.R
     cells = np.random.default_rng(0).integers(1024, 7168, size=(64, 2))
+    want = golden("g8192_open_cfg5")["emitter_out"]
+    assert want.shape == (64, 2, 8)
     with pvlib.Solver(mode_a_size(8192), mode_a_size(8192), 275) as s:
         assert (s.gx, s.gy, s.T) == (8192, 8192, 435)
-        for lx, ly in cells[:8]:
+        for k, (lx, ly) in enumerate(cells):
             lx, ly = int(lx), int(ly)
             L = w.listener_metres((lx, ly))
             E = [(L[0] + 16 * float(DX), 0.0, L[2]), (L[0], 0.0, L[2] + 16 * float(DX))]
             s.set_output_queries(E)
             s.run(L)
             ores, odelay = w.analyze((lx, ly), np.float32(s.efree))
-            for t in (0, 3, 150, 434):
-                plane = s.history_plane(t)
-                assert same_bits(plane[lx - R:lx + R + 1, ly - R:ly + R + 1],
-                                 w.hist_pr[t][c - R:c + R + 1, c - R:c + R + 1]).all(), t
-            res, delay = s.results()
-            sub = (slice(lx - R, lx + R + 1), slice(ly - R, ly + R + 1))
+            if k < 8:
+                for t in (0, 3, 150, 434):
+                    plane = s.history_plane(t)
+                    assert same_bits(plane[lx - R:lx + R + 1, ly - R:ly + R + 1],
+                                     w.hist_pr[t][c - R:c + R + 1, c - R:c + R + 1]).all(), t
+            res, delay = s.results_block(lx - R, ly - R, 2 * R + 1, 2 * R + 1)
+            if k == 0:  # the block read-back against the whole-map one
+                fr, fd = s.results()
+                assert np.array_equal(fr[lx - R:lx + R + 1, ly - R:ly + R + 1].view(np.uint32), res.view(np.uint32))
+                assert np.array_equal(fd[lx - R:lx + R + 1, ly - R:ly + R + 1].view(np.uint32), delay.view(np.uint32))
             osub = (slice(c - R, c + R + 1), slice(c - R, c + R + 1))
-            n = compare_maps(res[sub], delay[sub], ores[osub], odelay[osub], 435, 1443, "listener cell %d,%d" % (lx, ly))
+            n = compare_maps(res, delay, ores[osub], odelay[osub], 435, 1443, "listener cell %d,%d" % (lx, ly))
             assert n > 15000
             q = s.queried_outputs()
             assert same_bits(q[0], ores[c + 16, c]).all() and same_bits(q[1], ores[c, c + 16]).all()
+            assert same_bits(q, want[k]).all(), "run %d differs from the committed config-5 vectors" % k
     w.close()
 
 

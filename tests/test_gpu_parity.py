@@ -667,6 +667,38 @@ def test_streaming_equals_full_history_1024(pvlib):
             assert same_bits(st.get_output(e).as_array(), full.get_output(e).as_array()).all()
 
 
+def test_streaming_equals_full_history_2048_long(pvlib):
+    """The regime the sparse-emitter mode lives in (parity-breadth note): fields non-zero everywhere and a response
+    far longer than the ring.  2048^2 with PVA_OPT_NUM_STEPS = 2000 (31 ring passes; the full-history solver keeps all 2000
+    planes of the whole grid, 33.6 GB), scattered reflectors around an off-centre listener, three emitters: every cell's
+    onset, occlusion, lowpass and both directions, and wet gain / RT60 at the emitters, bit for bit."""
+    dx = np.float32(343.21) / np.float32(275) / np.float32(3.5)
+    size = float((2048 + 0.5) * dx)
+    L = (300.0, 0.0, 330.0)
+    E = [(310.0, 0.0, 338.0), (420.0, 0.0, 250.0), (150.3, 0.0, 600.9)]
+    walls = [[330.0, 340.0, 4.0, 60.0, 0.9], [280.0, 300.0, 80.0, 3.0, 0.7], [500.0, 500.0, 30.0, 30.0, 0.95],
+             [120.0, 580.0, 50.0, 5.0, 0.5], [360.0, 200.0, 6.0, 90.0, 0.85]]
+    T = 2000
+    with pvlib.Solver(size, size, 275, num_steps=T) as full, \
+            pvlib.Solver(size, size, 275, num_steps=T, streaming_analysis=1) as st:
+        for s in (full, st):
+            for wbox in walls:
+                s.add_geometry(wbox)
+        st.set_emitters(E)
+        full.run(L)
+        st.run(L)
+        pr, vx, vy = full.fields()
+        assert (pr != 0).mean() > 0.9, "the field is meant to be non-zero (almost) everywhere by the end"
+        for a, b in zip((pr, vx, vy), st.fields()):
+            assert same_bits(a, b).all()
+        rf, df = full.results()
+        rs, ds = st.results()
+        cells = [pvlib.host_cells(size, size, 275, e[0], e[2])[1] for e in E]
+        check_streaming_against(rs, ds, rf, df, T, 1443, cells, "2048 long")
+        for e in E:
+            assert same_bits(st.get_output(e).as_array(), full.get_output(e).as_array()).all()
+
+
 @pytest.mark.parametrize("size,res,scene", [(10.0, 500, "ExampleProject.pv"), (10.0, 750, "SmallRoom.pv"),
                                             (3.0, 275, None), (6.5, 375, "SmallRoom.pv")])
 def test_resolution_presets_and_tiny_grids_vs_oracle(pvlib, oracle, size, res, scene):
