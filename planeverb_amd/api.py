@@ -41,6 +41,7 @@ PVA_OPT_EDGE_TILES = 15
 PVA_OPT_ROW_BANDS = 16
 PVA_OPT_PATCH_KERNEL = 17
 PVA_OPT_PATCH_STRIP = 18
+PVA_OPT_LAZY_FAR_CELLS = 19
 
 
 class PlaneverbOutput(C.Structure):
@@ -495,6 +496,20 @@ class SlabRank:
         assert buf.size == self.halo_floats
         _check(lib().PvAmdSlabImportHalo(self._h, int(side), _f(buf)))
 
+    # the same four transfers with raw addresses of buffers that may live on the slab's device (torch tensors: .data_ptr()):
+    # what an RCCL transport uses, nothing is staged through the host (dist_slabs.TorchTransport)
+    def export_halo_to(self, side, ptr):
+        _check(lib().PvAmdSlabExportHalo(self._h, int(side), C.cast(C.c_void_p(int(ptr)), _fp)))
+
+    def import_halo_from(self, side, ptr):
+        _check(lib().PvAmdSlabImportHalo(self._h, int(side), C.cast(C.c_void_p(int(ptr)), _fp)))
+
+    def export_edge_history_to(self, ptr):
+        _check(lib().PvAmdSlabExportEdgeHistory(self._h, C.cast(C.c_void_p(int(ptr)), _fp)))
+
+    def import_above_history_from(self, ptr):
+        _check(lib().PvAmdSlabImportAboveHistory(self._h, C.cast(C.c_void_p(int(ptr)), _fp)))
+
     def export_edge_history(self):
         out = np.empty(self.history_floats, np.float32)
         _check(lib().PvAmdSlabExportEdgeHistory(self._h, _f(out)))
@@ -591,7 +606,8 @@ class Solver:
                 "packed_math": PVA_OPT_PACKED_MATH, "streaming_analysis": PVA_OPT_STREAMING_ANALYSIS,
                 "stream_rows": PVA_OPT_STREAM_ROWS, "merged_launch": PVA_OPT_MERGED_LAUNCH,
                 "edge_tiles": PVA_OPT_EDGE_TILES, "row_bands": PVA_OPT_ROW_BANDS,
-                "patch_kernel": PVA_OPT_PATCH_KERNEL, "patch_strip": PVA_OPT_PATCH_STRIP}
+                "patch_kernel": PVA_OPT_PATCH_KERNEL, "patch_strip": PVA_OPT_PATCH_STRIP,
+                "lazy_far_cells": PVA_OPT_LAZY_FAR_CELLS}
         for k, v in options.items():
             _check(lib().PvAmdSetOption(self._h, keys[k], int(v)))
         self.info = PvAmdInfo()

@@ -161,6 +161,14 @@ struct SmallArgs {
     int rxi, wi;  // tile interior (the history planes are tile-major: histOffset)
 };
 
+// where the far cells of the last run begin, and what their listener direction is (output gathers, pv_far_dir_kernel)
+struct FarInfo {
+    int on;              // 0: every cell's direction is in the result planes
+    int r0, c0, nr, nc;  // the last run's window block of the result map: directions inside it are in the planes
+    int gy;
+    float lx, lz, dx;
+};
+
 struct AnalyzeArgs {
     const float* hist;
     const uint16_t* codes;
@@ -195,6 +203,12 @@ struct AnalyzeArgs {
     // neighbouring slab as a dense [T][histPitch] array (window columns; zeros where nothing was recorded)
     int x0;
     const float* histAbove;
+    // Far cells (cells outside the history window: no onset, listener direction = unit vector listener -> cell) are not
+    // rewritten for the whole map on every run: lazyFar = 1 resets only the cells of the PREVIOUS run's window block
+    // [prevR0, +prevNR) x [prevC0, +prevNC) and of this run's (pv_far_frame_kernel); the direction of the other far cells
+    // is materialised when a whole-map reader asks (pv_far_dir_kernel) or computed in closed form by the output gathers.
+    int lazyFar;
+    int prevR0, prevC0, prevNR, prevNC;
     // streaming analysis (sparse-emitter mode): the history is a ring of `ring` planes and the forward sums of
     // every cell are carried in per-cell state planes between passes
     int ring;            // 0 = full history (plane index = t), else plane index = t % ring

@@ -22,6 +22,7 @@
 //     v - C*(p_i - p_n) stays a separate multiply and subtract (bit-identical fields).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
 #include <cstdlib>
 #include <climits>
@@ -2627,6 +2628,63 @@ __global__ __launch_bounds__(256) void pv_far_cells_kernel(const AnalyzeArgs a) 
     storeDirection(a, index, index);
 }
 
+// The far-cell pass restricted to where something can have changed: blockIdx.z = 0 the previous run's window block,
+// 1 this run's.  Every cell of both gets "no onset" and the default direction; the kernels that follow overwrite this
+// run's reached cells.  All other cells of the map keep delay = FLT_MAX from the solver's creation / their own last reset,
+// and their direction is made on demand (pv_far_dir_kernel, farDirectionOf).
+__global__ __launch_bounds__(256) void pv_far_frame_kernel(const AnalyzeArgs a) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && a.tileFirst) countActiveCells(a);
+    const DynParams dyn = *a.dyn;
+    int r0, c0, nr, nc;
+    if (blockIdx.z == 0) {
+        r0 = a.prevR0, c0 = a.prevC0, nr = a.prevNR, nc = a.prevNC;
+    } else {
+        r0 = dyn.histRow0 - a.G, c0 = dyn.histCol0 - a.G;
+        nr = min(a.winRows, a.gx - r0), nc = min(a.winCols, a.gy - c0);
+    }
+    const int wc = blockIdx.x * blockDim.x + threadIdx.x, wr = blockIdx.y;
+    if (wc >= nc || wr >= nr) return;
+    const int index = (r0 + wr) * a.gy + (c0 + wc);
+    a.delay[index] = FLT_MAX;
+    storeDirection(a, index, index);
+}
+
+// closed-form listener direction of a far cell (what storeDirection(a, index, index) writes)
+__device__ __forceinline__ void farDirectionOf(const FarInfo& f, long long cell, float* ox, float* oy) {
+    const int r = (int)(cell / f.gy), c = (int)(cell - (long long)r * f.gy);
+    float x = (float)r * f.dx - f.lx, y = (float)c * f.dx - f.lz;
+    float len = (x * x) + (y * y);
+    if (len != 0.f) {
+        len = sqrtf(len);
+        x /= len;
+        y /= len;
+    }
+    *ox = x;
+    *oy = y;
+}
+__device__ __forceinline__ bool isFarCell(const FarInfo& f, long long cell) {
+    if (!f.on) return false;
+    const int r = (int)(cell / f.gy), c = (int)(cell - (long long)r * f.gy);
+    return r < f.r0 || r >= f.r0 + f.nr || c < f.c0 || c >= f.c0 + f.nc;
+}
+
+// materialise the direction planes of the far cells (whole-map read-backs)
+__global__ __launch_bounds__(256) void pv_far_dir_kernel(float* __restrict__ dirX, float* __restrict__ dirY, long long n,
+                                                         const FarInfo f) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !isFarCell(f, i)) return;
+    float ox, oy;
+    farDirectionOf(f, i, &ox, &oy);
+    dirX[i] = ox;
+    dirY[i] = oy;
+}
+
+void launchFarDirections(float* res, long long n, const FarInfo& f, hipStream_t stream) {
+    hipLaunchKernelGGL(pv_far_dir_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, res + 4 * n, res + 5 * n, n, f);
+}
+
+void launchFillDelay(float* delay, long long n, hipStream_t stream);
+
 __global__ __launch_bounds__(256) void pv_direction_kernel(const AnalyzeArgs a) {
     const DynParams dyn = *a.dyn;
     int X, Y;
@@ -2799,29 +2857,44 @@ void launchPackWindow(const float* res, long long n, int gy, int r0, int c0, int
 }
 
 // one cell of the result map -> 8 floats in pinned host memory (Analyzer::GetResponseResult, Analyzer.cpp:106-116)
-__global__ void pv_gather_output_kernel(const float* __restrict__ res, long long n, long long cell, float* out8) {
-    if (threadIdx.x < 8) out8[threadIdx.x] = res[threadIdx.x * n + cell];
+__global__ void pv_gather_output_kernel(const float* __restrict__ res, long long n, long long cell, float* out8,
+                                        const FarInfo f) {
+    if (threadIdx.x < 8) {
+        float v = res[threadIdx.x * n + cell];
+        if ((threadIdx.x == 4 || threadIdx.x == 5) && isFarCell(f, cell)) {  // a far cell: its direction is not in the planes
+            float ox, oy;
+            farDirectionOf(f, cell, &ox, &oy);
+            v = threadIdx.x == 4 ? ox : oy;
+        }
+        out8[threadIdx.x] = v;
+    }
 }
 
-void launchGatherOutput(const float* res, long long n, long long cell, float* out8Host, hipStream_t stream) {
-    hipLaunchKernelGGL(pv_gather_output_kernel, dim3(1), dim3(64), 0, stream, res, n, cell, out8Host);
+void launchGatherOutput(const float* res, long long n, long long cell, float* out8Host, const FarInfo& f, hipStream_t stream) {
+    hipLaunchKernelGGL(pv_gather_output_kernel, dim3(1), dim3(64), 0, stream, res, n, cell, out8Host, f);
 }
 
 // the registered output queries of a run (PvAmdSetOutputQueries): nq result cells -> nq x 8 floats in pinned host
 // memory, enqueued behind the analysis so that the caller's one stream sync also delivers the outputs.
 // cells[] lives in pinned host memory too (cell < 0: position outside the result map, left to the host's sentinel)
 __global__ void pv_gather_queries_kernel(const float* __restrict__ res, long long n, const long long* cells, int nq,
-                                         float* out) {
+                                         float* out, const FarInfo f) {
     const int q = threadIdx.x >> 3, k = threadIdx.x & 7;
     if (q < nq) {
         const long long c = cells[q];
-        out[q * 8 + k] = c >= 0 ? res[k * n + c] : 0.f;
+        float v = c >= 0 ? res[k * n + c] : 0.f;
+        if (c >= 0 && (k == 4 || k == 5) && isFarCell(f, c)) {
+            float ox, oy;
+            farDirectionOf(f, c, &ox, &oy);
+            v = k == 4 ? ox : oy;
+        }
+        out[q * 8 + k] = v;
     }
 }
 
-void launchGatherQueries(const float* res, long long n, const long long* cellsHost, int nq, float* outHost,
+void launchGatherQueries(const float* res, long long n, const long long* cellsHost, int nq, float* outHost, const FarInfo& f,
                          hipStream_t stream) {
-    hipLaunchKernelGGL(pv_gather_queries_kernel, dim3(1), dim3(512), 0, stream, res, n, cellsHost, nq, outHost);
+    hipLaunchKernelGGL(pv_gather_queries_kernel, dim3(1), dim3(512), 0, stream, res, n, cellsHost, nq, outHost, f);
 }
 
 void launchPackResults(const float* res, long long n, float* res8, hipStream_t stream) {
@@ -2868,6 +2941,36 @@ void launchCopyBlock(const float* src, long long sstride, int spitch, int sr0, i
                        dstPlanesDev);
 }
 
+// Slab decomposition (pv_slabs.cpp): after a K-step launch a slab PUSHES the K rows next to each of its boundaries into the
+// neighbour's guard band -- one launch for all six blocks (3 planes x 2 directions) instead of six hipMemcpyAsync on the
+// receiver's stream (each a 5 us copy kernel of its own: 20-85 us per sweep in round 2).  Every block is K whole padded
+// rows = a contiguous run of floats (a multiple of 64); the destination may live on another device (peer access is
+// enabled by the group: plain stores over xGMI).
+struct HaloPushArgs {
+    const float* src[6];
+    float* dst[6];
+    long long n;  // floats per block
+};
+__global__ __launch_bounds__(256) void pv_halo_push_kernel(const HaloPushArgs h) {
+    const int b = blockIdx.y;
+    if (!h.dst[b]) return;
+    const float4* s = reinterpret_cast<const float4*>(h.src[b]);
+    float4* d = reinterpret_cast<float4*>(h.dst[b]);
+    const long long n4 = h.n >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) d[i] = s[i];
+}
+
+void launchHaloPush(const float* const src[6], float* const dst[6], long long n, hipStream_t stream) {
+    HaloPushArgs h;
+    for (int i = 0; i < 6; ++i) {
+        h.src[i] = src[i];
+        h.dst[i] = dst[i];
+    }
+    h.n = n;
+    const unsigned bx = (unsigned)std::min<long long>(64, (n / 4 + 255) / 256);
+    hipLaunchKernelGGL(pv_halo_push_kernel, dim3(bx, 6), dim3(256), 0, stream, h);
+}
+
 // far cells of the whole map (delay = FLT_MAX, default listener direction): the first analysis launch
 void launchFarCells(const AnalyzeArgs& a, hipStream_t stream) {
     const int n = a.gx * a.gy;
@@ -2890,9 +2993,19 @@ void launchAnalysisDirection(const AnalyzeArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL(pv_direction_kernel, grid, dim3(256), 0, stream, a);
 }
 
+void launchFillDelay(float* delay, long long n, hipStream_t stream) {
+    hipLaunchKernelGGL(pv_fill_delay_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, delay, (int)n);
+}
+
 void launchAnalysis(const AnalyzeArgs& a, hipStream_t stream) {
     const int n = a.gx * a.gy;
-    hipLaunchKernelGGL(pv_far_cells_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a);
+    if (a.lazyFar) {
+        const int nr = max(a.prevNR, min(a.winRows, a.gx)), nc = max(a.prevNC, min(a.winCols, a.gy));
+        hipLaunchKernelGGL(pv_far_frame_kernel, dim3((unsigned)((max(nc, 1) + 255) / 256), (unsigned)max(nr, 1), 2), dim3(256), 0,
+                           stream, a);
+    } else {
+        hipLaunchKernelGGL(pv_far_cells_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a);
+    }
     const dim3 grid = analysisWindowGrid(a);
     hipLaunchKernelGGL(pv_encode_kernel, grid, dim3(256), 0, stream, a);
     // wet gain + decay time of a room's cells (an open field's were done inside pv_encode_kernel: its blocks leave at once)

@@ -52,13 +52,19 @@ void launchAnalysis(const AnalyzeArgs& a, hipStream_t stream);
 void launchFarCells(const AnalyzeArgs& a, hipStream_t stream);
 void launchAnalysisCells(const AnalyzeArgs& a, hipStream_t stream);
 void launchAnalysisDirection(const AnalyzeArgs& a, hipStream_t stream);
+// slab halos: src[i] -> dst[i] for up to six blocks of n floats (n % 4 == 0, 16-byte aligned); dst[i] = NULL skips a block
+void launchHaloPush(const float* const src[6], float* const dst[6], long long n, hipStream_t stream);
 void launchHistRow(const AnalyzeArgs& a, int X, float* outTxPitch, hipStream_t stream);
 void launchCopyBlock(const float* src, long long sstride, int spitch, int sr0, int sc0, float* dst, long long dstride,
                      int dpitch, int dr0, int dc0, int nr, int nc, int nplanes, const int* srcPlanesDev,
                      const int* dstPlanesDev, hipStream_t stream);  // plane maps: NULL = identity
-void launchGatherQueries(const float* res, long long n, const long long* cellsHost, int nq, float* outHost,
+// (far: where the last run's far cells begin -- their listener direction is computed, not read: pv_device.h FarInfo)
+void launchGatherQueries(const float* res, long long n, const long long* cellsHost, int nq, float* outHost, const FarInfo& far,
                          hipStream_t stream);  // nq <= 64
-void launchGatherOutput(const float* res, long long n, long long cell, float* out8Host, hipStream_t stream);
+void launchGatherOutput(const float* res, long long n, long long cell, float* out8Host, const FarInfo& far, hipStream_t stream);
+// direction planes of the far cells, for whole-map read-backs; delay plane = "no onset" everywhere (solver creation)
+void launchFarDirections(float* res, long long n, const FarInfo& far, hipStream_t stream);
+void launchFillDelay(float* delay, long long n, hipStream_t stream);
 void launchPackResults(const float* res, long long n, float* res8, hipStream_t stream);
 void launchPackWindow(const float* res, long long n, int gy, int r0, int c0, int nr, int nc, float* out8,
                       hipStream_t stream);

@@ -68,7 +68,10 @@ bool SlabGroup::init(const GridSpec& spec, const std::vector<int>& devices, cons
             if (t < 0 || t >= S || devices_[(size_t)t] == devices_[(size_t)s]) continue;
             hipSetDevice(devices_[(size_t)s]);
             const hipError_t e = hipDeviceEnablePeerAccess(devices_[(size_t)t], 0);
-            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();  // copies then stage
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+                (void)hipGetLastError();  // copies then stage
+                if (t != 0 || t == s - 1 || t == s + 1) pushHalos_ = false;  // no peer stores into that neighbour's guard band
+            }
         }
     rootDevice_ = devices_[0];
     if (!hipOk(hipSetDevice(rootDevice_), "hipSetDevice")) return false;
@@ -225,43 +228,90 @@ bool SlabGroup::run(float lx, float ly, float lz) {
         if (!hipOk(hipMemcpyAsync(dynDev_, dynHost_, sizeof(DynParams), hipMemcpyHostToDevice, rootStream_), "dyn upload"))
             return false;
     }
-    // T steps, K per launch: every slab advances its rows, then takes its neighbours' K boundary rows of the set just
-    // written into its guard band.  Launch li + 1 of slab s is ordered behind launch li of s - 1, s, s + 1 only.
     const int nl = ceilDiv(T_, K_);
     const size_t haloFloats = (size_t)K_ * slabs_[0]->geo_.pitch;
-    for (int li = 0; li < nl; ++li) {
-        const int k = std::min(K_, T_ - li * K_);
-        for (int s = 0; s < S; ++s) {
-            Solver& v = *slabs_[(size_t)s];
-            hipSetDevice(v.device_);
-            if (!v.enqueueSteps(li * K_, k, true, true, li == 0)) return slabFailed(s);
-            hipEventRecord(stepEv_[(size_t)2 * s + (li & 1)], v.stream_);
-        }
-        for (int s = 0; s < S; ++s) {
-            Solver& v = *slabs_[(size_t)s];
-            hipSetDevice(v.device_);
-            const int set = v.cur_;  // the set launch li wrote (all slabs toggle together)
-            float* mine[3] = {v.pr_[set], v.vx_[set], v.vy_[set]};
-            const size_t G = (size_t)v.geo_.G, pitch = (size_t)v.geo_.pitch;
-            const size_t myRows = (size_t)v.geo_.ntx * rxi_;
-            if (s > 0) {  // rows just above my first row = the upper neighbour's last K rows
-                const Solver& u = *slabs_[(size_t)s - 1];
-                hipStreamWaitEvent(v.stream_, stepEv_[(size_t)2 * (s - 1) + (li & 1)], 0);
-                const float* theirs[3] = {u.pr_[set], u.vx_[set], u.vy_[set]};
-                const size_t uRows = (size_t)u.geo_.ntx * rxi_;
-                for (int f = 0; f < 3; ++f)
-                    if (!hipOk(hipMemcpyAsync(mine[f] + (G - K_) * pitch, theirs[f] + (G + uRows - K_) * pitch,
-                                              haloFloats * 4, hipMemcpyDefault, v.stream_), "halo copy"))
-                        return false;
+    if (pushHalos_) {
+        // T steps, K per launch: every slab advances its rows, then PUSHES the K rows next to each boundary into its neighbours'
+        // guard bands (one small launch behind its step launch: pv_halo_push_kernel; peer stores when the neighbour is on
+        // another device).  Launch li + 1 of slab s is ordered behind [step + push] li of slabs s - 1, s, s + 1 only: one event
+        // per slab and launch, nothing waits for the whole grid.  (Hazards: a push writes guard rows of the set the neighbour's
+        // launch li did not touch and its launch li + 1 will read -- after the event; the neighbour's launch li, which READ that
+        // set's guard rows of the previous round, finished before this slab's launch li started.)
+        for (int li = 0; li < nl; ++li) {
+            const int k = std::min(K_, T_ - li * K_);
+            for (int s = 0; s < S; ++s) {
+                Solver& v = *slabs_[(size_t)s];
+                hipSetDevice(v.device_);
+                if (li > 0) {
+                    if (s > 0) hipStreamWaitEvent(v.stream_, stepEv_[(size_t)2 * (s - 1) + ((li - 1) & 1)], 0);
+                    if (s + 1 < S) hipStreamWaitEvent(v.stream_, stepEv_[(size_t)2 * (s + 1) + ((li - 1) & 1)], 0);
+                }
+                if (!v.enqueueSteps(li * K_, k, true, true, li == 0)) return slabFailed(s);
+                const int set = v.cur_;  // the set launch li wrote (enqueueSteps has toggled cur_)
+                const size_t G = (size_t)v.geo_.G, pitch = (size_t)v.geo_.pitch;
+                const size_t myRows = (size_t)v.geo_.ntx * rxi_;
+                const float* mine[3] = {v.pr_[set], v.vx_[set], v.vy_[set]};
+                const float* src[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+                float* dst[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+                if (s > 0) {  // my first K rows -> the rows just below the upper neighbour's last row
+                    Solver& u = *slabs_[(size_t)s - 1];
+                    float* theirs[3] = {u.pr_[set], u.vx_[set], u.vy_[set]};
+                    const size_t uRows = (size_t)u.geo_.ntx * rxi_;
+                    for (int f = 0; f < 3; ++f) {
+                        src[f] = mine[f] + G * pitch;
+                        dst[f] = theirs[f] + (G + uRows) * pitch;
+                    }
+                }
+                if (s + 1 < S) {  // my last K rows -> the rows just above the lower neighbour's first row
+                    Solver& d = *slabs_[(size_t)s + 1];
+                    float* theirs[3] = {d.pr_[set], d.vx_[set], d.vy_[set]};
+                    for (int f = 0; f < 3; ++f) {
+                        src[3 + f] = mine[f] + (G + myRows - K_) * pitch;
+                        dst[3 + f] = theirs[f] + (G - K_) * pitch;
+                    }
+                }
+                launchHaloPush(src, dst, (long long)haloFloats, v.stream_);
+                hipEventRecord(stepEv_[(size_t)2 * s + (li & 1)], v.stream_);
             }
-            if (s + 1 < S) {  // rows just below my last row = the lower neighbour's first K rows
-                const Solver& d = *slabs_[(size_t)s + 1];
-                hipStreamWaitEvent(v.stream_, stepEv_[(size_t)2 * (s + 1) + (li & 1)], 0);
-                const float* theirs[3] = {d.pr_[set], d.vx_[set], d.vy_[set]};
-                for (int f = 0; f < 3; ++f)
-                    if (!hipOk(hipMemcpyAsync(mine[f] + (G + myRows) * pitch, theirs[f] + G * pitch, haloFloats * 4,
-                                              hipMemcpyDefault, v.stream_), "halo copy"))
-                        return false;
+        }
+    } else {
+        // (no peer access between two adjacent slabs' devices: the receiver pulls with hipMemcpyAsync, which stages)
+        // T steps, K per launch: every slab advances its rows, then takes its neighbours' K boundary rows of the set just
+        // written into its guard band.  Launch li + 1 of slab s is ordered behind launch li of s - 1, s, s + 1 only.
+        for (int li = 0; li < nl; ++li) {
+            const int k = std::min(K_, T_ - li * K_);
+            for (int s = 0; s < S; ++s) {
+                Solver& v = *slabs_[(size_t)s];
+                hipSetDevice(v.device_);
+                if (!v.enqueueSteps(li * K_, k, true, true, li == 0)) return slabFailed(s);
+                hipEventRecord(stepEv_[(size_t)2 * s + (li & 1)], v.stream_);
+            }
+            for (int s = 0; s < S; ++s) {
+                Solver& v = *slabs_[(size_t)s];
+                hipSetDevice(v.device_);
+                const int set = v.cur_;  // the set launch li wrote (all slabs toggle together)
+                float* mine[3] = {v.pr_[set], v.vx_[set], v.vy_[set]};
+                const size_t G = (size_t)v.geo_.G, pitch = (size_t)v.geo_.pitch;
+                const size_t myRows = (size_t)v.geo_.ntx * rxi_;
+                if (s > 0) {  // rows just above my first row = the upper neighbour's last K rows
+                    const Solver& u = *slabs_[(size_t)s - 1];
+                    hipStreamWaitEvent(v.stream_, stepEv_[(size_t)2 * (s - 1) + (li & 1)], 0);
+                    const float* theirs[3] = {u.pr_[set], u.vx_[set], u.vy_[set]};
+                    const size_t uRows = (size_t)u.geo_.ntx * rxi_;
+                    for (int f = 0; f < 3; ++f)
+                        if (!hipOk(hipMemcpyAsync(mine[f] + (G - K_) * pitch, theirs[f] + (G + uRows - K_) * pitch,
+                                                  haloFloats * 4, hipMemcpyDefault, v.stream_), "halo copy"))
+                            return false;
+                }
+                if (s + 1 < S) {  // rows just below my last row = the lower neighbour's first K rows
+                    const Solver& d = *slabs_[(size_t)s + 1];
+                    hipStreamWaitEvent(v.stream_, stepEv_[(size_t)2 * (s + 1) + (li & 1)], 0);
+                    const float* theirs[3] = {d.pr_[set], d.vx_[set], d.vy_[set]};
+                    for (int f = 0; f < 3; ++f)
+                        if (!hipOk(hipMemcpyAsync(mine[f] + (G + myRows) * pitch, theirs[f] + G * pitch, haloFloats * 4,
+                                                  hipMemcpyDefault, v.stream_), "halo copy"))
+                            return false;
+                }
             }
         }
     }
@@ -361,7 +411,7 @@ bool SlabGroup::getOutput(float ex, float ey, float ez, float out8[8], bool* val
     *valid = resultCell(g_, ex, ez, &cx, &cy);
     if (!*valid) return true;
     if (!hipOk(hipSetDevice(rootDevice_), "hipSetDevice")) return false;
-    launchGatherOutput(res_, (long long)g_.gx * g_.gy, (long long)cx * g_.gy + cy, outHost_, rootStream_);
+    launchGatherOutput(res_, (long long)g_.gx * g_.gy, (long long)cx * g_.gy + cy, outHost_, FarInfo{}, rootStream_);
     if (!hipOk(hipStreamSynchronize(rootStream_), "output sync")) return false;
     for (int k = 0; k < 8; ++k) out8[k] = outHost_[k];
     return true;
@@ -441,13 +491,15 @@ bool SlabRankOps::launch(Solver& v, int li) {
 
 int SlabRankOps::haloFloats(const Solver& v) { return 3 * v.K_ * v.geo_.pitch; }
 
+// (the `host` buffers of the four transfers below may be host OR device memory -- hipMemcpyDefault: a rank that talks RCCL
+// hands in the device tensors it sends / receives, dist_slabs.TorchTransport)
 bool SlabRankOps::exportHalo(Solver& v, int side, float* host) {
     hipSetDevice(v.device_);
     const size_t pitch = (size_t)v.geo_.pitch, n = (size_t)v.K_ * pitch;
     const size_t row = side == 0 ? (size_t)v.geo_.G : (size_t)v.geo_.G + (size_t)v.geo_.ntx * v.rxi_ - v.K_;
     const float* src[3] = {v.pr_[v.cur_], v.vx_[v.cur_], v.vy_[v.cur_]};
     for (int f = 0; f < 3; ++f)
-        if (!v.hipOk(hipMemcpyAsync(host + f * n, src[f] + row * pitch, n * 4, hipMemcpyDeviceToHost, v.stream_), "halo export"))
+        if (!v.hipOk(hipMemcpyAsync(host + f * n, src[f] + row * pitch, n * 4, hipMemcpyDefault, v.stream_), "halo export"))
             return false;
     return v.hipOk(hipStreamSynchronize(v.stream_), "halo export sync");
 }
@@ -458,7 +510,7 @@ bool SlabRankOps::importHalo(Solver& v, int side, const float* host) {
     const size_t row = side == 0 ? (size_t)v.geo_.G - v.K_ : (size_t)v.geo_.G + (size_t)v.geo_.ntx * v.rxi_;
     float* dst[3] = {v.pr_[v.cur_], v.vx_[v.cur_], v.vy_[v.cur_]};
     for (int f = 0; f < 3; ++f)
-        if (!v.hipOk(hipMemcpyAsync(dst[f] + row * pitch, host + f * n, n * 4, hipMemcpyHostToDevice, v.stream_), "halo import"))
+        if (!v.hipOk(hipMemcpyAsync(dst[f] + row * pitch, host + f * n, n * 4, hipMemcpyDefault, v.stream_), "halo import"))
             return false;
     return v.hipOk(hipStreamSynchronize(v.stream_), "halo import sync");  // (the host buffer may be reused at once)
 }
@@ -469,7 +521,7 @@ bool SlabRankOps::exportEdgeHistory(Solver& v, float* host) {
     if (!v.histEdge_) return v.fail("the last slab has no slab below it");
     hipSetDevice(v.device_);
     launchHistRow(v.analyzeArgs(v.lastLx_, v.lastLz_), v.lNX_ - 1, v.histEdge_, v.stream_);
-    if (!v.hipOk(hipMemcpyAsync(host, v.histEdge_, (size_t)historyFloats(v) * 4, hipMemcpyDeviceToHost, v.stream_), "history export"))
+    if (!v.hipOk(hipMemcpyAsync(host, v.histEdge_, (size_t)historyFloats(v) * 4, hipMemcpyDefault, v.stream_), "history export"))
         return false;
     return v.hipOk(hipStreamSynchronize(v.stream_), "history export sync");
 }
@@ -477,7 +529,7 @@ bool SlabRankOps::exportEdgeHistory(Solver& v, float* host) {
 bool SlabRankOps::importAboveHistory(Solver& v, const float* host) {
     if (!v.histAbove_) return v.fail("the first slab has no slab above it");
     hipSetDevice(v.device_);
-    if (!v.hipOk(hipMemcpyAsync(v.histAbove_, host, (size_t)historyFloats(v) * 4, hipMemcpyHostToDevice, v.stream_), "history import"))
+    if (!v.hipOk(hipMemcpyAsync(v.histAbove_, host, (size_t)historyFloats(v) * 4, hipMemcpyDefault, v.stream_), "history import"))
         return false;
     return v.hipOk(hipStreamSynchronize(v.stream_), "history import sync");
 }
@@ -650,7 +702,7 @@ bool SlabRoot::getOutput(float ex, float ey, float ez, float out8[8], bool* vali
     *valid = resultCell(g_, ex, ez, &cx, &cy);
     if (!*valid) return true;
     hipSetDevice(device_);
-    launchGatherOutput(res_, (long long)g_.gx * g_.gy, (long long)cx * g_.gy + cy, outHost_, stream_);
+    launchGatherOutput(res_, (long long)g_.gx * g_.gy, (long long)cx * g_.gy + cy, outHost_, FarInfo{}, stream_);
     if (hipStreamSynchronize(stream_) != hipSuccess) return fail("slab root: output sync failed");
     for (int k = 0; k < 8; ++k) out8[k] = outHost_[k];
     return true;

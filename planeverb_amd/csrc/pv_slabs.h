@@ -68,6 +68,7 @@ private:
     GridSpec g_;
     std::vector<Solver*> slabs_;
     std::vector<int> devices_;
+    bool pushHalos_ = true;  // halos are pushed by pv_halo_push_kernel (peer stores); false: pulled with hipMemcpyAsync
     std::vector<hipEvent_t> stepEv_;   // 2 per slab (launch parity)
     std::vector<hipEvent_t> miscEv_;   // 1 per slab: boundary history ready / cell analysis done
     int K_ = 0, rxi_ = 0, wi_ = 0, T_ = 0;

@@ -193,6 +193,9 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     if (!dalloc(&activeCount_, 1, true)) return false;
     if (!dalloc(&res_, (size_t)std::max(lgx_, 1) * g_.gy * 8, true)) return false;  // zeroed pool: PvContext.cpp:132
     if (!dalloc(&delay_, (size_t)std::max(lgx_, 1) * g_.gy, true)) return false;
+    // far cells lazily: whole grids with a windowed history (a slab group / the streaming mode run their own passes)
+    lazyFar_ = opt_.lazyFar && !isSlab() && !opt_.streaming;
+    if (lazyFar_) launchFillDelay(delay_, (long long)std::max(lgx_, 1) * g_.gy, stream_);  // "no onset", Analyzer.cpp:64-68
     scratchCount_ = std::max<size_t>({(size_t)3 * std::max(T_, g_.T), (size_t)lNX_ * g_.NY * 3,
                                      (size_t)geo_.ntx * rxi_ * geo_.nty * wi_});  // the last: direction scratch
     if (!dalloc(&scratch_, scratchCount_, true)) return false;
@@ -999,6 +1002,11 @@ AnalyzeArgs Solver::analyzeArgs(float lx, float lz) const {
     a.lx = lx;
     a.lz = lz;
     listenerCellRecip(g_, lx, lz, &a.lcx, &a.lcy);
+    a.lazyFar = lazyFar_ ? 1 : 0;
+    a.prevR0 = farWin_.r0;
+    a.prevC0 = farWin_.c0;
+    a.prevNR = farWin_.nr;
+    a.prevNC = farWin_.nc;
     a.ring = opt_.streaming ? ring_ : 0;
     a.sOnset = sOnset_;
     a.sEdry = sState_[0];
@@ -1011,6 +1019,46 @@ AnalyzeArgs Solver::analyzeArgs(float lx, float lz) const {
     a.numEmitters = numEmitters_;
     a.tileOpenOut = tileMarks_;
     return a;
+}
+
+Solver::Block Solver::curWindow() const {
+    Block b;
+    b.r0 = dynCur_.histRow0 - geo_.G;
+    b.c0 = dynCur_.histCol0 - geo_.G;
+    b.nr = std::max(0, std::min(histTilesX_ * rxi_, g_.gx - b.r0));
+    b.nc = std::max(0, std::min(histTilesY_ * wi_, g_.gy - b.c0));
+    return b;
+}
+
+FarInfo Solver::farInfo() const {
+    FarInfo f{};
+    f.on = (lazyFar_ && dynValid_ && !farDirValid_) ? 1 : 0;
+    f.r0 = farWin_.r0;
+    f.c0 = farWin_.c0;
+    f.nr = farWin_.nr;
+    f.nc = farWin_.nc;
+    f.gy = g_.gy;
+    f.lx = lastLx_;
+    f.lz = lastLz_;
+    f.dx = g_.dx;
+    return f;
+}
+
+// whole-map readers: give the far cells of the last run their listener direction (Analyzer.cpp:365-391,415-428)
+bool Solver::ensureFarDirections() {
+    if (!lazyFar_ || farDirValid_ || !dynValid_) return true;
+    launchFarDirections(res_, (long long)g_.gx * g_.gy, farInfo(), stream_);
+    farDirValid_ = true;
+    return hipOk(hipGetLastError(), "far directions");
+}
+
+// the analysis of the run enqueued on stream_ (history recorded, dynCur_ = its parameters)
+void Solver::enqueueAnalysis(float lx, float lz) {
+    launchAnalysis(analyzeArgs(lx, lz), stream_);
+    if (lazyFar_) {
+        farWin_ = curWindow();
+        farDirValid_ = false;
+    }
 }
 
 bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
@@ -1114,7 +1162,7 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
         if (!enqueueResetAndSteps()) return false;
     }
     hipEventRecord(ev_[1], stream_);
-    if (!opt_.skipAnalysis) launchAnalysis(analyzeArgs(lx, lz), stream_);
+    if (!opt_.skipAnalysis) enqueueAnalysis(lx, lz);
     hipEventRecord(ev_[2], stream_);
     enqueueQueries();
     pendingTimings_ = true;
@@ -1236,7 +1284,7 @@ bool Solver::runBatch(Solver* const* s, int n, const float* lxyz, bool wait, std
         Solver& v = *s[i];
         if (i > 0) hipStreamWaitEvent(v.stream_, lead.forkEv_, 0);
         hipEventRecord(v.ev_[1], v.stream_);
-        if (!v.opt_.skipAnalysis) launchAnalysis(v.analyzeArgs(v.lastLx_, v.lastLz_), v.stream_);
+        if (!v.opt_.skipAnalysis) v.enqueueAnalysis(v.lastLx_, v.lastLz_);
         hipEventRecord(v.ev_[2], v.stream_);
         v.enqueueQueries();
         v.pendingTimings_ = true;
@@ -1335,7 +1383,7 @@ bool Solver::getOutput(float ex, float ey, float ez, float out8[8], bool* valid)
     const size_t idx = (size_t)cx * g_.gy + cy;
     // 8 planes -> 8 floats: a one-wave kernel writes them straight into pinned host memory (a strided
     // hipMemcpy2DAsync of 8 x 4 bytes costs 0.4 ms on this runtime)
-    launchGatherOutput(res_, (long long)g_.gx * g_.gy, (long long)idx, outHost_, stream_);
+    launchGatherOutput(res_, (long long)g_.gx * g_.gy, (long long)idx, outHost_, farInfo(), stream_);
     if (!hipOk(hipStreamSynchronize(stream_), "output sync")) return false;
     for (int k = 0; k < 8; ++k) out8[k] = outHost_[k];
     return true;
@@ -1354,7 +1402,7 @@ bool Solver::setOutputQueries(const float* xyz, int n) {
 
 void Solver::enqueueQueries() {
     if (numQueries_ > 0 && !opt_.skipAnalysis)
-        launchGatherQueries(res_, (long long)g_.gx * g_.gy, qCellsHost_, numQueries_, qOutHost_, stream_);
+        launchGatherQueries(res_, (long long)g_.gx * g_.gy, qCellsHost_, numQueries_, qOutHost_, farInfo(), stream_);
 }
 
 // after sync(): the registered queries' outputs of the last run, straight from pinned memory
@@ -1371,6 +1419,7 @@ bool Solver::queriedOutputs(float* out8n, unsigned char* valid, int n) {
 // the reference's result map is an array of 8-float structs; ours is 8 planes.  Whole-map read-backs (tests, the live
 // module's host copy) get the AoS form from a pack kernel into a buffer that exists only once somebody asked.
 bool Solver::packResults() {
+    if (!ensureFarDirections()) return false;
     const size_t n = (size_t)g_.gx * g_.gy;
     if (!res8_) {
         if (!dalloc(&res8_, n * 8, false)) return false;
@@ -1395,6 +1444,10 @@ bool Solver::copyResultsBlock(int r0, int c0, int nr, int nc, float* res8, float
     if (isSlab()) return fail("copyResultsBlock is not available on a slab");
     if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
     const size_t cells = (size_t)nr * nc;
+    // (a block inside the last run's window needs no far cell)
+    if (res8 && (r0 < farWin_.r0 || c0 < farWin_.c0 || r0 + nr > farWin_.r0 + farWin_.nr || c0 + nc > farWin_.c0 + farWin_.nc) &&
+        !ensureFarDirections())
+        return false;
     if (res8) {
         float* tmp = nullptr;
         if (!hipOk(hipMalloc((void**)&tmp, cells * 32), "hipMalloc result block")) return false;

@@ -47,6 +47,7 @@ struct SolverOptions {
     // and keeps the K rows its neighbours own next to them current in its guard band (SlabGroup exchanges them after
     // every launch).  slabCount = 1: a whole grid.
     int slabIndex = 0, slabCount = 1;
+    bool lazyFar = true;  // far cells of the result map lazily (see Solver::lazyFar_)
     int patch = -1;       // air tiles by the persistent patch kernel (pv_patch.h): -1 = default of the configuration, 0 off, 1 on
     int patchStrip = 3;   // patch columns per strip of its walk
     int rowBands = 0;     // B > 1: each sweep = B launches (bands of tile rows, one stream each) with 3-point
@@ -156,6 +157,18 @@ private:
     void enqueueBeginRun(bool resetTiles);
     bool zeroPlanesIfNeeded();
     AnalyzeArgs analyzeArgs(float lx, float lz) const;
+    // Far cells lazily: a run resets only the previous and the current window block; the far cells'
+    // listener direction is materialised for whole-map read-backs and computed in closed form by the output gathers
+    bool lazyFar_ = false;
+    struct Block {
+        int r0 = 0, c0 = 0, nr = 0, nc = 0;
+    };
+    Block curWindow() const;        // the history-window block of the result map of the run prepared last
+    Block farWin_;                  // window block of the last ANALYSED run (the far cells lie outside it)
+    bool farDirValid_ = true;       // the direction planes hold the far cells' directions of that run
+    FarInfo farInfo() const;
+    bool ensureFarDirections();
+    void enqueueAnalysis(float lx, float lz);
     bool fail(const std::string& what);
     bool hipOk(hipError_t e, const char* what);
     template <typename Tp>

@@ -62,6 +62,14 @@ def valid_mask(delay, T, fs):
 
 @pytest.fixture(scope="session")
 def pvlib():
+    # torch first where a GPU is present (as bench.py does): libplaneverb_amd.so then binds to the HIP runtime torch has
+    # already loaded, and the tests that hand torch DEVICE tensors to the library (slab halos by address) see one runtime
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:  # noqa: BLE001 -- torch is plumbing for a few tests, not a requirement of the library
+        pass
     import planeverb_amd
     planeverb_amd.build()
     from planeverb_amd import api

@@ -667,6 +667,44 @@ def test_streaming_equals_full_history_1024(pvlib):
             assert same_bits(st.get_output(e).as_array(), full.get_output(e).as_array()).all()
 
 
+def test_lazy_far_cells_equal_the_full_rewrite_1024(pvlib):
+    """Far cells (outside the history window: no onset, default listener direction) are no longer rewritten for the whole map
+    on every run (PVA_OPT_LAZY_FAR_CELLS).  A sequence of runs whose window MOVES across the grid -- and comes back -- must
+    leave the same maps, records and blocks as the full rewrite of rounds 1-2, after every run: whole-map read-backs, a
+    block that straddles the window, single outputs and output queries of cells inside, just outside and far from it."""
+    dx = np.float32(343.21) / np.float32(275) / np.float32(3.5)
+    n = 1400  # the 873-cell window fits 1.6 times: consecutive windows overlap partly or not at all
+    size = float((n + 0.5) * dx)
+    cell = lambda cx, cy: ((cx + 0.5) * float(dx), 0.0, (cy + 0.5) * float(dx))
+    Ls = [cell(300, 350), cell(1100, 1000), cell(700, 700), cell(300, 350), cell(1390, 5), cell(1100, 1000)]
+    probes = [cell(310, 360), cell(5, 5), cell(1399, 1399), cell(760, 300), cell(1100, 990), cell(739, 738), cell(20, 1380)]
+    boxes = [[120.0, 130.0, 3.0, 40.0, 0.9], [390.0, 360.0, 40.0, 2.0, 0.8]]
+    with pvlib.Solver(size, size, 275, lazy_far_cells=1) as lazy, pvlib.Solver(size, size, 275, lazy_far_cells=0) as full:
+        for s in (lazy, full):
+            for b in boxes:
+                s.add_geometry(b)
+        for k, L in enumerate(Ls):
+            for s in (lazy, full):
+                s.set_output_queries(probes)
+                s.run(L)
+            ql, qf = lazy.queried_outputs(), full.queried_outputs()
+            assert np.array_equal(ql.view(np.uint32), qf.view(np.uint32)), "queries, run %d" % k
+            for p_ in probes:
+                a, b = lazy.get_output(p_).as_array(), full.get_output(p_).as_array()
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "get_output, run %d" % k
+            if k % 2 == 0:  # a block across the window's edge, BEFORE any whole-map read-back of this run
+                lcx, lcy = pvlib.host_cells(size, size, 275, L[0], L[2])[0]
+                r0, c0 = max(0, min(lcx - 600, n - 301)), max(0, min(lcy + 300, n - 401))
+                bl, bf = lazy.results_block(r0, c0, 300, 400), full.results_block(r0, c0, 300, 400)
+                assert np.array_equal(bl[0].view(np.uint32), bf[0].view(np.uint32)), "block, run %d" % k
+                assert np.array_equal(bl[1].view(np.uint32), bf[1].view(np.uint32)), "delay block, run %d" % k
+            if k != 1:  # (run 1 is followed by run 2 without a whole-map read-back in between)
+                rl, dl = lazy.results()
+                rf, df = full.results()
+                assert np.array_equal(dl.view(np.uint32), df.view(np.uint32)), "delay map, run %d" % k
+                assert np.array_equal(rl.view(np.uint32), rf.view(np.uint32)), "result map, run %d" % k
+
+
 def test_streaming_equals_full_history_2048_long(pvlib):
     """The regime the sparse-emitter mode lives in (parity-breadth note): fields non-zero everywhere and a response
     far longer than the ring.  2048^2 with PVA_OPT_NUM_STEPS = 2000 (31 ring passes; the full-history solver keeps all 2000

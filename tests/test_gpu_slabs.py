@@ -144,13 +144,18 @@ def test_slabs_open_field_4096_matches_single_solver(pvlib):
         assert (da < 1e30).sum() > 200000
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_slab_ranks_with_host_exchange_match_single_solver_1024(pvlib, world):
+@pytest.mark.parametrize("world,on_device", [(2, False), (3, False), (2, True), (3, True)])
+def test_slab_ranks_with_host_exchange_match_single_solver_1024(pvlib, world, on_device):
     """the decomposition with one slab per RANK (PvAmdCreateSlabRank + PvAmdSlab* primitives, whole-grid maps in
     PvAmdSlabRoot*): the exchange schedule of planeverb_amd.dist_slabs (the one that runs over torch.distributed / RCCL with
     one process per GPU; tests/test_dist_cpu.py runs it over gloo) driven in lock-step inside this process, halos, boundary
-    histories and result blocks passing through host buffers.  Bit-identical to one solver on the whole grid."""
+    histories and result blocks passing through host buffers -- or (on_device) through DEVICE tensors handed over by address,
+    the way TorchTransport moves them between RCCL ranks.  Bit-identical to one solver on the whole grid."""
     from planeverb_amd import dist_slabs
+    device = None
+    if on_device:
+        import torch
+        device = torch.device("cuda", 0)
     n = 1024
     opts = dict(steps_per_launch=8, tile_rows=24)
     size = size_of(n)
@@ -169,7 +174,7 @@ def test_slab_ranks_with_host_exchange_match_single_solver_1024(pvlib, world):
                     s.add_geometry(box)
             for L in Ls:
                 a.run(L)
-                dist_slabs.run_local(slabs, root, L)
+                dist_slabs.run_local(slabs, root, L, device=device)
                 ra, da = a.results()
                 rb, db = root.results()
                 assert same_bits(da, db).all(), "delay map"
