@@ -151,7 +151,7 @@ enum {
     PVA_OPT_NO_FREE_GRID = 7,  /* 1 = skip the free-field run (efree = 0; stencil-only use) */
     PVA_OPT_TIME_KERNELS = 8,  /* N > 0: HIP events around every Nth step-kernel launch (per-kernel durations) */
     PVA_OPT_TILE_ORDER = 9,    /* air-kernel workgroup->tile map: 0 linear, 1 XCD band of tile rows walked row-major, 2 the band column-major, 3 XCD strip of tile columns walked row-major (vertical halo neighbours stay in the XCD's L2), >= 4 sub-bands of that many tile rows; default: 3 for grids of >= 4500 tiles (3072^2 and up), else 1 */
-    PVA_OPT_SMALL_GRID_KERNEL = 10, /* 0 = auto (grids that fit one CU's LDS run in one resident kernel), 2 = never */
+    PVA_OPT_SMALL_GRID_KERNEL = 10, /* the kernel that keeps the whole grid in one CU's LDS for all T steps: 0 = auto (grids of up to 1536 array cells, where it beats the replayed tile-kernel graph: 28^2 ... 38^2), 1 = whenever the grid fits one CU (up to ~110^2), 2 = never */
     PVA_OPT_PACKED_MATH = 11,  /* air-tile kernel arithmetic: 1 = packed f32 (default), 0 = scalar f32 */
     PVA_OPT_STREAMING_ANALYSIS = 12, /* 1 = sparse-emitter mode: ring history + incremental analysis (see PvAmdSetEmitters) */
     PVA_OPT_STREAM_ROWS = 13,  /* N > 0: the air part of the grid is advanced by about N row-streaming segments per sweep (a wave streams down a 256-column strip, K time levels in flight) instead of one wave per air tile; tile configurations (8, 40) and (12, 36) only, ignored elsewhere and with slabs / row bands / graphs / streaming analysis.  Bit-identical; experimental: slower than the tile kernels at 4096^2.  Default 0 = off */

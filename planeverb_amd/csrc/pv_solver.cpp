@@ -1079,7 +1079,12 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
     cur_ = 0;  // the reset clears set 0; a run never depends on the previous run's fields
     hipEventRecord(ev_[0], stream_);
     // (an explicit tile configuration means "use the tile kernels")
-    const bool small = opt_.smallGrid != 2 && opt_.K == 0 && opt_.rxi == 0 && !opt_.timeKernels &&
+    // The whole-grid-resident kernel wins where a run is a chain of tiny launches even as a replayed graph: measured on
+    // MI355X (profiles/r03_presets.txt) 0.47 vs 0.62 ms at 28^2 and 0.67 vs 0.82 ms at 38^2 -- but 0.81 vs 0.69 ms at 39^2,
+    // 0.88 vs 0.71 ms at the Sandbox's 70^2 and 1.60 vs 0.97 ms at 95^2, where its two barriers per step over 5-9 cells per
+    // thread are slower than the 4-wave general tiles.  auto = up to 1536 array cells; 1 = whenever the grid fits one CU.
+    const bool smallWanted = opt_.smallGrid == 1 || (opt_.smallGrid == 0 && (long long)g_.NX * g_.NY <= 1536);
+    const bool small = smallWanted && opt_.K == 0 && opt_.rxi == 0 && !opt_.timeKernels &&
                        opt_.useGraph != 1 && !opt_.streaming && smallGridFits(g_.NX, g_.NY) &&
                        histTilesX_ == geo_.ntx && histTilesY_ == geo_.nty;
     if (opt_.streaming) {

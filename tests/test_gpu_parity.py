@@ -94,7 +94,7 @@ def test_golden_small(pvlib, name):
                                   dict(steps_per_launch=12, tile_rows=40), dict(steps_per_launch=10, tile_rows=40, packed_math=0),
                                   dict(steps_per_launch=10, tile_rows=40, merged_launch=0),
                                   dict(dense_history=1), dict(use_graph=1), dict(use_graph=2),
-                                  dict(small_grid_kernel=2), dict(small_grid_kernel=2, use_graph=2), dict(small_grid_kernel=2, packed_math=0), dict(small_grid_kernel=2, merged_launch=0),
+                                  dict(small_grid_kernel=1), dict(small_grid_kernel=2), dict(small_grid_kernel=2, use_graph=2), dict(small_grid_kernel=2, packed_math=0), dict(small_grid_kernel=2, merged_launch=0),
                                   dict(small_grid_kernel=2, merged_launch=0, use_graph=2)])
 def test_every_kernel_configuration(pvlib, opts):
     """every compiled (K, rows) instantiation and the dense-history mode produce the same bits"""
