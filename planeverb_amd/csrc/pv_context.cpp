@@ -164,35 +164,44 @@ void Context::workerLoop() {
     float lx, lz, ly = ly_.load();
     unpackXZ(lxz_.load(), &lx, &lz);
     std::unique_lock<std::mutex> solverLock(solverMutex_);
+    auto stop = [&]() {
+        finishPublish();  // (the last COMPLETED iteration's block may still be on its way: it is valid, make it visible)
+        // The worker stops; the host can see it: IsRunning reports 0, PvAmdLastError carries the reason, GetOutput keeps
+        // serving the last published iteration.
+        std::string e = solver_->lastError();
+        std::fprintf(stderr, "[planeverb_amd] simulation worker stopped: %s\n", e.c_str());
+        {
+            std::lock_guard<std::mutex> lock(errMutex_);
+            workerErr_ = std::move(e);
+        }
+        failed_.store(true, std::memory_order_release);
+        running_.store(false);
+    };
     while (running_.load(std::memory_order_acquire)) {
-        const bool ok = (!streaming_ || registerEmitters()) && solver_->run(lx, ly, lz, /*wait=*/false) && publish();
-        if (!ok) {
-            // The worker stops; the host can see it: IsRunning reports 0, PvAmdLastError carries the reason, GetOutput
-            // keeps serving the last published iteration.
-            std::string e = solver_->lastError();
-            std::fprintf(stderr, "[planeverb_amd] simulation worker stopped: %s\n", e.c_str());
-            {
-                std::lock_guard<std::mutex> lock(errMutex_);
-                workerErr_ = std::move(e);
-            }
-            failed_.store(true, std::memory_order_release);
-            running_.store(false);
+        // Iteration i: enqueue FDTD + analysis; make iteration i - 1 visible (its result block has been travelling to the
+        // host on the copy stream since it was packed); queue this iteration's block behind its analysis; wait for the
+        // DEVICE work of iteration i -- not for its copy, which overlaps the next iteration's first launches.
+        if (!((!streaming_ || registerEmitters()) && solver_->run(lx, ly, lz, /*wait=*/false) && finishPublish() &&
+              beginPublish() && solver_->sync())) {
+            stop();
             break;
         }
-        {
-            std::lock_guard<std::mutex> lock(iterMutex_);
-            iterations_.fetch_add(1, std::memory_order_acq_rel);
-        }
-        iterCv_.notify_all();
-        pushGeometryChanges();  // PvContext.cpp:86
+        pushGeometryChanges();            // PvContext.cpp:86: after the iteration's analysis
         unpackXZ(lxz_.load(), &lx, &lz);  // PvContext.cpp:89
         ly = ly_.load();
         if (solverWaiters_.load(std::memory_order_acquire) > 0) {  // a GetImpulseResponse call wants the solver
+            // (it reads the iteration just completed: publish it first, so that "the last completed iteration" and the
+            // published outputs agree)
+            if (!finishPublish()) {
+                stop();
+                break;
+            }
             solverLock.unlock();
             while (solverWaiters_.load(std::memory_order_acquire) > 0) std::this_thread::yield();
             solverLock.lock();
         }
     }
+    if (!failed_.load()) finishPublish();  // the last iteration's block
     solverLock.unlock();
     iterCv_.notify_all();
 }
@@ -237,11 +246,28 @@ inline void loadRelaxed(float* dst, const float* src, size_t n) {
 }  // namespace
 
 // Copy the block the finished iteration can have changed into the back slot, keep what leaves the window, flip.
-bool Context::publish() {
+// Two halves, so that the device -> host copy of iteration i overlaps iteration i + 1's first launches: beginPublish is
+// enqueued right behind iteration i's analysis (pack on the solver's stream, copy on a second stream into the BACK slot);
+// finishPublish -- called once iteration i + 1 has been enqueued -- waits for that copy alone, does the host bookkeeping and
+// flips the slots.  Readers only ever see the front slot, which no copy is writing.
+bool Context::beginPublish() {
     const int f = front_.load(std::memory_order_relaxed);
-    const int back = f < 0 ? 0 : f ^ 1;
-    Solver::WindowBlock w;
-    if (!solver_->publishWindowAsync(slots_[back].data, &w) || !solver_->sync()) return false;
+    pendBack_ = f < 0 ? 0 : f ^ 1;
+    // (small blocks -- the Sandbox's 157 kB -- ride on the solver's own stream: the cross-stream hand-over costs more than
+    // their copy, measured 0.77 against 0.71 ms per iteration at 71^2)
+    const bool overlap = solver_->windowCapacity() * 32 > (size_t)(1u << 20);
+    if (!solver_->publishWindowAsync(slots_[pendBack_].data, &pendWin_, overlap)) return false;
+    pendPublish_ = true;
+    return true;
+}
+
+bool Context::finishPublish() {
+    if (!pendPublish_) return true;
+    pendPublish_ = false;
+    const int f = front_.load(std::memory_order_relaxed);
+    const int back = pendBack_;
+    const Solver::WindowBlock w = pendWin_;
+    if (!solver_->waitPublish()) return false;
     if (f >= 0) {
         // Cells of the old block outside the new one keep the old block's values from now on (the reference leaves
         // m_results untouched where an iteration finds no onset, Analyzer.cpp:160-165).  Nobody can be reading these
@@ -284,6 +310,11 @@ bool Context::publish() {
     s.lz.store(w.lz, std::memory_order_relaxed);
     front_.store(back, std::memory_order_relaxed);
     pubSeq_.fetch_add(1, std::memory_order_seq_cst);  // even
+    {
+        std::lock_guard<std::mutex> lock(iterMutex_);
+        iterations_.fetch_add(1, std::memory_order_acq_rel);
+    }
+    iterCv_.notify_all();
     return true;
 }
 

@@ -107,7 +107,11 @@ private:
     ~Context();
     void workerLoop();
     void pushGeometryChanges();
-    bool publish();
+    bool beginPublish();
+    bool finishPublish();
+    bool pendPublish_ = false;
+    int pendBack_ = 0;
+    Solver::WindowBlock pendWin_;
     void beginRetire();
     bool registerEmitters();
     friend void retireContext(Context*);

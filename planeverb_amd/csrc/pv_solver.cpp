@@ -388,6 +388,8 @@ Solver::~Solver() {
     if (segList_) hipFree(segList_);
     for (auto& e : ev_)
         if (e) hipEventDestroy(e);
+    for (auto& e : pubEv_)
+        if (e) hipEventDestroy(e);
     dropGraph();
     for (auto& e : kev_) hipEventDestroy(e);
     for (auto& e : airDone_) hipEventDestroy(e);
@@ -1478,21 +1480,40 @@ size_t Solver::windowCapacity() const {
     return (size_t)std::min(histTilesX_ * rxi_, g_.gx) * (size_t)std::min(histTilesY_ * wi_, g_.gy);
 }
 
-bool Solver::publishWindowAsync(float* hostDst, WindowBlock* info) {
+bool Solver::publishWindowAsync(float* hostDst, WindowBlock* info, bool overlap) {
     if (!dynValid_) return fail("no simulation has run yet");
     WindowBlock w;
-    w.r0 = dynCur_.histRow0 - geo_.G;
-    w.c0 = dynCur_.histCol0 - geo_.G;
-    w.nr = std::max(0, std::min(histTilesX_ * rxi_, g_.gx - w.r0));
-    w.nc = std::max(0, std::min(histTilesY_ * wi_, g_.gy - w.c0));
+    const Block b = curWindow();
+    w.r0 = b.r0;
+    w.c0 = b.c0;
+    w.nr = b.nr;
+    w.nc = b.nc;
     w.lx = lastLx_;
     w.lz = lastLz_;
     if (!win8_ && !dalloc(&win8_, windowCapacity() * 8, false)) return false;
+    if (overlap && !pubEv_[0]) {
+        for (auto& e : pubEv_)
+            if (!hipOk(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate")) return false;
+    }
+    if (pubCopyPending_) hipStreamWaitEvent(stream_, pubEv_[1], 0);  // the staging block is free again
     launchPackWindow(res_, (long long)g_.gx * g_.gy, g_.gy, w.r0, w.c0, w.nr, w.nc, win8_, stream_);
     if (!hipOk(hipGetLastError(), "pack window")) return false;
     *info = w;
+    pubCopyPending_ = false;
     if (w.nr == 0 || w.nc == 0) return true;
-    return hipOk(hipMemcpyAsync(hostDst, win8_, (size_t)w.nr * w.nc * 32, hipMemcpyDeviceToHost, stream_), "window copy");
+    if (!overlap)
+        return hipOk(hipMemcpyAsync(hostDst, win8_, (size_t)w.nr * w.nc * 32, hipMemcpyDeviceToHost, stream_), "window copy");
+    hipEventRecord(pubEv_[0], stream_);
+    hipStreamWaitEvent(stream2_, pubEv_[0], 0);
+    if (!hipOk(hipMemcpyAsync(hostDst, win8_, (size_t)w.nr * w.nc * 32, hipMemcpyDeviceToHost, stream2_), "window copy")) return false;
+    hipEventRecord(pubEv_[1], stream2_);
+    pubCopyPending_ = true;
+    return true;
+}
+
+bool Solver::waitPublish() {
+    if (!pubCopyPending_) return true;
+    return hipOk(hipEventSynchronize(pubEv_[1]), "window copy sync");
 }
 
 void* Solver::hostAlloc(size_t bytes) {

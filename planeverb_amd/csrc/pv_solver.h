@@ -127,7 +127,10 @@ public:
         float lx = 0, lz = 0;                // the run's listener position, metres
     };
     size_t windowCapacity() const;  // records: upper bound of nr*nc for any listener position
-    bool publishWindowAsync(float* hostDst, WindowBlock* info);
+    // overlap = true: only the pack runs on the solver's stream; the device -> host copy goes to a second stream, so that the
+    // NEXT run's launches need not wait for it (the live module's loop); waitPublish() then waits for that copy alone.
+    bool publishWindowAsync(float* hostDst, WindowBlock* info, bool overlap = false);
+    bool waitPublish();
     // pinned host memory for the buffers above
     static void* hostAlloc(size_t bytes);
     static void hostFree(void* p);
@@ -202,6 +205,8 @@ private:
     void dropGraph();
     bool enqueueResetAndSteps();
     hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t pubEv_[2] = {nullptr, nullptr};  // window block packed / copied to the host (publishWindowAsync, overlap form)
+    bool pubCopyPending_ = false;
     long long deviceBytes_ = 0;
     std::string err_;
 

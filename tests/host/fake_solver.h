@@ -106,7 +106,8 @@ public:
         out[7] = (float)(cx + cy);
     }
 
-    bool publishWindowAsync(float* dst, WindowBlock* info) {
+    bool waitPublish() { return true; }
+    bool publishWindowAsync(float* dst, WindowBlock* info, bool = false) {
         WindowBlock w;
         w.r0 = r0_;
         w.c0 = c0_;
