@@ -42,6 +42,7 @@ PVA_OPT_ROW_BANDS = 16
 PVA_OPT_PATCH_KERNEL = 17
 PVA_OPT_PATCH_STRIP = 18
 PVA_OPT_LAZY_FAR_CELLS = 19
+PVA_OPT_STREAM_FUSE = 20
 
 
 class PlaneverbOutput(C.Structure):
@@ -607,7 +608,7 @@ class Solver:
                 "stream_rows": PVA_OPT_STREAM_ROWS, "merged_launch": PVA_OPT_MERGED_LAUNCH,
                 "edge_tiles": PVA_OPT_EDGE_TILES, "row_bands": PVA_OPT_ROW_BANDS,
                 "patch_kernel": PVA_OPT_PATCH_KERNEL, "patch_strip": PVA_OPT_PATCH_STRIP,
-                "lazy_far_cells": PVA_OPT_LAZY_FAR_CELLS}
+                "lazy_far_cells": PVA_OPT_LAZY_FAR_CELLS, "stream_fuse": PVA_OPT_STREAM_FUSE}
         for k, v in options.items():
             _check(lib().PvAmdSetOption(self._h, keys[k], int(v)))
         self.info = PvAmdInfo()

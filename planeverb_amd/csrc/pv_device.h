@@ -161,6 +161,36 @@ struct SmallArgs {
     int rxi, wi;  // tile interior (the history planes are tile-major: histOffset)
 };
 
+// sparse-emitter mode with the forward sums inside the stencil (pv_stream.h)
+struct OpenArgs {
+    int* sOnset;            // per result cell: onset step, -1 = none yet
+    float* sEdry;
+    float* sFx;
+    float* sFy;
+    uint8_t* cellsOpen2;    // per tile half: some interior cell's dry window is still open
+    const int* openList;    // tile * 2 + half
+    const int* openCount;
+    int* nextCount;         // the other of the two counters (they alternate from launch to launch)
+    int nDir, nDry;
+    int gxRes, gyRes;       // result map
+};
+
+struct ClassifyArgs {
+    const uint8_t* tileClass;   // static: 0 air, 1 general, 2 edge
+    const uint8_t* tileEmit;    // holds a registered emitter
+    const uint8_t* tileOpenRing;  // accumulate pass: ring tile still has an open window (or has not been reached)
+    const uint8_t* nzPrev;      // per tile: non-zero at the end of the previous launch (conservative)
+    const uint8_t* cellsOpen2;
+    const DynParams* dyn;
+    uint8_t* classOut;          // per-launch classes for the merged kernel
+    uint8_t* ringOpenOut;       // the step kernels' `tileOpen`
+    uint8_t* nzNext;            // this launch's flag plane: cleared for open tiles (their two halves only ever set it)
+    int* openList;
+    int* openCount;             // zeroed by the caller before the launch
+    int ntx, nty, G, K, rxi, wi, rows;
+    int withPulse;
+};
+
 // where the far cells of the last run begin, and what their listener direction is (output gathers, pv_far_dir_kernel)
 struct FarInfo {
     int on;              // 0: every cell's direction is in the result planes
@@ -220,6 +250,10 @@ struct AnalyzeArgs {
     float* sVx;
     float* sVy;
     uint8_t* tileOpenOut; // per tile: set to 1 by any cell whose window is still open after this pass
+    // forward sums inside the stencil (pv_stream.h): the accumulate pass skips the cells of fused tiles.  NULL = off
+    const uint8_t* fuseClass;  // static tile classes
+    const uint8_t* fuseEmit;   // per tile: holds a registered emitter
+    int fuseK;
     const int* emCells;  // registered emitter cells: X*gy + Y
     float* emTrace;      // numEmitters x T pressure traces
     int numEmitters;

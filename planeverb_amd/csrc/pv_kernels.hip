@@ -1776,7 +1776,37 @@ __device__ __forceinline__ bool deadTileSkippable(const StepArgs& a, int tile) {
 }  // namespace pva
 #include "pv_seg.h"
 #include "pv_patch.h"
+#include "pv_stream.h"
 namespace pva {
+
+// configurations whose sparse-emitter mode advances the forward sums inside the stencil (pv_stream.h)
+#define PV_OPEN_CONFIGS(X) X(12, 36) X(10, 36) X(8, 24)
+
+bool openConfigOk(int K, int rxi) {
+#define X(k, r) \
+    if (K == k && rxi == r) return true;
+    PV_OPEN_CONFIGS(X)
+#undef X
+    return false;
+}
+
+void launchStreamClassify(const ClassifyArgs& c, hipStream_t stream) {
+    const int n = c.ntx * c.nty;
+    hipLaunchKernelGGL(pv_stream_classify_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, c);
+}
+
+// open tiles of one sweep: one wave per listed half tile; the grid is sized for the capacity (2 halves x ntiles), the live
+// count is read on the device
+void launchStepOpen(int K, int rxi, const StepArgs& a, const OpenArgs& o, hipStream_t stream) {
+    const int blocks = (2 * a.ntiles + 3) / 4;
+#define X(k, r) \
+    if (K == k && rxi == r) { \
+        hipLaunchKernelGGL((pv_step_open_kernel<k, r>), dim3(blocks), dim3(256), 0, stream, a, o); \
+        return; \
+    }
+    PV_OPEN_CONFIGS(X)
+#undef X
+}
 
 // configurations with a persistent patch kernel (pv_patch.h): the large-grid tile
 #define PV_PATCH_CONFIGS(X) X(12, 36)
@@ -3035,6 +3065,10 @@ __global__ __launch_bounds__(256) void pv_stream_accum_kernel(const AnalyzeArgs 
     const int s = X * a.gy + Y;
     const DynParams dyn = *a.dyn;
     const int tile = (X / a.rxi) * a.nty + (Y / a.wi);
+    // tiles whose sums advance inside the stencil (pv_stream.h) are not this pass's business
+    if (a.fuseClass &&
+        fusedTile(a.fuseClass, a.fuseEmit, dyn, X / a.rxi, Y / a.wi, a.nty, a.G, a.fuseK, a.rxi, a.wi, a.rxi + 2 * a.fuseK, 1))
+        return;
     const int tFirst = a.tileFirst[tile];
     if (tFirst == INT_MAX || tFirst >= a.tB) return;
     int onset = a.sOnset[s];

@@ -24,6 +24,11 @@ void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream, int which
 // of 8); the general tiles of the sweep are launched with launchStep(..., which = 16)
 bool patchConfigOk(int K, int rxi);
 void launchStepPatch(int K, int rxi, const StepArgs& a, int blocks, hipStream_t stream);
+// sparse-emitter mode with the forward sums inside the stencil (pv_stream.h): per K-step launch the classify pass, the merged
+// launch with the per-launch tile classes, and the open half tiles
+bool openConfigOk(int K, int rxi);
+void launchStreamClassify(const ClassifyArgs& c, hipStream_t stream);
+void launchStepOpen(int K, int rxi, const StepArgs& a, const OpenArgs& o, hipStream_t stream);
 // row-streaming air segments (pv_seg.h): columns per lane of the configuration's segment kernel (0 = it has none), the
 // tile columns a segment can span, and the launch (general tiles + a.numSeg segments in one grid)
 int segConfigColumns(int K, int rxi);

@@ -246,6 +246,15 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         if (!dalloc(&tileOpen_, (size_t)ntiles, true) || !dalloc(&tileMarks_, (size_t)ntiles, true) ||
             !dalloc(&tileEmit_, (size_t)ntiles, true))
             return false;
+        // measured on MI355X (profiles/r03_modeB_fuse.txt): 4 % faster at 4096^2 (11 742 tiles), 14-40 % slower at 2048^2 and
+        // below, where a sweep is launch-bound and the classify + open-tile launches weigh more than the ring traffic they save
+        const bool fuseWanted = opt_.streamFuse > 0 || (opt_.streamFuse < 0 && ntiles >= 8000);
+        streamFuse_ = fuseWanted && openConfigOk(K_, rxi_) && opt_.packed && opt_.merged == 1 && mergedConfigOk(K_, rxi_) &&
+                      !stepConfigStacked(K_, rxi_) && opt_.timeKernels == 0;
+        if (streamFuse_ && (!dalloc(&classStream_, (size_t)ntiles, true) || !dalloc(&ringOpen_, (size_t)ntiles, true) ||
+                            !dalloc(&cellsOpen2_, (size_t)2 * ntiles, true) || !dalloc(&openList_, (size_t)2 * ntiles, true) ||
+                            !dalloc(&openCount_, 2, true)))
+            return false;
     }
     if (!hipOk(hipHostMalloc((void**)&dynHost_, sizeof(DynParams)), "hipHostMalloc")) return false;
     if (!hipOk(hipHostMalloc((void**)&outHost_, 8 * sizeof(float)), "hipHostMalloc")) return false;
@@ -361,6 +370,8 @@ Solver::~Solver() {
     if (tileOpen_) hipFree(tileOpen_);
     if (tileMarks_) hipFree(tileMarks_);
     if (tileEmit_) hipFree(tileEmit_);
+    for (void* p : {(void*)classStream_, (void*)ringOpen_, (void*)cellsOpen2_, (void*)openList_, (void*)openCount_})
+        if (p) hipFree(p);
     if (emCells_) hipFree(emCells_);
     if (emTrace_) hipFree(emTrace_);
     void* ptrs[] = {codes_,     matDev_, lutDev_, pulseDev_, hist_,  tileFirst_, tileClass_, generalList_,
@@ -918,6 +929,48 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
             // the segment kernel always advances exactly K levels; a run's short last launch takes the tile kernel
             if (a.segList && k == K_) {
                 launchStepSeg(K_, rxi_, a, stream_);
+            } else if (streamFuse_ && record) {
+                // sparse-emitter mode, forward sums inside the stencil (pv_stream.h): classify, the merged launch without
+                // the open air tiles, the open half tiles
+                ClassifyArgs c{};
+                c.tileClass = tileClass_;
+                c.tileEmit = tileEmit_;
+                c.tileOpenRing = tileOpen_;
+                c.nzPrev = a.nzIn;
+                c.cellsOpen2 = cellsOpen2_;
+                c.dyn = dynDev_;
+                c.classOut = classStream_;
+                c.ringOpenOut = ringOpen_;
+                c.nzNext = a.nzOut;
+                c.openList = openList_;
+                c.openCount = openCount_ + (li & 1);
+                c.ntx = geo_.ntx;
+                c.nty = geo_.nty;
+                c.G = geo_.G;
+                c.K = K_;
+                c.rxi = rxi_;
+                c.wi = wi_;
+                c.rows = rxi_ + 2 * K_;
+                c.withPulse = withPulse ? 1 : 0;
+                launchStreamClassify(c, stream_);
+                StepArgs a2 = a;
+                a2.tileClass = classStream_;
+                a2.tileOpen = ringOpen_;
+                launchStep(K_, rxi_, a2, stream_, 4);
+                OpenArgs o{};
+                o.sOnset = sOnset_;
+                o.sEdry = sState_[0];
+                o.sFx = sState_[1];
+                o.sFy = sState_[2];
+                o.cellsOpen2 = cellsOpen2_;
+                o.openList = openList_;
+                o.openCount = openCount_ + (li & 1);
+                o.nextCount = openCount_ + ((li & 1) ^ 1);
+                o.nDir = g_.nDir;
+                o.nDry = g_.nDry;
+                o.gxRes = g_.gx;
+                o.gyRes = g_.gy;
+                launchStepOpen(K_, rxi_, a2, o, stream_);
             } else if (usePatch_) {
                 // general tiles in their 4-wave blocks, then the air tiles by the resident workgroups (disjoint tiles of
                 // the same output set; neither reads what the other writes)
@@ -1016,6 +1069,9 @@ AnalyzeArgs Solver::analyzeArgs(float lx, float lz) const {
     a.sFy = sState_[2];
     a.sVx = sState_[3];
     a.sVy = sState_[4];
+    a.fuseClass = streamFuse_ ? tileClass_ : nullptr;
+    a.fuseEmit = tileEmit_;
+    a.fuseK = K_;
     a.emCells = emCells_;
     a.emTrace = emTrace_;
     a.numEmitters = numEmitters_;
@@ -1097,6 +1153,9 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
             if (!hipOk(hipMemsetAsync(p, 0, nres * 4, stream_), "state reset")) return false;
         if (numEmitters_ > 0 &&
             !hipOk(hipMemsetAsync(emTrace_, 0, (size_t)numEmitters_ * T_ * 4, stream_), "trace reset"))
+            return false;
+        if (streamFuse_ && (!hipOk(hipMemsetAsync(cellsOpen2_, 1, (size_t)2 * ntiles, stream_), "open flags") ||
+                            !hipOk(hipMemsetAsync(openCount_, 0, 2 * sizeof(int), stream_), "open count")))
             return false;
         launchCap_ = numGeneral_;
         enqueueBeginRun(true);
@@ -1543,14 +1602,16 @@ bool Solver::setEmitters(const float* xyz, int n) {
         if (!dalloc(&emCells_, (size_t)emCap_, true) || !dalloc(&emTrace_, (size_t)emCap_ * T_, true)) return false;
     }
     numEmitters_ = (int)cells.size();
-    {
-        std::vector<uint8_t> te((size_t)geo_.ntx * geo_.nty, 0);
-        for (int c : cells) te[(size_t)((c / g_.gy) / rxi_) * geo_.nty + (c % g_.gy) / wi_] = 1;
-        if (!hipOk(hipMemcpy(tileEmit_, te.data(), te.size(), hipMemcpyHostToDevice), "emitter tiles")) return false;
-    }
-    if (numEmitters_ > 0 && !hipOk(hipMemcpy(emCells_, cells.data(), cells.size() * 4, hipMemcpyHostToDevice), "emitters"))
+    // The uploads go through stream_, behind the zero fill dalloc() queued there (a synchronous hipMemcpy is not ordered with
+    // a non-blocking stream: the fill could land AFTER it and leave every emitter at cell 0 -- seen as wet gain / RT60 = 0 in
+    // about one process out of four).
+    std::vector<uint8_t> te((size_t)geo_.ntx * geo_.nty, 0);
+    for (int c : cells) te[(size_t)((c / g_.gy) / rxi_) * geo_.nty + (c % g_.gy) / wi_] = 1;
+    if (!hipOk(hipMemcpyAsync(tileEmit_, te.data(), te.size(), hipMemcpyHostToDevice, stream_), "emitter tiles")) return false;
+    if (numEmitters_ > 0 &&
+        !hipOk(hipMemcpyAsync(emCells_, cells.data(), cells.size() * 4, hipMemcpyHostToDevice, stream_), "emitters"))
         return false;
-    return true;
+    return hipOk(hipStreamSynchronize(stream_), "emitter upload");
 }
 
 bool Solver::impulseResponse(int cx, int cy, float* out3T) {

@@ -47,6 +47,7 @@ struct SolverOptions {
     // and keeps the K rows its neighbours own next to them current in its guard band (SlabGroup exchanges them after
     // every launch).  slabCount = 1: a whole grid.
     int slabIndex = 0, slabCount = 1;
+    int streamFuse = -1;  // sparse-emitter mode: forward sums of air tiles inside the stencil (pv_stream.h): -1 = by grid size (on from 8000 tiles: it costs two more launches per sweep and pays where the ring traffic binds), 0 = ring + accumulate pass for every tile (round 2's form), 1 = on
     bool lazyFar = true;  // far cells of the result map lazily (see Solver::lazyFar_)
     int patch = -1;       // air tiles by the persistent patch kernel (pv_patch.h): -1 = default of the configuration, 0 off, 1 on
     int patchStrip = 3;   // patch columns per strip of its walk
@@ -248,6 +249,13 @@ private:
     uint8_t* tileOpen_ = nullptr;   // per tile: history still wanted (streaming mode)
     uint8_t* tileMarks_ = nullptr;  // scratch of one accumulate pass
     uint8_t* tileEmit_ = nullptr;   // per tile: holds a registered emitter
+    // forward sums inside the stencil (pv_stream.h)
+    bool streamFuse_ = false;
+    uint8_t* classStream_ = nullptr;   // per-launch tile classes (open air tiles masked out of the merged launch)
+    uint8_t* ringOpen_ = nullptr;      // per-launch `tileOpen` of the step kernels: open RING tiles only
+    uint8_t* cellsOpen2_ = nullptr;    // per tile half: a dry window is still open
+    int* openList_ = nullptr;
+    int* openCount_ = nullptr;         // two counters, alternating from launch to launch
     int* emCells_ = nullptr;
     float* emTrace_ = nullptr;
     int numEmitters_ = 0, emCap_ = 0;

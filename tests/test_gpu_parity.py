@@ -606,15 +606,16 @@ def check_streaming_against(res, delay, rres, rdelay, T, fs, emitter_cells, ctx=
             assert rel_err(res[cx, cy, 2], rres[cx, cy, 2]).max() <= RT60_TOL, ctx + " rt60 at emitter"
 
 
+@pytest.mark.parametrize("fuse", [1, 0])
 @pytest.mark.parametrize("name", ["g71_smallroom", "g71_hugeroom", "g71_floorplan", "g96_smallroom_res375"])
-def test_streaming_mode_small(pvlib, name):
+def test_streaming_mode_small(pvlib, name, fuse):
     g = golden(name)
     gx, gy, T, fs = (int(v) for v in g["dims"])
     size, res = float(g["size"]), int(g["res"])
     rng = np.random.default_rng(1)
     extra = rng.uniform(0.5, size - 0.5, (12, 3)).astype(np.float32)
     emitters = np.concatenate([g["emitters"], extra])
-    with pvlib.Solver(size, size, res, streaming_analysis=1) as s:
+    with pvlib.Solver(size, size, res, streaming_analysis=1, stream_fuse=fuse) as s:
         for b in g["boxes"]:
             s.add_geometry(b)
         s.set_emitters(emitters)
@@ -632,14 +633,16 @@ def test_streaming_mode_small(pvlib, name):
         compare_output(s.get_output(g["emitters"][0]), g["emitter_out"][0], name + " rerun")
 
 
-def test_streaming_mode_512_mode_b(pvlib):
-    """T = 3179: 50 ring passes; checked against the reference vectors of BASELINE config 2 / Mode B"""
+@pytest.mark.parametrize("fuse", [1, 0])
+def test_streaming_mode_512_mode_b(pvlib, fuse):
+    """T = 3179: 50 ring passes; checked against the reference vectors of BASELINE config 2 / Mode B (fuse: see
+    test_streaming_equals_full_history_1024)"""
     g = golden("g512B_shoebox")
     gx, gy, T, fs = (int(v) for v in g["dims"])
     c = g["cells"]
     dx = np.float32(343.21) / np.float32(2009) / np.float32(3.5)
     em_pos = np.stack([(c[:, 0] + 0.5) * float(dx), np.zeros(len(c)), (c[:, 1] + 0.5) * float(dx)], 1)
-    with pvlib.Solver(25.0, 25.0, 2009, streaming_analysis=1) as s:
+    with pvlib.Solver(25.0, 25.0, 2009, streaming_analysis=1, stream_fuse=fuse) as s:
         for b in g["boxes"]:
             s.add_geometry(b)
         s.set_emitters(np.concatenate([g["emitters"], em_pos]))
@@ -649,11 +652,14 @@ def test_streaming_mode_512_mode_b(pvlib):
         compare_output(s.get_output(g["emitters"][0]), g["emitter_out"][0])
 
 
-def test_streaming_equals_full_history_1024(pvlib):
+@pytest.mark.parametrize("fuse", [1, 0])
+def test_streaming_equals_full_history_1024(pvlib, fuse):
+    """fuse = 1: the forward sums of air tiles advance inside the step kernel (PVA_OPT_STREAM_FUSE, csrc/pv_stream.h);
+    0: ring + accumulate pass for every tile (round 2's form)"""
     dx = np.float32(343.21) / np.float32(275) / np.float32(3.5)
     size = float((1024 + 0.5) * dx)
     L, E = (91.0, 0.0, 91.0), [(95.0, 0.0, 97.0), (100.0, 0.0, 80.0), (60.3, 0.0, 110.9)]
-    with pvlib.Solver(size, size, 275) as full, pvlib.Solver(size, size, 275, streaming_analysis=1) as st:
+    with pvlib.Solver(size, size, 275) as full, pvlib.Solver(size, size, 275, streaming_analysis=1, stream_fuse=fuse) as st:
         for s in (full, st):
             s.load_scene(os.path.join(SCENES, "Shoebox.pv"))
         st.set_emitters(E)
@@ -705,7 +711,8 @@ def test_lazy_far_cells_equal_the_full_rewrite_1024(pvlib):
                 assert np.array_equal(rl.view(np.uint32), rf.view(np.uint32)), "result map, run %d" % k
 
 
-def test_streaming_equals_full_history_2048_long(pvlib):
+@pytest.mark.parametrize("fuse", [1, 0])
+def test_streaming_equals_full_history_2048_long(pvlib, fuse):
     """The regime the sparse-emitter mode lives in (parity-breadth note): fields non-zero everywhere and a response
     far longer than the ring.  2048^2 with PVA_OPT_NUM_STEPS = 2000 (31 ring passes; the full-history solver keeps all 2000
     planes of the whole grid, 33.6 GB), scattered reflectors around an off-centre listener, three emitters: every cell's
@@ -718,7 +725,7 @@ def test_streaming_equals_full_history_2048_long(pvlib):
              [120.0, 580.0, 50.0, 5.0, 0.5], [360.0, 200.0, 6.0, 90.0, 0.85]]
     T = 2000
     with pvlib.Solver(size, size, 275, num_steps=T) as full, \
-            pvlib.Solver(size, size, 275, num_steps=T, streaming_analysis=1) as st:
+            pvlib.Solver(size, size, 275, num_steps=T, streaming_analysis=1, stream_fuse=fuse) as st:
         for s in (full, st):
             for wbox in walls:
                 s.add_geometry(wbox)
