@@ -254,6 +254,8 @@ struct AnalyzeArgs {
     const uint8_t* fuseClass;  // static tile classes
     const uint8_t* fuseEmit;   // per tile: holds a registered emitter
     int fuseK;
+    const int* ringList;       // the tiles this pass serves when the others are fused (NULL: every tile, addressed by cell)
+    int numRing;
     const int* emCells;  // registered emitter cells: X*gy + Y
     float* emTrace;      // numEmitters x T pressure traces
     int numEmitters;

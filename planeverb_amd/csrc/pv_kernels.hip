@@ -1795,6 +1795,10 @@ void launchStreamClassify(const ClassifyArgs& c, hipStream_t stream) {
     hipLaunchKernelGGL(pv_stream_classify_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, c);
 }
 
+void launchStreamIdle(const ClassifyArgs& c, int* idleHost, hipStream_t stream) {
+    hipLaunchKernelGGL(pv_stream_idle_kernel, dim3(1), dim3(256), 0, stream, c, idleHost);
+}
+
 // open tiles of one sweep: one wave per listed half tile; the grid is sized for the capacity (2 halves x ntiles), the live
 // count is read on the device
 void launchStepOpen(int K, int rxi, const StepArgs& a, const OpenArgs& o, hipStream_t stream) {
@@ -3059,14 +3063,26 @@ void launchAnalysis(const AnalyzeArgs& a, hipStream_t stream) {
 // per-emitter traces, from which wet gain and RT60 are computed at the end exactly as pv_encode_kernel does.
 
 __global__ __launch_bounds__(256) void pv_stream_accum_kernel(const AnalyzeArgs a) {
-    const int Y = blockIdx.x * blockDim.x + threadIdx.x;
-    const int X = blockIdx.y;
+    int X, Y;
+    if (a.ringList) {
+        // forward sums of the air tiles inside the stencil (pv_stream.h): this pass serves only the listed tiles (walls, grid
+        // edges, listener, registered emitters) -- blockIdx.y = list entry, blockIdx.x = 256-cell chunk of the tile
+        const int t = a.ringList[blockIdx.y];
+        const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+        if (idx >= a.rxi * a.wi) return;
+        const int ti = t / a.nty, r = idx / a.wi;
+        X = ti * a.rxi + r;
+        Y = (t - ti * a.nty) * a.wi + (idx - r * a.wi);
+    } else {
+        Y = blockIdx.x * blockDim.x + threadIdx.x;
+        X = blockIdx.y;
+    }
     if (Y >= a.gy || X >= a.gx) return;
     const int s = X * a.gy + Y;
     const DynParams dyn = *a.dyn;
     const int tile = (X / a.rxi) * a.nty + (Y / a.wi);
     // tiles whose sums advance inside the stencil (pv_stream.h) are not this pass's business
-    if (a.fuseClass &&
+    if (a.fuseClass && !a.ringList &&
         fusedTile(a.fuseClass, a.fuseEmit, dyn, X / a.rxi, Y / a.wi, a.nty, a.G, a.fuseK, a.rxi, a.wi, a.rxi + 2 * a.fuseK, 1))
         return;
     const int tFirst = a.tileFirst[tile];
@@ -3239,8 +3255,9 @@ __global__ void pv_stream_tilegate_kernel(const uint8_t* marks, const uint8_t* h
 void launchStreamAccum(const AnalyzeArgs& a, const uint8_t* hasEmitter, uint8_t* tileOpen, int ntiles,
                        hipStream_t stream) {
     dim3 grid((a.gy + 255) / 256, a.gx);
+    if (a.ringList) grid = dim3((a.rxi * a.wi + 255) / 256, a.numRing > 0 ? a.numRing : 1);
     hipMemsetAsync(a.tileOpenOut, 0, (size_t)ntiles, stream);
-    hipLaunchKernelGGL(pv_stream_accum_kernel, grid, dim3(256), 0, stream, a);
+    if (!a.ringList || a.numRing > 0) hipLaunchKernelGGL(pv_stream_accum_kernel, grid, dim3(256), 0, stream, a);
     hipLaunchKernelGGL(pv_stream_tilegate_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, stream, a.tileOpenOut,
                        hasEmitter, a.tileFirst, a.tB, tileOpen, ntiles);
     const int n = a.numEmitters * (a.tB - a.tA);

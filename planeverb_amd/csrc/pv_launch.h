@@ -28,6 +28,7 @@ void launchStepPatch(int K, int rxi, const StepArgs& a, int blocks, hipStream_t 
 // launch with the per-launch tile classes, and the open half tiles
 bool openConfigOk(int K, int rxi);
 void launchStreamClassify(const ClassifyArgs& c, hipStream_t stream);
+void launchStreamIdle(const ClassifyArgs& c, int* idleHost, hipStream_t stream);
 void launchStepOpen(int K, int rxi, const StepArgs& a, const OpenArgs& o, hipStream_t stream);
 // row-streaming air segments (pv_seg.h): columns per lane of the configuration's segment kernel (0 = it has none), the
 // tile columns a segment can span, and the launch (general tiles + a.numSeg segments in one grid)

@@ -246,14 +246,17 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         if (!dalloc(&tileOpen_, (size_t)ntiles, true) || !dalloc(&tileMarks_, (size_t)ntiles, true) ||
             !dalloc(&tileEmit_, (size_t)ntiles, true))
             return false;
-        // measured on MI355X (profiles/r03_modeB_fuse.txt): 4 % faster at 4096^2 (11 742 tiles), 14-40 % slower at 2048^2 and
-        // below, where a sweep is launch-bound and the classify + open-tile launches weigh more than the ring traffic they save
-        const bool fuseWanted = opt_.streamFuse > 0 || (opt_.streamFuse < 0 && ntiles >= 8000);
+        // measured on MI355X (profiles/r03_modeB_fuse.txt): +44 % at 8192^2, +10-14 % at 4096^2 (11 742 tiles), +2 % at 3059^2
+        // (6545 tiles), -2 % at 2048^2, -17 / -28 % at 1024^2 / 512^2, where a sweep is launch-bound and the classify +
+        // open-tile launches of the front phase weigh more than the ring traffic they save
+        const bool fuseWanted = opt_.streamFuse > 0 || (opt_.streamFuse < 0 && ntiles >= 6000);
         streamFuse_ = fuseWanted && openConfigOk(K_, rxi_) && opt_.packed && opt_.merged == 1 && mergedConfigOk(K_, rxi_) &&
                       !stepConfigStacked(K_, rxi_) && opt_.timeKernels == 0;
         if (streamFuse_ && (!dalloc(&classStream_, (size_t)ntiles, true) || !dalloc(&ringOpen_, (size_t)ntiles, true) ||
                             !dalloc(&cellsOpen2_, (size_t)2 * ntiles, true) || !dalloc(&openList_, (size_t)2 * ntiles, true) ||
-                            !dalloc(&openCount_, 2, true)))
+                            !dalloc(&openCount_, 2, true) || !dalloc(&ringList_, (size_t)ntiles, true) ||
+                            !hipOk(hipHostMalloc((void**)&ringHost_, sizeof(int) * (size_t)ntiles), "hipHostMalloc") ||
+                            !hipOk(hipHostMalloc((void**)&idleHost_, 2 * sizeof(int)), "hipHostMalloc")))
             return false;
     }
     if (!hipOk(hipHostMalloc((void**)&dynHost_, sizeof(DynParams)), "hipHostMalloc")) return false;
@@ -370,8 +373,10 @@ Solver::~Solver() {
     if (tileOpen_) hipFree(tileOpen_);
     if (tileMarks_) hipFree(tileMarks_);
     if (tileEmit_) hipFree(tileEmit_);
-    for (void* p : {(void*)classStream_, (void*)ringOpen_, (void*)cellsOpen2_, (void*)openList_, (void*)openCount_})
+    for (void* p : {(void*)classStream_, (void*)ringOpen_, (void*)cellsOpen2_, (void*)openList_, (void*)openCount_, (void*)ringList_})
         if (p) hipFree(p);
+    if (ringHost_) hipHostFree(ringHost_);
+    if (idleHost_) hipHostFree(idleHost_);
     if (emCells_) hipFree(emCells_);
     if (emTrace_) hipFree(emTrace_);
     void* ptrs[] = {codes_,     matDev_, lutDev_, pulseDev_, hist_,  tileFirst_, tileClass_, generalList_,
@@ -929,29 +934,10 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
             // the segment kernel always advances exactly K levels; a run's short last launch takes the tile kernel
             if (a.segList && k == K_) {
                 launchStepSeg(K_, rxi_, a, stream_);
-            } else if (streamFuse_ && record) {
+            } else if (streamFuse_ && record && !fuseIdle_) {
                 // sparse-emitter mode, forward sums inside the stencil (pv_stream.h): classify, the merged launch without
                 // the open air tiles, the open half tiles
-                ClassifyArgs c{};
-                c.tileClass = tileClass_;
-                c.tileEmit = tileEmit_;
-                c.tileOpenRing = tileOpen_;
-                c.nzPrev = a.nzIn;
-                c.cellsOpen2 = cellsOpen2_;
-                c.dyn = dynDev_;
-                c.classOut = classStream_;
-                c.ringOpenOut = ringOpen_;
-                c.nzNext = a.nzOut;
-                c.openList = openList_;
-                c.openCount = openCount_ + (li & 1);
-                c.ntx = geo_.ntx;
-                c.nty = geo_.nty;
-                c.G = geo_.G;
-                c.K = K_;
-                c.rxi = rxi_;
-                c.wi = wi_;
-                c.rows = rxi_ + 2 * K_;
-                c.withPulse = withPulse ? 1 : 0;
+                const ClassifyArgs c = classifyArgs(a, li, withPulse);
                 launchStreamClassify(c, stream_);
                 StepArgs a2 = a;
                 a2.tileClass = classStream_;
@@ -1017,6 +1003,30 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
     return hipOk(hipGetLastError(), "step launch");
 }
 
+ClassifyArgs Solver::classifyArgs(const StepArgs& a, int li, bool withPulse) const {
+    ClassifyArgs c{};
+    c.tileClass = tileClass_;
+    c.tileEmit = tileEmit_;
+    c.tileOpenRing = tileOpen_;
+    c.nzPrev = a.nzIn;
+    c.cellsOpen2 = cellsOpen2_;
+    c.dyn = dynDev_;
+    c.classOut = classStream_;
+    c.ringOpenOut = ringOpen_;
+    c.nzNext = a.nzOut;
+    c.openList = openList_;
+    c.openCount = openCount_ + (li & 1);
+    c.ntx = geo_.ntx;
+    c.nty = geo_.nty;
+    c.G = geo_.G;
+    c.K = K_;
+    c.rxi = rxi_;
+    c.wi = wi_;
+    c.rows = rxi_ + 2 * K_;
+    c.withPulse = withPulse ? 1 : 0;
+    return c;
+}
+
 AnalyzeArgs Solver::analyzeArgs(float lx, float lz) const {
     AnalyzeArgs a{};
     a.hist = hist_;
@@ -1072,6 +1082,8 @@ AnalyzeArgs Solver::analyzeArgs(float lx, float lz) const {
     a.fuseClass = streamFuse_ ? tileClass_ : nullptr;
     a.fuseEmit = tileEmit_;
     a.fuseK = K_;
+    a.ringList = streamFuse_ ? ringList_ : nullptr;
+    a.numRing = numRing_;
     a.emCells = emCells_;
     a.emTrace = emTrace_;
     a.numEmitters = numEmitters_;
@@ -1159,6 +1171,26 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
             return false;
         launchCap_ = numGeneral_;
         enqueueBeginRun(true);
+        if (streamFuse_) {
+            // what is left to the ring and the accumulate pass: the run's general list (walls, edges, the tiles whose loaded
+            // region holds the listener: prepareDyn) and the tiles of the registered emitters -- the complement of
+            // fusedTile() (pv_stream.h)
+            std::vector<uint8_t> in((size_t)ntiles, 0);
+            int n = 0;
+            auto add = [&](int t) {
+                if (!in[(size_t)t]) {
+                    in[(size_t)t] = 1;
+                    ringHost_[n++] = t;
+                }
+            };
+            for (int i = 0; i < numGeneral_; ++i) add(listHost_[i]);
+            for (int t = 0; t < ntiles; ++t)
+                if (tileClassHost_[(size_t)t] != 0 || (t < (int)emTilesHost_.size() && emTilesHost_[(size_t)t])) add(t);
+            numRing_ = n;
+            if (n > 0 && !hipOk(hipMemcpyAsync(ringList_, ringHost_, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, stream_),
+                                "ring list"))
+                return false;
+        }
         AnalyzeArgs aa = analyzeArgs(lx, lz);
         if (streamEv_[0] == nullptr)
             for (auto& e : streamEv_)
@@ -1168,8 +1200,18 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
         // the per-tile "history still wanted" flags they produce reach the step kernels half a ring later than in a serial
         // schedule, which only means a tile may record a few planes nobody reads.
         int pass = 0;
+        fuseIdle_ = false;
+        if (streamFuse_) idleHost_[0] = idleHost_[1] = 0;
         for (int tA = 0; tA < T_; tA += halfRing_, ++pass) {
             const int n = std::min(halfRing_, T_ - tA), h = pass & 1;
+            if (streamFuse_ && !fuseIdle_ && pass >= 2) {
+                // Feedback from the device, two passes old (the GPU keeps pass - 1 queued while the host waits here): once
+                // every fused tile has closed for good -- the wave front has passed and the dry windows behind it are over,
+                // a third of the way into a Mode B run -- the rest of the run needs neither the classify pass nor the
+                // open-tile kernel, i.e. one launch per sweep instead of three.
+                if (!hipOk(hipEventSynchronize(streamEv_[2 + h]), "pass sync")) return false;
+                fuseIdle_ = idleHost_[h] != 0;
+            }
             if (pass >= 2) hipStreamWaitEvent(stream_, streamEv_[2 + h], 0);
             if (!enqueueSteps(tA, n, true, true, tA == 0)) return false;
             hipEventRecord(streamEv_[h], stream_);
@@ -1177,6 +1219,7 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
             aa.tA = tA;
             aa.tB = tA + n;
             launchStreamAccum(aa, tileEmit_, tileOpen_, ntiles, stream2_);
+            if (streamFuse_ && !fuseIdle_) launchStreamIdle(classifyArgs(baseStepArgs(true, true), 0, true), idleHost_ + h, stream2_);
             hipEventRecord(streamEv_[2 + h], stream2_);
         }
         hipStreamWaitEvent(stream_, streamEv_[2], 0);
@@ -1607,6 +1650,7 @@ bool Solver::setEmitters(const float* xyz, int n) {
     // about one process out of four).
     std::vector<uint8_t> te((size_t)geo_.ntx * geo_.nty, 0);
     for (int c : cells) te[(size_t)((c / g_.gy) / rxi_) * geo_.nty + (c % g_.gy) / wi_] = 1;
+    emTilesHost_ = te;
     if (!hipOk(hipMemcpyAsync(tileEmit_, te.data(), te.size(), hipMemcpyHostToDevice, stream_), "emitter tiles")) return false;
     if (numEmitters_ > 0 &&
         !hipOk(hipMemcpyAsync(emCells_, cells.data(), cells.size() * 4, hipMemcpyHostToDevice, stream_), "emitters"))

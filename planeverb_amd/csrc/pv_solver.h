@@ -47,7 +47,7 @@ struct SolverOptions {
     // and keeps the K rows its neighbours own next to them current in its guard band (SlabGroup exchanges them after
     // every launch).  slabCount = 1: a whole grid.
     int slabIndex = 0, slabCount = 1;
-    int streamFuse = -1;  // sparse-emitter mode: forward sums of air tiles inside the stencil (pv_stream.h): -1 = by grid size (on from 8000 tiles: it costs two more launches per sweep and pays where the ring traffic binds), 0 = ring + accumulate pass for every tile (round 2's form), 1 = on
+    int streamFuse = -1;  // sparse-emitter mode: forward sums of air tiles inside the stencil (pv_stream.h): -1 = by grid size (on from 6000 tiles: it costs two more launches per sweep and pays where the ring traffic binds), 0 = ring + accumulate pass for every tile (round 2's form), 1 = on
     bool lazyFar = true;  // far cells of the result map lazily (see Solver::lazyFar_)
     int patch = -1;       // air tiles by the persistent patch kernel (pv_patch.h): -1 = default of the configuration, 0 off, 1 on
     int patchStrip = 3;   // patch columns per strip of its walk
@@ -255,6 +255,13 @@ private:
     uint8_t* ringOpen_ = nullptr;      // per-launch `tileOpen` of the step kernels: open RING tiles only
     uint8_t* cellsOpen2_ = nullptr;    // per tile half: a dry window is still open
     int* openList_ = nullptr;
+    int* idleHost_ = nullptr;          // pinned, 2 ints (one per ring half): every fused tile has closed for good
+    bool fuseIdle_ = false;            // ... as the host has seen it: the rest of the run is plain merged launches
+    ClassifyArgs classifyArgs(const StepArgs& a, int li, bool withPulse) const;
+    int* ringList_ = nullptr;          // the tiles the accumulate pass still serves (general list + emitter tiles), per run
+    int* ringHost_ = nullptr;          // pinned staging of it
+    int numRing_ = 0;
+    std::vector<uint8_t> emTilesHost_; // host copy of tileEmit_
     int* openCount_ = nullptr;         // two counters, alternating from launch to launch
     int* emCells_ = nullptr;
     float* emTrace_ = nullptr;

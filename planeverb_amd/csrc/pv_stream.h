@@ -65,6 +65,22 @@ __global__ __launch_bounds__(256) void pv_stream_classify_kernel(const ClassifyA
     c.classOut[t] = cls;
 }
 
+// Has every fused tile closed for good?  (a half's flag only ever goes 1 -> 0: once all of its cells have had their onset and
+// their dry windows are over; a tile the sound never reaches keeps it at 1.)  One block; the answer goes to pinned host
+// memory, where Solver::enqueueRun reads it two passes later and stops launching the classify pass and the open-tile kernel.
+__global__ __launch_bounds__(256) void pv_stream_idle_kernel(const ClassifyArgs c, int* idleHost) {
+    const DynParams dyn = *c.dyn;
+    int busy = 0;
+    for (int t = threadIdx.x; t < c.ntx * c.nty; t += 256) {
+        const int ti = t / c.nty, tj = t - ti * c.nty;
+        if ((c.cellsOpen2[2 * t] || c.cellsOpen2[2 * t + 1]) &&
+            fusedTile(c.tileClass, c.tileEmit, dyn, ti, tj, c.nty, c.G, c.K, c.rxi, c.wi, c.rows, c.withPulse))
+            busy = 1;
+    }
+    busy = __syncthreads_or(busy);
+    if (threadIdx.x == 0) *idleHost = busy ? 0 : 1;
+}
+
 template <int K, int RXI>
 struct OpenGeom {
     static constexpr int HX = RXI / 2;        // interior rows of a half tile
