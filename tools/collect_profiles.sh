@@ -41,7 +41,7 @@ ls -la $O
 bash tools/pmc_r02.sh > $O/pmc_r02.log 2>&1
 python tools/gpu_live_rate.py --out $O/live_rate.txt > /dev/null 2>&1
 python tools/gpu_slabs.py 4096 2048 > $O/slabs_one_device.txt 2>&1
-python tools/modeb_probe.py 2009 8034 16067 > $O/modeB_streaming.txt 2>&1
+python tools/modeb_probe.py 2009 8034 16067 32134 > $O/modeB_streaming.txt 2>&1
 # round 3 additions: the reference's resolution presets, 1-rank RCCL self-test of bench.py's distributed path, patch-kernel A/B
 python tools/gpu_presets.py > $O/presets.txt 2>&1
 PV_BENCH_FORCE_DIST=1 python bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/bench_force_dist.json 2> $O/bench_force_dist.err
