@@ -107,18 +107,19 @@ __global__ void pv_lane_selftest_kernel(float* out) {
 // face codes
 // ---------------------------------------------------------------------------------------------------------------
 
-// mat: (gx+1)*(gy+1) bytes, bit0 = beta (Grid.cpp:88-108,229-246), bits 1..7 = palette index of R.
+// mat: (gx+1)*(gy+1) x u16, bit0 = beta (Grid.cpp:88-108,229-246), bits 1..15 = palette index of R.
 // One thread per padded cell.  Folds FDTD.cpp:143-223 into one coefficient index per face:
 //   air|air   : v = v - C*(p_i - p_n)                                   (FDTD.cpp:162-163, beta*beta_n = 1)
 //   wall(n)|air(i): v = -Y_n * p_i ; air(n)|wall(i): v = +Y_i * p_n      (FDTD.cpp:165-168)
 //   grid edges: vx[0,y] = -p[0,y], vx[gx,y] = p[gx-1,y], vy likewise     (FDTD.cpp:201-223)
-__global__ void pv_codes_kernel(const uint8_t* __restrict__ mat, uint16_t* __restrict__ codes, Geometry g) {
+__global__ void pv_codes_kernel(const mat_t* __restrict__ mat, code_t* __restrict__ codes, Geometry g) {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     const int row = blockIdx.y;
     if (col >= g.pitch || row >= g.rows) return;
     // (x, y) in the WHOLE grid's cell array: a slab's guard rows hold its neighbours' true face codes
     const int x = row - g.G + g.x0, y = col - g.G;
-    unsigned kx = kLutWall, ky = kLutWall;
+    const unsigned wall = (unsigned)g.lutWall, posBase = wall + 1u;
+    unsigned kx = wall, ky = wall;
     if (x >= 0 && x < g.NXg && y >= 0 && y < g.NY) {
         const bool ghost = (x == g.gxg) || (y == g.gy);
         const unsigned mi = mat[(size_t)x * g.NY + y];
@@ -126,83 +127,72 @@ __global__ void pv_codes_kernel(const uint8_t* __restrict__ mat, uint16_t* __res
         const unsigned pi = ghost ? 0u : (mi >> 1);
         // x face: neighbour n = (x-1, y)
         if (x == 0) {
-            kx = (bi && y < g.gy) ? (unsigned)kLutNegBase : (unsigned)kLutWall;
+            kx = (bi && y < g.gy) ? (unsigned)kLutNegBase : wall;
         } else if (x == g.gxg) {
-            kx = (y < g.gy) ? (unsigned)kLutPosBase : (unsigned)kLutWall;
+            kx = (y < g.gy) ? posBase : wall;
         } else {
             const unsigned mn = mat[(size_t)(x - 1) * g.NY + y];
             const bool bn = (mn & 1u) && (y != g.gy);
             const unsigned pn = (y == g.gy) ? 0u : (mn >> 1);
             kx = (bi && bn) ? (unsigned)kLutAir
-                            : bi ? kLutNegBase + pn : bn ? kLutPosBase + pi : (unsigned)kLutWall;
+                            : bi ? kLutNegBase + pn : bn ? posBase + pi : wall;
         }
         // y face: neighbour n = (x, y-1)
         if (y == 0) {
-            ky = (bi && x < g.gxg) ? (unsigned)kLutNegBase : (unsigned)kLutWall;
+            ky = (bi && x < g.gxg) ? (unsigned)kLutNegBase : wall;
         } else if (y == g.gy) {
-            ky = (x < g.gxg) ? (unsigned)kLutPosBase : (unsigned)kLutWall;
+            ky = (x < g.gxg) ? posBase : wall;
         } else {
             const unsigned mn = mat[(size_t)x * g.NY + (y - 1)];
             const bool bn = (mn & 1u) && (x != g.gxg);
             const unsigned pn = (x == g.gxg) ? 0u : (mn >> 1);
             ky = (bi && bn) ? (unsigned)kLutAir
-                            : bi ? kLutNegBase + pn : bn ? kLutPosBase + pi : (unsigned)kLutWall;
+                            : bi ? kLutNegBase + pn : bn ? posBase + pi : wall;
         }
     }
-    codes[(size_t)row * g.pitch + col] = (uint16_t)(kx | (ky << 8));
+    codes[(size_t)row * g.pitch + col] = (code_t)(kx | (ky << kIdxBits));
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // fused K-step stencil
 // ---------------------------------------------------------------------------------------------------------------
 
-template <int ROWS, bool FAST>
-__device__ __forceinline__ void leapfrogStep(float (&pr)[ROWS], float (&vx)[ROWS], float (&vy)[ROWS],
-                                             const uint32_t (&cd)[(ROWS + 1) / 2], const float* lut,
-                                             const float C) {
-    // pressure sweep, FDTD.cpp:124-141:  p = beta * (p - C * ((vx[x+1] - vx[x]) + (vy[y+1] - vy[y])))
+// face coefficients of the 16-bit LUT indices in N face codes, in a step kernel: straight from the global table.  (Rounds 1-2
+// copied a 256-entry table into LDS first -- a global round trip and a barrier BEFORE a general tile's loads could start; read
+// like this the look-ups are issued as the code loads come back, beside the field loads, and a launch of a launch-bound grid
+// is no slower with 16-bit indices than it was with 8-bit ones.)
+template <int N>
+__device__ __forceinline__ void faceCoefs(const StepArgs& a, const uint32_t (&c)[N], float (&kx)[N], float (&ky)[N]) {
+    typedef const __attribute__((address_space(1))) float* glb_cptr;
+    const glb_cptr g = (glb_cptr)a.lut;
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+        kx[r] = g[c[r] & kIdxMask];
+        ky[r] = g[c[r] >> kIdxBits];
+    }
+}
+
+// air rows only (every face air|air): FDTD.cpp:124-199 without coefficients
+template <int ROWS>
+__device__ __forceinline__ void leapfrogStep(float (&pr)[ROWS], float (&vx)[ROWS], float (&vy)[ROWS], const float C) {
+    // pressure sweep, FDTD.cpp:124-141:  p = p - C * ((vx[x+1] - vx[x]) + (vy[y+1] - vy[y]))
 #pragma unroll
     for (int r = 0; r < ROWS - 1; ++r) {
         const float vyR = laneNext(vy[r]);
         const float div = (vx[r + 1] - vx[r]) + (vyR - vy[r]);
-        const float p = pr[r] - C * div;
-        if (FAST) {
-            pr[r] = p;
-        } else {
-            const uint32_t kxi = (cd[r >> 1] >> (16 * (r & 1))) & 0xffu;
-            pr[r] = (kxi < (uint32_t)kLutWall) ? p : 0.f;
-        }
+        pr[r] = pr[r] - C * div;
     }
-    // velocity sweeps, FDTD.cpp:143-199 (+ edges :201-223 through the face codes)
+    // velocity sweeps, FDTD.cpp:143-199
 #pragma unroll
     for (int r = ROWS - 1; r >= 1; --r) {
         const float pi = pr[r], pn = pr[r - 1];
-        const float air = vx[r] - C * (pi - pn);
-        if (FAST) {
-            vx[r] = air;
-        } else {
-            const uint32_t kxi = (cd[r >> 1] >> (16 * (r & 1))) & 0xffu;
-            const float k = lut[kxi];
-            const float wall = k * (pi + pn);
-            vx[r] = (k != k) ? air : wall;
-            // keep the coefficient reads of at most 4 rows in flight (otherwise all ROWS are hoisted and spill)
-            if ((r & 3) == 0) __builtin_amdgcn_sched_barrier(0);
-        }
+        vx[r] = vx[r] - C * (pi - pn);
     }
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         const float pi = pr[r];
         const float pn = lanePrev(pi);
-        const float air = vy[r] - C * (pi - pn);
-        if (FAST) {
-            vy[r] = air;
-        } else {
-            const uint32_t kyi = (cd[r >> 1] >> (16 * (r & 1) + 8)) & 0xffu;
-            const float k = lut[kyi];
-            const float wall = k * (pi + pn);
-            vy[r] = (k != k) ? air : wall;
-            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
+        vy[r] = vy[r] - C * (pi - pn);
     }
 }
 
@@ -293,7 +283,6 @@ __device__ __forceinline__ void stepTile(const StepArgs& a, const int tile, cons
     float pr[ROWS], vx[ROWS], vy[ROWS];
     constexpr int CR = GENERAL ? ROWS : 1;
     float kx[CR], ky[CR], bt[CR];
-    uint32_t cd[(ROWS + 1) / 2];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         const int so = soff0 + r * pitchB;
@@ -301,16 +290,14 @@ __device__ __forceinline__ void stepTile(const StepArgs& a, const int tile, cons
         vx[r] = bufLoadF(rVxIn, voff, so);
         vy[r] = bufLoadF(rVyIn, voff, so);
     }
-    if (GENERAL) {
-        const rsrc_t rCodes = makeRsrc(a.codes, a.planeBytes / 2);
+    if constexpr (GENERAL) {
+        const rsrc_t rCodes = makeRsrc(a.codes, a.planeBytes);
+        uint32_t c[CR];
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            const uint32_t c =
-                __builtin_amdgcn_raw_buffer_load_b16(rCodes, lane * 2, (soff0 >> 1) + r * (pitchB >> 1), 0);
-            kx[r] = lut[c & 0xffu];
-            ky[r] = lut[(c >> 8) & 0xffu];
-            bt[r] = (c & 0xffu) < (uint32_t)kLutWall ? 1.f : 0.f;
-        }
+        for (int r = 0; r < CR; ++r) c[r] = __builtin_amdgcn_raw_buffer_load_b32(rCodes, voff, soff0 + r * pitchB, 0);
+        faceCoefs<CR>(a, c, kx, ky);
+#pragma unroll
+        for (int r = 0; r < CR; ++r) bt[r] = (c[r] & kIdxMask) < (uint32_t)a.lutWall ? 1.f : 0.f;
     }
 
     // is anything non-zero in the tile?  (sign bit ignored: -0 from v = -p at the grid edges is still zero)
@@ -357,7 +344,7 @@ __device__ __forceinline__ void stepTile(const StepArgs& a, const int tile, cons
 #pragma unroll 1
     for (int s = 0; s < a.nsteps; ++s) {
         if constexpr (!GENERAL) {
-            leapfrogStep<ROWS, true>(pr, vx, vy, cd, lut, C);
+            leapfrogStep<ROWS>(pr, vx, vy, C);
         } else {
             leapfrogStepCoef<ROWS>(pr, vx, vy, kx, ky, bt, C);
         }
@@ -971,19 +958,24 @@ __device__ __forceinline__ void stepTileGeneral4Scalar(const StepArgs& a, const 
 
     const rsrc_t rPrIn = makeRsrc(a.prIn, a.inBytes), rVxIn = makeRsrc(a.vxIn, a.inBytes),
                  rVyIn = makeRsrc(a.vyIn, a.inBytes);
-    const rsrc_t rCodes = makeRsrc(a.codes, a.planeBytes / 2);
+    const rsrc_t rCodes = makeRsrc(a.codes, a.planeBytes);
     float pr[R], vx[R], vy[R], kx[R], ky[R], bt[R];
+    // the face codes first: their table look-ups then run while the field loads are still in flight
+    uint32_t c[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) c[r] = __builtin_amdgcn_raw_buffer_load_b32(rCodes, voff, soff0 + r * pitchB, 0);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int so = soff0 + r * pitchB;
         pr[r] = bufLoadF(rPrIn, voff, so);
         vx[r] = bufLoadF(rVxIn, voff, so);
         vy[r] = bufLoadF(rVyIn, voff, so);
-        const uint32_t c = __builtin_amdgcn_raw_buffer_load_b16(rCodes, lane * 2, so >> 1, 0);
-        kx[r] = lut[c & 0xffu];
-        ky[r] = lut[(c >> 8) & 0xffu];
-        bt[r] = (c & 0xffu) < (uint32_t)kLutWall ? 1.f : 0.f;
     }
+    __builtin_amdgcn_sched_group_barrier(0x020, R, 0);      // (VMEM reads: the R code loads before ...
+    __builtin_amdgcn_sched_group_barrier(0x020, 3 * R, 0);  //  ... the field loads; left alone the scheduler mixes them)
+    faceCoefs<R>(a, c, kx, ky);
+#pragma unroll
+    for (int r = 0; r < R; ++r) bt[r] = (c[r] & kIdxMask) < (uint32_t)a.lutWall ? 1.f : 0.f;
 
     const DynParams dyn = *a.dyn;
     // listener row inside this wave's window: rows 0..R-2 hold a live pressure (row 0 = the copy of the previous
@@ -1122,7 +1114,7 @@ __device__ __forceinline__ void stepTileGeneral4Packed(const StepArgs& a, const 
 
     const rsrc_t rPrIn = makeRsrc(a.prIn, a.inBytes), rVxIn = makeRsrc(a.vxIn, a.inBytes),
                  rVyIn = makeRsrc(a.vyIn, a.inBytes);
-    const rsrc_t rCodes = makeRsrc(a.codes, a.planeBytes / 2);
+    const rsrc_t rCodes = makeRsrc(a.codes, a.planeBytes);
     // row r of the window lives in pair r / 2, component r % 2
     v2f pr[NP], vx[NP], vy[NP], kx[NP], ky[NP], bt[NP];
     u2 mx[NP], my[NP];  // all-ones where the face is air|air
@@ -1130,18 +1122,28 @@ __device__ __forceinline__ void stepTileGeneral4Packed(const StepArgs& a, const 
     auto setc = [](v2f& v, int r, float val) {
         if (r & 1) v.y = val; else v.x = val;
     };
+    // the face codes first: their table look-ups then run while the field loads are still in flight
+    uint32_t c[R];
+    float kxr[R], kyr[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) c[r] = __builtin_amdgcn_raw_buffer_load_b32(rCodes, voff, soff0 + r * pitchB, 0);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int so = soff0 + r * pitchB;
+        setc(pr[r / 2], r, bufLoadF(rPrIn, voff, so));
+        setc(vx[r / 2], r, bufLoadF(rVxIn, voff, so));
+        setc(vy[r / 2], r, bufLoadF(rVyIn, voff, so));
+    }
+    __builtin_amdgcn_sched_group_barrier(0x020, R, 0);      // (VMEM reads: the R code loads before ...
+    __builtin_amdgcn_sched_group_barrier(0x020, 3 * R, 0);  //  ... the field loads; left alone the scheduler mixes them)
+    faceCoefs<R>(a, c, kxr, kyr);
 #pragma unroll
     for (int r = 0; r < 2 * NP; ++r) {
         if (r < R) {
-            const int so = soff0 + r * pitchB;
-            setc(pr[r / 2], r, bufLoadF(rPrIn, voff, so));
-            setc(vx[r / 2], r, bufLoadF(rVxIn, voff, so));
-            setc(vy[r / 2], r, bufLoadF(rVyIn, voff, so));
-            const uint32_t c = __builtin_amdgcn_raw_buffer_load_b16(rCodes, lane * 2, so >> 1, 0);
-            const float kxv = lut[c & 0xffu], kyv = lut[(c >> 8) & 0xffu];
+            const float kxv = kxr[r < R ? r : 0], kyv = kyr[r < R ? r : 0];
             setc(kx[r / 2], r, kxv);
             setc(ky[r / 2], r, kyv);
-            setc(bt[r / 2], r, (c & 0xffu) < (uint32_t)kLutWall ? 1.f : 0.f);
+            setc(bt[r / 2], r, (c[r < R ? r : 0] & kIdxMask) < (uint32_t)a.lutWall ? 1.f : 0.f);
             if (r & 1) {
                 mx[r / 2].y = (kxv != kxv) ? 0xffffffffu : 0u;
                 my[r / 2].y = (kyv != kyv) ? 0xffffffffu : 0u;
@@ -1559,9 +1561,7 @@ template <int K, int RXI, int SUB>
 __global__ __launch_bounds__(256, 2) void pv_step_general_kernel(const StepArgs a) {
     constexpr int S = RXI / SUB;
     static_assert(S * SUB == RXI, "general-tile split must divide the tile");
-    __shared__ float lut[256];
-    lut[threadIdx.x] = a.lut[threadIdx.x];
-    __syncthreads();
+    const float* lut = nullptr;  // (the face coefficients come straight from the global table: faceCoefs)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int idx = blockIdx.x * 4 + wave;
@@ -1578,7 +1578,7 @@ __global__ __launch_bounds__(256, 2) void pv_step_general_kernel(const StepArgs 
 // fits inside the air arm's register budget.  SUB is the slice height of the two-kernel form and unused here.
 template <int K, int RXI, int WPS, int SUB>
 __global__ __launch_bounds__(256, WPS) void pv_step_merged_kernel(const StepArgs a) {
-    __shared__ float lut[256];
+    const float* lut = nullptr;  // (the face coefficients come straight from the global table: faceCoefs)
     __shared__ GenShared gsh;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1590,8 +1590,6 @@ __global__ __launch_bounds__(256, WPS) void pv_step_merged_kernel(const StepArgs
         if ((int)blockIdx.x >= a.dyn->numGeneral) return;
         const int tile = __builtin_amdgcn_readfirstlane(a.generalList[blockIdx.x]);
         if (deadTileSkippable<K, RXI>(a, tile)) return;  // (block-uniform)
-        lut[threadIdx.x] = a.lut[threadIdx.x];
-        __syncthreads();
         stepTileGeneral4<K, RXI>(a, tile, wave, lane, lut, gsh);
         return;
     }
@@ -1620,7 +1618,7 @@ __global__ __launch_bounds__(256, WPS) void pv_step_merged_kernel(const StepArgs
 // XCD (b - gblocks) % 8.
 template <int K, int RXI, int WPS, int SUB>
 __global__ __launch_bounds__(256, WPS) void pv_step_batch_kernel(const BatchArgs ba) {
-    __shared__ float lut[256];
+    const float* lut = nullptr;  // (the face coefficients come straight from the global table: faceCoefs)
     __shared__ GenShared gsh;
     const StepArgs& a = ba.a[blockIdx.y];
     const int lane = threadIdx.x & 63;
@@ -1630,8 +1628,6 @@ __global__ __launch_bounds__(256, WPS) void pv_step_batch_kernel(const BatchArgs
         if ((int)blockIdx.x >= a.dyn->numGeneral) return;
         const int tile = __builtin_amdgcn_readfirstlane(a.generalList[blockIdx.x]);
         if (deadTileSkippable<K, RXI>(a, tile)) return;  // (block-uniform)
-        lut[threadIdx.x] = a.lut[threadIdx.x];
-        __syncthreads();
         stepTileGeneral4<K, RXI>(a, tile, wave, lane, lut, gsh);
         return;
     }
@@ -1658,7 +1654,7 @@ template <int K, int NP, int X, int SUB>
 __global__ __launch_bounds__(256, 2) void pv_step_stack_kernel(const StepArgs a) {
     constexpr int W = 4;
     using Gm = StackGeom<K, NP, W, X>;
-    __shared__ float lut[256];
+    const float* lut = nullptr;  // (the face coefficients come straight from the global table: faceCoefs)
     __shared__ StackShared<W> sh;
     constexpr int S = X / SUB;
     static_assert(S * SUB == X, "general-tile split must divide the tile");
@@ -1666,8 +1662,6 @@ __global__ __launch_bounds__(256, 2) void pv_step_stack_kernel(const StepArgs a)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int gblocks = (a.numGeneral * S + 3) / 4;
     if ((int)blockIdx.x < gblocks) {
-        lut[threadIdx.x] = a.lut[threadIdx.x];
-        __syncthreads();
         const int idx = blockIdx.x * 4 + wave;
         if (idx >= a.dyn->numGeneral * S) return;
         const int tile = __builtin_amdgcn_readfirstlane(a.generalList[idx / S]);
@@ -1690,21 +1684,22 @@ __global__ __launch_bounds__(256, 2) void pv_step_stack_kernel(const StepArgs a)
 // One wave per tile.  Tiles of class 1 are also appended to generalList (order irrelevant).
 // face code of cell (x, y) in an EMPTY grid (pv_codes_kernel with every cell air): what an edge tile must hold
 __device__ __forceinline__ uint32_t emptyGridCode(int x, int y, const Geometry& g) {
-    if (x < 0 || x >= g.NX || y < 0 || y >= g.NY) return (uint32_t)kLutWall | ((uint32_t)kLutWall << 8);
+    const uint32_t wall = (uint32_t)g.lutWall, posBase = wall + 1u;
+    if (x < 0 || x >= g.NX || y < 0 || y >= g.NY) return wall | (wall << kIdxBits);
     uint32_t kx, ky;
     if (x == 0)
-        kx = y < g.gy ? kLutNegBase : kLutWall;
+        kx = y < g.gy ? kLutNegBase : wall;
     else if (x == g.gx)
-        kx = y < g.gy ? kLutPosBase : kLutWall;
+        kx = y < g.gy ? posBase : wall;
     else
-        kx = y != g.gy ? kLutAir : kLutWall;
+        kx = y != g.gy ? kLutAir : wall;
     if (y == 0)
-        ky = x < g.gx ? kLutNegBase : kLutWall;
+        ky = x < g.gx ? kLutNegBase : wall;
     else if (y == g.gy)
-        ky = x < g.gx ? kLutPosBase : kLutWall;
+        ky = x < g.gx ? posBase : wall;
     else
-        ky = x != g.gx ? kLutAir : kLutWall;
-    return kx | (ky << 8);
+        ky = x != g.gx ? kLutAir : wall;
+    return kx | (ky << kIdxBits);
 }
 
 // Per-tile class.  0 = every face code in the tile's loaded region is air|air (air path).  2 = edge tile (EDGE
@@ -1712,7 +1707,7 @@ __device__ __forceinline__ uint32_t emptyGridCode(int x, int y, const Geometry& 
 // x = gx -- air path plus the edge overrides (stepTileAirMirror<EDGE>).  1 = everything else: general path; these
 // are also appended to generalList (order irrelevant).  One wave per tile.
 template <int K, int RXI, int ROWS = RXI + 2 * K, bool EDGE = false>
-__global__ __launch_bounds__(256) void pv_tileclass_kernel(const uint16_t* codes, uint8_t* tileClass,
+__global__ __launch_bounds__(256) void pv_tileclass_kernel(const code_t* codes, uint8_t* tileClass,
                                                            int* generalList, int* generalCount, Geometry g,
                                                            int allowEdge) {
     constexpr int WI = 64 - 2 * K;
@@ -1740,7 +1735,7 @@ __global__ __launch_bounds__(256) void pv_tileclass_kernel(const uint16_t* codes
 // Dead tiles: every interior cell is a wall cell whose x and y faces are wall|wall (code 0x8080).  Then pr = beta * (...)
 // = 0 (FDTD.cpp:139) and both velocities are 0 (FDTD.cpp:165-168 with beta = beta_n = 0) whatever the halo holds, so a
 // run that starts from zero fields never has to touch the tile: both buffer sets keep their zeros there.  One wave per tile.
-__global__ __launch_bounds__(256) void pv_tiledead_kernel(const uint16_t* codes, uint8_t* dead, int* count, Geometry g,
+__global__ __launch_bounds__(256) void pv_tiledead_kernel(const code_t* codes, uint8_t* dead, int* count, Geometry g,
                                                           int K) {
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1750,7 +1745,7 @@ __global__ __launch_bounds__(256) void pv_tiledead_kernel(const uint16_t* codes,
     const size_t base = (size_t)(g.G + ti * g.rxi) * g.pitch + (g.G + tj * WI - K + lane);
     bool ok = true;
     if (lane >= K && lane < 64 - K)
-        for (int r = 0; r < g.rxi; ++r) ok = ok && codes[base + (size_t)r * g.pitch] == (uint16_t)(kLutWall | (kLutWall << 8));
+        for (int r = 0; r < g.rxi; ++r) ok = ok && codes[base + (size_t)r * g.pitch] == (code_t)((uint32_t)g.lutWall | ((uint32_t)g.lutWall << kIdxBits));
     const bool d = __ballot(!ok) == 0ull;
     if (lane == 0) {
         dead[tile] = d ? 1 : 0;
@@ -1758,7 +1753,7 @@ __global__ __launch_bounds__(256) void pv_tiledead_kernel(const uint16_t* codes,
     }
 }
 
-void launchTileDead(const uint16_t* codes, uint8_t* dead, int* count, const Geometry& g, int K, hipStream_t stream) {
+void launchTileDead(const code_t* codes, uint8_t* dead, int* count, const Geometry& g, int K, hipStream_t stream) {
     hipLaunchKernelGGL(pv_tiledead_kernel, dim3((g.ntx * g.nty + 3) / 4), dim3(256), 0, stream, codes, dead, count, g, K);
 }
 
@@ -1840,7 +1835,7 @@ void launchStepPatch(int K, int rxi, const StepArgs& a, int blocks, hipStream_t 
 // y-halo columns stream down side by side on the same L2.
 template <int K, int RXI, int NC, int WPS>
 __global__ __launch_bounds__(256, WPS) void pv_step_seg_kernel(const StepArgs a) {
-    __shared__ float lut[256];
+    const float* lut = nullptr;  // (the face coefficients come straight from the global table: faceCoefs)
     __shared__ GenShared gsh;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1849,8 +1844,6 @@ __global__ __launch_bounds__(256, WPS) void pv_step_seg_kernel(const StepArgs a)
         if ((int)blockIdx.x >= a.dyn->numGeneral) return;
         const int tile = __builtin_amdgcn_readfirstlane(a.generalList[blockIdx.x]);
         if (deadTileSkippable<K, RXI>(a, tile)) return;  // (block-uniform)
-        lut[threadIdx.x] = a.lut[threadIdx.x];
-        __syncthreads();
         stepTileGeneral4<K, RXI>(a, tile, wave, lane, lut, gsh);
         return;
     }
@@ -1944,7 +1937,7 @@ static void launchBatchT(const BatchArgs& ba, hipStream_t stream) {
 }
 
 template <int K, int RXI, int ROWS = RXI + 2 * K, bool EDGE = false>
-static void launchTileClassT(const uint16_t* codes, uint8_t* tileClass, int* list, int* count, const Geometry& g,
+static void launchTileClassT(const code_t* codes, uint8_t* tileClass, int* list, int* count, const Geometry& g,
                              hipStream_t stream, int allowEdge) {
     const int blocks = (g.ntx * g.nty + 3) / 4;
     hipLaunchKernelGGL((pv_tileclass_kernel<K, RXI, ROWS, EDGE>), dim3(blocks), dim3(256), 0, stream, codes,
@@ -2016,7 +2009,7 @@ void launchBatch(int K, int rxi, const BatchArgs& ba, hipStream_t stream) {
 #undef X
 }
 
-void launchTileClass(int K, int rxi, const uint16_t* codes, uint8_t* tileClass, int* list, int* count,
+void launchTileClass(int K, int rxi, const code_t* codes, uint8_t* tileClass, int* list, int* count,
                      const Geometry& g, hipStream_t stream, bool allowEdge) {
 #define X(k, np, x, sub) \
     if (K == k && rxi == x) \
@@ -2105,7 +2098,7 @@ void launchBeginRun(const BeginArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(pv_begin_run_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a);
 }
 
-void launchCodes(const uint8_t* mat, uint16_t* codes, const Geometry& g, hipStream_t stream) {
+void launchCodes(const mat_t* mat, code_t* codes, const Geometry& g, hipStream_t stream) {
     dim3 grid((g.pitch + 255) / 256, g.rows);
     hipLaunchKernelGGL(pv_codes_kernel, grid, dim3(256), 0, stream, mat, codes, g);
 }
@@ -2160,9 +2153,9 @@ __global__ __launch_bounds__(kSmallThreads) void pv_small_grid_kernel(const Smal
         if (i < cells) {
             const int x = i / NY, y = i - x * NY;
             const unsigned code = a.codes[(size_t)(x + a.G) * a.pitch + (y + a.G)];
-            kx[j] = a.lut[code & 0xffu];
-            ky[j] = a.lut[code >> 8];
-            if ((code & 0xffu) < (unsigned)kLutWall) beta |= 1u << j;
+            kx[j] = a.lut[code & kIdxMask];
+            ky[j] = a.lut[code >> kIdxBits];
+            if ((code & kIdxMask) < (unsigned)a.lutWall) beta |= 1u << j;
             hoff[j] = (int)histOffset(x + a.G - dyn.histRow0, y + a.G - dyn.histCol0, a.rxi, a.wi, dyn.histTilesY);
         }
     }
@@ -2409,7 +2402,7 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
     }
 
     const uint32_t code = a.codes[(size_t)prow * a.pitch + pcol];
-    const float kx = a.lut[code & 0xffu], ky = a.lut[code >> 8];
+    const float kx = a.lut[code & kIdxMask], ky = a.lut[code >> kIdxBits];
     const bool airX = kx != kx, airY = ky != ky;
     const float C = a.courant;
 
@@ -2423,7 +2416,7 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
     // samples per memory round trip: the air cells outside a closed room but inside an active tile leave here; through
     // the recurrence below each of them walked three planes for all T - tFirst samples, 8 at a time (100 of 112 us at
     // 512^2).  An open field has next to no such cells and is bandwidth-bound: no second pass there.
-    if ((code & 0xffu) >= (uint32_t)kLutWall) {
+    if ((code & kIdxMask) >= (uint32_t)a.lutWall) {
         a.delay[s] = FLT_MAX;
         return;
     }
@@ -3092,7 +3085,7 @@ __global__ __launch_bounds__(256) void pv_stream_accum_kernel(const AnalyzeArgs 
     int directEnd = onset >= 0 ? onset + a.nDry : INT_MAX;
     if (a.tA >= directEnd) return;  // this cell's dry window is closed
     // a wall cell's pressure is identically zero: it never has an onset and must not keep its tile recording
-    if ((a.codes[(size_t)(X + a.G) * a.pitch + (Y + a.G)] & 0xffu) >= (unsigned)kLutWall) return;
+    if ((a.codes[(size_t)(X + a.G) * a.pitch + (Y + a.G)] & kIdxMask) >= (unsigned)a.lutWall) return;
 
     const int prow = X + a.G, pcol = Y + a.G;
     const int hr = prow - dyn.histRow0, hcol = pcol - dyn.histCol0;
@@ -3104,7 +3097,7 @@ __global__ __launch_bounds__(256) void pv_stream_accum_kernel(const AnalyzeArgs 
     const float* hx = a.hist + (tFx != INT_MAX ? histOffset(hr - 1, hcol, a.rxi, a.wi, dyn.histTilesY) : hoff);
     const float* hy = a.hist + (tFy != INT_MAX ? histOffset(hr, hcol - 1, a.rxi, a.wi, dyn.histTilesY) : hoff);
     const uint32_t code = a.codes[(size_t)prow * a.pitch + pcol];
-    const float kx = a.lut[code & 0xffu], ky = a.lut[code >> 8];
+    const float kx = a.lut[code & kIdxMask], ky = a.lut[code >> kIdxBits];
     const bool airX = kx != kx, airY = ky != ky;
     const float C = a.courant;
 
@@ -3310,7 +3303,7 @@ __global__ void pv_ir_kernel(const AnalyzeArgs a, int X, int Y, float* out) {
     const long long hoffX = tFx != INT_MAX ? histOffset(prow - 1 - dyn.histRow0, pcol - dyn.histCol0, a.rxi, a.wi, dyn.histTilesY) : 0;
     const long long hoffY = tFy != INT_MAX ? histOffset(prow - dyn.histRow0, pcol - 1 - dyn.histCol0, a.rxi, a.wi, dyn.histTilesY) : 0;
     const uint32_t code = a.codes[(size_t)prow * a.pitch + pcol];
-    const float kx = a.lut[code & 0xffu], ky = a.lut[code >> 8];
+    const float kx = a.lut[code & kIdxMask], ky = a.lut[code >> kIdxBits];
     const bool airX = kx != kx, airY = ky != ky;
     const bool above = X == 0 && a.histAbove;  // first row of a slab: the row above lives in the neighbouring slab
     float vx = 0.f, vy = 0.f;

@@ -142,6 +142,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     geo_.x0 = x0_;
     geo_.NXg = g_.NX;
     geo_.gxg = g_.gx;
+    geo_.lutWall = kLutWallSmall;
     const int kGuard = std::max(kMinGuard, K_ + stepConfigExtraRows(K_, rxi_));
     geo_.G = kGuard;
     geo_.rxi = rxi_;
@@ -179,7 +180,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     }
     if (!dalloc(&codes_, plane, true)) return false;
     if (!dalloc(&matDev_, (size_t)g_.NX * g_.NY, true)) return false;
-    if (!dalloc(&lutDev_, 256, true)) return false;
+    if (!dalloc(&lutDev_, (size_t)kLutSize, true)) return false;
     if (!dalloc(&pulseDev_, (size_t)std::max(T_, g_.T), true)) return false;
     if (!dalloc(&tileFirst_, (size_t)ntiles, true)) return false;
     if (!dalloc(&tileClass_, (size_t)ntiles, true)) return false;
@@ -475,8 +476,8 @@ bool Solver::applyGeometry() {
     if (lo < hi) {
         const auto& beta = mat_.beta();
         const auto& R = mat_.R();
-        // material byte of every cell of rows [a, b): beta | palette index << 1; false = a value found no free slot
-        auto encodeRows = [&](int a, int b) {
+        // material word of every cell of rows [a, b): beta | palette index << 1; false = the palette would pass `limit` values
+        auto encodeRows = [&](int a, int b, int limit) {
             for (int x = a; x < b; ++x) {
                 for (int y = 0; y < g_.NY; ++y) {
                     const size_t i = (size_t)x * g_.NY + y;
@@ -486,7 +487,7 @@ bool Solver::applyGeometry() {
                         std::memcpy(&bits, &R[i], 4);
                         auto it = paletteIndex_.find(bits);
                         if (it == paletteIndex_.end()) {
-                            if ((int)palette_.size() > kPaletteMax - 1) return false;
+                            if ((int)palette_.size() > limit - 1) return false;
                             p = (int)palette_.size();
                             palette_.push_back(R[i]);
                             paletteIndex_[bits] = p;
@@ -494,41 +495,54 @@ bool Solver::applyGeometry() {
                             p = it->second;
                         }
                     }
-                    matHost_[i] = (uint8_t)((beta[i] ? 1 : 0) | (p << 1));
+                    matHost_[i] = (mat_t)((beta[i] ? 1 : 0) | (p << 1));
                     byHost_[i] = mat_.by()[i];
                 }
             }
             return true;
         };
-        if (!encodeRows(lo, hi)) {
-            // The palette only grows while boxes come and go (a long session that keeps changing absorptions through
-            // UpdateGeometry).  Rebuild it from what the plane holds NOW; only more than 127 values alive at the same
-            // time is an error (the reference has no such limit: DESIGN.md section 3).
+        auto rebuildAll = [&]() {
             palette_.assign(1, 0.f);
             paletteIndex_.clear();
             paletteIndex_[0u] = 0;
             lo = 0;
             hi = g_.NX;
-            if (!encodeRows(lo, hi))
-                return fail("more than 127 distinct absorption values alive in the scene at once");
-        }
+            return encodeRows(lo, hi, kPaletteMax);
+        };
+        // The palette only grows while boxes come and go (a long session that keeps changing absorptions through
+        // UpdateGeometry).  While it fits the step kernels' 256-entry table (127 values) the dirty rows are encoded
+        // incrementally; when it would outgrow that, and on every change while it has, it is rebuilt from what the plane
+        // holds NOW, so the wide table is in use exactly while more than 127 values are ALIVE.  Only more than 32767 values
+        // alive at the same time is an error (the reference has no limit: DESIGN.md section 3).
+        const bool ok = (int)palette_.size() > kPaletteSmallMax ? rebuildAll()
+                                                                : (encodeRows(lo, hi, kPaletteSmallMax) || rebuildAll());
+        if (!ok) return fail("more than 32767 distinct absorption values alive in the scene at once");
         if (!hipOk(hipMemcpyAsync(matDev_ + (size_t)lo * g_.NY, matHost_.data() + (size_t)lo * g_.NY,
-                                  (size_t)(hi - lo) * g_.NY, hipMemcpyHostToDevice, stream_),
+                                  (size_t)(hi - lo) * g_.NY * sizeof(mat_t), hipMemcpyHostToDevice, stream_),
                    "material upload"))
             return false;
     }
-    // coefficient LUT: Y = (1 - R) / (1 + R), FDTD.cpp:150,156
-    float lut[256];
-    for (float& v : lut) v = 0.f;
-    lut[kLutAir] = std::numeric_limits<float>::quiet_NaN();
-    for (size_t p = 0; p < palette_.size(); ++p) {
+    // coefficient LUT: Y = (1 - R) / (1 + R), FDTD.cpp:150,156, in the index layout the palette's size asks for (pv_device.h);
+    // the face codes below are regenerated in the same layout
+    const size_t P = palette_.size();
+    const int wallBefore = lutWall_;
+    lutWall_ = P > (size_t)kPaletteSmallMax ? kLutWallWide : kLutWallSmall;
+    if (lutWall_ != wallBefore) dropGraph();  // (a captured run holds the layout among its kernel arguments)
+    geo_.lutWall = lutWall_;
+    lutHost_.assign((size_t)kLutSize, 0.f);
+    lutHost_[kLutAir] = std::numeric_limits<float>::quiet_NaN();
+    for (size_t p = 0; p < P; ++p) {
         const float Rv = palette_[p];
         const float Y = (1.f - Rv) / (1.f + Rv);
-        lut[kLutNegBase + p] = -Y;
-        lut[kLutPosBase + p] = Y;
+        lutHost_[(size_t)kLutNegBase + p] = -Y;
+        lutHost_[(size_t)lutWall_ + 1 + p] = Y;
     }
-    lut[kLutWall] = 0.f;
-    if (!hipOk(hipMemcpyAsync(lutDev_, lut, sizeof(lut), hipMemcpyHostToDevice, stream_), "lut upload"))
+    lutHost_[(size_t)lutWall_] = 0.f;
+    // (only what a palette of P values uses: [0, 1 + P) and [wall, wall + 1 + P))
+    if (!hipOk(hipMemcpyAsync(lutDev_, lutHost_.data(), (1 + P) * sizeof(float), hipMemcpyHostToDevice, stream_), "lut upload") ||
+        !hipOk(hipMemcpyAsync(lutDev_ + lutWall_, lutHost_.data() + lutWall_, (1 + P) * sizeof(float), hipMemcpyHostToDevice,
+                              stream_),
+               "lut upload"))
         return false;
     launchCodes(matDev_, codes_, geo_, stream_);
     if (!hipOk(hipMemsetAsync(generalCount_, 0, sizeof(int), stream_), "memset")) return false;
@@ -775,6 +789,7 @@ StepArgs Solver::baseStepArgs(bool withPulse, bool record) const {
     StepArgs a{};
     a.codes = codes_;
     a.lut = lutDev_;
+    a.lutWall = lutWall_;
     a.pulse = pulseDev_;
     a.hist = hist_;
     a.tileFirst = tileFirst_;
@@ -1032,6 +1047,7 @@ AnalyzeArgs Solver::analyzeArgs(float lx, float lz) const {
     a.hist = hist_;
     a.codes = codes_;
     a.lut = lutDev_;
+    a.lutWall = lutWall_;
     a.tileFirst = tileFirst_;
     a.dyn = dynDev_;
     a.out = res_;
@@ -1241,6 +1257,7 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
         sa.vyOut = vy_[0];
         sa.codes = codes_;
         sa.lut = lutDev_;
+        sa.lutWall = lutWall_;
         sa.pulse = pulseDev_;
         sa.hist = hist_;
         sa.dyn = dynDev_;
@@ -1260,12 +1277,20 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
     } else if (graph) {
         // the grid of the general kernel is captured for a capacity; the live count is read from dyn on the device
         const int cap = (int)wallTiles_.size() + 4;
-        if (!graphExec_ || graphCap_ != cap) {
-            if (!buildGraph(cap)) return false;
+        if ((!graphExec_ || graphCap_ != cap) && !buildGraph(cap)) {
+            // The capture did not survive (another host thread's hipFree / device-wide synchronisation while this stream was
+            // capturing invalidates it: seen once in seven runs of the live-module test, whose worker captures its first
+            // iteration while the test thread builds a solver of its own).  This run goes out as plain launches; the next
+            // one captures again.
+            (void)hipGetLastError();
+            err_.clear();
+            launchCap_ = numGeneral_;
+            if (!enqueueResetAndSteps()) return false;
+        } else {
+            if (!hipOk(hipGraphLaunch(graphExec_, stream_), "hipGraphLaunch")) return false;
+            tim_.stepLaunches = ceilDiv(T_, K_);
+            cur_ = tim_.stepLaunches & 1;
         }
-        if (!hipOk(hipGraphLaunch(graphExec_, stream_), "hipGraphLaunch")) return false;
-        tim_.stepLaunches = ceilDiv(T_, K_);
-        cur_ = tim_.stepLaunches & 1;
     } else {
         launchCap_ = numGeneral_;
         if (!enqueueResetAndSteps()) return false;
@@ -1308,15 +1333,26 @@ bool Solver::buildGraph(int cap) {
     const int savedCur = cur_;
     const int savedLaunches = tim_.stepLaunches;
     if (!hipOk(hipStreamBeginCapture(stream_, hipStreamCaptureModeRelaxed), "hipStreamBeginCapture")) return false;
-    const bool ok = enqueueResetAndSteps();
+    bool ok = enqueueResetAndSteps();
     hipGraph_t g = nullptr;
     const hipError_t e = hipStreamEndCapture(stream_, &g);
+    // test hook (tests/test_gpu_parity.py::test_run_survives_a_lost_graph_capture): the solver's first capture counts as lost
+    if (!captureLossInjected_ && std::getenv("PVA_DEBUG_LOSE_FIRST_CAPTURE")) {
+        captureLossInjected_ = true;
+        ok = false;
+    }
     cur_ = savedCur;
     tim_.stepLaunches = savedLaunches;
-    if (!ok) return false;
-    if (!hipOk(e, "hipStreamEndCapture")) return false;
+    if (!ok || e != hipSuccess || !g) {  // (the caller falls back to plain launches)
+        if (g) hipGraphDestroy(g);
+        return false;
+    }
     graph_ = g;
-    if (!hipOk(hipGraphInstantiate(&graphExec_, graph_, nullptr, nullptr, 0), "hipGraphInstantiate")) return false;
+    if (hipGraphInstantiate(&graphExec_, graph_, nullptr, nullptr, 0) != hipSuccess) {
+        graphExec_ = nullptr;
+        dropGraph();
+        return false;
+    }
     graphCap_ = cap;
     return true;
 }

@@ -202,6 +202,7 @@ private:
     hipGraph_t graph_ = nullptr;
     hipGraphExec_t graphExec_ = nullptr;
     int graphCap_ = -1;  // general-list capacity the graph was captured with
+    bool captureLossInjected_ = false;  // (test hook, buildGraph)
     bool buildGraph(int cap);
     void dropGraph();
     bool enqueueResetAndSteps();
@@ -216,9 +217,12 @@ private:
     float* vx_[2] = {nullptr, nullptr};
     float* vy_[2] = {nullptr, nullptr};
     int cur_ = 0;  // which set holds the current fields
-    uint16_t* codes_ = nullptr;
-    uint8_t* matDev_ = nullptr;
-    float* lutDev_ = nullptr;
+    code_t* codes_ = nullptr;
+    mat_t* matDev_ = nullptr;
+    float* lutDev_ = nullptr;       // kLutSize face coefficients, in the layout of lutWall_ (pv_device.h)
+    int lutWall_ = kLutWallSmall;   // small layout (the 256-entry table of rounds 1-2) while <= 127
+                                    // absorption values are alive, wide otherwise
+    std::vector<float> lutHost_;
     float* pulseDev_ = nullptr;
     float* hist_ = nullptr;
     long long histPlane_ = 0;
@@ -292,7 +296,7 @@ private:
 
     // host state
     MaterialPlane mat_;
-    std::vector<uint8_t> matHost_;
+    std::vector<mat_t> matHost_;
     std::vector<uint8_t> byHost_;  // Cell::by as of the last applyGeometry() (= during the last run)
     std::vector<float> palette_;  // R values; [0] = 0
     std::unordered_map<uint32_t, int> paletteIndex_;
