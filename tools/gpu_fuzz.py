@@ -25,6 +25,9 @@ CONFIGS = [dict(), dict(), dict(steps_per_launch=12, tile_rows=36), dict(steps_p
            dict(steps_per_launch=12, tile_rows=36, merged_launch=0), dict(steps_per_launch=1, tile_rows=30),
            dict(streaming_analysis=1), dict(streaming_analysis=1, steps_per_launch=12, tile_rows=36),
            dict(streaming_analysis=1, steps_per_launch=4, tile_rows=32),
+           # round 3: forward sums of air tiles inside the stencil (pv_stream.h), forced on (auto: from 6000 tiles)
+           dict(streaming_analysis=1, stream_fuse=1), dict(streaming_analysis=1, stream_fuse=1, steps_per_launch=12, tile_rows=36),
+           dict(streaming_analysis=1, stream_fuse=1, steps_per_launch=10, tile_rows=36),
            dict(steps_per_launch=8, tile_rows=40, edge_tiles=1), dict(steps_per_launch=10, tile_rows=36, edge_tiles=1),
            dict(steps_per_launch=12, tile_rows=36, edge_tiles=1),
            # round 2: row bands, single-grid decomposition into slabs (falls back to a plain solver where the grid has
