@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import planeverb_amd.api as pv
 
 SCENE = os.environ.get("SCENE", "HugeRoom.pv")
-FUSE = int(os.environ.get("FUSE", "1"))  # PVA_OPT_STREAM_FUSE
+FUSE = int(os.environ.get("FUSE", "-1"))  # PVA_OPT_STREAM_FUSE (-1: by grid size)
 for res in [int(a) for a in sys.argv[1:]] or [2009, 4017, 8034, 16067]:
     t0 = time.time()
     s = pv.Solver(25.0, 25.0, res, streaming_analysis=1, stream_fuse=FUSE)
