@@ -265,8 +265,7 @@ __device__ __forceinline__ bool historyWanted(const StepArgs& a, int ti, int tj)
 // of the tile's RXI rows (air tiles: SUB == RXI, part 0; general tiles are split over RXI/SUB waves to shorten the
 // latency of that small, VALU-heavier kernel).
 template <int K, int RXI, int SUB, bool GENERAL>
-__device__ __forceinline__ void stepTile(const StepArgs& a, const int tile, const int part, const int lane,
-                                         const float* lut) {
+__device__ __forceinline__ void stepTile(const StepArgs& a, const int tile, const int part, const int lane) {
     constexpr int ROWS = SUB + 2 * K;
     constexpr int WI = 64 - 2 * K;
     const int ti = tile / a.nty;
@@ -941,8 +940,7 @@ struct GenShared {
 };
 
 template <int K, int RXI>
-__device__ __forceinline__ void stepTileGeneral4Scalar(const StepArgs& a, const int tile, const int wave, const int lane,
-                                                 const float* lut, GenShared& sh) {
+__device__ __forceinline__ void stepTileGeneral4Scalar(const StepArgs& a, const int tile, const int wave, const int lane, GenShared& sh) {
     using Gm = GenStackGeom<K, RXI>;
     constexpr int R = Gm::R;
     constexpr int WI = 64 - 2 * K;
@@ -1096,8 +1094,7 @@ __device__ __forceinline__ void stepTileGeneral4Scalar(const StepArgs& a, const 
 typedef unsigned int u2 __attribute__((ext_vector_type(2)));
 
 template <int K, int RXI>
-__device__ __forceinline__ void stepTileGeneral4Packed(const StepArgs& a, const int tile, const int wave, const int lane,
-                                                       const float* lut, GenShared& sh) {
+__device__ __forceinline__ void stepTileGeneral4Packed(const StepArgs& a, const int tile, const int wave, const int lane, GenShared& sh) {
     using Gm = GenStackGeom<K, RXI>;
     constexpr int R = Gm::R;
     constexpr int NP = (R + 1) / 2;  // row pairs (R odd: the last pair's second row is a spare row below the window)
@@ -1282,16 +1279,15 @@ __device__ __forceinline__ void stepTileGeneral4Packed(const StepArgs& a, const 
 }
 
 template <int K, int RXI>
-__device__ __forceinline__ void stepTileGeneral4(const StepArgs& a, const int tile, const int wave, const int lane,
-                                                 const float* lut, GenShared& sh) {
+__device__ __forceinline__ void stepTileGeneral4(const StepArgs& a, const int tile, const int wave, const int lane, GenShared& sh) {
     // Measured (profiles/r02_ab_general_packed.txt): +9-10 % at 512^2 (4 runs in flight, K = 8 tiles: a quarter of all
     // tiles are general), +1.5 % at 2048^2 (K = 10) -- and 3 % SLOWER at 4096^2 / 8192^2, where 4 % of the tiles are
     // general and the changed arm disturbs the register allocation of the air arm that shares its kernel (DESIGN.md 8.4
     // has two more cases of that).  So the large-grid tile (K = 12) keeps the scalar form.
     if constexpr (PV_GENERAL_PACKED == 1 ? K < 12 : PV_GENERAL_PACKED != 0)
-        stepTileGeneral4Packed<K, RXI>(a, tile, wave, lane, lut, sh);
+        stepTileGeneral4Packed<K, RXI>(a, tile, wave, lane, sh);
     else
-        stepTileGeneral4Scalar<K, RXI>(a, tile, wave, lane, lut, sh);
+        stepTileGeneral4Scalar<K, RXI>(a, tile, wave, lane, sh);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1552,7 +1548,7 @@ __global__ __launch_bounds__(256, WPS) void pv_step_air_kernel(const StepArgs a)
     if constexpr (PACKED && (RXI + 2 * K) % 2 == 0) {
         airTilePacked<K, RXI>(a, tile, lane, cls == 2);
     } else {
-        stepTile<K, RXI, RXI, false>(a, tile, 0, lane, nullptr);
+        stepTile<K, RXI, RXI, false>(a, tile, 0, lane);
     }
 }
 
@@ -1561,7 +1557,6 @@ template <int K, int RXI, int SUB>
 __global__ __launch_bounds__(256, 2) void pv_step_general_kernel(const StepArgs a) {
     constexpr int S = RXI / SUB;
     static_assert(S * SUB == RXI, "general-tile split must divide the tile");
-    const float* lut = nullptr;  // (the face coefficients come straight from the global table: faceCoefs)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int idx = blockIdx.x * 4 + wave;
@@ -1569,7 +1564,7 @@ __global__ __launch_bounds__(256, 2) void pv_step_general_kernel(const StepArgs 
     // few, long, latency-bound waves that run beside the air kernel: let them win VALU/issue arbitration
     __builtin_amdgcn_s_setprio(3);
     const int tile = __builtin_amdgcn_readfirstlane(a.generalList[idx / S]);
-    stepTile<K, RXI, SUB, true>(a, tile, idx % S, lane, lut);
+    stepTile<K, RXI, SUB, true>(a, tile, idx % S, lane);
 }
 
 // Merged form: ONE launch per K steps.  The first numGeneral blocks advance one general tile each (4 waves sharing
@@ -1578,7 +1573,6 @@ __global__ __launch_bounds__(256, 2) void pv_step_general_kernel(const StepArgs 
 // fits inside the air arm's register budget.  SUB is the slice height of the two-kernel form and unused here.
 template <int K, int RXI, int WPS, int SUB>
 __global__ __launch_bounds__(256, WPS) void pv_step_merged_kernel(const StepArgs a) {
-    const float* lut = nullptr;  // (the face coefficients come straight from the global table: faceCoefs)
     __shared__ GenShared gsh;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1590,7 +1584,7 @@ __global__ __launch_bounds__(256, WPS) void pv_step_merged_kernel(const StepArgs
         if ((int)blockIdx.x >= a.dyn->numGeneral) return;
         const int tile = __builtin_amdgcn_readfirstlane(a.generalList[blockIdx.x]);
         if (deadTileSkippable<K, RXI>(a, tile)) return;  // (block-uniform)
-        stepTileGeneral4<K, RXI>(a, tile, wave, lane, lut, gsh);
+        stepTileGeneral4<K, RXI>(a, tile, wave, lane, gsh);
         return;
     }
     const int b = blockIdx.x - gblocks;
@@ -1606,7 +1600,7 @@ __global__ __launch_bounds__(256, WPS) void pv_step_merged_kernel(const StepArgs
     if constexpr ((RXI + 2 * K) % 2 == 0) {
         airTilePacked<K, RXI>(a, tile, lane, cls == 2);
     } else {
-        stepTile<K, RXI, RXI, false>(a, tile, 0, lane, nullptr);
+        stepTile<K, RXI, RXI, false>(a, tile, 0, lane);
     }
 }
 
@@ -1618,7 +1612,6 @@ __global__ __launch_bounds__(256, WPS) void pv_step_merged_kernel(const StepArgs
 // XCD (b - gblocks) % 8.
 template <int K, int RXI, int WPS, int SUB>
 __global__ __launch_bounds__(256, WPS) void pv_step_batch_kernel(const BatchArgs ba) {
-    const float* lut = nullptr;  // (the face coefficients come straight from the global table: faceCoefs)
     __shared__ GenShared gsh;
     const StepArgs& a = ba.a[blockIdx.y];
     const int lane = threadIdx.x & 63;
@@ -1628,7 +1621,7 @@ __global__ __launch_bounds__(256, WPS) void pv_step_batch_kernel(const BatchArgs
         if ((int)blockIdx.x >= a.dyn->numGeneral) return;
         const int tile = __builtin_amdgcn_readfirstlane(a.generalList[blockIdx.x]);
         if (deadTileSkippable<K, RXI>(a, tile)) return;  // (block-uniform)
-        stepTileGeneral4<K, RXI>(a, tile, wave, lane, lut, gsh);
+        stepTileGeneral4<K, RXI>(a, tile, wave, lane, gsh);
         return;
     }
     const int b = blockIdx.x - gblocks;
@@ -1644,7 +1637,7 @@ __global__ __launch_bounds__(256, WPS) void pv_step_batch_kernel(const BatchArgs
     if constexpr ((RXI + 2 * K) % 2 == 0) {
         airTilePacked<K, RXI, true>(a, tile, lane, cls == 2);
     } else {
-        stepTile<K, RXI, RXI, false>(a, tile, 0, lane, nullptr);
+        stepTile<K, RXI, RXI, false>(a, tile, 0, lane);
     }
 }
 
@@ -1654,7 +1647,6 @@ template <int K, int NP, int X, int SUB>
 __global__ __launch_bounds__(256, 2) void pv_step_stack_kernel(const StepArgs a) {
     constexpr int W = 4;
     using Gm = StackGeom<K, NP, W, X>;
-    const float* lut = nullptr;  // (the face coefficients come straight from the global table: faceCoefs)
     __shared__ StackShared<W> sh;
     constexpr int S = X / SUB;
     static_assert(S * SUB == X, "general-tile split must divide the tile");
@@ -1665,7 +1657,7 @@ __global__ __launch_bounds__(256, 2) void pv_step_stack_kernel(const StepArgs a)
         const int idx = blockIdx.x * 4 + wave;
         if (idx >= a.dyn->numGeneral * S) return;
         const int tile = __builtin_amdgcn_readfirstlane(a.generalList[idx / S]);
-        stepTile<K, X, SUB, true>(a, tile, idx % S, lane, lut);
+        stepTile<K, X, SUB, true>(a, tile, idx % S, lane);
         return;
     }
     const int b = blockIdx.x - gblocks;
@@ -1835,7 +1827,6 @@ void launchStepPatch(int K, int rxi, const StepArgs& a, int blocks, hipStream_t 
 // y-halo columns stream down side by side on the same L2.
 template <int K, int RXI, int NC, int WPS>
 __global__ __launch_bounds__(256, WPS) void pv_step_seg_kernel(const StepArgs a) {
-    const float* lut = nullptr;  // (the face coefficients come straight from the global table: faceCoefs)
     __shared__ GenShared gsh;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1844,7 +1835,7 @@ __global__ __launch_bounds__(256, WPS) void pv_step_seg_kernel(const StepArgs a)
         if ((int)blockIdx.x >= a.dyn->numGeneral) return;
         const int tile = __builtin_amdgcn_readfirstlane(a.generalList[blockIdx.x]);
         if (deadTileSkippable<K, RXI>(a, tile)) return;  // (block-uniform)
-        stepTileGeneral4<K, RXI>(a, tile, wave, lane, lut, gsh);
+        stepTileGeneral4<K, RXI>(a, tile, wave, lane, gsh);
         return;
     }
     const int b = blockIdx.x - gblocks;

@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""One-off parity check at a BASELINE grid size against the UNMODIFIED reference (oracle/_ref/libpvref.so on one host core of
+the GPU box; two (N+1)^2 x 435 x 16 B cubes in host memory: 242 GB at 4097^2).  The test suite holds the headline size
+through the closed-room records of config 4 (a 71-cell room in a 4096^2 grid equals the 71^2 run); here the scene is OPEN --
+scattered reflectors around an off-centre listener, so that sound fills the whole history window -- and EVERY cell of the
+16.8 M-cell result map is compared: onset on all cells, the eight outputs on every cell whose windows lie inside the response
+(SURVEY Q5), final fields, a recorded pressure plane, and the records of a few emitters.
+
+    python tools/reference_fullsize_check.py [cells=4097]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import planeverb_amd.api as pv  # noqa: E402
+from oracle import pvref  # noqa: E402  (checker only)
+
+NAMES = ["occlusion", "wetGain", "rt60", "lowpass", "dirX", "dirY", "srcDirX", "srcDirY"]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def same_bits(a, b):
+    a = np.asarray(a, np.float32)
+    b = np.asarray(b, np.float32)
+    return (bits(a) == bits(b)) | ((a == 0) & (b == 0)) | (np.isnan(a) & np.isnan(b))
+
+
+cells = int(sys.argv[1]) if len(sys.argv) > 1 else 4097
+dx = np.float32(343.21) / np.float32(275) / np.float32(3.5)
+size = float((cells - 1 + 0.5) * dx)
+need_gb = 2 * cells * cells * 435 * 16 / 1e9 + 8
+avail_gb = 0.0
+with open("/proc/meminfo") as f:
+    for line in f:
+        if line.startswith("MemAvailable"):
+            avail_gb = int(line.split()[1]) / 1e6
+print("%d^2 cells: the reference needs about %.0f GB of host memory, %.0f GB available" % (cells, need_gb, avail_gb), flush=True)
+if avail_gb < 1.3 * need_gb:
+    raise SystemExit("not enough host memory for a safe run")
+
+# listener at 0.37 / 0.41 of the grid; reflectors of several absorptions within the 873-cell history window around it
+c = lambda cx, cy: ((cx + 0.5) * float(dx), 0.0, (cy + 0.5) * float(dx))
+lcx, lcy = int(0.37 * cells), int(0.41 * cells)
+L = c(lcx, lcy)
+m = float(dx) * max(cells / 4097.0, 0.2)  # (offsets scale with the grid for trial runs at smaller sizes)
+boxes = np.array([[L[0] + 40 * m, L[2] + 10 * m, 6 * m, 160 * m, 0.9], [L[0] - 90 * m, L[2] - 30 * m, 120 * m, 5 * m, 0.7],
+                  [L[0] + 150 * m, L[2] + 200 * m, 60 * m, 60 * m, 0.95], [L[0] - 200 * m, L[2] + 250 * m, 80 * m, 8 * m, 0.5],
+                  [L[0] + 20 * m, L[2] - 220 * m, 10 * m, 180 * m, 0.85], [L[0] - 300 * m, L[2] - 150 * m, 30 * m, 30 * m, 0.6]],
+                 np.float32)
+f = max(cells / 4097.0, 0.2)
+E = [c(lcx + 12, lcy + 6), c(lcx + int(100 * f), lcy - int(40 * f)), c(lcx - int(250 * f), lcy + int(300 * f)),
+     c(lcx + int(380 * f), lcy + 20), c(5, 5)]
+
+t0 = time.time()
+ref = pvref.RefSolver(size, size, 275, boxes)
+print("reference constructed in %.1f s (grid %.1f s, free grid %.1f s)" % (time.time() - t0, ref.ctor_grid_s, ref.ctor_free_s), flush=True)
+tf = ref.generate(L)
+ta = ref.analyze(L)
+rres, rdelay = ref.results()
+rf = ref.snapshot(ref.T - 1)
+rp200 = ref.snapshot(200)[0]
+rout = [ref.output(e) for e in E]
+T, fs, gx = ref.T, ref.fs, ref.gx
+print("reference FDTD %.1f s (%.3e cell-updates/s on one core), analysis %.1f s" % (tf, cells * cells * T / tf, ta), flush=True)
+ref.close()
+
+n_dry = int(np.float32(0.01) * np.float32(fs))
+valid = (rdelay < 1e30) & (rdelay + n_dry + 2 <= T - n_dry)
+bad = []
+with pv.Solver(size, size, 275) as s:
+    for b in boxes:
+        s.add_geometry(b)
+    s.run(L)
+    ms = s.timings().fdtdMs + s.timings().analysisMs
+    res, delay = s.results()
+    if not same_bits(delay, rdelay).all():
+        bad.append("delay: %d cells" % (~same_bits(delay, rdelay)).sum())
+    for k in range(8):
+        mk = valid if k not in (4, 5) else np.ones_like(valid)
+        ne = ~same_bits(res[..., k][mk], rres[..., k][mk])
+        if ne.any():
+            bad.append("%s: %d cells" % (NAMES[k], ne.sum()))
+    # (the reference's snapshot of step T - 1 is taken before that step's pulse sample is added, FDTD.cpp:226-234: the
+    # listener's own cell is compared through the pressure history instead)
+    pr, vx, vy = s.fields()
+    pr = pr.copy()
+    pr[lcx, lcy] = rf[0][lcx, lcy]
+    if not same_bits(s.history_plane(T - 1)[lcx, lcy], rf[0][lcx, lcy]):
+        bad.append("listener cell, last recorded pressure")
+    for nm, a, b in (("final pr", pr, rf[0]), ("final vx", vx, rf[1]), ("final vy", vy, rf[2]), ("pr at step 200", s.history_plane(200), rp200)):
+        ne = ~same_bits(a, b)
+        if ne.any():
+            bad.append("%s: %d cells" % (nm, ne.sum()))
+    for e, ro in zip(E, rout):
+        o = s.get_output(e).as_array()
+        if ro is None:
+            continue
+        cx, cy = pv.host_cells(size, size, 275, e[0], e[2])[1]
+        if valid[cx, cy] and not same_bits(o, ro).all():
+            bad.append("record of emitter %s: %r vs %r" % (e, o, ro))
+print("GPU: %.2f ms for the run; %d of %d cells have an onset, %d inside the Q5 mask: %s" % (
+    ms, (rdelay < 1e30).sum(), rdelay.size, valid.sum(), "every map, field and record bit-identical to the reference" if not bad else "; ".join(bad)),
+    flush=True)
+sys.exit(1 if bad else 0)
