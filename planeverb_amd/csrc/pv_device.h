@@ -5,10 +5,8 @@
 //   array cell (x, y) of the reference's (gx+1) x (gy+1) grid lives at padded (x + G, y + G);
 //   y is the contiguous dimension (reference index = x*(gy+1) + y, FDTD.cpp:99) so wave lanes run along y.
 //   pr/vx/vy : float32, ping-pong pair (a fused K-step launch reads one set and writes the other)
-//   codes    : uint32 per cell = kxIdx | kyIdx << 16, 16-bit indices into a 65536-entry float LUT that folds beta,
-//              wall admittance Y=(1-R)/(1+R) and the absorbing grid edges into one per-face coefficient (read by
-//              general tiles and the analysis only; 32767 distinct absorption values: the reference has no limit,
-//              rounds 1-2 had 127)
+//   coef     : three float32 per cell: the coefficients of its x and y face + its beta (FaceCoef below)
+//              (read by general tiles and the analysis only)
 //   hist     : float32 pr[t][window tile][row in tile][col in tile] over a tile-aligned window around the listener
 //              (tile-major: a tile's block of one step is one contiguous chunk; cells that the pulse cannot have
 //              reached are exactly zero and are not stored)
@@ -28,22 +26,23 @@ constexpr float kAudibleThresholdDev = 0.00000316f;
 constexpr float kDistanceGainDev = 0.891251f;
 constexpr float kDelayCloseDev = 5.f;
 
-// LUT layout: beta(cell) == (kxIdx < wall), in one of two index layouts chosen by the number of absorption values alive:
-//   small (<= 127 values: every scene the reference ships): wall = 128 -- the 256-entry table of rounds 1-2 (1 KB: it stays
-//          in the L1 / L2 of whoever reads it);
-//   wide  (<= 32767 values): wall = 32768.
-// The face codes are regenerated from the material plane whenever the layout changes (Solver::applyGeometry).
-typedef uint32_t code_t;          // face codes of a cell: kxIdx | kyIdx << 16
-typedef uint16_t mat_t;           // material of a cell: beta | palette index << 1
-constexpr int kIdxBits = 16;
-constexpr uint32_t kIdxMask = 0xffffu;
-constexpr int kLutAir = 0;        // air|air face: v -= C * grad(p)           (entry = NaN sentinel)
-constexpr int kLutNegBase = 1;    // 1 + p : wall(n)|air(i):  v = -Y[p] * p_i  (p = palette index of cell n)
-//                  wall          :          wall|wall face: v = 0
-//                  wall + 1 + p  :          air(n)|wall(i): v = +Y[p] * p_n (p = palette index of cell i)
-constexpr int kLutWallSmall = 128, kLutWallWide = 32768;
-constexpr int kPaletteSmallMax = 127, kPaletteMax = 32767;  // palette index 0 is always R = 0 (Y = 1)
-constexpr int kLutSmallSize = 256, kLutSize = 65536;
+// Face coefficients.  beta, the wall admittance Y = (1 - R) / (1 + R) and the absorbing grid edges (FDTD.cpp:143-223) fold
+// into ONE float per face, stored per cell for its x face (neighbour (x-1, y)) and its y face (neighbour (x, y-1)):
+//   air|air        : NaN (kAirFaceBits)  ->  v = v - C * (p_i - p_n)
+//   wall(n)|air(i) : -Y_n                ->  v = k * (p_i + p_n)   (p_n = 0 inside the wall)
+//   air(n)|wall(i) : +Y_i
+//   wall|wall      : +0
+//   grid edges     : the same two forms with Y = 1
+// Rounds 1-2 stored 8-bit indices into a 256-entry table of such values (127 absorption values alive at once), round 3 first
+// 16-bit ones; the values themselves need no table, no palette and no limit (the reference has none), and a general tile's
+// load phase loses its dependent table look-up.  beta of the cell (1.f = air) rides along as a third float: it cannot be told
+// from the coefficients when an absorption above 1 makes Y negative, and one 12-byte load per row keeps a general tile at four
+// loads per row (a fifth passed the 63 loads a wave can have in flight: 2048^2 BigRoom.pv 2.6 % slower).
+struct FaceCoef {
+    float kx, ky, beta;
+};
+constexpr uint32_t kAirFaceBits = 0x7fc00000u;  // the quiet NaN pv_coef_kernel writes for an air|air face
+// material plane (host -> pv_coef_kernel): NaN = air cell (beta 1), else the cell's admittance Y (beta 0)
 
 struct Geometry {
     int gx, gy, NX, NY;
@@ -54,7 +53,6 @@ struct Geometry {
     // row slab of a larger grid (single-grid decomposition, pv_slabs.cpp): local array row 0 is row x0 of the whole
     // grid, whose cell array has NXg = gxg + 1 rows.  A whole grid has x0 = 0, NXg = NX, gxg = gx.
     int x0, NXg, gxg;
-    int lutWall;     // index layout of the face codes (kLutWallSmall / kLutWallWide), set by Solver::applyGeometry
 };
 
 // per-run parameters that change with the listener; lives in device memory so a captured graph can be replayed
@@ -79,9 +77,7 @@ struct StepArgs {
     float* prOut;
     float* vxOut;
     float* vyOut;
-    const code_t* codes;
-    const float* lut;      // kLutSize floats, in the layout of `lutWall`
-    int lutWall;           // kLutWallSmall / kLutWallWide
+    const FaceCoef* coef;  // face coefficients + beta of every padded cell (general tiles only)
     const float* pulse;    // T floats
     float* hist;           // window base, plane stride histPlane
     int* tileFirst;        // per tile: first step block in which the tile was non-zero (INT_MAX = never)
@@ -162,9 +158,7 @@ struct SmallArgs {
     float* prOut;
     float* vxOut;
     float* vyOut;
-    const code_t* codes;
-    const float* lut;
-    int lutWall;
+    const FaceCoef* coef;
     const float* pulse;
     float* hist;
     const DynParams* dyn;
@@ -218,9 +212,7 @@ struct FarInfo {
 
 struct AnalyzeArgs {
     const float* hist;
-    const code_t* codes;
-    const float* lut;
-    int lutWall;
+    const FaceCoef* coef;
     const int* tileFirst;
     const DynParams* dyn;
     float* out;    // 8 planes of gx*gy floats (SoA): occlusion, wet gain, RT60, lowpass, direction x/y, source

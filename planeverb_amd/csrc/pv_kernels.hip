@@ -3,7 +3,7 @@
 //
 // Reference semantics implemented here (paths relative to /root/reference/ProjectPlaneverb):
 //   pv_step_kernel      src/FDTD/FDTD.cpp:122-235   pressure / vx / vy sweeps, edge absorption, record, pulse
-//   pv_codes_kernel     src/FDTD/FDTD.cpp:143-223 + src/FDTD/Grid.cpp:88-108   (beta, Y, edges -> face codes)
+//   pv_coef_kernel      src/FDTD/FDTD.cpp:143-223 + src/FDTD/Grid.cpp:88-108   (beta, Y, edges -> face coefficients)
 //   pv_encode_kernel    src/DSP/Analyzer.cpp:139-328  onset, dry gain, source direction, lowpass, wet, RT60
 //   pv_direction_kernel src/DSP/Analyzer.cpp:340-431  listener direction by delay-map descent
 //   pv_efree_kernel     src/FDTD/FreeGrid.cpp:96-110  free-field energy sum
@@ -104,73 +104,58 @@ __global__ void pv_lane_selftest_kernel(float* out) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// face codes
+// face coefficients
 // ---------------------------------------------------------------------------------------------------------------
 
-// mat: (gx+1)*(gy+1) x u16, bit0 = beta (Grid.cpp:88-108,229-246), bits 1..15 = palette index of R.
-// One thread per padded cell.  Folds FDTD.cpp:143-223 into one coefficient index per face:
+// mat: (gx+1)*(gy+1) floats: NaN = air cell (beta = 1, Grid.cpp:88-108,229-246), else the admittance Y = (1 - R) / (1 + R) of
+// the wall cell (FDTD.cpp:150,156; computed on the host in the reference's float arithmetic).
+// One thread per padded cell.  Folds FDTD.cpp:143-223 into one coefficient per face (FaceCoef, pv_device.h):
 //   air|air   : v = v - C*(p_i - p_n)                                   (FDTD.cpp:162-163, beta*beta_n = 1)
 //   wall(n)|air(i): v = -Y_n * p_i ; air(n)|wall(i): v = +Y_i * p_n      (FDTD.cpp:165-168)
 //   grid edges: vx[0,y] = -p[0,y], vx[gx,y] = p[gx-1,y], vy likewise     (FDTD.cpp:201-223)
-__global__ void pv_codes_kernel(const mat_t* __restrict__ mat, code_t* __restrict__ codes, Geometry g) {
+__global__ void pv_coef_kernel(const float* __restrict__ mat, FaceCoef* __restrict__ coef, Geometry g) {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     const int row = blockIdx.y;
     if (col >= g.pitch || row >= g.rows) return;
-    // (x, y) in the WHOLE grid's cell array: a slab's guard rows hold its neighbours' true face codes
+    // (x, y) in the WHOLE grid's cell array: a slab's guard rows hold its neighbours' true face coefficients
     const int x = row - g.G + g.x0, y = col - g.G;
-    const unsigned wall = (unsigned)g.lutWall, posBase = wall + 1u;
-    unsigned kx = wall, ky = wall;
+    const float air = __uint_as_float(kAirFaceBits);
+    float kx = 0.f, ky = 0.f;  // wall|wall
+    bool bi = false;
     if (x >= 0 && x < g.NXg && y >= 0 && y < g.NY) {
         const bool ghost = (x == g.gxg) || (y == g.gy);
-        const unsigned mi = mat[(size_t)x * g.NY + y];
-        const bool bi = (mi & 1u) && !ghost;
-        const unsigned pi = ghost ? 0u : (mi >> 1);
+        const float mi = mat[(size_t)x * g.NY + y];
+        bi = (mi != mi) && !ghost;
+        const float Yi = (ghost || mi != mi) ? 1.f : mi;  // (the ghost row / column: R = 0)
         // x face: neighbour n = (x-1, y)
         if (x == 0) {
-            kx = (bi && y < g.gy) ? (unsigned)kLutNegBase : wall;
+            kx = (bi && y < g.gy) ? -1.f : 0.f;
         } else if (x == g.gxg) {
-            kx = (y < g.gy) ? posBase : wall;
+            kx = (y < g.gy) ? 1.f : 0.f;
         } else {
-            const unsigned mn = mat[(size_t)(x - 1) * g.NY + y];
-            const bool bn = (mn & 1u) && (y != g.gy);
-            const unsigned pn = (y == g.gy) ? 0u : (mn >> 1);
-            kx = (bi && bn) ? (unsigned)kLutAir
-                            : bi ? kLutNegBase + pn : bn ? posBase + pi : wall;
+            const float mn = mat[(size_t)(x - 1) * g.NY + y];
+            const bool bn = (mn != mn) && (y != g.gy);
+            const float Yn = (y == g.gy || mn != mn) ? 1.f : mn;
+            kx = (bi && bn) ? air : bi ? -Yn : bn ? Yi : 0.f;
         }
         // y face: neighbour n = (x, y-1)
         if (y == 0) {
-            ky = (bi && x < g.gxg) ? (unsigned)kLutNegBase : wall;
+            ky = (bi && x < g.gxg) ? -1.f : 0.f;
         } else if (y == g.gy) {
-            ky = (x < g.gxg) ? posBase : wall;
+            ky = (x < g.gxg) ? 1.f : 0.f;
         } else {
-            const unsigned mn = mat[(size_t)x * g.NY + (y - 1)];
-            const bool bn = (mn & 1u) && (x != g.gxg);
-            const unsigned pn = (x == g.gxg) ? 0u : (mn >> 1);
-            ky = (bi && bn) ? (unsigned)kLutAir
-                            : bi ? kLutNegBase + pn : bn ? posBase + pi : wall;
+            const float mn = mat[(size_t)x * g.NY + (y - 1)];
+            const bool bn = (mn != mn) && (x != g.gxg);
+            const float Yn = (x == g.gxg || mn != mn) ? 1.f : mn;
+            ky = (bi && bn) ? air : bi ? -Yn : bn ? Yi : 0.f;
         }
     }
-    codes[(size_t)row * g.pitch + col] = (code_t)(kx | (ky << kIdxBits));
+    coef[(size_t)row * g.pitch + col] = FaceCoef{kx, ky, bi ? 1.f : 0.f};
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // fused K-step stencil
 // ---------------------------------------------------------------------------------------------------------------
-
-// face coefficients of the 16-bit LUT indices in N face codes, in a step kernel: straight from the global table.  (Rounds 1-2
-// copied a 256-entry table into LDS first -- a global round trip and a barrier BEFORE a general tile's loads could start; read
-// like this the look-ups are issued as the code loads come back, beside the field loads, and a launch of a launch-bound grid
-// is no slower with 16-bit indices than it was with 8-bit ones.)
-template <int N>
-__device__ __forceinline__ void faceCoefs(const StepArgs& a, const uint32_t (&c)[N], float (&kx)[N], float (&ky)[N]) {
-    typedef const __attribute__((address_space(1))) float* glb_cptr;
-    const glb_cptr g = (glb_cptr)a.lut;
-#pragma unroll
-    for (int r = 0; r < N; ++r) {
-        kx[r] = g[c[r] & kIdxMask];
-        ky[r] = g[c[r] >> kIdxBits];
-    }
-}
 
 // air rows only (every face air|air): FDTD.cpp:124-199 without coefficients
 template <int ROWS>
@@ -244,6 +229,23 @@ __device__ __forceinline__ void bufStoreF(float v, rsrc_t r, int voff, int soff)
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
 }
 
+// face coefficients + beta of this lane's cell in N rows of a general tile (row r at byte offset soff0 + r * pitchB of a float
+// plane: the FaceCoef plane has three times that pitch): ONE independent 12-byte load per row, issued with the field loads
+template <int N>
+__device__ __forceinline__ void loadFaceCoefs(const StepArgs& a, const int lane, const int soff0, const int pitchB,
+                                              float (&kx)[N], float (&ky)[N], float (&bt)[N]) {
+    typedef unsigned int u3v __attribute__((ext_vector_type(3)));
+    const rsrc_t rCoef = makeRsrc(a.coef, a.planeBytes * 3);
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+        const u3v c = __builtin_amdgcn_raw_buffer_load_b96(rCoef, lane * 12, 3 * (soff0 + r * pitchB), 0);
+        kx[r] = __uint_as_float(c.x);
+        ky[r] = __uint_as_float(c.y);
+        bt[r] = __uint_as_float(c.z);
+    }
+}
+
+
 // Streaming-analysis mode: a tile's pressure history is only consumed while one of its cells -- or a cell of the
 // tile below / to the right, whose velocity reconstruction reads this tile's last row / column -- still has an open
 // forward-analysis window, or while it holds a registered emitter.  Once all of that is closed (N_dry samples after
@@ -289,15 +291,7 @@ __device__ __forceinline__ void stepTile(const StepArgs& a, const int tile, cons
         vx[r] = bufLoadF(rVxIn, voff, so);
         vy[r] = bufLoadF(rVyIn, voff, so);
     }
-    if constexpr (GENERAL) {
-        const rsrc_t rCodes = makeRsrc(a.codes, a.planeBytes);
-        uint32_t c[CR];
-#pragma unroll
-        for (int r = 0; r < CR; ++r) c[r] = __builtin_amdgcn_raw_buffer_load_b32(rCodes, voff, soff0 + r * pitchB, 0);
-        faceCoefs<CR>(a, c, kx, ky);
-#pragma unroll
-        for (int r = 0; r < CR; ++r) bt[r] = (c[r] & kIdxMask) < (uint32_t)a.lutWall ? 1.f : 0.f;
-    }
+    if constexpr (GENERAL) loadFaceCoefs<CR>(a, lane, soff0, pitchB, kx, ky, bt);
 
     // is anything non-zero in the tile?  (sign bit ignored: -0 from v = -p at the grid edges is still zero)
     uint32_t nz = 0;
@@ -695,7 +689,7 @@ __device__ __forceinline__ void leapfrogStepMirror(v2f (&pr)[NP], v2f (&vx)[NP],
 #endif
 
 // Edge tiles (tile class 2): tiles of an otherwise EMPTY region that touch the grid's x = 0, y = 0 or y = gy edge.
-// Their only non-air faces are the absorbing edge itself (FDTD.cpp:201-223; codes kLutNegBase / kLutPosBase with
+// Their only non-air faces are the absorbing edge itself (FDTD.cpp:201-223; face coefficients -1 / +1, i.e.
 // Y = 1) and the dead cells outside the grid, so they run the air tile's code plus three overrides per step instead
 // of the general path (which costs 3.7 air tiles):
 //   x = 0    (row K of the first tile row):      vx[0, y] = -p[0, y]                    after the vx sweep
@@ -956,12 +950,7 @@ __device__ __forceinline__ void stepTileGeneral4Scalar(const StepArgs& a, const 
 
     const rsrc_t rPrIn = makeRsrc(a.prIn, a.inBytes), rVxIn = makeRsrc(a.vxIn, a.inBytes),
                  rVyIn = makeRsrc(a.vyIn, a.inBytes);
-    const rsrc_t rCodes = makeRsrc(a.codes, a.planeBytes);
     float pr[R], vx[R], vy[R], kx[R], ky[R], bt[R];
-    // the face codes first: their table look-ups then run while the field loads are still in flight
-    uint32_t c[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) c[r] = __builtin_amdgcn_raw_buffer_load_b32(rCodes, voff, soff0 + r * pitchB, 0);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int so = soff0 + r * pitchB;
@@ -969,11 +958,7 @@ __device__ __forceinline__ void stepTileGeneral4Scalar(const StepArgs& a, const 
         vx[r] = bufLoadF(rVxIn, voff, so);
         vy[r] = bufLoadF(rVyIn, voff, so);
     }
-    __builtin_amdgcn_sched_group_barrier(0x020, R, 0);      // (VMEM reads: the R code loads before ...
-    __builtin_amdgcn_sched_group_barrier(0x020, 3 * R, 0);  //  ... the field loads; left alone the scheduler mixes them)
-    faceCoefs<R>(a, c, kx, ky);
-#pragma unroll
-    for (int r = 0; r < R; ++r) bt[r] = (c[r] & kIdxMask) < (uint32_t)a.lutWall ? 1.f : 0.f;
+    loadFaceCoefs<R>(a, lane, soff0, pitchB, kx, ky, bt);
 
     const DynParams dyn = *a.dyn;
     // listener row inside this wave's window: rows 0..R-2 hold a live pressure (row 0 = the copy of the previous
@@ -1111,7 +1096,6 @@ __device__ __forceinline__ void stepTileGeneral4Packed(const StepArgs& a, const 
 
     const rsrc_t rPrIn = makeRsrc(a.prIn, a.inBytes), rVxIn = makeRsrc(a.vxIn, a.inBytes),
                  rVyIn = makeRsrc(a.vyIn, a.inBytes);
-    const rsrc_t rCodes = makeRsrc(a.codes, a.planeBytes);
     // row r of the window lives in pair r / 2, component r % 2
     v2f pr[NP], vx[NP], vy[NP], kx[NP], ky[NP], bt[NP];
     u2 mx[NP], my[NP];  // all-ones where the face is air|air
@@ -1119,11 +1103,7 @@ __device__ __forceinline__ void stepTileGeneral4Packed(const StepArgs& a, const 
     auto setc = [](v2f& v, int r, float val) {
         if (r & 1) v.y = val; else v.x = val;
     };
-    // the face codes first: their table look-ups then run while the field loads are still in flight
-    uint32_t c[R];
-    float kxr[R], kyr[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) c[r] = __builtin_amdgcn_raw_buffer_load_b32(rCodes, voff, soff0 + r * pitchB, 0);
+    float kxr[R], kyr[R], btr[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int so = soff0 + r * pitchB;
@@ -1131,16 +1111,14 @@ __device__ __forceinline__ void stepTileGeneral4Packed(const StepArgs& a, const 
         setc(vx[r / 2], r, bufLoadF(rVxIn, voff, so));
         setc(vy[r / 2], r, bufLoadF(rVyIn, voff, so));
     }
-    __builtin_amdgcn_sched_group_barrier(0x020, R, 0);      // (VMEM reads: the R code loads before ...
-    __builtin_amdgcn_sched_group_barrier(0x020, 3 * R, 0);  //  ... the field loads; left alone the scheduler mixes them)
-    faceCoefs<R>(a, c, kxr, kyr);
+    loadFaceCoefs<R>(a, lane, soff0, pitchB, kxr, kyr, btr);
 #pragma unroll
     for (int r = 0; r < 2 * NP; ++r) {
         if (r < R) {
             const float kxv = kxr[r < R ? r : 0], kyv = kyr[r < R ? r : 0];
             setc(kx[r / 2], r, kxv);
             setc(ky[r / 2], r, kyv);
-            setc(bt[r / 2], r, (c[r < R ? r : 0] & kIdxMask) < (uint32_t)a.lutWall ? 1.f : 0.f);
+            setc(bt[r / 2], r, btr[r < R ? r : 0]);
             if (r & 1) {
                 mx[r / 2].y = (kxv != kxv) ? 0xffffffffu : 0u;
                 my[r / 2].y = (kyv != kyv) ? 0xffffffffu : 0u;
@@ -1674,24 +1652,25 @@ __global__ __launch_bounds__(256, 2) void pv_step_stack_kernel(const StepArgs a)
 
 // Per-tile class: 0 = every face code in the tile's loaded region is air|air, 1 = needs the general kernel.
 // One wave per tile.  Tiles of class 1 are also appended to generalList (order irrelevant).
-// face code of cell (x, y) in an EMPTY grid (pv_codes_kernel with every cell air): what an edge tile must hold
-__device__ __forceinline__ uint32_t emptyGridCode(int x, int y, const Geometry& g) {
-    const uint32_t wall = (uint32_t)g.lutWall, posBase = wall + 1u;
-    if (x < 0 || x >= g.NX || y < 0 || y >= g.NY) return wall | (wall << kIdxBits);
-    uint32_t kx, ky;
+// face coefficients of cell (x, y) in an EMPTY grid (pv_coef_kernel with every cell air), as bits: what an edge tile must hold
+__device__ __forceinline__ void emptyGridCoef(int x, int y, const Geometry& g, uint32_t* kxBits, uint32_t* kyBits) {
+    constexpr uint32_t neg1 = 0xbf800000u, pos1 = 0x3f800000u, wall = 0u, air = kAirFaceBits;
+    if (x < 0 || x >= g.NX || y < 0 || y >= g.NY) {
+        *kxBits = *kyBits = wall;
+        return;
+    }
     if (x == 0)
-        kx = y < g.gy ? kLutNegBase : wall;
+        *kxBits = y < g.gy ? neg1 : wall;
     else if (x == g.gx)
-        kx = y < g.gy ? posBase : wall;
+        *kxBits = y < g.gy ? pos1 : wall;
     else
-        kx = y != g.gy ? kLutAir : wall;
+        *kxBits = y != g.gy ? air : wall;
     if (y == 0)
-        ky = x < g.gx ? kLutNegBase : wall;
+        *kyBits = x < g.gx ? neg1 : wall;
     else if (y == g.gy)
-        ky = x < g.gx ? posBase : wall;
+        *kyBits = x < g.gx ? pos1 : wall;
     else
-        ky = x != g.gx ? kLutAir : wall;
-    return kx | (ky << kIdxBits);
+        *kyBits = x != g.gx ? air : wall;
 }
 
 // Per-tile class.  0 = every face code in the tile's loaded region is air|air (air path).  2 = edge tile (EDGE
@@ -1699,7 +1678,7 @@ __device__ __forceinline__ uint32_t emptyGridCode(int x, int y, const Geometry& 
 // x = gx -- air path plus the edge overrides (stepTileAirMirror<EDGE>).  1 = everything else: general path; these
 // are also appended to generalList (order irrelevant).  One wave per tile.
 template <int K, int RXI, int ROWS = RXI + 2 * K, bool EDGE = false>
-__global__ __launch_bounds__(256) void pv_tileclass_kernel(const code_t* codes, uint8_t* tileClass,
+__global__ __launch_bounds__(256) void pv_tileclass_kernel(const FaceCoef* coef, uint8_t* tileClass,
                                                            int* generalList, int* generalCount, Geometry g,
                                                            int allowEdge) {
     constexpr int WI = 64 - 2 * K;
@@ -1709,11 +1688,16 @@ __global__ __launch_bounds__(256) void pv_tileclass_kernel(const code_t* codes, 
     const int ti = tile / g.nty, tj = tile - ti * g.nty;
     const int x0 = ti * RXI - K, y = tj * WI - K + lane;  // grid coordinates of the first loaded row / this lane
     const size_t base = (size_t)(g.G + x0) * g.pitch + (g.G + y);
-    uint32_t any = 0, diff = 0;
+    uint32_t any = 0, diff = 0;  // any: some face of the region is not air|air
     for (int r = 0; r < ROWS; ++r) {
-        const uint32_t c = codes[base + (size_t)r * g.pitch];
-        any |= c;
-        if (EDGE) diff |= c ^ emptyGridCode(x0 + r, y, g);
+        const FaceCoef c = coef[base + (size_t)r * g.pitch];
+        const uint32_t bx = __float_as_uint(c.kx), by = __float_as_uint(c.ky);
+        any |= (bx ^ kAirFaceBits) | (by ^ kAirFaceBits);
+        if (EDGE) {
+            uint32_t ex, ey;
+            emptyGridCoef(x0 + r, y, g, &ex, &ey);
+            diff |= (bx ^ ex) | (by ^ ey);
+        }
     }
     const bool air = __ballot(any != 0u) == 0ull;
     const bool edge =
@@ -1724,10 +1708,11 @@ __global__ __launch_bounds__(256) void pv_tileclass_kernel(const code_t* codes, 
     }
 }
 
-// Dead tiles: every interior cell is a wall cell whose x and y faces are wall|wall (code 0x8080).  Then pr = beta * (...)
+// Dead tiles: every interior cell is a wall cell whose x and y face coefficients are +0 (wall|wall, or a wall of admittance 0
+// against air: the same update).  Then pr = beta * (...)
 // = 0 (FDTD.cpp:139) and both velocities are 0 (FDTD.cpp:165-168 with beta = beta_n = 0) whatever the halo holds, so a
 // run that starts from zero fields never has to touch the tile: both buffer sets keep their zeros there.  One wave per tile.
-__global__ __launch_bounds__(256) void pv_tiledead_kernel(const code_t* codes, uint8_t* dead, int* count, Geometry g,
+__global__ __launch_bounds__(256) void pv_tiledead_kernel(const FaceCoef* coef, uint8_t* dead, int* count, Geometry g,
                                                           int K) {
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1737,7 +1722,10 @@ __global__ __launch_bounds__(256) void pv_tiledead_kernel(const code_t* codes, u
     const size_t base = (size_t)(g.G + ti * g.rxi) * g.pitch + (g.G + tj * WI - K + lane);
     bool ok = true;
     if (lane >= K && lane < 64 - K)
-        for (int r = 0; r < g.rxi; ++r) ok = ok && codes[base + (size_t)r * g.pitch] == (code_t)((uint32_t)g.lutWall | ((uint32_t)g.lutWall << kIdxBits));
+        for (int r = 0; r < g.rxi; ++r) {
+            const FaceCoef c = coef[base + (size_t)r * g.pitch];
+            ok = ok && (__float_as_uint(c.kx) | __float_as_uint(c.ky)) == 0u;
+        }
     const bool d = __ballot(!ok) == 0ull;
     if (lane == 0) {
         dead[tile] = d ? 1 : 0;
@@ -1745,8 +1733,8 @@ __global__ __launch_bounds__(256) void pv_tiledead_kernel(const code_t* codes, u
     }
 }
 
-void launchTileDead(const code_t* codes, uint8_t* dead, int* count, const Geometry& g, int K, hipStream_t stream) {
-    hipLaunchKernelGGL(pv_tiledead_kernel, dim3((g.ntx * g.nty + 3) / 4), dim3(256), 0, stream, codes, dead, count, g, K);
+void launchTileDead(const FaceCoef* coef, uint8_t* dead, int* count, const Geometry& g, int K, hipStream_t stream) {
+    hipLaunchKernelGGL(pv_tiledead_kernel, dim3((g.ntx * g.nty + 3) / 4), dim3(256), 0, stream, coef, dead, count, g, K);
 }
 
 // general arm: may this block leave at once?  (a dead tile, unless the listener sits in its loaded region: the pulse is
@@ -1928,10 +1916,10 @@ static void launchBatchT(const BatchArgs& ba, hipStream_t stream) {
 }
 
 template <int K, int RXI, int ROWS = RXI + 2 * K, bool EDGE = false>
-static void launchTileClassT(const code_t* codes, uint8_t* tileClass, int* list, int* count, const Geometry& g,
+static void launchTileClassT(const FaceCoef* coef, uint8_t* tileClass, int* list, int* count, const Geometry& g,
                              hipStream_t stream, int allowEdge) {
     const int blocks = (g.ntx * g.nty + 3) / 4;
-    hipLaunchKernelGGL((pv_tileclass_kernel<K, RXI, ROWS, EDGE>), dim3(blocks), dim3(256), 0, stream, codes,
+    hipLaunchKernelGGL((pv_tileclass_kernel<K, RXI, ROWS, EDGE>), dim3(blocks), dim3(256), 0, stream, coef,
                        tileClass, list, count, g, allowEdge);
 }
 
@@ -2000,16 +1988,16 @@ void launchBatch(int K, int rxi, const BatchArgs& ba, hipStream_t stream) {
 #undef X
 }
 
-void launchTileClass(int K, int rxi, const code_t* codes, uint8_t* tileClass, int* list, int* count,
+void launchTileClass(int K, int rxi, const FaceCoef* coef, uint8_t* tileClass, int* list, int* count,
                      const Geometry& g, hipStream_t stream, bool allowEdge) {
 #define X(k, np, x, sub) \
     if (K == k && rxi == x) \
-        return launchTileClassT<k, x, StackGeom<k, np, 4, x>::L>(codes, tileClass, list, count, g, stream, 0);
+        return launchTileClassT<k, x, StackGeom<k, np, 4, x>::L>(coef, tileClass, list, count, g, stream, 0);
     PV_STACK_CONFIGS(X)
 #undef X
 #define X(k, r, w, sub) \
     if (K == k && rxi == r) \
-        return launchTileClassT<k, r, r + 2 * k, edgeTilesOk<k, r>()>(codes, tileClass, list, count, g, stream, \
+        return launchTileClassT<k, r, r + 2 * k, edgeTilesOk<k, r>()>(coef, tileClass, list, count, g, stream, \
                                                                       allowEdge ? 1 : 0);
     PV_STEP_CONFIGS(X)
 #undef X
@@ -2089,9 +2077,9 @@ void launchBeginRun(const BeginArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(pv_begin_run_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a);
 }
 
-void launchCodes(const mat_t* mat, code_t* codes, const Geometry& g, hipStream_t stream) {
+void launchCoefs(const float* mat, FaceCoef* coef, const Geometry& g, hipStream_t stream) {
     dim3 grid((g.pitch + 255) / 256, g.rows);
-    hipLaunchKernelGGL(pv_codes_kernel, grid, dim3(256), 0, stream, mat, codes, g);
+    hipLaunchKernelGGL(pv_coef_kernel, grid, dim3(256), 0, stream, mat, coef, g);
 }
 
 void launchLaneSelfTest(float* out, hipStream_t stream) {
@@ -2143,10 +2131,11 @@ __global__ __launch_bounds__(kSmallThreads) void pv_small_grid_kernel(const Smal
         hoff[j] = 0;
         if (i < cells) {
             const int x = i / NY, y = i - x * NY;
-            const unsigned code = a.codes[(size_t)(x + a.G) * a.pitch + (y + a.G)];
-            kx[j] = a.lut[code & kIdxMask];
-            ky[j] = a.lut[code >> kIdxBits];
-            if ((code & kIdxMask) < (unsigned)a.lutWall) beta |= 1u << j;
+            const size_t ci = (size_t)(x + a.G) * a.pitch + (y + a.G);
+            const FaceCoef c = a.coef[ci];
+            kx[j] = c.kx;
+            ky[j] = c.ky;
+            if (c.beta != 0.f) beta |= 1u << j;
             hoff[j] = (int)histOffset(x + a.G - dyn.histRow0, y + a.G - dyn.histCol0, a.rxi, a.wi, dyn.histTilesY);
         }
     }
@@ -2392,8 +2381,8 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
         tFx = 0;
     }
 
-    const uint32_t code = a.codes[(size_t)prow * a.pitch + pcol];
-    const float kx = a.lut[code & kIdxMask], ky = a.lut[code >> kIdxBits];
+    const FaceCoef fc = a.coef[(size_t)prow * a.pitch + pcol];
+    const float kx = fc.kx, ky = fc.ky;
     const bool airX = kx != kx, airY = ky != ky;
     const float C = a.courant;
 
@@ -2407,7 +2396,7 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
     // samples per memory round trip: the air cells outside a closed room but inside an active tile leave here; through
     // the recurrence below each of them walked three planes for all T - tFirst samples, 8 at a time (100 of 112 us at
     // 512^2).  An open field has next to no such cells and is bandwidth-bound: no second pass there.
-    if ((code & kIdxMask) >= (uint32_t)a.lutWall) {
+    if (fc.beta == 0.f) {
         a.delay[s] = FLT_MAX;
         return;
     }
@@ -3076,7 +3065,7 @@ __global__ __launch_bounds__(256) void pv_stream_accum_kernel(const AnalyzeArgs 
     int directEnd = onset >= 0 ? onset + a.nDry : INT_MAX;
     if (a.tA >= directEnd) return;  // this cell's dry window is closed
     // a wall cell's pressure is identically zero: it never has an onset and must not keep its tile recording
-    if ((a.codes[(size_t)(X + a.G) * a.pitch + (Y + a.G)] & kIdxMask) >= (unsigned)a.lutWall) return;
+    if (a.coef[(size_t)(X + a.G) * a.pitch + (Y + a.G)].beta == 0.f) return;
 
     const int prow = X + a.G, pcol = Y + a.G;
     const int hr = prow - dyn.histRow0, hcol = pcol - dyn.histCol0;
@@ -3087,8 +3076,8 @@ __global__ __launch_bounds__(256) void pv_stream_accum_kernel(const AnalyzeArgs 
     const float* hc = a.hist + hoff;
     const float* hx = a.hist + (tFx != INT_MAX ? histOffset(hr - 1, hcol, a.rxi, a.wi, dyn.histTilesY) : hoff);
     const float* hy = a.hist + (tFy != INT_MAX ? histOffset(hr, hcol - 1, a.rxi, a.wi, dyn.histTilesY) : hoff);
-    const uint32_t code = a.codes[(size_t)prow * a.pitch + pcol];
-    const float kx = a.lut[code & kIdxMask], ky = a.lut[code >> kIdxBits];
+    const FaceCoef fc = a.coef[(size_t)prow * a.pitch + pcol];
+    const float kx = fc.kx, ky = fc.ky;
     const bool airX = kx != kx, airY = ky != ky;
     const float C = a.courant;
 
@@ -3293,8 +3282,8 @@ __global__ void pv_ir_kernel(const AnalyzeArgs a, int X, int Y, float* out) {
     if (Y > 0 && pcol - 1 >= dyn.histCol0) tFy = a.tileFirst[ti * a.nty + ((Y - 1) / a.wi)];
     const long long hoffX = tFx != INT_MAX ? histOffset(prow - 1 - dyn.histRow0, pcol - dyn.histCol0, a.rxi, a.wi, dyn.histTilesY) : 0;
     const long long hoffY = tFy != INT_MAX ? histOffset(prow - dyn.histRow0, pcol - 1 - dyn.histCol0, a.rxi, a.wi, dyn.histTilesY) : 0;
-    const uint32_t code = a.codes[(size_t)prow * a.pitch + pcol];
-    const float kx = a.lut[code & kIdxMask], ky = a.lut[code >> kIdxBits];
+    const FaceCoef fc = a.coef[(size_t)prow * a.pitch + pcol];
+    const float kx = fc.kx, ky = fc.ky;
     const bool airX = kx != kx, airY = ky != ky;
     const bool above = X == 0 && a.histAbove;  // first row of a slab: the row above lives in the neighbouring slab
     float vx = 0.f, vy = 0.f;

@@ -42,16 +42,16 @@ bool edgeConfigOk(int K, int rxi);  // the batched kernel of this configuration 
 void launchBatch(int K, int rxi, const BatchArgs& ba, hipStream_t stream);
 // tile classes: 0 air, 1 general (also appended to `list`), 2 edge tile (only when allowEdge and the configuration
 // has the mirror-pair air tile)
-void launchTileClass(int K, int rxi, const code_t* codes, uint8_t* tileClass, int* list, int* count,
+void launchTileClass(int K, int rxi, const FaceCoef* coef, uint8_t* tileClass, int* list, int* count,
                      const Geometry& g, hipStream_t stream, bool allowEdge);
 // dead tiles (all-wall interior): dead[tile] = 1, *count += number of them
-void launchTileDead(const code_t* codes, uint8_t* dead, int* count, const Geometry& g, int K, hipStream_t stream);
+void launchTileDead(const FaceCoef* coef, uint8_t* dead, int* count, const Geometry& g, int K, hipStream_t stream);
 // cells = NX*NY must satisfy smallGridFits()
 bool smallGridFits(int NX, int NY);
 void launchSmallGrid(const SmallArgs& a, hipStream_t stream);
 void launchZero(float* p, long long n, hipStream_t stream);
 void launchBeginRun(const BeginArgs& a, hipStream_t stream);
-void launchCodes(const mat_t* mat, code_t* codes, const Geometry& g, hipStream_t stream);
+void launchCoefs(const float* mat, FaceCoef* coef, const Geometry& g, hipStream_t stream);
 void launchLaneSelfTest(float* out128, hipStream_t stream);
 void launchAnalysis(const AnalyzeArgs& a, hipStream_t stream);
 // the three phases of launchAnalysis separately (slab groups run the middle one per slab, the others on the whole map)

@@ -142,7 +142,6 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     geo_.x0 = x0_;
     geo_.NXg = g_.NX;
     geo_.gxg = g_.gx;
-    geo_.lutWall = kLutWallSmall;
     const int kGuard = std::max(kMinGuard, K_ + stepConfigExtraRows(K_, rxi_));
     geo_.G = kGuard;
     geo_.rxi = rxi_;
@@ -178,9 +177,8 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         vx_[i] = pr_[i] + plane;
         vy_[i] = pr_[i] + 2 * plane;
     }
-    if (!dalloc(&codes_, plane, true)) return false;
+    if (!dalloc(&coef_, plane, true)) return false;
     if (!dalloc(&matDev_, (size_t)g_.NX * g_.NY, true)) return false;
-    if (!dalloc(&lutDev_, (size_t)kLutSize, true)) return false;
     if (!dalloc(&pulseDev_, (size_t)std::max(T_, g_.T), true)) return false;
     if (!dalloc(&tileFirst_, (size_t)ntiles, true)) return false;
     if (!dalloc(&tileClass_, (size_t)ntiles, true)) return false;
@@ -328,12 +326,9 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         return false;
 
     mat_.init(g_);
-    matHost_.assign((size_t)g_.NX * g_.NY, 0);
+    matHost_.assign((size_t)g_.NX * g_.NY, 0.f);
+    betaHost_.assign((size_t)g_.NX * g_.NY, 0);
     byHost_.assign((size_t)g_.NX * g_.NY, 0);
-    palette_.assign(1, 0.f);
-    paletteIndex_.clear();
-    uint32_t zeroBits = 0;
-    paletteIndex_[zeroBits] = 0;
     geometryDirty_ = true;
     if (!applyGeometry()) return false;
     if (!hipOk(hipStreamSynchronize(stream_), "init sync")) return false;
@@ -380,7 +375,7 @@ Solver::~Solver() {
     if (idleHost_) hipHostFree(idleHost_);
     if (emCells_) hipFree(emCells_);
     if (emTrace_) hipFree(emTrace_);
-    void* ptrs[] = {codes_,     matDev_, lutDev_, pulseDev_, hist_,  tileFirst_, tileClass_, generalList_,
+    void* ptrs[] = {coef_,      matDev_, pulseDev_, hist_,  tileFirst_, tileClass_, generalList_,
                     generalCount_, dynDev_, errFlag_, res8_,     delay_, scratch_, res_, activeCount_, win8_,
                     histAbove_, histEdge_, tileDead_, deadCount_};
     for (void* p : ptrs)
@@ -476,80 +471,28 @@ bool Solver::applyGeometry() {
     if (lo < hi) {
         const auto& beta = mat_.beta();
         const auto& R = mat_.R();
-        // material word of every cell of rows [a, b): beta | palette index << 1; false = the palette would pass `limit` values
-        auto encodeRows = [&](int a, int b, int limit) {
-            for (int x = a; x < b; ++x) {
-                for (int y = 0; y < g_.NY; ++y) {
-                    const size_t i = (size_t)x * g_.NY + y;
-                    int p = 0;
-                    if (R[i] != 0.f) {
-                        uint32_t bits;
-                        std::memcpy(&bits, &R[i], 4);
-                        auto it = paletteIndex_.find(bits);
-                        if (it == paletteIndex_.end()) {
-                            if ((int)palette_.size() > limit - 1) return false;
-                            p = (int)palette_.size();
-                            palette_.push_back(R[i]);
-                            paletteIndex_[bits] = p;
-                        } else {
-                            p = it->second;
-                        }
-                    }
-                    matHost_[i] = (mat_t)((beta[i] ? 1 : 0) | (p << 1));
-                    byHost_[i] = mat_.by()[i];
-                }
+        // material of every cell of the dirty rows: NaN = air (beta 1), else the wall's admittance Y = (1 - R) / (1 + R)
+        // (FDTD.cpp:150,156, in the reference's float arithmetic) -- any number of absorption values, as in the reference
+        // (rounds 1-2 palettised them: 127 alive at once)
+        for (int x = lo; x < hi; ++x)
+            for (int y = 0; y < g_.NY; ++y) {
+                const size_t i = (size_t)x * g_.NY + y;
+                const float Rv = R[i];
+                matHost_[i] = beta[i] ? std::numeric_limits<float>::quiet_NaN() : (1.f - Rv) / (1.f + Rv);
+                betaHost_[i] = beta[i] ? 1 : 0;
+                byHost_[i] = mat_.by()[i];
             }
-            return true;
-        };
-        auto rebuildAll = [&]() {
-            palette_.assign(1, 0.f);
-            paletteIndex_.clear();
-            paletteIndex_[0u] = 0;
-            lo = 0;
-            hi = g_.NX;
-            return encodeRows(lo, hi, kPaletteMax);
-        };
-        // The palette only grows while boxes come and go (a long session that keeps changing absorptions through
-        // UpdateGeometry).  While it fits the step kernels' 256-entry table (127 values) the dirty rows are encoded
-        // incrementally; when it would outgrow that, and on every change while it has, it is rebuilt from what the plane
-        // holds NOW, so the wide table is in use exactly while more than 127 values are ALIVE.  Only more than 32767 values
-        // alive at the same time is an error (the reference has no limit: DESIGN.md section 3).
-        const bool ok = (int)palette_.size() > kPaletteSmallMax ? rebuildAll()
-                                                                : (encodeRows(lo, hi, kPaletteSmallMax) || rebuildAll());
-        if (!ok) return fail("more than 32767 distinct absorption values alive in the scene at once");
         if (!hipOk(hipMemcpyAsync(matDev_ + (size_t)lo * g_.NY, matHost_.data() + (size_t)lo * g_.NY,
-                                  (size_t)(hi - lo) * g_.NY * sizeof(mat_t), hipMemcpyHostToDevice, stream_),
+                                  (size_t)(hi - lo) * g_.NY * sizeof(float), hipMemcpyHostToDevice, stream_),
                    "material upload"))
             return false;
     }
-    // coefficient LUT: Y = (1 - R) / (1 + R), FDTD.cpp:150,156, in the index layout the palette's size asks for (pv_device.h);
-    // the face codes below are regenerated in the same layout
-    const size_t P = palette_.size();
-    const int wallBefore = lutWall_;
-    lutWall_ = P > (size_t)kPaletteSmallMax ? kLutWallWide : kLutWallSmall;
-    if (lutWall_ != wallBefore) dropGraph();  // (a captured run holds the layout among its kernel arguments)
-    geo_.lutWall = lutWall_;
-    lutHost_.assign((size_t)kLutSize, 0.f);
-    lutHost_[kLutAir] = std::numeric_limits<float>::quiet_NaN();
-    for (size_t p = 0; p < P; ++p) {
-        const float Rv = palette_[p];
-        const float Y = (1.f - Rv) / (1.f + Rv);
-        lutHost_[(size_t)kLutNegBase + p] = -Y;
-        lutHost_[(size_t)lutWall_ + 1 + p] = Y;
-    }
-    lutHost_[(size_t)lutWall_] = 0.f;
-    // (only what a palette of P values uses: [0, 1 + P) and [wall, wall + 1 + P))
-    if (!hipOk(hipMemcpyAsync(lutDev_, lutHost_.data(), (1 + P) * sizeof(float), hipMemcpyHostToDevice, stream_), "lut upload") ||
-        !hipOk(hipMemcpyAsync(lutDev_ + lutWall_, lutHost_.data() + lutWall_, (1 + P) * sizeof(float), hipMemcpyHostToDevice,
-                              stream_),
-               "lut upload"))
-        return false;
-    launchCodes(matDev_, codes_, geo_, stream_);
+    launchCoefs(matDev_, coef_, geo_, stream_);
     if (!hipOk(hipMemsetAsync(generalCount_, 0, sizeof(int), stream_), "memset")) return false;
-    launchTileClass(K_, rxi_, codes_, tileClass_, generalList_, generalCount_, geo_, stream_,
+    launchTileClass(K_, rxi_, coef_, tileClass_, generalList_, generalCount_, geo_, stream_,
                     opt_.edgeTiles);
     if (!hipOk(hipMemsetAsync(deadCount_, 0, sizeof(int), stream_), "memset")) return false;
-    launchTileDead(codes_, tileDead_, deadCount_, geo_, K_, stream_);
+    launchTileDead(coef_, tileDead_, deadCount_, geo_, K_, stream_);
     int count = 0;
     if (!hipOk(hipMemcpyAsync(&numDead_, deadCount_, sizeof(int), hipMemcpyDeviceToHost, stream_), "count copy"))
         return false;
@@ -787,9 +730,7 @@ void Solver::enqueueBeginRun(bool resetTiles) {
 // the part of a launch's arguments that does not change from launch to launch
 StepArgs Solver::baseStepArgs(bool withPulse, bool record) const {
     StepArgs a{};
-    a.codes = codes_;
-    a.lut = lutDev_;
-    a.lutWall = lutWall_;
+    a.coef = coef_;
     a.pulse = pulseDev_;
     a.hist = hist_;
     a.tileFirst = tileFirst_;
@@ -855,7 +796,7 @@ StepArgs Solver::bandStepArgs(const StepArgs& a, int b) const {
     v.prOut += off;
     v.vxOut += off;
     v.vyOut += off;
-    v.codes += off;
+    v.coef += off;
     v.tileFirst += (long long)r0 * geo_.nty;
     v.tileClass += (long long)r0 * geo_.nty;
     if (v.tileDead) v.tileDead += (long long)r0 * geo_.nty;
@@ -1045,9 +986,7 @@ ClassifyArgs Solver::classifyArgs(const StepArgs& a, int li, bool withPulse) con
 AnalyzeArgs Solver::analyzeArgs(float lx, float lz) const {
     AnalyzeArgs a{};
     a.hist = hist_;
-    a.codes = codes_;
-    a.lut = lutDev_;
-    a.lutWall = lutWall_;
+    a.coef = coef_;
     a.tileFirst = tileFirst_;
     a.dyn = dynDev_;
     a.out = res_;
@@ -1255,9 +1194,7 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
         sa.prOut = pr_[0];
         sa.vxOut = vx_[0];
         sa.vyOut = vy_[0];
-        sa.codes = codes_;
-        sa.lut = lutDev_;
-        sa.lutWall = lutWall_;
+        sa.coef = coef_;
         sa.pulse = pulseDev_;
         sa.hist = hist_;
         sa.dyn = dynDev_;
@@ -1714,7 +1651,7 @@ bool Solver::impulseResponseCells(int cx, int cy, void* out16T) {
     };
     static_assert(sizeof(RefCell) == 16, "PvTypes.h:106-121");
     const size_t i = (size_t)(cx + x0_) * g_.NY + cy;
-    const short b = (short)(matHost_[i] & 1), by = (short)byHost_[i];
+    const short b = (short)betaHost_[i], by = (short)byHost_[i];
     RefCell* out = static_cast<RefCell*>(out16T);
     for (int t = 0; t < T_; ++t) out[t] = RefCell{f[(size_t)3 * t], f[(size_t)3 * t + 1], f[(size_t)3 * t + 2], b, by};
     return true;

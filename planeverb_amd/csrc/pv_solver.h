@@ -10,7 +10,6 @@
 
 #include <cstdint>
 #include <string>
-#include <unordered_map>
 #include <vector>
 
 #include "pv_core.h"
@@ -217,12 +216,8 @@ private:
     float* vx_[2] = {nullptr, nullptr};
     float* vy_[2] = {nullptr, nullptr};
     int cur_ = 0;  // which set holds the current fields
-    code_t* codes_ = nullptr;
-    mat_t* matDev_ = nullptr;
-    float* lutDev_ = nullptr;       // kLutSize face coefficients, in the layout of lutWall_ (pv_device.h)
-    int lutWall_ = kLutWallSmall;   // small layout (the 256-entry table of rounds 1-2) while <= 127
-                                    // absorption values are alive, wide otherwise
-    std::vector<float> lutHost_;
+    FaceCoef* coef_ = nullptr;      // face coefficients + beta of every padded cell (pv_device.h)
+    float* matDev_ = nullptr;       // material plane: NaN = air cell, else the wall cell's admittance Y
     float* pulseDev_ = nullptr;
     float* hist_ = nullptr;
     long long histPlane_ = 0;
@@ -296,10 +291,9 @@ private:
 
     // host state
     MaterialPlane mat_;
-    std::vector<mat_t> matHost_;
+    std::vector<float> matHost_;     // host copy of matDev_
+    std::vector<uint8_t> betaHost_;  // Cell::b as of the last applyGeometry() (= during the last run)
     std::vector<uint8_t> byHost_;  // Cell::by as of the last applyGeometry() (= during the last run)
-    std::vector<float> palette_;  // R values; [0] = 0
-    std::unordered_map<uint32_t, int> paletteIndex_;
     std::vector<float> pulse_;
     std::vector<int> wallTiles_;
     std::vector<uint8_t> tileClassHost_;

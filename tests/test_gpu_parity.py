@@ -369,10 +369,10 @@ def many_material_boxes(n, per, spacing, width, origin=0.6):
 
 
 def test_many_absorption_values_vs_oracle(pvlib, oracle):
-    """The reference takes any number of absorption values; rounds 1-2 failed a run with more than 127 alive at once.  Face
-    codes are 16-bit indices now (32767 values), and the step kernels keep their 256-entry LDS table while the palette fits
-    it.  One solver (70^2: the replayed-graph path) goes small -> wide -> small: 5, then 400, then 90 distinct values alive;
-    maps, recorded planes and final fields against the oracle each time."""
+    """The reference takes any number of absorption values; rounds 1-2 palettised them and failed a run with more than 127
+    alive at once.  Face coefficients are stored as values now (csrc/pv_device.h FaceCoef).  One solver (70^2: the
+    replayed-graph path) holds 5, then 400, then 90 distinct values; maps, recorded planes and final fields against the
+    oracle each time."""
     boxes = many_material_boxes(400, 20, 1.2, 0.6)
     assert len(np.unique(boxes[:, 4])) == 400
     L = (12.0, 0.0, 12.0)
@@ -435,9 +435,9 @@ def test_many_absorption_values_512_merged_kernel(pvlib, oracle):
             compare_maps(res, delay, rres, rdelay, 435, 1443, "700 values %r" % (opts,))
 
 
-def test_palette_is_rebuilt_when_values_come_and_go(pvlib, oracle):
+def test_absorption_values_come_and_go(pvlib, oracle):
     """A long session that keeps changing one wall's absorption through UpdateGeometry passes 127 distinct values since
-    creation with only a handful alive: the palette is rebuilt from the live plane instead of failing (the reference
+    creation with only a handful alive (rounds 1-2 rebuilt their palette here; there is none any more) (the reference
     accepts any number of values), and the results still equal the oracle's for the final scene"""
     g = golden("g71_smallroom")
     L = g["listener"]
