@@ -146,14 +146,21 @@ class GpuHooks:
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("bench.py needs a HIP device (no CPU path)")
+        # PV_BENCH_DEVICES="0,0": device of every local rank (development: the multi-rank orchestration on a one-GPU box --
+        # with PV_BENCH_BACKEND=gloo, since RCCL refuses two ranks on one device; the collectives then carry host tensors)
+        devmap = os.environ.get("PV_BENCH_DEVICES")
+        self.rank_index = local_rank
+        if devmap:
+            local_rank = int(devmap.split(",")[local_rank])
         torch.cuda.set_device(local_rank)
         self.torch = torch
         self.local_rank = local_rank
-        self.device = torch.device("cuda", local_rank)
+        host = os.environ.get("PV_BENCH_BACKEND", self.backend_default) != "nccl"
+        self.device = torch.device("cpu") if host else torch.device("cuda", local_rank)
 
     def init_process_group(self, dist, backend, rank, world):
         if backend == "nccl":
-            dist.init_process_group(backend, rank=rank, world_size=world, device_id=self.device)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=self.torch.device("cuda", self.local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
