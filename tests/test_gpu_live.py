@@ -266,20 +266,35 @@ def test_live_module_sparse_emitter_mode_512_mode_b(pvlib, monkeypatch):
 
 def test_live_module_falls_back_to_sparse_emitter_mode_by_itself(pvlib, monkeypatch):
     """PlaneverbInit(25, 25, 16067, ...) -- a 4096^2 grid with T = 25 432, whose history window would take 1.7 TB --
-    comes up by itself in the sparse-emitter mode (Planeverb::Init accepts any resolution >= 275, PvContext.cpp:101-107).
-    Only initialisation, an emitter and the Exit racing the first 0.5 s iteration are exercised here."""
+    comes up by itself in the sparse-emitter mode (Planeverb::Init accepts any resolution >= 275, PvContext.cpp:101-107),
+    at this size with the forward sums of the air tiles inside the stencil (csrc/pv_stream.h).  The real 25 m room
+    (HugeRoom.pv) with two emitters: the records of the module's iterations equal those of a batch solver in the same mode."""
     monkeypatch.delenv("PLANEVERB_AMD_LIVE_STREAMING", raising=False)
+    L, E = (5.0, 0.0, 4.0), [(5.0, 0.0, 6.0), (12.0, 0.0, 9.0)]
+    boxes = pvlib.load_pv(os.path.join(SCENES, "HugeRoom.pv"))
     pvlib.Init(pvlib.Config((25.0, 25.0), 16067, 0, ".", 0, pvlib.pv_GPU))
     try:
         assert pvlib.IsRunning()
         assert pvlib.lib().PlaneverbIsStreaming() == 1
-        pvlib.SetListenerPosition((5.0, 0.0, 4.0))
-        e = pvlib.Emit((5.0, 0.0, 6.0))
-        assert e == 0
-        assert pvlib.WaitIterations(1, 120000) >= 1
+        pvlib.SetListenerPosition(L)
+        for b in boxes:
+            pvlib.AddGeometry(b)
+        ids = [pvlib.Emit(e) for e in E]
+        assert ids == [0, 1]
+        settle(pvlib, 2)
         assert pvlib.IsRunning(), pvlib.last_error()
+        live = [pvlib.GetOutput(i).as_array() for i in ids]
     finally:
         pvlib.Exit()
+    with pvlib.Solver(25.0, 25.0, 16067, streaming_analysis=1) as s:
+        for b in boxes:
+            s.add_geometry(b)
+        s.set_emitters(E)
+        s.run(L)
+        for e, o in zip(E, live):
+            want = s.get_output(e).as_array()
+            assert want[1] > 0 and want[2] > 0
+            assert np.array_equal(o.view(np.uint32), want.view(np.uint32)), (e, o, want)
     # a config whose history fits stays in the full-history mode
     pvlib.Init(pvlib.Config((25.0, 25.0), 275, 0, ".", 0, pvlib.pv_GPU))
     try:
