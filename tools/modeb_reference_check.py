@@ -46,6 +46,10 @@ with open("/proc/meminfo") as f:
         if line.startswith("MemAvailable"):
             avail_gb = int(line.split()[1]) / 1e6
 print("grid %d^2, T = %d: the reference needs about %.0f GB of host memory, %.0f GB available" % (gx, T, need_gb, avail_gb), flush=True)
+# (242 GB at 4097^2 ran fine; 934 GB at 8193^2 took the GPU box down although /proc/meminfo showed 3 TB available: the
+# pool's boxes are not to be trusted beyond a few hundred GB)
+if need_gb > 320 and not os.environ.get("PV_ALLOW_HUGE_REFERENCE"):
+    raise SystemExit("refusing a reference run of %.0f GB (set PV_ALLOW_HUGE_REFERENCE=1 to override)" % need_gb)
 if avail_gb < 1.3 * need_gb:
     raise SystemExit("not enough host memory for a safe run")
 
