@@ -125,6 +125,7 @@ typedef struct PvAmdInfo {
     int histRows, histPitch;/* history window geometry */
     int numGeometry;
     long long deviceBytes;  /* bytes of HBM held by this solver */
+    int streamFuse;         /* streaming analysis: 1 = the forward sums of air tiles advance inside the step kernel (PVA_OPT_STREAM_FUSE as resolved for this grid and tile) */
 } PvAmdInfo;
 
 typedef struct PvAmdTimings {

@@ -69,7 +69,7 @@ class PvAmdInfo(C.Structure):
                 ("dx", C.c_float), ("dt", C.c_float), ("efree", C.c_float), ("device", C.c_int),
                 ("stepsPerLaunch", C.c_int), ("tileRows", C.c_int), ("tileCols", C.c_int), ("pitch", C.c_int),
                 ("rows", C.c_int), ("histRows", C.c_int), ("histPitch", C.c_int), ("numGeometry", C.c_int),
-                ("deviceBytes", C.c_longlong)]
+                ("deviceBytes", C.c_longlong), ("streamFuse", C.c_int)]
 
 
 class PvAmdSlabInfo(C.Structure):

@@ -507,6 +507,7 @@ int PvAmdGetInfo(PvAmdSolver* h, PvAmdInfo* out) {
     out->histPitch = h->s->histPitch();
     out->numGeometry = h->s->numBoxes();
     out->deviceBytes = h->s->deviceBytes();
+    out->streamFuse = h->s->streamFuse() ? 1 : 0;
     return 0;
 }
 

@@ -1932,14 +1932,15 @@ static void launchStackT(const StepArgs& a, hipStream_t stream) {
 
 // (K steps per launch, interior rows per tile, waves/SIMD bound of the air kernel, rows per general-tile slice)
 #ifdef PV_DEV_FAST  // development builds: two configurations only (make EXTRA=-DPV_DEV_FAST)
-#define PV_STEP_CONFIGS(X) X(8, 24, 3, 12) X(12, 36, 2, 9) X(8, 40, 2, 10)
+#define PV_STEP_CONFIGS(X) X(8, 24, 3, 12) X(12, 36, 2, 9) X(8, 40, 2, 10) X(12, 12, 3, 6) X(10, 20, 3, 10)
 #define PV_STACK_CONFIGS(X)
-#define PV_BATCH_CONFIGS(X) X(8, 24, 3, 12) X(12, 36, 2, 9) X(8, 40, 2, 10)
+#define PV_BATCH_CONFIGS(X) X(8, 24, 3, 12) X(12, 36, 2, 9) X(8, 40, 2, 10) X(12, 12, 3, 6) X(10, 20, 3, 10)
 #else
 #define PV_STEP_CONFIGS(X) \
     X(4, 32, 3, 8) X(4, 24, 4, 6) X(2, 28, 4, 7) X(1, 30, 4, 15) X(8, 24, 3, 12) X(6, 28, 3, 14) X(3, 26, 4, 13) \
     X(8, 48, 2, 12) X(12, 40, 2, 10) X(8, 40, 2, 10) X(12, 32, 2, 8) X(10, 36, 2, 9) X(8, 44, 2, 11) X(10, 40, 2, 10) X(12, 36, 2, 9) \
-    X(9, 42, 2, 14) X(11, 36, 2, 9) X(9, 40, 2, 10)
+    X(9, 42, 2, 14) X(11, 36, 2, 9) X(9, 40, 2, 10) \
+    X(12, 12, 3, 6) X(10, 20, 3, 10) /* round 3: deep K on small tiles for launch-bound grids (profiles/r03_small_tiles.txt) */
 
 // stacked tiles (K steps per launch, row pairs per wave, interior rows per tile, rows per general-tile slice); the
 // tile's interior height doubles as the configuration's `rxi`
@@ -1961,7 +1962,7 @@ void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream, int which
 // configurations with a batched kernel: the defaults of every grid-size class (pv_solver.cpp) and the other
 // merged-launch tiles of the tuning sweeps
 #ifndef PV_DEV_FAST
-#define PV_BATCH_CONFIGS(X) X(8, 24, 3, 12) X(6, 28, 3, 14) X(10, 36, 2, 9) X(12, 36, 2, 9) X(8, 40, 2, 10)
+#define PV_BATCH_CONFIGS(X) X(8, 24, 3, 12) X(6, 28, 3, 14) X(10, 36, 2, 9) X(12, 36, 2, 9) X(8, 40, 2, 10) X(12, 12, 3, 6) X(10, 20, 3, 10)
 #endif
 
 bool batchConfigOk(int K, int rxi) {

@@ -99,7 +99,10 @@ bool SlabGroup::init(const GridSpec& spec, const std::vector<int>& devices, cons
     if (!hipOk(hipMemsetAsync(res_, 0, n * 8 * 4, rootStream_), "memset")) return false;  // zeroed pool: PvContext.cpp:132
     if (!hipOk(hipMemsetAsync(delay_, 0, n * 4, rootStream_), "memset")) return false;
     const int planes[6] = {0, 1, 2, 3, 6, 7};
-    if (!hipOk(hipMemcpy(planesDev_, planes, sizeof(planes), hipMemcpyHostToDevice), "planes upload")) return false;
+    // (never the legacy stream: see Solver::applyGeometry)
+    if (!hipOk(hipMemcpyAsync(planesDev_, planes, sizeof(planes), hipMemcpyHostToDevice, rootStream_), "planes upload") ||
+        !hipOk(hipStreamSynchronize(rootStream_), "planes upload"))
+        return false;
     if (!hipOk(hipHostMalloc((void**)&dynHost_, sizeof(DynParams)), "hipHostMalloc")) return false;
     if (!hipOk(hipHostMalloc((void**)&outHost_, 8 * sizeof(float)), "hipHostMalloc")) return false;
     if (!hipOk(hipStreamSynchronize(rootStream_), "init sync")) return false;
@@ -391,7 +394,9 @@ bool SlabGroup::run(float lx, float ly, float lz) {
         v.pendingTimings_ = false;
         if (!hipOk(hipStreamSynchronize(v.stream_), "slab sync")) return false;
         int flag = 0;
-        if (!hipOk(hipMemcpy(&flag, v.errFlag_, sizeof(int), hipMemcpyDeviceToHost), "errFlag copy")) return false;
+        if (!hipOk(hipMemcpyAsync(&flag, v.errFlag_, sizeof(int), hipMemcpyDeviceToHost, v.stream_), "errFlag copy") ||
+            !hipOk(hipStreamSynchronize(v.stream_), "errFlag sync"))
+            return false;
         if (flag) return fail("slab " + std::to_string(s) + ": pressure history window overflow");
     }
     hipSetDevice(rootDevice_);
@@ -542,7 +547,9 @@ bool SlabRankOps::analyze(Solver& v) {
     if (!v.hipOk(hipGetLastError(), "slab analysis")) return false;
     if (!v.hipOk(hipStreamSynchronize(v.stream_), "slab analysis sync")) return false;
     int flag = 0;
-    if (!v.hipOk(hipMemcpy(&flag, v.errFlag_, sizeof(int), hipMemcpyDeviceToHost), "errFlag copy")) return false;
+    if (!v.hipOk(hipMemcpyAsync(&flag, v.errFlag_, sizeof(int), hipMemcpyDeviceToHost, v.stream_), "errFlag copy") ||
+        !v.hipOk(hipStreamSynchronize(v.stream_), "errFlag sync"))
+        return false;
     if (flag) return v.fail("pressure history window overflow (a tile outside the window became non-zero)");
     return true;
 }
@@ -593,8 +600,10 @@ SlabRoot* SlabRoot::create(const Solver& a, int device, std::string* err) {
               hipMalloc((void**)&r->planesDev_, sizeof(planes)) == hipSuccess &&
               hipMalloc((void**)&r->dynDev_, sizeof(DynParams)) == hipSuccess &&
               hipHostMalloc((void**)&r->outHost_, 32) == hipSuccess &&
-              hipMemset(r->res_, 0, n * 32) == hipSuccess && hipMemset(r->delay_, 0, n * 4) == hipSuccess &&
-              hipMemcpy(r->planesDev_, planes, sizeof(planes), hipMemcpyHostToDevice) == hipSuccess;
+              hipMemsetAsync(r->res_, 0, n * 32, r->stream_) == hipSuccess &&
+              hipMemsetAsync(r->delay_, 0, n * 4, r->stream_) == hipSuccess &&
+              hipMemcpyAsync(r->planesDev_, planes, sizeof(planes), hipMemcpyHostToDevice, r->stream_) == hipSuccess &&
+              hipStreamSynchronize(r->stream_) == hipSuccess;  // (never the legacy stream: see Solver::applyGeometry)
     if (!ok) {
         if (err) *err = "slab root: allocation failed";
         delete r;
@@ -663,7 +672,8 @@ bool SlabRoot::begin(float lx, float ly, float lz) {
     d.histTilesY = histTilesY_;
     d.histRow0 = G_ + gtx0 * rxi_;
     d.histCol0 = G_ + ty0 * wi_;
-    if (hipSetDevice(device_) != hipSuccess || hipMemcpy(dynDev_, &d, sizeof(d), hipMemcpyHostToDevice) != hipSuccess)
+    if (hipSetDevice(device_) != hipSuccess || hipMemcpyAsync(dynDev_, &d, sizeof(d), hipMemcpyHostToDevice, stream_) != hipSuccess ||
+        hipStreamSynchronize(stream_) != hipSuccess)
         return fail("slab root: dyn upload failed");
     launchFarCells(args(), stream_);
     return hipGetLastError() == hipSuccess ? true : fail("slab root: far cells launch failed");

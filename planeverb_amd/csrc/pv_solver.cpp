@@ -90,9 +90,20 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     } else if (tiles36 >= 1500) {
         K_ = 10;
         rxi_ = 36;
-    } else {
+    } else if (tiles36 >= 1000) {
         K_ = 8;
         rxi_ = 24;
+    } else if (tiles36 >= 150) {
+        // launch-bound grids (450^2 ... 1150^2): the chip is far from full, so a deeper K on a smaller tile trades halo
+        // recomputation nobody waits for against fewer dependent launches: +7-15 % at 512^2 ... 1024^2 with four runs in flight
+        // (profiles/r03_small_tiles.txt)
+        K_ = 10;
+        rxi_ = 20;
+    } else {
+        // the reference's own presets (70^2 ... 382^2: a handful of general tiles, one run at a time): 36 loaded rows over four
+        // waves instead of 40, 12 steps per launch instead of 8: 7-19 % off an iteration
+        K_ = 12;
+        rxi_ = 12;
     }
     if (!stepConfigSupported(K_, rxi_)) return fail("unsupported (stepsPerLaunch, tileRows) configuration");
     if (opt_.tileOrder < 0) opt_.tileOrder = tiles36 >= 4500 ? 3 : 1;  // (measured: profiles/r02_tile_order.txt)
@@ -343,7 +354,8 @@ Solver::~Solver() {
     if (stream_) hipStreamSynchronize(stream_);
     if (patchTrace_) {  // development aid: phase stamps of the LAST launch (block 0), cycles relative to the first stamp
         std::vector<long long> t((size_t)8 * 16 * 16);
-        hipMemcpy(t.data(), patchTrace_, t.size() * 8, hipMemcpyDeviceToHost);
+        hipMemcpyAsync(t.data(), patchTrace_, t.size() * 8, hipMemcpyDeviceToHost, stream_);
+        hipStreamSynchronize(stream_);
         long long t0 = 0;
         for (long long v : t)
             if (v && (!t0 || v < t0)) t0 = v;
@@ -499,16 +511,20 @@ bool Solver::applyGeometry() {
     if (!hipOk(hipMemcpyAsync(&count, generalCount_, sizeof(int), hipMemcpyDeviceToHost, stream_), "count copy"))
         return false;
     if (!hipOk(hipStreamSynchronize(stream_), "geometry sync")) return false;
+    // (copies on the solver's own stream: a synchronous hipMemcpy runs on the LEGACY stream, which the runtime refuses while
+    // any other host thread is capturing a run graph -- "operation would make the legacy stream depend on a capturing blocking
+    // stream" -- and which invalidates that thread's capture: the live module's worker beside a caller's own solver)
     wallTiles_.resize((size_t)count);
     if (count > 0 &&
-        !hipOk(hipMemcpy(wallTiles_.data(), generalList_, sizeof(int) * (size_t)count, hipMemcpyDeviceToHost),
+        !hipOk(hipMemcpyAsync(wallTiles_.data(), generalList_, sizeof(int) * (size_t)count, hipMemcpyDeviceToHost, stream_),
                "list copy"))
         return false;
-    std::sort(wallTiles_.begin(), wallTiles_.end());
     tileClassHost_.resize((size_t)geo_.ntx * geo_.nty);
-    if (!hipOk(hipMemcpy(tileClassHost_.data(), tileClass_, tileClassHost_.size(), hipMemcpyDeviceToHost),
-               "class copy"))
+    if (!hipOk(hipMemcpyAsync(tileClassHost_.data(), tileClass_, tileClassHost_.size(), hipMemcpyDeviceToHost, stream_),
+               "class copy") ||
+        !hipOk(hipStreamSynchronize(stream_), "geometry sync"))
         return false;
+    std::sort(wallTiles_.begin(), wallTiles_.end());
     mat_.clearDirty();
     geometryDirty_ = false;
     planesDirty_ = true;  // a tile that is dead now may hold an earlier scene's fields
@@ -1425,7 +1441,9 @@ bool Solver::sync() {
             tim_.generalLaunches = numGeneral_ > 0 ? n : 0;
         }
         int flag = 0;
-        if (!hipOk(hipMemcpy(&flag, errFlag_, sizeof(int), hipMemcpyDeviceToHost), "errFlag copy")) return false;
+        if (!hipOk(hipMemcpyAsync(&flag, errFlag_, sizeof(int), hipMemcpyDeviceToHost, stream_), "errFlag copy") ||
+            !hipOk(hipStreamSynchronize(stream_), "errFlag sync"))
+            return false;
         if (flag) return fail("pressure history window overflow (a tile outside the window became non-zero)");
     }
     return true;

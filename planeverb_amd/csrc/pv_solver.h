@@ -86,6 +86,7 @@ public:
     int histRows() const { return histRows_; }
     int histPitch() const { return histPitch_; }
     const std::string& lastError() const { return err_; }
+    bool streamFuse() const { return streamFuse_; }
     SolverOptions& options() { return opt_; }
 
     // geometry table with the reference's id recycling (Geometry/GeometryManager.cpp:67-121)

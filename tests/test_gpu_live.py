@@ -301,3 +301,36 @@ def test_live_module_falls_back_to_sparse_emitter_mode_by_itself(pvlib, monkeypa
         assert pvlib.lib().PlaneverbIsStreaming() == 0
     finally:
         pvlib.Exit()
+
+
+def test_solvers_on_concurrent_host_threads(pvlib):
+    """Several host threads creating, running and destroying solvers on one device at the same time -- what the live module's
+    worker and a caller's own batch solver do.  Small grids replay a captured run graph; a synchronous hipMemcpy of ANOTHER thread
+    runs on the legacy stream, which the runtime refuses while a capture is open anywhere ("operation would make the legacy stream
+    depend on a capturing blocking stream") and which invalidates that capture: 4 of 80 solvers failed with two threads, 40 of
+    100 with four, until every copy went through the solver's own stream (tools/capture_stress.py)."""
+    import threading
+    g = golden("g71_smallroom")
+    fails, outs = [], []
+
+    def work(tid):
+        for i in range(6):
+            try:
+                with pvlib.Solver(25.0, 25.0, 275) as s:
+                    for b in g["boxes"]:
+                        s.add_geometry(b)
+                    for _ in range(2):
+                        s.run(g["listener"])
+                    outs.append(s.get_output(g["emitters"][0]).as_array())
+            except Exception as e:  # noqa: BLE001
+                fails.append((tid, i, str(e)))
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not fails, fails[:3]
+    assert len(outs) == 24
+    for o in outs:
+        assert np.array_equal(o.view(np.uint32), np.asarray(g["emitter_out"][0], np.float32).view(np.uint32))

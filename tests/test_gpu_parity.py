@@ -694,6 +694,12 @@ def check_streaming_against(res, delay, rres, rdelay, T, fs, emitter_cells, ctx=
             assert rel_err(res[cx, cy, 2], rres[cx, cy, 2]).max() <= RT60_TOL, ctx + " rt60 at emitter"
 
 
+def fuse_opts(fuse):
+    """stream_fuse = 1 needs a tile configuration that has the open-tile kernel (csrc/pv_kernels.hip PV_OPEN_CONFIGS); the default
+    tile of small grids has none and the option would be ignored"""
+    return dict(stream_fuse=1, steps_per_launch=8, tile_rows=24) if fuse else dict(stream_fuse=0)
+
+
 @pytest.mark.parametrize("fuse", [1, 0])
 @pytest.mark.parametrize("name", ["g71_smallroom", "g71_hugeroom", "g71_floorplan", "g96_smallroom_res375"])
 def test_streaming_mode_small(pvlib, name, fuse):
@@ -703,7 +709,8 @@ def test_streaming_mode_small(pvlib, name, fuse):
     rng = np.random.default_rng(1)
     extra = rng.uniform(0.5, size - 0.5, (12, 3)).astype(np.float32)
     emitters = np.concatenate([g["emitters"], extra])
-    with pvlib.Solver(size, size, res, streaming_analysis=1, stream_fuse=fuse) as s:
+    with pvlib.Solver(size, size, res, streaming_analysis=1, **fuse_opts(fuse)) as s:
+        assert s.info.streamFuse == fuse
         for b in g["boxes"]:
             s.add_geometry(b)
         s.set_emitters(emitters)
@@ -730,7 +737,8 @@ def test_streaming_mode_512_mode_b(pvlib, fuse):
     c = g["cells"]
     dx = np.float32(343.21) / np.float32(2009) / np.float32(3.5)
     em_pos = np.stack([(c[:, 0] + 0.5) * float(dx), np.zeros(len(c)), (c[:, 1] + 0.5) * float(dx)], 1)
-    with pvlib.Solver(25.0, 25.0, 2009, streaming_analysis=1, stream_fuse=fuse) as s:
+    with pvlib.Solver(25.0, 25.0, 2009, streaming_analysis=1, **fuse_opts(fuse)) as s:
+        assert s.info.streamFuse == fuse
         for b in g["boxes"]:
             s.add_geometry(b)
         s.set_emitters(np.concatenate([g["emitters"], em_pos]))
@@ -747,7 +755,8 @@ def test_streaming_equals_full_history_1024(pvlib, fuse):
     dx = np.float32(343.21) / np.float32(275) / np.float32(3.5)
     size = float((1024 + 0.5) * dx)
     L, E = (91.0, 0.0, 91.0), [(95.0, 0.0, 97.0), (100.0, 0.0, 80.0), (60.3, 0.0, 110.9)]
-    with pvlib.Solver(size, size, 275) as full, pvlib.Solver(size, size, 275, streaming_analysis=1, stream_fuse=fuse) as st:
+    with pvlib.Solver(size, size, 275) as full, pvlib.Solver(size, size, 275, streaming_analysis=1, **fuse_opts(fuse)) as st:
+        assert st.info.streamFuse == fuse
         for s in (full, st):
             s.load_scene(os.path.join(SCENES, "Shoebox.pv"))
         st.set_emitters(E)
@@ -814,6 +823,7 @@ def test_streaming_equals_full_history_2048_long(pvlib, fuse):
     T = 2000
     with pvlib.Solver(size, size, 275, num_steps=T) as full, \
             pvlib.Solver(size, size, 275, num_steps=T, streaming_analysis=1, stream_fuse=fuse) as st:
+        assert st.info.streamFuse == fuse
         for s in (full, st):
             for wbox in walls:
                 s.add_geometry(wbox)

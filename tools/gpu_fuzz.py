@@ -21,12 +21,13 @@ from test_gpu_parity import check_streaming_against, compare_maps, random_scene 
 
 CONFIGS = [dict(), dict(), dict(steps_per_launch=12, tile_rows=36), dict(steps_per_launch=10, tile_rows=36),
            dict(steps_per_launch=8, tile_rows=24), dict(steps_per_launch=4, tile_rows=32),
-           dict(steps_per_launch=8, tile_rows=40), dict(small_grid_kernel=2), dict(small_grid_kernel=2, use_graph=2),
+           dict(steps_per_launch=8, tile_rows=40), dict(steps_per_launch=12, tile_rows=12), dict(steps_per_launch=10, tile_rows=20),
+           dict(small_grid_kernel=2), dict(small_grid_kernel=2, use_graph=2),
            dict(steps_per_launch=12, tile_rows=36, merged_launch=0), dict(steps_per_launch=1, tile_rows=30),
            dict(streaming_analysis=1), dict(streaming_analysis=1, steps_per_launch=12, tile_rows=36),
            dict(streaming_analysis=1, steps_per_launch=4, tile_rows=32),
            # round 3: forward sums of air tiles inside the stencil (pv_stream.h), forced on (auto: from 6000 tiles)
-           dict(streaming_analysis=1, stream_fuse=1), dict(streaming_analysis=1, stream_fuse=1, steps_per_launch=12, tile_rows=36),
+           dict(streaming_analysis=1, stream_fuse=1, steps_per_launch=8, tile_rows=24), dict(streaming_analysis=1, stream_fuse=1, steps_per_launch=12, tile_rows=36),
            dict(streaming_analysis=1, stream_fuse=1, steps_per_launch=10, tile_rows=36),
            dict(steps_per_launch=8, tile_rows=40, edge_tiles=1), dict(steps_per_launch=10, tile_rows=36, edge_tiles=1),
            dict(steps_per_launch=12, tile_rows=36, edge_tiles=1),
