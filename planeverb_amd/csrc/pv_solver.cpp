@@ -1231,10 +1231,9 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
         // the grid of the general kernel is captured for a capacity; the live count is read from dyn on the device
         const int cap = (int)wallTiles_.size() + 4;
         if ((!graphExec_ || graphCap_ != cap) && !buildGraph(cap)) {
-            // The capture did not survive (another host thread's hipFree / device-wide synchronisation while this stream was
-            // capturing invalidates it: seen once in seven runs of the live-module test, whose worker captures its first
-            // iteration while the test thread builds a solver of its own).  This run goes out as plain launches; the next
-            // one captures again.
+            // The capture did not survive: some legacy-stream operation of another host thread while this stream was capturing
+            // invalidates it (this library issues none any more -- see applyGeometry -- but a host application may).  This
+            // run goes out as plain launches; the next one captures again.
             (void)hipGetLastError();
             err_.clear();
             launchCap_ = numGeneral_;
