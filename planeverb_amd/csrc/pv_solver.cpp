@@ -1229,7 +1229,11 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
         tim_.stepLaunches = 1;
     } else if (graph) {
         // the grid of the general kernel is captured for a capacity; the live count is read from dyn on the device
-        const int cap = (int)wallTiles_.size() + 4;
+        // (+ the tiles whose loaded region can hold the listener: ceil(loaded rows / tile rows) x ceil(64 / tile columns) --
+        // 2 x 2 for every tile of rounds 1-2, 3 x 2 for the 12-row tile at K = 12, whose two extra listener tiles fell off a
+        // capacity of "+ 4" and were advanced by nobody: tools/gpu_fuzz.py seeds 30051 / 30098 / 30172)
+        const int rowsL = rxi_ + 2 * K_ + (stepConfigStacked(K_, rxi_) ? stepConfigExtraRows(K_, rxi_) : 0);
+        const int cap = (int)wallTiles_.size() + ceilDiv(rowsL, rxi_) * ceilDiv(64, wi_);
         if ((!graphExec_ || graphCap_ != cap) && !buildGraph(cap)) {
             // The capture did not survive: some legacy-stream operation of another host thread while this stream was capturing
             // invalidates it (this library issues none any more -- see applyGeometry -- but a host application may).  This

@@ -1263,3 +1263,28 @@ def test_edge_tiles_match_general_path_1024(pvlib, cell):
         rb, db = b.results()
         assert same_bits(da, db).all() and same_bits(ra, rb).all()
         assert (da < 1e30).sum() > 50000
+
+
+def test_listener_tiles_of_the_small_tile_in_a_replayed_graph(pvlib, oracle):
+    """The default tile of the reference's presets (12 rows at 12 steps per launch) has the listener inside the loaded regions
+    of 3 x 2 tiles, not 2 x 2: the replayed run graph sized its general-tile launch for four and nobody advanced the other two
+    (tools/gpu_fuzz.py seeds 30051 / 30098 / 30172: open scenes, where those tiles are air otherwise).  An open 187^2 grid:
+    recorded planes, final fields and maps against the oracle."""
+    size, res, L = 61.22308529983864, 300, (45.2920940650875, 0.0, 26.158050733506652)
+    o = oracle.OracleGrid(size, size, res, None)
+    f = o.fdtd(L, want_fields=True)
+    hist, _, _ = o.history()
+    hp = {t: hist[t].copy() for t in (3, 11, 12, 17, 40, o.T - 1)}
+    rres, rdelay, _ = o.analyze(oracle.free_energy(size, size, res), L)
+    T, fs = o.T, o.fs
+    o.close()
+    with pvlib.Solver(size, size, res) as s:
+        assert (s.info.stepsPerLaunch, s.info.tileRows) == (12, 12)
+        for rep in range(2):  # captured, then replayed
+            s.run(L)
+            for t, want in hp.items():
+                assert same_bits(s.history_plane(t), want).all(), "recorded pr, step %d (run %d)" % (t, rep)
+            for mine, ref in zip(s.fields(), f):
+                assert same_bits(mine, ref).all(), "final fields"
+            res8, delay = s.results()
+            compare_maps(res8, delay, rres, rdelay, T, fs, "open 187^2")

@@ -79,7 +79,12 @@ def one(seed):
         if not opts.get("streaming_analysis"):
             for t in sorted(set([0, 1, 2, 3, 17, o.T // 3, o.T // 2, o.T - 2, o.T - 1])):
                 if t <= tmax:
-                    assert same_bits(s.history_plane(t), hp[t]).all(), "pr step %d" % t
+                    ok = same_bits(s.history_plane(t), hp[t])
+                    if not ok.all():
+                        idx = np.argwhere(~ok)
+                        raise AssertionError("pr step %d: %d cells (first %s, rows %d..%d, cols %d..%d) grid %dx%d res %d boxes %d K %d rows %d %r L %r" % (
+                            t, (~ok).sum(), idx[0], idx[:, 0].min(), idx[:, 0].max(), idx[:, 1].min(), idx[:, 1].max(), o.gx, o.gy, res,
+                            len(boxes), s.info.stepsPerLaunch, s.info.tileRows, opts, L))
         nvalid = -1
         if tmax == o.T - 1 and not opts.get("streaming_analysis"):
             for cx, cy in rng.integers(0, o.gx, (4, 2)):
