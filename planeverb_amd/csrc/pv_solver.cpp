@@ -71,6 +71,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         hipDeviceGetStreamPriorityRange(&lo, &hi);
         if (!hipOk(hipStreamCreateWithPriority(&stream2_, hipStreamNonBlocking, hi), "hipStreamCreate")) return false;
     }
+    if (!hipOk(hipStreamCreateWithFlags(&flagStream_, hipStreamNonBlocking), "hipStreamCreate")) return false;
     if (!hipOk(hipEventCreateWithFlags(&forkEv_, hipEventDisableTiming), "hipEventCreate")) return false;
     for (auto& e : ev_)
         if (!hipOk(hipEventCreate(&e), "hipEventCreate")) return false;
@@ -419,6 +420,7 @@ Solver::~Solver() {
     for (auto& e : airDone_) hipEventDestroy(e);
     for (auto& e : genDone_) hipEventDestroy(e);
     if (forkEv_) hipEventDestroy(forkEv_);
+    if (flagStream_) hipStreamDestroy(flagStream_);
     if (stream2_) hipStreamDestroy(stream2_);
     if (stream_) hipStreamDestroy(stream_);
 }
@@ -1444,8 +1446,8 @@ bool Solver::sync() {
             tim_.generalLaunches = numGeneral_ > 0 ? n : 0;
         }
         int flag = 0;
-        if (!hipOk(hipMemcpyAsync(&flag, errFlag_, sizeof(int), hipMemcpyDeviceToHost, stream_), "errFlag copy") ||
-            !hipOk(hipStreamSynchronize(stream_), "errFlag sync"))
+        if (!hipOk(hipMemcpyAsync(&flag, errFlag_, sizeof(int), hipMemcpyDeviceToHost, flagStream_), "errFlag copy") ||
+            !hipOk(hipStreamSynchronize(flagStream_), "errFlag sync"))
             return false;
         if (flag) return fail("pressure history window overflow (a tile outside the window became non-zero)");
     }

@@ -196,6 +196,7 @@ private:
     int T_ = 0;
     hipStream_t stream_ = nullptr;
     hipStream_t stream2_ = nullptr;        // general-tile kernels run here, concurrently with the air kernel
+    hipStream_t flagStream_ = nullptr;     // small device -> host reads that must not queue behind stream_ (sync(): the next batch's launches may already be there) -- and never the legacy stream (applyGeometry)
     std::vector<hipEvent_t> airDone_, genDone_;  // per-launch cross-stream dependencies (no timing)
     hipEvent_t forkEv_ = nullptr;
     // captured launch schedule of one run (reset + all step launches on both streams), replayed per run
