@@ -161,6 +161,7 @@ enum {
     PVA_OPT_PATCH_KERNEL = 17, /* air tiles by the persistent per-CU kernel with LDS-DMA run-ahead (csrc/pv_patch.h: one 512-thread workgroup per CU, the next 4-tile patch lands in LDS while the current one computes) instead of one wave per tile; general tiles in a launch of their own.  Only the large-grid tile (steps per launch 12, tile rows 36) has the kernel; ignored elsewhere and with streaming analysis, slabs, edge tiles, kernel timing.  -1 = default for the configuration, 0 = off, 1 = on */
     PVA_OPT_LAZY_FAR_CELLS = 19, /* 1 (default): a run resets "no onset" / the default listener direction only in the previous and the current history-window block of the result map; the listener direction of the other far cells (unit vector listener -> cell, Analyzer.cpp:365-391,415-428) is materialised when a whole-map read-back asks for it and computed in closed form by PvAmdGetOutput / the output queries.  0: rewrite every far cell on every run (201 MB at 4096^2), the form of rounds 1-2 (validation) */
     PVA_OPT_STREAM_FUSE = 20,  /* streaming analysis only: the forward sums of the analysis (onset, dry energy, source-direction flux) of AIR tiles advance inside the step kernel (csrc/pv_stream.h: open half tiles with the sums in registers); the ring of pressure planes and the accumulate pass then serve only tiles with walls, grid edges, the listener or a registered emitter.  -1 (default): by grid size (on from 6000 tiles, where the ring traffic binds); 0: ring + accumulate pass for every tile (round 2's form); 1: on */
+    PVA_OPT_AUX_STREAMS = 21,  /* HIP streams the solver creates beside its own two and never launches on (default 0).  The streams of a process share a handful of hardware queues, handed out by creation order, and two step loops that land on one queue run their launches strictly one after the other.  Measured on MI355X / ROCm 7.0 at 512^2: with 1, the two batch groups' step loops overlap (batched launches 33 instead of 63 us: 3.5e11 instead of 2.1e11 cell-updates/s); with 0, four pipelined single runs keep 2.8e11 instead of 2.5e11.  api.batch_solver_options sets 1 */
     PVA_OPT_PATCH_STRIP = 18,  /* patch columns per strip of the patch kernel's walk over the grid (development; default 3) */
     PVA_OPT_EDGE_TILES = 15    /* 1 = tiles whose only non-air faces are the grid's absorbing edges run the air-tile code + edge overrides (tile class 2) instead of the general path.  Only the batched kernels of the mirror-pair tiles (K, rows = (8,40), (10,36), (12,36)) have that arm -- inside the merged kernel it slows the air tiles by 25-40 %, DESIGN.md 8.4 -- so every run of such a solver goes through PvAmdRunBatch's kernel (PvAmdRun = a batch of one) and PvAmdRunSteps is refused; ignored for other configurations.  Default 0 */
 };

@@ -43,6 +43,7 @@ PVA_OPT_PATCH_KERNEL = 17
 PVA_OPT_PATCH_STRIP = 18
 PVA_OPT_LAZY_FAR_CELLS = 19
 PVA_OPT_STREAM_FUSE = 20
+PVA_OPT_AUX_STREAMS = 21
 
 
 class PlaneverbOutput(C.Structure):
@@ -376,10 +377,10 @@ def batch_solver_options(n):
     batched kernel has the edge-tile arm (grid-border tiles on the air path, tile class 2), measured on MI355X:
     +13 % at 512^2, +25 % at 1024^2 over the default tile of the size"""
     if n <= 768:
-        return dict(steps_per_launch=8, tile_rows=40, edge_tiles=1)
+        return dict(steps_per_launch=8, tile_rows=40, edge_tiles=1, aux_streams=1)
     if n <= 1536:
-        return dict(steps_per_launch=10, tile_rows=36, edge_tiles=1)
-    return dict(steps_per_launch=12, tile_rows=36, edge_tiles=1)
+        return dict(steps_per_launch=10, tile_rows=36, edge_tiles=1, aux_streams=1)
+    return dict(steps_per_launch=12, tile_rows=36, edge_tiles=1, aux_streams=1)
 
 
 def shard_plan(n_runs, world, rank, n_local_solvers):
@@ -608,7 +609,7 @@ class Solver:
                 "stream_rows": PVA_OPT_STREAM_ROWS, "merged_launch": PVA_OPT_MERGED_LAUNCH,
                 "edge_tiles": PVA_OPT_EDGE_TILES, "row_bands": PVA_OPT_ROW_BANDS,
                 "patch_kernel": PVA_OPT_PATCH_KERNEL, "patch_strip": PVA_OPT_PATCH_STRIP,
-                "lazy_far_cells": PVA_OPT_LAZY_FAR_CELLS, "stream_fuse": PVA_OPT_STREAM_FUSE}
+                "lazy_far_cells": PVA_OPT_LAZY_FAR_CELLS, "stream_fuse": PVA_OPT_STREAM_FUSE, "aux_streams": PVA_OPT_AUX_STREAMS}
         for k, v in options.items():
             _check(lib().PvAmdSetOption(self._h, keys[k], int(v)))
         self.info = PvAmdInfo()

@@ -454,6 +454,7 @@ int PvAmdSetOption(PvAmdSolver* h, int key, long long value) {
         case PVA_OPT_PATCH_KERNEL: h->opt.patch = (int)value; break;
         case PVA_OPT_LAZY_FAR_CELLS: h->opt.lazyFar = value != 0; break;
         case PVA_OPT_STREAM_FUSE: h->opt.streamFuse = (int)value; break;
+        case PVA_OPT_AUX_STREAMS: h->opt.auxStreams = (int)std::max<long long>(0, std::min<long long>(value, 8)); break;
         case PVA_OPT_PATCH_STRIP: h->opt.patchStrip = (int)value; break;
         default: g_lastError = "unknown option"; return -1;
     }

@@ -71,7 +71,11 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         hipDeviceGetStreamPriorityRange(&lo, &hi);
         if (!hipOk(hipStreamCreateWithPriority(&stream2_, hipStreamNonBlocking, hi), "hipStreamCreate")) return false;
     }
-    if (!hipOk(hipStreamCreateWithFlags(&flagStream_, hipStreamNonBlocking), "hipStreamCreate")) return false;
+    for (int i = 0; i < opt.auxStreams; ++i) {
+        hipStream_t x = nullptr;
+        if (!hipOk(hipStreamCreateWithFlags(&x, hipStreamNonBlocking), "hipStreamCreate")) return false;
+        auxStreams_.push_back(x);
+    }
     if (!hipOk(hipEventCreateWithFlags(&forkEv_, hipEventDisableTiming), "hipEventCreate")) return false;
     for (auto& e : ev_)
         if (!hipOk(hipEventCreate(&e), "hipEventCreate")) return false;
@@ -420,7 +424,7 @@ Solver::~Solver() {
     for (auto& e : airDone_) hipEventDestroy(e);
     for (auto& e : genDone_) hipEventDestroy(e);
     if (forkEv_) hipEventDestroy(forkEv_);
-    if (flagStream_) hipStreamDestroy(flagStream_);
+    for (hipStream_t x : auxStreams_) hipStreamDestroy(x);
     if (stream2_) hipStreamDestroy(stream2_);
     if (stream_) hipStreamDestroy(stream_);
 }
@@ -1200,6 +1204,7 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
         hipEventRecord(ev_[1], stream_);
         launchStreamFinalize(aa, stream_);
         hipEventRecord(ev_[2], stream_);
+        lastRunBatched_ = false;
         enqueueQueries();
         pendingTimings_ = true;
         return hipOk(hipGetLastError(), "run launch");
@@ -1256,6 +1261,7 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
     hipEventRecord(ev_[1], stream_);
     if (!opt_.skipAnalysis) enqueueAnalysis(lx, lz);
     hipEventRecord(ev_[2], stream_);
+    lastRunBatched_ = false;
     enqueueQueries();
     pendingTimings_ = true;
     return hipOk(hipGetLastError(), "run launch");
@@ -1389,6 +1395,7 @@ bool Solver::runBatch(Solver* const* s, int n, const float* lxyz, bool wait, std
         hipEventRecord(v.ev_[1], v.stream_);
         if (!v.opt_.skipAnalysis) v.enqueueAnalysis(v.lastLx_, v.lastLz_);
         hipEventRecord(v.ev_[2], v.stream_);
+        v.lastRunBatched_ = n > 1;
         v.enqueueQueries();
         v.pendingTimings_ = true;
     }
@@ -1445,9 +1452,15 @@ bool Solver::sync() {
             tim_.airLaunches = n;
             tim_.generalLaunches = numGeneral_ > 0 ? n : 0;
         }
+        // The error flag, never through the legacy stream (applyGeometry).  WHICH stream was measured on MI355X / ROCm 7.0
+        // (profiles/r03_ab_errflag.txt): read behind stream_, the batched launches of a batch member's NEXT step loop take twice as
+        // long (63 instead of 33 us at 512^2: 2.2e11 instead of 3.7e11 cell-updates/s); with one more stream per solver for it, four
+        // pipelined runs of a 512^2 grid lose 11 % (the streams of a process share a handful of hardware queues by creation
+        // order).  So: by the kind of run, and through the solver's second stream, which the batched mode does not use.
         int flag = 0;
-        if (!hipOk(hipMemcpyAsync(&flag, errFlag_, sizeof(int), hipMemcpyDeviceToHost, flagStream_), "errFlag copy") ||
-            !hipOk(hipStreamSynchronize(flagStream_), "errFlag sync"))
+        hipStream_t fs = lastRunBatched_ ? stream2_ : stream_;  // (stream2_ is idle in the batched mode)
+        if (!hipOk(hipMemcpyAsync(&flag, errFlag_, sizeof(int), hipMemcpyDeviceToHost, fs), "errFlag copy") ||
+            !hipOk(hipStreamSynchronize(fs), "errFlag sync"))
             return false;
         if (flag) return fail("pressure history window overflow (a tile outside the window became non-zero)");
     }

@@ -46,6 +46,7 @@ struct SolverOptions {
     // and keeps the K rows its neighbours own next to them current in its guard band (SlabGroup exchanges them after
     // every launch).  slabCount = 1: a whole grid.
     int slabIndex = 0, slabCount = 1;
+    int auxStreams = 0;   // streams created and never used (PVA_OPT_AUX_STREAMS: hardware-queue placement of the solvers' main streams)
     int streamFuse = -1;  // sparse-emitter mode: forward sums of air tiles inside the stencil (pv_stream.h): -1 = by grid size (on from 6000 tiles: it costs two more launches per sweep and pays where the ring traffic binds), 0 = ring + accumulate pass for every tile (round 2's form), 1 = on
     bool lazyFar = true;  // far cells of the result map lazily (see Solver::lazyFar_)
     int patch = -1;       // air tiles by the persistent patch kernel (pv_patch.h): -1 = default of the configuration, 0 off, 1 on
@@ -196,7 +197,8 @@ private:
     int T_ = 0;
     hipStream_t stream_ = nullptr;
     hipStream_t stream2_ = nullptr;        // general-tile kernels run here, concurrently with the air kernel
-    hipStream_t flagStream_ = nullptr;     // small device -> host reads that must not queue behind stream_ (sync(): the next batch's launches may already be there) -- and never the legacy stream (applyGeometry)
+    bool lastRunBatched_ = false;          // the last run was a member of a batch of several
+    std::vector<hipStream_t> auxStreams_;  // PVA_OPT_AUX_STREAMS
     std::vector<hipEvent_t> airDone_, genDone_;  // per-launch cross-stream dependencies (no timing)
     hipEvent_t forkEv_ = nullptr;
     // captured launch schedule of one run (reset + all step launches on both streams), replayed per run
