@@ -465,7 +465,8 @@ def main(argv=None, hooks=None):
                         "valu_quad_cycles_per_launch": q, "effective_clock_ghz": clk,
                         "how": "SQ_ACTIVE_INST_VALU (quad-cycles per launch, rocprofv3 --pmc) x 4 / 1024 SIMDs / (live "
                                "launch_ms / concurrent_launches x effective clock = GRBM_GUI_ACTIVE / 8 / duration)",
-                        "collected_at_head": sqprof.get("collected_at_head"), "source": "profiles/r02_sq_pmc.md"}
+                        "collected_at_head": sqprof.get("collected_at_head"),
+                        "source": "profiles/%s_sq_pmc.md" % sqprof.get("round", "r02")}
         value = world * B * cells * T * args.steps / elapsed
         fd = float(np.mean(fdtd_ms)) * 1e-3
         out = {
