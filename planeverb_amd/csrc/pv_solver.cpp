@@ -1029,8 +1029,13 @@ AnalyzeArgs Solver::analyzeArgs(float lx, float lz) const {
     a.winCols = histTilesY_ * wi_;
     a.activeCount = activeCount_;
     a.dirScratch = reinterpret_cast<int*>(scratch_);
-    // wide windows can hold walks of hundreds of steps; the dense-history (validation) mode keeps the plain walk
-    a.dirJump = (!opt_.denseHistory && a.winRows > 256 && a.winCols > 256) ? 1 : 0;
+    // Listener direction: pointer jumping (six tiny launches at T = 1187, path-length independent) wherever a walk can be
+    // long or launches are cheap -- wide windows, and every grid small enough to run as one replayed graph, where the plain
+    // walk was 10-13 % of a run (191^2, T = 1187: 241 us of 1.83 ms; profiles/r03_presets.txt).  A small room inside a
+    // large grid keeps the plain walk (short walks, one launch instead of five queued behind another run's stencil), and
+    // so does the dense-history (validation) mode.
+    const bool smallWindow = a.winRows <= 256 && a.winCols <= 256;
+    a.dirJump = (!opt_.denseHistory && !(smallWindow && geo_.ntx * geo_.nty > 4096)) ? 1 : 0;
     a.T = T_;
     a.nDir = g_.nDir;
     a.nDry = g_.nDry;
