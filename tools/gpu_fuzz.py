@@ -43,6 +43,8 @@ SEG_CONFIGS = [dict(steps_per_launch=k, tile_rows=r, stream_rows=n, use_graph=2)
                for k, r in ((8, 40), (12, 36)) for n in (1, 7, 40, 400)]
 if os.environ.get("PV_FUZZ_SEG"):  # a campaign on the segment kernels only
     CONFIGS = SEG_CONFIGS
+if os.environ.get("PV_FUZZ_CONFIG"):  # a campaign on one configuration: PV_FUZZ_CONFIG="steps_per_launch=16,tile_rows=12"
+    CONFIGS = [dict((k, int(v)) for k, v in (kv.split("=") for kv in os.environ["PV_FUZZ_CONFIG"].split(",")))]
 
 
 def one(seed):
