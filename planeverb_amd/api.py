@@ -44,6 +44,7 @@ PVA_OPT_PATCH_STRIP = 18
 PVA_OPT_LAZY_FAR_CELLS = 19
 PVA_OPT_STREAM_FUSE = 20
 PVA_OPT_AUX_STREAMS = 21
+PVA_OPT_RESIDENT_KERNEL = 22
 
 
 class PlaneverbOutput(C.Structure):
@@ -70,7 +71,7 @@ class PvAmdInfo(C.Structure):
                 ("dx", C.c_float), ("dt", C.c_float), ("efree", C.c_float), ("device", C.c_int),
                 ("stepsPerLaunch", C.c_int), ("tileRows", C.c_int), ("tileCols", C.c_int), ("pitch", C.c_int),
                 ("rows", C.c_int), ("histRows", C.c_int), ("histPitch", C.c_int), ("numGeometry", C.c_int),
-                ("deviceBytes", C.c_longlong), ("streamFuse", C.c_int)]
+                ("deviceBytes", C.c_longlong), ("streamFuse", C.c_int), ("residentKernel", C.c_int)]
 
 
 class PvAmdSlabInfo(C.Structure):
@@ -609,7 +610,8 @@ class Solver:
                 "stream_rows": PVA_OPT_STREAM_ROWS, "merged_launch": PVA_OPT_MERGED_LAUNCH,
                 "edge_tiles": PVA_OPT_EDGE_TILES, "row_bands": PVA_OPT_ROW_BANDS,
                 "patch_kernel": PVA_OPT_PATCH_KERNEL, "patch_strip": PVA_OPT_PATCH_STRIP,
-                "lazy_far_cells": PVA_OPT_LAZY_FAR_CELLS, "stream_fuse": PVA_OPT_STREAM_FUSE, "aux_streams": PVA_OPT_AUX_STREAMS}
+                "lazy_far_cells": PVA_OPT_LAZY_FAR_CELLS, "stream_fuse": PVA_OPT_STREAM_FUSE, "aux_streams": PVA_OPT_AUX_STREAMS,
+                "resident_kernel": PVA_OPT_RESIDENT_KERNEL}
         for k, v in options.items():
             _check(lib().PvAmdSetOption(self._h, keys[k], int(v)))
         self.info = PvAmdInfo()

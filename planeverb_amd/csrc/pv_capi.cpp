@@ -456,6 +456,7 @@ int PvAmdSetOption(PvAmdSolver* h, int key, long long value) {
         case PVA_OPT_STREAM_FUSE: h->opt.streamFuse = (int)value; break;
         case PVA_OPT_AUX_STREAMS: h->opt.auxStreams = (int)std::max<long long>(0, std::min<long long>(value, 8)); break;
         case PVA_OPT_PATCH_STRIP: h->opt.patchStrip = (int)value; break;
+        case PVA_OPT_RESIDENT_KERNEL: h->opt.resident = (int)value; break;
         default: g_lastError = "unknown option"; return -1;
     }
     return 0;
@@ -509,6 +510,7 @@ int PvAmdGetInfo(PvAmdSolver* h, PvAmdInfo* out) {
     out->numGeometry = h->s->numBoxes();
     out->deviceBytes = h->s->deviceBytes();
     out->streamFuse = h->s->streamFuse() ? 1 : 0;
+    out->residentKernel = h->s->residentKernel() ? 1 : 0;
     return 0;
 }
 

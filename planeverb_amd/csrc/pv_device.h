@@ -178,6 +178,27 @@ struct SmallArgs {
     int rxi, wi;  // tile interior (the history planes are tile-major: histOffset)
 };
 
+// resident kernel (pv_resident.hip): every tile a workgroup that stays on its CU for all T steps of a run; epochs of K
+// steps, neighbours hand their interiors over through the two buffer sets + one flag word per tile
+struct ResidentArgs {
+    float* pr[2];
+    float* vx[2];
+    float* vy[2];          // the two buffer sets: epoch e reads set e & 1 (nothing for e = 0) and publishes into the other
+    const FaceCoef* coef;
+    const float* pulse;    // >= T floats
+    float* hist;           // window base (the window is the whole grid), plane stride histPlane
+    int* tileFirst;        // per tile: first step block in which the tile was non-zero (reset to INT_MAX before the launch)
+    const DynParams* dyn;
+    int* errFlag;          // 3 = a block gave up waiting for a neighbour (every block then leaves: the run failed)
+    unsigned* flags;       // ntiles epoch counters + 1 abort word, zeroed before every launch
+    long long histPlane;   // floats per recorded step
+    long long planeBytes;  // bytes of one padded float plane
+    int pitch, G;
+    int ntx, nty, ntiles;
+    int T;
+    float courant;
+};
+
 // sparse-emitter mode with the forward sums inside the stencil (pv_stream.h)
 struct OpenArgs {
     int* sOnset;            // per result cell: onset step, -1 = none yet

@@ -46,6 +46,14 @@ void launchTileClass(int K, int rxi, const FaceCoef* coef, uint8_t* tileClass, i
                      const Geometry& g, hipStream_t stream, bool allowEdge);
 // dead tiles (all-wall interior): dead[tile] = 1, *count += number of them
 void launchTileDead(const FaceCoef* coef, uint8_t* dead, int* count, const Geometry& g, int K, hipStream_t stream);
+// resident kernel (pv_resident.hip): one launch per run; a.ntiles workgroups that must all be co-resident
+bool residentConfigOk(int K, int rxi);
+int residentExtraRows(int K, int rxi);   // rows its blocks load beyond rxi + 2K at the bottom
+int residentMaxBlocks(int K, int rxi, int device);
+void launchResident(int K, int rxi, const ResidentArgs& a, hipStream_t stream);
+#ifdef PV_RESIDENT_TRACE
+void residentDumpTrace();  // development builds: the phase stamps of the last launch to stderr
+#endif
 // cells = NX*NY must satisfy smallGridFits()
 bool smallGridFits(int NX, int NY);
 void launchSmallGrid(const SmallArgs& a, hipStream_t stream);

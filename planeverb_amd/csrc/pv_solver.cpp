@@ -2,6 +2,7 @@
 #include "pv_solver.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <climits>
 #include <cmath>
@@ -24,6 +25,18 @@ inline int roundUp(int v, int m) { return (v + m - 1) / m * m; }
 inline int ceilDiv(int a, int b) { return (a + b - 1) / b; }
 inline int floorDiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 }  // namespace
+
+// resident kernel (pv_resident.hip): blocks of runs in flight per device, all solvers of the process
+static constexpr int kResidentMaxTiles = 512;
+static std::atomic<int>& residentInFlight(int device) {
+    static std::atomic<int> n[64];
+    return n[device & 63];
+}
+
+void Solver::releaseResident() {
+    if (residentHeld_ > 0) residentInFlight(device_).fetch_sub(residentHeld_);
+    residentHeld_ = 0;
+}
 
 bool Solver::fail(const std::string& what) {
     err_ = what;
@@ -334,6 +347,23 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         if (!hipOk(hipHostMalloc((void**)&dynBandsHost_, sizeof(DynParams) * (size_t)nb_), "hipHostMalloc")) return false;
     }
 
+    // Resident kernel (pv_resident.hip): the launch-bound grids whose history window is the whole grid -- the reference's own
+    // presets -- run as ONE launch of ntiles workgroups that hand their interiors to their neighbours every K steps.  All of
+    // them must be co-resident (they wait for each other inside the launch): the grid is capped by the occupancy query, and
+    // concurrent runs of several solvers share a per-device budget (enqueueRun).
+    {
+        const bool explicitTile = opt.K > 0 || opt.rxi > 0;
+        const bool wanted = opt_.resident == 1 || (opt_.resident == 0 && !explicitTile && opt_.useGraph != 1);
+        useResident_ = wanted && residentConfigOk(K_, rxi_) && !opt_.streaming && !isSlab() && opt_.timeKernels == 0 &&
+                       !opt_.denseHistory && !opt_.edgeTiles && opt_.merged == 1 && histTilesX_ == geo_.ntx &&
+                       histTilesY_ == geo_.nty && kGuard >= K_ + residentExtraRows(K_, rxi_) && T_ >= 1;
+        if (useResident_) {
+            const int cap = residentMaxBlocks(K_, rxi_, device_);
+            if (ntiles > std::min(cap / 2, kResidentMaxTiles)) useResident_ = false;
+        }
+        if (useResident_ && !dalloc(&resFlags_, (size_t)ntiles + 1, true)) return false;
+    }
+
     warnIfPulseDiffers();
     pulse_ = gaussianPulse(g_);
     pulse_.resize((size_t)std::max(T_, g_.T), 0.f);  // an extended run (numSteps > T) injects nothing after T
@@ -390,6 +420,11 @@ Solver::~Solver() {
         if (p) hipFree(p);
     if (ringHost_) hipHostFree(ringHost_);
     if (idleHost_) hipHostFree(idleHost_);
+    releaseResident();
+#ifdef PV_RESIDENT_TRACE
+    if (useResident_) residentDumpTrace();
+#endif
+    if (resFlags_) hipFree(resFlags_);
     if (emCells_) hipFree(emCells_);
     if (emTrace_) hipFree(emTrace_);
     void* ptrs[] = {coef_,      matDev_, pulseDev_, hist_,  tileFirst_, tileClass_, generalList_,
@@ -1214,7 +1249,50 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
         pendingTimings_ = true;
         return hipOk(hipGetLastError(), "run launch");
     }
-    if (small) {
+    // resident kernel: one launch per run.  Its blocks wait for each other, so they must all be on the chip at once: a run
+    // takes its blocks out of the device's budget until sync(); when concurrent runs of other solvers have used the budget
+    // up, this run goes out as the replayed graph instead (never a wait, never a deadlock)
+    bool resident = useResident_ && !(small && opt_.resident != 1);
+    if (resident) {
+        const int budget = residentMaxBlocks(K_, rxi_, device_) * 3 / 4;
+        std::atomic<int>& inFlight = residentInFlight(device_);
+        if (inFlight.fetch_add(ntiles) + ntiles > budget) {
+            inFlight.fetch_sub(ntiles);
+            resident = false;
+        } else {
+            residentHeld_ = ntiles;
+        }
+    }
+    if (resident) {
+        enqueueBeginRun(true);
+        if (!hipOk(hipMemsetAsync(resFlags_, 0, sizeof(unsigned) * ((size_t)ntiles + 1), stream_), "resident flags"))
+            return false;
+        ResidentArgs ra{};
+        for (int i = 0; i < 2; ++i) {
+            ra.pr[i] = pr_[i];
+            ra.vx[i] = vx_[i];
+            ra.vy[i] = vy_[i];
+        }
+        ra.coef = coef_;
+        ra.pulse = pulseDev_;
+        ra.hist = hist_;
+        ra.tileFirst = tileFirst_;
+        ra.dyn = dynDev_;
+        ra.errFlag = errFlag_;
+        ra.flags = resFlags_;
+        ra.histPlane = histPlane_;
+        ra.planeBytes = (long long)geo_.rows * geo_.pitch * 4;
+        ra.pitch = geo_.pitch;
+        ra.G = geo_.G;
+        ra.ntx = geo_.ntx;
+        ra.nty = geo_.nty;
+        ra.ntiles = ntiles;
+        ra.T = T_;
+        ra.courant = g_.courant;
+        launchResident(K_, rxi_, ra, stream_);
+        tim_.stepLaunches = ceilDiv(T_, K_);
+        cur_ = tim_.stepLaunches & 1;
+    } else if (small) {
         // the whole grid lives in one CU's LDS for all T steps: one launch, every cell recorded from step 0
         enqueueBeginRun(false);
         if (!hipOk(hipMemsetAsync(tileFirst_, 0, sizeof(int) * (size_t)ntiles, stream_), "tileFirst")) return false;
@@ -1436,6 +1514,7 @@ bool Solver::run(float lx, float ly, float lz, bool wait) {
 bool Solver::sync() {
     if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
     if (!hipOk(hipStreamSynchronize(stream_), "stream sync")) return false;
+    releaseResident();
     if (pendingTimings_) {
         pendingTimings_ = false;
         hipEventElapsedTime(&tim_.fdtdMs, ev_[0], ev_[1]);
@@ -1467,6 +1546,7 @@ bool Solver::sync() {
         if (!hipOk(hipMemcpyAsync(&flag, errFlag_, sizeof(int), hipMemcpyDeviceToHost, fs), "errFlag copy") ||
             !hipOk(hipStreamSynchronize(fs), "errFlag sync"))
             return false;
+        if (flag == 3) return fail("resident kernel: a workgroup gave up waiting for its neighbours (run aborted)");
         if (flag) return fail("pressure history window overflow (a tile outside the window became non-zero)");
     }
     return true;

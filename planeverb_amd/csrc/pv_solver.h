@@ -51,6 +51,9 @@ struct SolverOptions {
     bool lazyFar = true;  // far cells of the result map lazily (see Solver::lazyFar_)
     int patch = -1;       // air tiles by the persistent patch kernel (pv_patch.h): -1 = default of the configuration, 0 off, 1 on
     int patchStrip = 3;   // patch columns per strip of its walk
+    int resident = 0;     // resident kernel (pv_resident.hip: one launch per run, every tile a workgroup that stays on its CU for
+                          // all T steps): 0 = auto (default tile of the launch-bound grids, whole-grid history window, all
+                          // blocks co-resident), 1 = also with an explicitly chosen tile, 2 = never
     int rowBands = 0;     // B > 1: each sweep = B launches (bands of tile rows, one stream each) with 3-point
                           // dependencies between consecutive sweeps; 0 = auto, 1 = off
 };
@@ -88,6 +91,8 @@ public:
     int histPitch() const { return histPitch_; }
     const std::string& lastError() const { return err_; }
     bool streamFuse() const { return streamFuse_; }
+    bool residentKernel() const { return useResident_; }  // runs of this solver go through pv_resident_kernel (when the
+                                                          // device's resident-block budget allows: else the replayed graph)
     SolverOptions& options() { return opt_; }
 
     // geometry table with the reference's id recycling (Geometry/GeometryManager.cpp:67-121)
@@ -269,6 +274,11 @@ private:
     int* emCells_ = nullptr;
     float* emTrace_ = nullptr;
     int numEmitters_ = 0, emCap_ = 0;
+    // resident kernel (pv_resident.hip)
+    bool useResident_ = false;
+    unsigned* resFlags_ = nullptr;     // ntiles epoch counters + 1 abort word
+    int residentHeld_ = 0;             // blocks of the device's resident budget held by the run in flight
+    void releaseResident();
     float* scratch_ = nullptr;  // max(3T, NX*NY) floats
     size_t scratchCount_ = 0;
 
