@@ -68,9 +68,15 @@ struct ResShared {
     int abort;
 };
 
-__device__ __forceinline__ float getc(const v2f& v, int r) { return (r & 1) ? v.y : v.x; }
-__device__ __forceinline__ void setc(v2f& v, int r, float val) {
-    if (r & 1) v.y = val; else v.x = val;
+// STRIDED pairing: row r of a wave's window lives in pair r % NP, component r / NP (rows 0 .. NP-1 in the .x halves, rows
+// NP .. 2 NP - 1 in the .y halves).  The x-neighbour of BOTH halves of pair i is then pair i +- 1 itself, so the row
+// differences of the pressure and vx sweeps are whole-pair subtracts; only the seam (pair NP-1 -> pair 0) costs a shuffle.
+// (Adjacent-row pairs (2i, 2i+1), as in the tile kernels' general arm, pay a shuffle for every pair and sweep.)
+template <int NP>
+__device__ __forceinline__ float rowGet(const v2f (&f)[NP], int r) { return (r >= NP) ? f[r - NP].y : f[r].x; }
+template <int NP>
+__device__ __forceinline__ void rowSet(v2f (&f)[NP], int r, float val) {
+    if (r >= NP) f[r - NP].y = val; else f[r].x = val;
 }
 __device__ __forceinline__ v2f selMask(const u2 m, const v2f airv, const v2f wallv) {  // v_bfi_b32 x 2
     const u2 ua = __builtin_bit_cast(u2, airv), uw = __builtin_bit_cast(u2, wallv);
@@ -89,7 +95,7 @@ __device__ __forceinline__ void storeRows(const v2f (&f)[NP], const rsrc_t rs, c
 #pragma unroll
     for (int r = 1; r < R - 1; ++r)
         if (r >= rLo && r < rHi)
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(getc(f[r / 2], r)), rs, voff, soff0 + r * pitchB, AUX);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rowGet(f, r)), rs, voff, soff0 + r * pitchB, AUX);
 }
 
 // The K (or fewer) steps of an epoch for wave WV of the block: the step loop holds no load, no wait for memory and -- with
@@ -107,18 +113,18 @@ __device__ __forceinline__ void residentSteps(const ResidentArgs& a, ResShared<W
     float* hplane = a.hist + (long long)t0 * a.histPlane;
     // the two faces of vx this wave receives from its neighbours each step travel in loop-carried registers and are put in
     // place at the top of the NEXT step: their LDS reads then complete under the first dozen instructions of the pressure sweep
-    float in0 = vx[0].x, inL = getc(vx[(R - 1) / 2], R - 1);
+    float in0 = rowGet(vx, 0), inL = rowGet(vx, R - 1);
 #pragma unroll 1
     for (int s = 0; s < nsteps; ++s) {
-        vx[0].x = in0;
-        setc(vx[(R - 1) / 2], R - 1, inL);
+        rowSet(vx, 0, in0);
+        rowSet(vx, R - 1, inL);
         // pressure sweep, FDTD.cpp:124-141 (row R-1 holds no live pressure; what is computed there is never read);
         // breadth-first over the pairs, so that consecutive instructions of the lone wave are independent
         {
             v2f dx[NP], dy[NP];
 #pragma unroll
-            for (int i = 0; i < NP; ++i)  // vx of rows r+1
-                dx[i] = (i + 1 < NP) ? __builtin_shufflevector(vx[i], vx[i + 1], 1, 2) : v2f{vx[i].y, 0.f};
+            for (int i = 0; i < NP; ++i)  // vx of rows r+1 (the seam: row NP is pair 0's .y; row 2 NP does not exist)
+                dx[i] = (i + 1 < NP) ? vx[i + 1] : v2f{vx[0].y, 0.f};
 #pragma unroll
             for (int i = 0; i < NP; ++i) dy[i] = v2f{laneNext(vy[i].x) - vy[i].x, laneNext(vy[i].y) - vy[i].y};
 #pragma unroll
@@ -133,22 +139,22 @@ __device__ __forceinline__ void residentSteps(const ResidentArgs& a, ResShared<W
         // vx sweep, FDTD.cpp:143-170 (+ edges :201-223 through the coefficients): own rows only (1 .. R-2); row 0's and
         // row R-1's faces come from the neighbouring waves, and whatever is computed for them here is overwritten
         {
-            const float vx0keep = vx[0].x, vxLkeep = getc(vx[(R - 1) / 2], R - 1);
+            const float vx0keep = rowGet(vx, 0), vxLkeep = rowGet(vx, R - 1);
             v2f d[NP];
 #pragma unroll
-            for (int i = 0; i < NP; ++i)  // pressure of rows r-1
-                d[i] = (i > 0) ? __builtin_shufflevector(pr[i - 1], pr[i], 1, 2) : v2f{pr[0].x, pr[0].x};
+            for (int i = 0; i < NP; ++i)  // pressure of rows r-1 (the seam: row NP-1 is pair NP-1's .x; row -1 does not exist)
+                d[i] = (i > 0) ? pr[i - 1] : v2f{pr[0].x, pr[NP - 1].x};
 #pragma unroll
             for (int i = 0; i < NP; ++i) d[i] = pr[i] - d[i];
 #pragma unroll
             for (int i = 0; i < NP; ++i) d[i] = cx[i] * d[i];
 #pragma unroll
             for (int i = 0; i < NP; ++i) vx[i] = __builtin_elementwise_fma(ax[i], vx[i], -d[i]);
-            vx[0].x = vx0keep;
-            setc(vx[(R - 1) / 2], R - 1, vxLkeep);
+            rowSet(vx, 0, vx0keep);
+            rowSet(vx, R - 1, vxLkeep);
         }
-        sh.xch[s & 1][WV][0][lane] = vx[0].y;                      // vx[1]
-        sh.xch[s & 1][WV][1][lane] = getc(vx[(R - 2) / 2], R - 2);  // vx[R-2]
+        sh.xch[s & 1][WV][0][lane] = rowGet(vx, 1);
+        sh.xch[s & 1][WV][1][lane] = rowGet(vx, R - 2);
         // (LDS only: the history stores stay in flight across the barrier.)  The reads are issued at once and land under
         // the vy sweep, which needs neither
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -182,12 +188,12 @@ __device__ __forceinline__ void residentSteps(const ResidentArgs& a, ResShared<W
                 const float pv = (lane == lc) ? pvCur : 0.f;
 #pragma unroll
                 for (int r = 0; r < R - 1; ++r)
-                    if (r == lr) setc(pr[r / 2], r, getc(pr[r / 2], r) + pv);
+                    if (r == lr) rowSet(pr, r, rowGet(pr, r) + pv);
             }
         }
     }
-    vx[0].x = in0;
-    setc(vx[(R - 1) / 2], R - 1, inL);
+    rowSet(vx, 0, in0);
+    rowSet(vx, R - 1, inL);
 }
 
 template <int K, int RXI, int W, int WV, int NP>
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(64 * W) void pv_resident_kernel(const ResidentArgs 
     const int pitchB = a.pitch * 4;
     const int soff0 = (row0 * a.pitch + col0) * 4;
 
-    // coefficients of this wave's cells (see the header): once per run.  row r of the window lives in pair r / 2, component r % 2
+    // coefficients of this wave's cells (see the header): once per run.  row r of the window: rowGet / rowSet (strided pairing)
     const float C = a.courant;
     v2f pr[NP], vx[NP], vy[NP], cb[NP], ax[NP], cx[NP], ay[NP], cy[NP];
     {
@@ -262,11 +268,11 @@ __global__ __launch_bounds__(64 * W) void pv_resident_kernel(const ResidentArgs 
                 btv = __uint_as_float(c.z);
             }
             const bool air = btv != 0.f, airX = kxv != kxv, airY = kyv != kyv;
-            setc(cb[r / 2], r, air ? C : 0.f);
-            setc(ax[r / 2], r, airX ? 1.f : 0.f);
-            setc(cx[r / 2], r, airX ? C : (air ? -kxv : kxv));
-            setc(ay[r / 2], r, airY ? 1.f : 0.f);
-            setc(cy[r / 2], r, airY ? C : (air ? -kyv : kyv));
+            rowSet(cb, r, air ? C : 0.f);
+            rowSet(ax, r, airX ? 1.f : 0.f);
+            rowSet(cx, r, airX ? C : (air ? -kxv : kxv));
+            rowSet(ay, r, airY ? 1.f : 0.f);
+            rowSet(cy, r, airY ? C : (air ? -kyv : kyv));
         }
     }
 #pragma unroll
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(64 * W) void pv_resident_kernel(const ResidentArgs 
     bool lAir = false;
 #pragma unroll
     for (int r = 0; r < R - 1; ++r)
-        if (r == lr) lAir = getc(cb[r / 2], r) != 0.f;
+        if (r == lr) lAir = rowGet(cb, r) != 0.f;
     const int lrT = dyn.lrow - (row0 - ws);
     const bool tileHasL = lrT >= 0 && lrT < Gm::L && lc >= 0 && lc < 64;
     const int hti = ti - dyn.histTileX0, htj = tj - dyn.histTileY0;  // (the window is the whole grid: host precondition)
@@ -338,9 +344,9 @@ __global__ __launch_bounds__(64 * W) void pv_resident_kernel(const ResidentArgs 
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int so = soff0 + r * pitchB;
-                setc(pr[r / 2], r, __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rPr, voff, so, kSc1)));
-                setc(vx[r / 2], r, __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rVx, voff, so, kSc1)));
-                setc(vy[r / 2], r, __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rVy, voff, so, kSc1)));
+                rowSet(pr, r, __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rPr, voff, so, kSc1)));
+                rowSet(vx, r, __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rVx, voff, so, kSc1)));
+                rowSet(vy, r, __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rVy, voff, so, kSc1)));
             }
         }
         // tileFirst[tile] = first step block in which the tile (halo included) was non-zero; the analysis reads its
