@@ -1,0 +1,76 @@
+// pv_analysis.h -- device helpers shared by the analysis kernels of pv_kernels.hip and pv_rt60.hip (moved here unchanged)
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+
+#include "pv_device.h"
+#include "pv_prims.h"
+
+namespace pva {
+
+struct CellHistory {
+    const float* h;     // this cell, step 0
+    long long plane;
+    __device__ __forceinline__ float at(int t) const { return h[(long long)t * plane]; }
+};
+
+// FreeGrid::GetEFreePerR, FreeGrid.cpp:41-59
+__device__ __forceinline__ float efreePerR(float efree, float dx, int lX, int lY, int eX, int eY) {
+    const float lx = (float)lX * dx, ly = (float)lY * dx;
+    const float ex = (float)eX * dx, ey = (float)eY * dx;
+    const float r = sqrtf((ex - lx) * (ex - lx) + (ey - ly) * (ey - ly));
+    if (r == 0.f) return efree;
+    return efree / r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// RT60: backward Schroeder integration + linear regression (Analyzer.cpp:282-327): forms with the same bits
+// ---------------------------------------------------------------------------------------------------------------
+// All forms keep the three running sums (energy decay, sum y x, sum y) strictly sequential in the reference's order; they
+// differ in how many LANES share a cell (pv_rt60.hip).  Which one runs is decided on the device from the number of cells
+// of the window's ever-non-zero tiles (an upper bound of the reached cells, counted by block 0 of the far-cells pass):
+// few cells -> sixteen lanes per cell (parallelism), more -> four (fewer instructions per sample).
+constexpr int kRt60WaveMaxCells = 65536;  // below this a window counts as "a room" (pv_encode_kernel's pre-scan for an audible sample)
+__device__ __forceinline__ int rt60LanesPerCell(const AnalyzeArgs& a, int activeCells) {
+    if (a.rt60Lanes) return a.rt60Lanes;  // (PVA_OPT_RT60_LANES: validation / measurement)
+    return activeCells <= 8192 ? 16 : 4;  // (measured on MI355X, profiles/r04_rt60.txt: 70^2 0.093 / 0.098 ms, 127^2 0.156 / 0.148 ms)
+}
+
+struct Rt60Cell {
+    int s;              // result index, < 0: nothing to do
+    CellHistory hc;
+    int startingPoint;  // onset + N_dry + 1
+};
+
+// the part shared by both forms: which cell, its history, its onset (read back from the delay map)
+__device__ __forceinline__ Rt60Cell rt60Cell(const AnalyzeArgs& a, const DynParams& dyn, int X, int Y) {
+    Rt60Cell c{-1, {nullptr, 0}, 0};
+    if (X >= a.gx || Y >= a.gy) return c;
+    const int s = X * a.gy + Y;
+    const float d = a.delay[s];
+    if (d == FLT_MAX) return c;
+    c.s = s;
+    c.hc = CellHistory{a.hist + histOffset(X + a.G - dyn.histRow0, Y + a.G - dyn.histCol0, a.rxi, a.wi, dyn.histTilesY),
+                       a.histPlane};
+    c.startingPoint = (int)d + a.nDry + 1;
+    return c;
+}
+
+__device__ __forceinline__ float rt60FromSums(const AnalyzeArgs& a, int startingPoint, float xysum, float ysum) {
+    const int endPoint = a.T - a.nCut;
+    const int regressN = endPoint - startingPoint;
+    const float rn = (float)regressN;
+    const float xmean = (rn - 1.0f) * 0.5f;
+    const float xsum = rn * xmean;
+    const float denominator = (1.0f / 12.0f) * rn * (rn * rn - 1.0f);
+    const float ymean = ysum / rn;
+    const float numerator = xysum - ymean * xsum - xmean * ysum + rn * xmean * ymean;
+    const float slopePerSample = numerator / denominator;
+    const float slopePerSec = slopePerSample * (float)a.fs;
+    return -60.f / slopePerSec;
+}
+
+
+}  // namespace pva

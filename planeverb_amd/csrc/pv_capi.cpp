@@ -457,6 +457,7 @@ int PvAmdSetOption(PvAmdSolver* h, int key, long long value) {
         case PVA_OPT_AUX_STREAMS: h->opt.auxStreams = (int)std::max<long long>(0, std::min<long long>(value, 8)); break;
         case PVA_OPT_PATCH_STRIP: h->opt.patchStrip = (int)value; break;
         case PVA_OPT_RESIDENT_KERNEL: h->opt.resident = (int)value; break;
+        case PVA_OPT_RT60_LANES: h->opt.rt60Lanes = (int)value; break;
         default: g_lastError = "unknown option"; return -1;
     }
     return 0;

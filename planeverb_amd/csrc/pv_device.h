@@ -256,6 +256,7 @@ struct AnalyzeArgs {
     int* activeCount;      // cells of this run with an onset (reset by pv_far_cells_kernel, counted by pv_encode_kernel)
     int* dirScratch;       // winRows x winCols ints for the listener-direction pointer jumping
     int dirJump;           // listener direction by pointer jumping (wide windows) instead of the plain walk
+    int rt60Lanes;         // 0 = by the number of reachable cells (rt60LanesPerCell); 16 / 4 / 1 = that form of the decay-time pass
     int T;
     int nDir, nDry, nWet, nCut;
     unsigned fs;

@@ -32,6 +32,7 @@
 #include "pv_launch.h"
 #include "pv_libm.h"
 #include "pv_prims.h"
+#include "pv_analysis.h"
 
 namespace pva {
 
@@ -2133,21 +2134,6 @@ void launchSmallGrid(const SmallArgs& a, hipStream_t stream) {
 
 // pvLog10f / pvPowf: glibc-2.35-exact log10f and powf, see pv_libm.h
 
-struct CellHistory {
-    const float* h;     // this cell, step 0
-    long long plane;
-    __device__ __forceinline__ float at(int t) const { return h[(long long)t * plane]; }
-};
-
-// FreeGrid::GetEFreePerR, FreeGrid.cpp:41-59
-__device__ __forceinline__ float efreePerR(float efree, float dx, int lX, int lY, int eX, int eY) {
-    const float lx = (float)lX * dx, ly = (float)lY * dx;
-    const float ex = (float)eX * dx, ey = (float)eY * dx;
-    const float r = sqrtf((ex - lx) * (ex - lx) + (ey - ly) * (ey - ly));
-    if (r == 0.f) return efree;
-    return efree / r;
-}
-
 // CH samples (i0, i0-1, ..., i0-CH+1; those below startingPoint are skipped) of the backward Schroeder integration
 // + regression sums, Analyzer.cpp:300-318.  Three passes over the chunk: the running energy (sequential, the
 // reference's order), 10*log10f of each partial sum (independent of each other: branch-free, so the compiler
@@ -2170,86 +2156,6 @@ __device__ __forceinline__ void rt60Chunk(const float (&pc)[CH], const int i0, c
         xysum = v ? xysum + y[k] * (float)(i0 - k - startingPoint) : xysum;
         ysum = v ? ysum + y[k] : ysum;
     }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// RT60: backward Schroeder integration + linear regression (Analyzer.cpp:282-327), two forms with the same bits
-// ---------------------------------------------------------------------------------------------------------------
-// Windows whose ever-non-zero tiles hold fewer cells than this (closed rooms: a few thousand reachable cells; the
-// count is made by block 0 of pv_far_cells_kernel) take the wave form; an open field's 760 000 take the cell form
-constexpr int kRt60WaveMaxCells = 65536;
-
-struct Rt60Cell {
-    int s;              // result index, < 0: nothing to do
-    CellHistory hc;
-    int startingPoint;  // onset + N_dry + 1
-};
-
-// the part shared by both forms: which cell, its history, its onset (read back from the delay map)
-__device__ __forceinline__ Rt60Cell rt60Cell(const AnalyzeArgs& a, const DynParams& dyn, int X, int Y) {
-    Rt60Cell c{-1, {nullptr, 0}, 0};
-    if (X >= a.gx || Y >= a.gy) return c;
-    const int s = X * a.gy + Y;
-    const float d = a.delay[s];
-    if (d == FLT_MAX) return c;
-    c.s = s;
-    c.hc = CellHistory{a.hist + histOffset(X + a.G - dyn.histRow0, Y + a.G - dyn.histCol0, a.rxi, a.wi, dyn.histTilesY),
-                       a.histPlane};
-    c.startingPoint = (int)d + a.nDry + 1;
-    return c;
-}
-
-__device__ __forceinline__ float rt60FromSums(const AnalyzeArgs& a, int startingPoint, float xysum, float ysum) {
-    const int endPoint = a.T - a.nCut;
-    const int regressN = endPoint - startingPoint;
-    const float rn = (float)regressN;
-    const float xmean = (rn - 1.0f) * 0.5f;
-    const float xsum = rn * xmean;
-    const float denominator = (1.0f / 12.0f) * rn * (rn * rn - 1.0f);
-    const float ymean = ysum / rn;
-    const float numerator = xysum - ymean * xsum - xmean * ysum + rn * xmean * ymean;
-    const float slopePerSample = numerator / denominator;
-    const float slopePerSec = slopePerSample * (float)a.fs;
-    return -60.f / slopePerSec;
-}
-
-// Cell form of the wet gain (Analyzer.cpp:235-247) and the decay time: one thread per result cell, the history walked
-// in chunks of CH samples (loads issued together, sums in the reference's order).
-__device__ __forceinline__ void cellWetAndRt60(const AnalyzeArgs& a, const CellHistory& hc, const int startingPoint,
-                                               float* wet, float* rt60) {
-    constexpr int CH = 8;
-    const int T = a.T;
-    const int endPoint = T - a.nCut;
-    float wetEnergy = 0.f;
-    {
-        int end = startingPoint + a.nWet;
-        if (T < end) end = T;
-        for (int j0 = startingPoint; j0 < end; j0 += CH) {
-            float pc[CH];
-#pragma unroll
-            for (int k = 0; k < CH; ++k) pc[k] = hc.at(min(j0 + k, T - 1));
-#pragma unroll
-            for (int k = 0; k < CH; ++k)
-                if (j0 + k < end) wetEnergy += pc[k] * pc[k];
-        }
-    }
-    *wet = sqrtf(wetEnergy / a.efree);
-    float edc = 0.f, xysum = 0.f, ysum = 0.f;
-    for (int i0 = T - 1; i0 >= endPoint && i0 >= 0; i0 -= CH) {
-        float pc[CH];
-#pragma unroll
-        for (int k = 0; k < CH; ++k) pc[k] = hc.at(max(i0 - k, 0));
-#pragma unroll
-        for (int k = 0; k < CH; ++k)
-            if (i0 - k >= endPoint && i0 - k >= 0) edc += pc[k] * pc[k];
-    }
-    for (int i0 = endPoint - 1; i0 >= startingPoint; i0 -= CH) {
-        float pc[CH];
-#pragma unroll
-        for (int k = 0; k < CH; ++k) pc[k] = hc.at(max(i0 - k, 0));
-        rt60Chunk<CH>(pc, i0, startingPoint, edc, xysum, ysum);
-    }
-    *rt60 = rt60FromSums(a, startingPoint, xysum, ysum);
 }
 
 // One thread per result cell (X, Y); lanes along Y so every history read is a coalesced row segment of one
@@ -2406,14 +2312,7 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
     const float lowpass = -147.f + (18390.f) / (1.f + pvPowf(rr / 12.f, 0.8f));
 
 
-    // wet gain and decay time: here, one thread per cell, when the window is full of reachable cells (open field:
-    // the kernel streams the whole history once, at HBM speed); by pv_rt60_wave_kernel in a room
-    if (!roomRegime) {
-        float wet, rt60;
-        cellWetAndRt60(a, hc, directEnd + 1, &wet, &rt60);
-        a.out[a.resN + s] = wet;
-        a.out[2 * a.resN + s] = rt60;
-    }
+    // (wet gain and decay time: pv_rt60_wave_kernel / pv_rt60_blocked_kernel, by the number of reachable cells)
     a.out[s] = occ;
     a.out[3 * a.resN + s] = lowpass;
     a.out[6 * a.resN + s] = sdx;
@@ -2448,7 +2347,7 @@ __device__ __forceinline__ void rowChains(float (&acc)[NCH], const float (&add)[
 }
 
 __global__ __launch_bounds__(256) void pv_rt60_wave_kernel(const AnalyzeArgs a) {
-    if (*a.activeCount >= kRt60WaveMaxCells) return;
+    if (rt60LanesPerCell(a, *a.activeCount) != 16) return;  // (more cells: the blocked forms of pv_rt60.hip)
     const DynParams dyn = *a.dyn;
     // 16 cells per 256-thread block along the window's columns, one window row per blockIdx.y
     const int sub = threadIdx.x & 15;
@@ -2916,6 +2815,7 @@ void launchAnalysisCells(const AnalyzeArgs& a, hipStream_t stream) {
     const dim3 grid = analysisWindowGrid(a);
     hipLaunchKernelGGL(pv_encode_kernel, grid, dim3(256), 0, stream, a);
     hipLaunchKernelGGL(pv_rt60_wave_kernel, dim3((a.winCols + 15) / 16, a.winRows), dim3(256), 0, stream, a);
+    launchRt60Blocked(a, stream);
 }
 
 void launchAnalysisDirection(const AnalyzeArgs& a, hipStream_t stream) {
@@ -2941,8 +2841,10 @@ void launchAnalysis(const AnalyzeArgs& a, hipStream_t stream) {
     }
     const dim3 grid = analysisWindowGrid(a);
     hipLaunchKernelGGL(pv_encode_kernel, grid, dim3(256), 0, stream, a);
-    // wet gain + decay time of a room's cells (an open field's were done inside pv_encode_kernel: its blocks leave at once)
+    // wet gain + decay time: sixteen, four or one lane per cell by the number of reachable cells, decided on the device
+    // (the launches of the other forms leave at once)
     hipLaunchKernelGGL(pv_rt60_wave_kernel, dim3((a.winCols + 15) / 16, a.winRows), dim3(256), 0, stream, a);
+    launchRt60Blocked(a, stream);
     // listener direction: the plain walk where walks are short (small windows: rooms, the sandbox's grids), pointer
     // jumping where a window is wide enough for hundreds of steps (a dozen tiny launches, path-length independent)
     if (a.dirJump)

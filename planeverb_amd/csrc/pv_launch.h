@@ -66,6 +66,8 @@ void launchAnalysis(const AnalyzeArgs& a, hipStream_t stream);
 void launchFarCells(const AnalyzeArgs& a, hipStream_t stream);
 void launchAnalysisCells(const AnalyzeArgs& a, hipStream_t stream);
 void launchAnalysisDirection(const AnalyzeArgs& a, hipStream_t stream);
+// wet gain + decay time, blocked forms (pv_rt60.hip: four lanes / one lane per cell; each launch checks on the device whether it is the one)
+void launchRt60Blocked(const AnalyzeArgs& a, hipStream_t stream);
 // slab halos: src[i] -> dst[i] for up to six blocks of n floats (n % 4 == 0, 16-byte aligned); dst[i] = NULL skips a block
 void launchHaloPush(const float* const src[6], float* const dst[6], long long n, hipStream_t stream);
 void launchHistRow(const AnalyzeArgs& a, int X, float* outTxPitch, hipStream_t stream);

@@ -86,16 +86,27 @@ PV_HD inline float pvLog10f(float x) {
 // block and the compiler interleaves their dependent chains and table reads.  With one thread per cell and fewer
 // waves than SIMDs (the live module's grids) the loop is bound by exactly that latency: ~1800 cycles per sample with
 // the branching form.  Bit-identical to pvLog10f for every x >= +0, inf and NaN included (tools/libm_check.cpp).
-PV_HD inline float pvLog10fNonNeg(float x) {
-    constexpr double T[16][2] = {
-        {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2},
-        {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2},  {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3},
-        {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3},
-        {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4},
-        {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5}, {0x1p+0, 0x0p+0},
-        {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},
-        {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3},
-        {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},  {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
+// (the table fetch is a functor: the RT60 kernels of pv_rt60.hip keep the 16 entries in LDS -- a per-lane index into a
+// constant array is a global load whose latency sits at the head of every evaluation's dependent chain -- and the host
+// check of tools/libm_check.cpp runs the very same arithmetic through pvLog10fNonNeg below)
+struct PvLogTabConst {
+    PV_HD void operator()(int i, double* invc, double* logc) const {
+        constexpr double T[16][2] = {
+            {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2},
+            {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2},  {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3},
+            {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3},
+            {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4},
+            {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5}, {0x1p+0, 0x0p+0},
+            {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},
+            {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3},
+            {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},  {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
+        *invc = T[i][0];
+        *logc = T[i][1];
+    }
+};
+
+template <class TabF>
+PV_HD inline float pvLog10fNonNegT(float x, const TabF& tab) {
     const float two25 = 3.3554432000e+07f, ivln10 = 4.3429449201e-01f, log10_2hi = 3.0102920532e-01f,
                 log10_2lo = 7.9034151668e-07f;
     const int hx0 = (int)pvBitsF(x);
@@ -114,7 +125,8 @@ PV_HD inline float pvLog10fNonNeg(float x) {
     const int i = (int)((tmp >> 19) & 15u);
     const int kk = (int)tmp >> 23;
     const uint32_t iz = ix - (tmp & (0x1ffu << 23));
-    const double invc = T[i][0], logc = T[i][1];
+    double invc, logc;
+    tab(i, &invc, &logc);
     const double z = (double)pvFloatBits(iz);
     const double r = z * invc - 1.0;
     const double y0 = logc + (double)kk * 0x1.62e42fefa39efp-1;
@@ -127,6 +139,8 @@ PV_HD inline float pvLog10fNonNeg(float x) {
     const float res = zf + yk * log10_2hi;
     return zero ? -two25 / 0.f : infnan ? x + x : res;
 }
+
+PV_HD inline float pvLog10fNonNeg(float x) { return pvLog10fNonNegT(x, PvLogTabConst{}); }
 
 // powf for x >= 0 (zero, subnormal, inf and NaN included) and a positive finite y with |y * log2(x)| < 126 -- the
 // analysis calls it with y = 0.8f, for which the overflow / underflow branches of glibc's powf cannot be taken.

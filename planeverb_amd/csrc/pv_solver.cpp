@@ -1071,6 +1071,7 @@ AnalyzeArgs Solver::analyzeArgs(float lx, float lz) const {
     // so does the dense-history (validation) mode.
     const bool smallWindow = a.winRows <= 256 && a.winCols <= 256;
     a.dirJump = (!opt_.denseHistory && !(smallWindow && geo_.ntx * geo_.nty > 4096)) ? 1 : 0;
+    a.rt60Lanes = (opt_.rt60Lanes == 16 || opt_.rt60Lanes == 4) ? opt_.rt60Lanes : 0;
     a.T = T_;
     a.nDir = g_.nDir;
     a.nDry = g_.nDry;
