@@ -172,6 +172,20 @@ __device__ __forceinline__ void loadFaceCoefs(const StepArgs& a, const int lane,
 }
 
 
+// The pulse samples of a launch: lane s holds pulse[t0 + s] (ONE load, issued with the tile loads); step s takes its sample
+// with v_readlane.  A load inside the step loop put an s_waitcnt vmcnt(0) behind it, i.e. the wave that holds the listener
+// waited for ITS OWN history stores to drain on every step (~0.5 us each) -- and a launch-bound grid's launch lasts as long
+// as its slowest tile (found with the resident kernel's phase stamps, round 4).  Used by the launch-bound grids' tile only
+// (12 steps x 12 rows: the presets' replayed graph 10 % faster at 70^2, 5 % at 191^2); in the other instantiations the
+// change moved the air arm's code (512^2 with four runs in flight 4 % slower) and is not what bounds them.
+constexpr bool pulseLanesConfig(int K, int RXI) { return K == 12 && RXI == 12; }
+__device__ __forceinline__ float loadPulseLanes(const StepArgs& a, const int lane) {
+    return a.pulse[a.t0 + min(lane, a.nsteps - 1)];
+}
+__device__ __forceinline__ float pulseOfStep(const float pvec, const int s) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pvec), s));
+}
+
 // Streaming-analysis mode: a tile's pressure history is only consumed while one of its cells -- or a cell of the
 // tile below / to the right, whose velocity reconstruction reads this tile's last row / column -- still has an open
 // forward-analysis window, or while it holds a registered emitter.  Once all of that is closed (N_dry samples after
@@ -892,6 +906,8 @@ __device__ __forceinline__ void stepTileGeneral4Scalar(const StepArgs& a, const 
     const int lr = dyn.lrow - row0;
     const int lc = dyn.lcol - col0;
     const bool hasL = a.withPulse && lr >= 0 && lr <= R - 2 && lc >= 0 && lc < 64;
+    float pvec = 0.f;
+    if constexpr (pulseLanesConfig(K, RXI)) pvec = hasL ? loadPulseLanes(a, lane) : 0.f;
     const int lrT = dyn.lrow - (row0 - ws);  // listener row in loaded-tile rows: is it anywhere in the block?
     const bool tileHasL = a.withPulse && lrT >= 0 && lrT < Gm::L && lc >= 0 && lc < 64;
     // general tiles are recorded on every step
@@ -962,7 +978,11 @@ __device__ __forceinline__ void stepTileGeneral4Scalar(const StepArgs& a, const 
         hplane += a.histPlane;
 
         if (hasL) {  // soft source: p[listener] += pulse[t], FDTD.cpp:234
-            const float pv = (lane == lc) ? a.pulse[a.t0 + s] : 0.f;
+            float pv;
+            if constexpr (pulseLanesConfig(K, RXI))
+                pv = (lane == lc) ? pulseOfStep(pvec, s) : 0.f;
+            else
+                pv = (lane == lc) ? a.pulse[a.t0 + s] : 0.f;
 #pragma unroll
             for (int r = 0; r < R - 1; ++r) pr[r] += (r == lr) ? pv : 0.f;
         }
@@ -1069,6 +1089,8 @@ __device__ __forceinline__ void stepTileGeneral4Packed(const StepArgs& a, const 
     const int lr = dyn.lrow - row0;
     const int lc = dyn.lcol - col0;
     const bool hasL = a.withPulse && lr >= 0 && lr <= R - 2 && lc >= 0 && lc < 64;
+    float pvec = 0.f;
+    if constexpr (pulseLanesConfig(K, RXI)) pvec = hasL ? loadPulseLanes(a, lane) : 0.f;
     const int lrT = dyn.lrow - (row0 - ws);  // listener row in loaded-tile rows: is it anywhere in the block?
     const bool tileHasL = a.withPulse && lrT >= 0 && lrT < Gm::L && lc >= 0 && lc < 64;
     // general tiles are recorded on every step
@@ -1150,7 +1172,11 @@ __device__ __forceinline__ void stepTileGeneral4Packed(const StepArgs& a, const 
         hplane += a.histPlane;
 
         if (hasL) {  // soft source: p[listener] += pulse[t], FDTD.cpp:234
-            const float pv = (lane == lc) ? a.pulse[a.t0 + s] : 0.f;
+            float pv;
+            if constexpr (pulseLanesConfig(K, RXI))
+                pv = (lane == lc) ? pulseOfStep(pvec, s) : 0.f;
+            else
+                pv = (lane == lc) ? a.pulse[a.t0 + s] : 0.f;
 #pragma unroll
             for (int r = 0; r < R - 1; ++r) setc(pr[r / 2], r, getc(pr[r / 2], r) + ((r == lr) ? pv : 0.f));
         }
