@@ -7,7 +7,12 @@ per GPU; listener positions cycle through the eight of SURVEY.md 8d.  A "step" i
 field reset + T fused leapfrog steps incl. pressure-history record + per-cell IR analysis (what one iteration of the
 reference's background loop does, PvContext.cpp:80-83).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid 4096] [--inflight B] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--repeats R] [--grid 4096] [--inflight B] [--no-cpu-baseline]
+
+The block of K steps -- barrier + device sync on both sides, max over ranks -- is timed R times back to back (default 5) in
+one invocation; `ms_per_step` and `value` are the MEDIAN block, `spread` holds every block, min / max and their relative
+spread: one 0.07 s block cannot tell a 3 % change from the box's noise.  `device` says what the line was measured on
+(name, CUs, partition modes, shader clock sampled beside the in-flight warm-up runs and right after the timed blocks).
 
 Runs in flight: independent runs share nothing, so a GPU can work on B of them at once (B solver instances, each with
 its own planes and HIP stream; default B = 2).  One launch of the step kernel fills the chip for ~130 us and then
@@ -183,6 +188,29 @@ class GpuHooks:
     def device_sync(self):
         self.torch.cuda.synchronize()
 
+    def clock_probe(self):
+        from planeverb_amd import api
+        return api.clock_probe(self.local_rank)[0]
+
+    def device_record(self):
+        p = self.torch.cuda.get_device_properties(self.local_rank)
+        rec = {"name": p.name, "arch": getattr(p, "gcnArchName", None), "compute_units": p.multi_processor_count,
+               "hbm_bytes": int(p.total_memory), "max_clock_mhz": getattr(p, "clock_rate", 0) / 1e3 or None,
+               "torch_hip": self.torch.version.hip}
+
+        def sysfs(name):  # amdgpu exposes the partition modes per card
+            import glob
+            vals = []
+            for f in sorted(glob.glob("/sys/class/drm/card*/device/" + name)):
+                try:
+                    vals.append(open(f).read().strip())
+                except Exception:
+                    pass
+            return vals[self.local_rank] if len(vals) > self.local_rank else (vals[0] if vals else None)
+        rec["compute_partition"] = sysfs("current_compute_partition")
+        rec["memory_partition"] = sysfs("current_memory_partition")
+        return rec
+
     def barrier(self, dist, backend):
         if backend == "nccl":
             dist.barrier(device_ids=[self.local_rank])
@@ -195,6 +223,8 @@ def main(argv=None, hooks=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the block of --steps steps is timed this many times back to back; value = the median block")
     ap.add_argument("--grid", type=int, default=4096)
     ap.add_argument("--scene", default="HugeRoom.pv", help="a .pv file under tests/scenes, or 'none' (empty grid)")
     ap.add_argument("--open-field", action="store_true",
@@ -308,7 +338,8 @@ def main(argv=None, hooks=None):
 
     # warm-up: the first round one run at a time, which also gives the step kernel's duration with a single run in
     # flight; further rounds in flight together like the timed steps
-    single_loop_ms = []
+    single_loop_ms, clock_loaded = [], []
+    t_setup0 = time.perf_counter()
     for w in range(args.warmup):
         if w == 0:
             for b, sv in enumerate(solvers):
@@ -317,12 +348,16 @@ def main(argv=None, hooks=None):
         else:
             for g in range(G):
                 start_group(w, g)
+            if hasattr(hooks, "clock_probe"):
+                clock_loaded.append(hooks.clock_probe())  # (a stream of its own: beside the runs in flight)
             for sv in solvers:
                 sv.sync()
     # The one collective of the data path: the C++ side's own RCCL communicator (PvAmdComm: ncclCommInitRank /
     # ncclAllGather inside libplaneverb_amd.so; torch.distributed only carries the 128-byte id to the ranks).  Should
     # RCCL not bind there, torch.distributed's all_gather does the same job and the JSON line says so.
     comm, gather_how = None, "single process: no collective"
+    warmup_s = time.perf_counter() - t_setup0
+    t_comm0 = time.perf_counter()
     if use_dist and os.environ.get("PV_BENCH_GATHER") == "torch":
         gather_how = "torch.distributed.all_gather_into_tensor (PV_BENCH_GATHER=torch)"
         pvd.gather_outputs({run_id(0, b): np.zeros((2, 8), np.float32) for b in range(B)}, B * world, dist, dev)
@@ -344,9 +379,10 @@ def main(argv=None, hooks=None):
             pvd.gather_outputs_native(warm, B * world, comm, n_em=2)
         else:
             pvd.gather_outputs(warm, B * world, dist, dev)
+    comm_init_s = time.perf_counter() - t_comm0  # communicator + first (channel set-up) gather
     n_runs = args.steps * B * world
     local = {}
-    fdtd_ms, ana_ms, air_ms, gen_ms, loop_ms = [], [], [], [], []
+    fdtd_ms, ana_ms, air_ms, gen_ms, loop_ms, reached = [], [], [], [], [], []
     pending = [None] * B
 
     def collect(b):  # wait for solver b's run, fetch its per-emitter outputs and timings
@@ -359,37 +395,62 @@ def main(argv=None, hooks=None):
         air_ms.append(t.airKernelMs)
         gen_ms.append(t.generalKernelMs)
         loop_ms.append(t.stepLoopMs)
+        reached.append(getattr(t, "reachedCells", 0))
         pending[b] = None
 
-    sync()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        for g in range(G):
-            for b in range(g * NB, (g + 1) * NB):
-                if pending[b] is not None:
-                    collect(b)  # the other groups' runs keep the GPU busy meanwhile
-            start_group(k, g)
-            for b in range(g * NB, (g + 1) * NB):
-                pending[b] = k
-    for b in range(B):
-        if pending[b] is not None:
-            collect(b)
-    if comm is not None:
-        gathered = pvd.gather_outputs_native(local, n_runs, comm, n_em=2)  # the one RCCL gather, in C++
-    else:
-        gathered = pvd.gather_outputs(local, n_runs, dist if use_dist else None, dev)
-    sync()
-    elapsed = time.perf_counter() - t0
+    def timed_block():  # EXACTLY args.steps steps between barrier + device sync, max over ranks
+        local.clear()
+        sync()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            for g in range(G):
+                for b in range(g * NB, (g + 1) * NB):
+                    if pending[b] is not None:
+                        collect(b)  # the other groups' runs keep the GPU busy meanwhile
+                start_group(k, g)
+                for b in range(g * NB, (g + 1) * NB):
+                    pending[b] = k
+        for b in range(B):
+            if pending[b] is not None:
+                collect(b)
+        if comm is not None:
+            got = pvd.gather_outputs_native(local, n_runs, comm, n_em=2)  # the one RCCL gather, in C++
+        else:
+            got = pvd.gather_outputs(local, n_runs, dist if use_dist else None, dev)
+        sync()
+        mine = time.perf_counter() - t0
+        el = mine
+        if use_dist:
+            tt = torch.tensor([mine], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el, mine, got
+
+    blocks, mine_blocks, gathered_all = [], [], []
+    for _ in range(max(1, args.repeats)):
+        el, mine, got = timed_block()
+        blocks.append(el)
+        mine_blocks.append(mine)
+        gathered_all.append(got)
+    clock_after = hooks.clock_probe() if hasattr(hooks, "clock_probe") else None
+    elapsed = float(np.median(blocks))
+    gathered = gathered_all[0]
+    # per-rank record (a first multi-GPU run must be diagnosable from the one line rank 0 prints)
+    rank_rec = {"rank": rank, "local_rank": local_rank, "block_s": [round(x, 6) for x in mine_blocks],
+                "warmup_s": round(warmup_s, 3), "comm_init_and_first_gather_s": round(comm_init_s, 3),
+                "gather": gather_how, "clock_mhz_loaded": clock_loaded, "clock_mhz_after": clock_after}
+    ranks = [rank_rec]
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        ranks = [None] * world
+        dist.all_gather_object(ranks, rank_rec)
 
     if rank == 0:
-        assert gathered.shape == (n_runs, 2, 8)
-        # run k of the gathered array = global run index k (gather_outputs orders by run index) = listener k mod 8
-        verified_runs, verified_how = verify_records(gathered, args.scene, args.open_field, lambda k: k % len(LISTENERS),
-                                                     args.grid)
+        verified_runs, verified_how = 0, None
+        for got in gathered_all:  # every timed block's records
+            assert got.shape == (n_runs, 2, 8)
+            # run k of the gathered array = global run index k (gather_outputs orders by run index) = listener k mod 8
+            v, verified_how = verify_records(got, args.scene, args.open_field, lambda k: k % len(LISTENERS), args.grid)
+            verified_runs = None if v is None else verified_runs + v
         info = s.info
         K = info.stepsPerLaunch
         launches = s.timings().stepLaunches
@@ -422,7 +483,7 @@ def main(argv=None, hooks=None):
         # Counter profile of the dominant kernel (profiles/hbm_traffic.json, written by tools/summarize_profiles.py from
         # rocprofv3 --pmc passes): quoted only if it was collected on THIS device code (kernel_source_hash) and tile
         from planeverb_amd.build import kernel_source_hash
-        traffic, traffic_note, prof, sqprof = None, None, None, None
+        traffic, traffic_note, prof, sqprof, allp = None, None, None, None, None
         pmc = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(pmc):
             try:
@@ -469,9 +530,52 @@ def main(argv=None, hooks=None):
                         "source": "profiles/%s_sq_pmc.md" % sqprof.get("round", "r02")}
         value = world * B * cells * T * args.steps / elapsed
         fd = float(np.mean(fdtd_ms)) * 1e-3
+        ms_blocks = [b / args.steps * 1e3 for b in blocks]
+        spread = {"repeats": len(blocks), "ms_per_step_all": [round(x, 4) for x in ms_blocks],
+                  "ms_per_step_min": min(ms_blocks), "ms_per_step_max": max(ms_blocks),
+                  "ms_per_step_median": float(np.median(ms_blocks)),
+                  "rel_spread": (max(ms_blocks) - min(ms_blocks)) / float(np.median(ms_blocks)),
+                  "value_best": world * B * cells * T * args.steps / min(blocks),
+                  "value_worst": world * B * cells * T * args.steps / max(blocks),
+                  "how": "the block of %d steps timed %d times back to back in this invocation (barrier + device sync "
+                         "around each, max over ranks); value / ms_per_step = the median block" % (args.steps, len(blocks))}
+        device = hooks.device_record() if hasattr(hooks, "device_record") else {}
+        device["effective_clock_ghz"] = (float(np.median(clock_loaded)) / 1e3) if clock_loaded else None
+        device["effective_clock_how"] = ("one wave's timed s_sleep (812 800 shader-clock cycles against the 100 MHz counter, "
+                                         "PvAmdClockProbe) beside the in-flight warm-up runs: median of %d samples; "
+                                         "clock_mhz_after = one more sample right behind the last timed block" % len(clock_loaded))
+        device["clock_mhz_after"] = clock_after
+        # the analysis half of the metric: impulse responses per second, counted on the cells that HAVE one (an onset),
+        # and the bytes their analysis must read at least: every recorded pressure sample of a reached cell once
+        # (4 B x T), + 36 B of results per cell.  The other cells of the map leave the analysis at once.
+        n_reached = float(np.mean(reached)) if reached else 0.0
+        ana_s = float(np.mean(ana_ms)) * 1e-3
+        ana_alg = n_reached * (4.0 * T + 36.0)
+        ana_prof = None
+        try:
+            ana_prof = (allp or {}).get("analysis_%d" % args.grid)
+            if ana_prof is not None and ana_prof.get("kernel_source_hash") != kernel_source_hash():
+                ana_prof = None
+        except Exception:
+            ana_prof = None
+        analysis = {
+            "reached_cells_per_run": n_reached, "cells_per_run": s.gx * s.gy,
+            "reached_ir_per_s": world * B * n_reached * args.steps / elapsed,
+            "analysis_only_reached_ir_per_s": (n_reached / ana_s) if ana_s > 0 else None,
+            "analysis_ms": ana_s * 1e3, "bound": "latency" if n_reached < 65536 else "hbm",
+            "algorithmic_bytes_per_run": ana_alg,
+            "achieved": (ana_alg / ana_s / 1e9) if ana_s > 0 else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": (ana_alg / ana_s / 1e9 / HBM_PEAK_GBS) if ana_s > 0 else None,
+            "traffic": (ana_prof or {}).get("bytes_per_run"),
+            "traffic_source": (ana_prof or {}).get("source"),
+            "note": "kernels: pv_far_frame + pv_encode (onset, dry gain, flux, lowpass) + pv_rt60_wave / pv_rt60_blocked (wet "
+                    "gain, decay time) + listener direction; analysis_ms = HIP events around the chain of one run, beside the "
+                    "other runs in flight.  A closed room in a large grid reaches a few thousand cells: the chain is bound by "
+                    "its dependent launches and memory round trips, not by bytes; profiles/r04_analysis_pmc.md has the "
+                    "all-cells-reached workload (Shoebox 25 m at 512^2, T = 3179)"}
         out = {
             "metric": "grid_cell_updates_per_s", "value": value, "unit": "cell-updates/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "steps": args.steps, "warmup": args.warmup, "repeats": len(blocks), "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s in a %dx%d grid (Mode A: 275 Hz, dx=%.4f m, %.3f m), T=%d; 1 run = reset + T "
                                    "leapfrog steps with pr-history record + per-cell IR analysis for one listener "
@@ -487,9 +591,12 @@ def main(argv=None, hooks=None):
                        "backend": backend if use_dist else None},
             "fdtd_cell_updates_per_s": world * B * cells * T / fd,
             "impulse_responses_per_s": world * B * s.gx * s.gy * args.steps / elapsed,
+            "impulse_responses_per_s_note": "all cells of the map incl. the ones without an onset (early-out); "
+                                            "roofline.analysis.reached_ir_per_s counts the analysed ones",
+            "spread": spread, "device": device, "ranks": ranks,
             "fdtd_ms": fd * 1e3, "analysis_ms": float(np.mean(ana_ms)),
             "hbm_bytes_held": int(info.deviceBytes) * B,
-            "verified_runs": verified_runs, "timed_runs": n_runs, "verified_how": verified_how,
+            "verified_runs": verified_runs, "timed_runs": n_runs * len(blocks), "verified_how": verified_how,
             "roofline": {"bound": "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "basis": "achieved / peak / frac are on SURVEY.md 8d's basis: ALGORITHMIC bytes (24 B per "
@@ -502,7 +609,7 @@ def main(argv=None, hooks=None):
                          "launch_ms": air, "launch_ms_from": how, "launches_per_run": launches,
                          "concurrent_launches": G, "runs_per_launch": NB,
                          "algorithmic_bytes_per_launch": alg_bytes * NB,
-                         "single_run": single,
+                         "single_run": single, "analysis": analysis,
                          "note": "algorithmic = 24 B per cell-step x cells x K fused steps; K-step temporal "
                                  "blocking makes frac > 1 possible (SURVEY.md 8d).  achieved = concurrent_launches x "
                                  "algorithmic_bytes_per_launch / launch_ms: the launches of the runs in flight "

@@ -140,6 +140,8 @@ typedef struct PvAmdTimings {
     int airLaunches, generalLaunches;
     float stepLoopMs;       /* HIP-event time of the back-to-back step launches alone (fdtdMs minus the field reset);
                                0 when the run was replayed from a hipGraph */
+    int reachedCells;       /* cells with an onset in the last run's analysis (Analyzer.cpp:146-165): the impulse responses that
+                               were actually analysed -- the others leave at once */
 } PvAmdTimings;
 
 /* option keys for PvAmdSetOption (must be set before the first run) */
@@ -257,6 +259,10 @@ PVA_EXPORT int PvAmdSync(PvAmdSolver* s);
  * Afterwards every solver holds its own run's results exactly as after PvAmdRun (same bits).  wait = 0 returns after
  * enqueueing; PvAmdSync each solver before reading results. */
 PVA_EXPORT int PvAmdRunBatch(PvAmdSolver* const* solvers, int n, const float* listenersXYZ, int wait);
+/* The shader clock (MHz) the device sustains at this moment: one wave sleeps a known number of shader-clock cycles and times
+ * them against the constant 100 MHz counter, on a stream of its own (so it can run beside solvers at work).  *byMemtimeMHz
+ * (optional) = the same span by s_memtime.  0 on failure.  bench.py's device record. */
+PVA_EXPORT float PvAmdClockProbe(int device, float* byMemtimeMHz);
 PVA_EXPORT int PvAmdGetTimings(PvAmdSolver* s, PvAmdTimings* out);
 
 /* Streaming-analysis (sparse-emitter) mode only -- SURVEY.md 8f N3.  Registers the emitter positions (n x {x,y,z})

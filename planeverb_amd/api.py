@@ -84,7 +84,7 @@ class PvAmdSlabInfo(C.Structure):
 class PvAmdTimings(C.Structure):
     _fields_ = [("fdtdMs", C.c_float), ("analysisMs", C.c_float), ("geometryMs", C.c_float),
                 ("stepKernelMs", C.c_float), ("stepLaunches", C.c_int), ("airKernelMs", C.c_float), ("generalKernelMs", C.c_float), ("airLaunches", C.c_int),
-                ("generalLaunches", C.c_int), ("stepLoopMs", C.c_float)]
+                ("generalLaunches", C.c_int), ("stepLoopMs", C.c_float), ("reachedCells", C.c_int)]
 
 
 # every symbol include/planeverb_amd.h declares: name -> (restype, argtypes)
@@ -151,6 +151,7 @@ SYMBOLS = {
     "PvAmdSync": (C.c_int, [_vp]),
     "PvAmdRunBatch": (C.c_int, [C.POINTER(_vp), C.c_int, _fp, C.c_int]),
     "PvAmdGetTimings": (C.c_int, [_vp, C.POINTER(PvAmdTimings)]),
+    "PvAmdClockProbe": (C.c_float, [C.c_int, _fp]),
     "PvAmdSetEmitters": (C.c_int, [_vp, _fp, C.c_int]),
     "PvAmdGetOutput": (C.c_int, [_vp] + [C.c_float] * 3 + [C.POINTER(PlaneverbOutput)]),
     "PvAmdSetOutputQueries": (C.c_int, [_vp, _fp, C.c_int]),
@@ -364,6 +365,13 @@ def host_cells(size_x, size_y, res, x, z):
     v = [C.c_int() for _ in range(5)]
     _check(lib().PvAmdHostCells(float(size_x), float(size_y), int(res), float(x), float(z), *v))
     return (v[0].value, v[1].value), ((v[2].value, v[3].value) if v[4].value else None)
+
+
+def clock_probe(device=0):
+    """(MHz by a timed s_sleep, MHz by s_memtime) of the device's shader clock at this moment (PvAmdClockProbe)"""
+    m = C.c_float(0.0)
+    v = lib().PvAmdClockProbe(int(device), C.byref(m))
+    return float(v), float(m.value)
 
 
 def device_count():

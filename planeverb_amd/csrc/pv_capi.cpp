@@ -10,6 +10,7 @@
 #ifndef PVA_HOST_TEST  // (tests/host/: HIP-less sanitizer build of the live module against a fake Solver)
 #include "pv_shard.h"
 #include "pv_slabs.h"
+#include "pv_launch.h"
 #include "pv_solver.h"
 #endif
 
@@ -584,6 +585,14 @@ int PvAmdSync(PvAmdSolver* h) {
     return ret(h, h->s->sync());
 }
 
+float PvAmdClockProbe(int device, float* byMemtimeMHz) {
+    try {
+        return clockProbeMHz(device, byMemtimeMHz);
+    } catch (...) {
+        return 0.f;
+    }
+}
+
 int PvAmdGetTimings(PvAmdSolver* h, PvAmdTimings* out) {
     if (!out || !ensure(h, true)) return -1;
     const SolverTimings& t = h->g ? h->g->timings() : h->s->timings();
@@ -597,6 +606,7 @@ int PvAmdGetTimings(PvAmdSolver* h, PvAmdTimings* out) {
     out->airLaunches = t.airLaunches;
     out->generalLaunches = t.generalLaunches;
     out->stepLoopMs = t.stepLoopMs;
+    out->reachedCells = t.reachedCells;
     return 0;
 }
 

@@ -253,7 +253,9 @@ struct AnalyzeArgs {
     int gx, gy;
     int rxi, wi, nty;
     int winRows, winCols;  // extent of the history window in cells: the analysis kernels' launch grid
-    int* activeCount;      // cells of this run with an onset (reset by pv_far_cells_kernel, counted by pv_encode_kernel)
+    int* activeCount;      // [0]: cells of the window's ever-non-zero tiles (an upper bound of the reached cells: chooses the
+                           // decay-time form on the device), [1]: cells with an onset (counted by pv_encode_kernel; both reset by
+                           // the first launch of the analysis)
     int* dirScratch;       // winRows x winCols ints for the listener-direction pointer jumping
     int dirJump;           // listener direction by pointer jumping (wide windows) instead of the plain walk
     int rt60Lanes;         // 0 = by the number of reachable cells (rt60LanesPerCell); 16 / 4 / 1 = that form of the decay-time pass

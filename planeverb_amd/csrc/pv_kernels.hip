@@ -2325,6 +2325,10 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
         return;
     }
     a.delay[s] = (float)onset;
+    {  // reached cells of this run (bench / PvAmdTimings.reachedCells): one atomic per wave
+        const unsigned long long m = __ballot(1);
+        if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(a.activeCount + 1, __popcll(m));
+    }
 
     // obstruction gain + source directivity, Analyzer.cpp:197-220
     const float EfreePr = efreePerR(a.efree, a.dx, a.lcx, a.lcy, X + a.x0, Y);
@@ -2475,7 +2479,10 @@ __device__ __forceinline__ void countActiveCells(const AnalyzeArgs& a) {
         if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *a.activeCount = part[0];
+    if (threadIdx.x == 0) {
+        a.activeCount[0] = part[0];
+        a.activeCount[1] = 0;
+    }
 }
 
 __global__ __launch_bounds__(256) void pv_far_cells_kernel(const AnalyzeArgs a) {

@@ -51,6 +51,8 @@ bool residentConfigOk(int K, int rxi);
 int residentExtraRows(int K, int rxi);   // rows its blocks load beyond rxi + 2K at the bottom
 int residentMaxBlocks(int K, int rxi, int device);
 void launchResident(int K, int rxi, const ResidentArgs& a, hipStream_t stream);
+// shader clock of the moment (pv_probe.hip): MHz by a timed s_sleep, or 0
+float clockProbeMHz(int device, float* byMemtime);
 #ifdef PV_RESIDENT_TRACE
 void residentDumpTrace();  // development builds: the phase stamps of the last launch to stderr
 #endif

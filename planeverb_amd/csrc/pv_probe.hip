@@ -1,0 +1,34 @@
+// pv_probe.hip -- the shader clock the chip sustains right now, for bench.py's device record.
+// One wave sleeps 100 x s_sleep 127 = 812 800 shader-clock cycles and times that with s_memrealtime (constant 100 MHz): the
+// clock of the moment it runs in, whatever else the chip is doing (tools/clock_probe.hip, made callable).  Launched on a
+// stream of its own so that it can sit beside the solvers' launches.
+#include <hip/hip_runtime.h>
+
+#include "pv_launch.h"
+
+namespace pva {
+
+namespace {
+__global__ void pv_clock_probe_kernel(unsigned long long* out) {
+    const unsigned long long c0 = clock64(), s0 = wall_clock64();
+    for (int i = 0; i < 100; ++i) __builtin_amdgcn_s_sleep(127);
+    out[0] = wall_clock64() - s0;  // 10 ns ticks
+    out[1] = clock64() - c0;       // s_memtime ticks over the same span
+}
+}  // namespace
+
+// MHz by the s_sleep method (and by s_memtime in *byMemtime), or 0 on failure
+float clockProbeMHz(int device, float* byMemtime) {
+    if (hipSetDevice(device) != hipSuccess) return 0.f;
+    static thread_local hipStream_t stream = nullptr;
+    static thread_local unsigned long long* host = nullptr;
+    if (!stream && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) return 0.f;
+    if (!host && hipHostMalloc((void**)&host, 16) != hipSuccess) return 0.f;
+    host[0] = host[1] = 0;
+    hipLaunchKernelGGL(pv_clock_probe_kernel, dim3(1), dim3(64), 0, stream, host);
+    if (hipStreamSynchronize(stream) != hipSuccess || host[0] == 0) return 0.f;
+    if (byMemtime) *byMemtime = (float)((double)host[1] / (double)host[0] * 100.0);
+    return (float)(100.0 * 127.0 * 64.0 / (double)host[0] * 100.0);
+}
+
+}  // namespace pva

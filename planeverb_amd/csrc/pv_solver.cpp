@@ -218,7 +218,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     if (!dalloc(&generalCount_, 1, true)) return false;
     if (!dalloc(&dynDev_, 1, true)) return false;
     if (!dalloc(&errFlag_, 1, true)) return false;
-    if (!dalloc(&activeCount_, 1, true)) return false;
+    if (!dalloc(&activeCount_, 2, true)) return false;
     if (!dalloc(&res_, (size_t)std::max(lgx_, 1) * g_.gy * 8, true)) return false;  // zeroed pool: PvContext.cpp:132
     if (!dalloc(&delay_, (size_t)std::max(lgx_, 1) * g_.gy, true)) return false;
     // far cells lazily: whole grids with a windowed history (a slab group / the streaming mode run their own passes)
@@ -1542,11 +1542,13 @@ bool Solver::sync() {
         // long (63 instead of 33 us at 512^2: 2.2e11 instead of 3.7e11 cell-updates/s); with one more stream per solver for it, four
         // pipelined runs of a 512^2 grid lose 11 % (the streams of a process share a handful of hardware queues by creation
         // order).  So: by the kind of run, and through the solver's second stream, which the batched mode does not use.
-        int flag = 0;
+        int flag = 0, counts[2] = {0, 0};
         hipStream_t fs = lastRunBatched_ ? stream2_ : stream_;  // (stream2_ is idle in the batched mode)
         if (!hipOk(hipMemcpyAsync(&flag, errFlag_, sizeof(int), hipMemcpyDeviceToHost, fs), "errFlag copy") ||
+            !hipOk(hipMemcpyAsync(counts, activeCount_, sizeof(counts), hipMemcpyDeviceToHost, fs), "count copy") ||
             !hipOk(hipStreamSynchronize(fs), "errFlag sync"))
             return false;
+        tim_.reachedCells = counts[1];
         if (flag == 3) return fail("resident kernel: a workgroup gave up waiting for its neighbours (run aborted)");
         if (flag) return fail("pressure history window overflow (a tile outside the window became non-zero)");
     }

@@ -65,6 +65,7 @@ struct SolverTimings {
     float airKernelMs = 0, generalKernelMs = 0;  // mean duration per launch (timeKernels only)
     int airLaunches = 0, generalLaunches = 0;
     int stepLaunches = 0;
+    int reachedCells = 0;  // cells with an onset in the last analysed run (whole grids, full-history analysis)
 };
 
 class SlabGroup;

@@ -118,7 +118,19 @@ def test_bench_orchestration_gloo_world2(comm_mode, tmp_path):
     j = json.loads(lines0[0])
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 2 and j["scaling"] == "weak"
     assert j["metric"] == "grid_cell_updates_per_s" and j["higher_is_better"] is True
-    assert j["timed_runs"] == 3 * 2 * 2 and j["verified_runs"] == j["timed_runs"]  # steps x in flight x ranks
+    # steps x in flight x ranks, in every one of the 5 timed blocks (bench.py --repeats); every block's records verified
+    assert j["repeats"] == 5 and j["timed_runs"] == 5 * 3 * 2 * 2 and j["verified_runs"] == j["timed_runs"]
+    sp = j["spread"]
+    assert sp["repeats"] == 5 and len(sp["ms_per_step_all"]) == 5
+    assert sp["ms_per_step_min"] <= sp["ms_per_step_median"] <= sp["ms_per_step_max"]
+    assert j["ms_per_step"] == pytest.approx(sp["ms_per_step_median"], rel=1e-9)
+    # one record per rank: its own block times, warm-up and communicator set-up seconds, how it gathered
+    assert [r["rank"] for r in j["ranks"]] == [0, 1]
+    for r in j["ranks"]:
+        assert len(r["block_s"]) == 5 and all(b > 0 for b in r["block_s"])
+        assert r["warmup_s"] >= 0 and r["comm_init_and_first_gather_s"] >= 0
+        assert "torch.distributed.all_gather_into_tensor" in r["gather"]
+    assert j["roofline"]["analysis"]["cells_per_run"] == 4096 * 4096
     assert "torch.distributed.all_gather_into_tensor" in j["config"]["gather"]
     assert j["config"]["backend"] == "gloo"
     assert j["value"] == pytest.approx(2 * 2 * 4097 * 4097 * 435 * 3 / (j["ms_per_step"] * 3e-3), rel=1e-9)
