@@ -251,6 +251,12 @@ PVA_EXPORT int PvAmdSaveScene(PvAmdSolver* s, const char* pvPath);
 PVA_EXPORT int PvAmdRun(PvAmdSolver* s, float lx, float ly, float lz);
 /* Enqueue the same work on the solver's stream without waiting; PvAmdSync waits. */
 PVA_EXPORT int PvAmdRunAsync(PvAmdSolver* s, float lx, float ly, float lz);
+/* Two solvers taking turns on ONE sequence of iterations (what the live module does for small grids: two iterations in
+ * flight): a run of `s` that continues `prev`'s result map -- the cells in which this run finds no onset keep the values the
+ * run enqueued LAST on `prev` left there (the reference never touches them, Analyzer.cpp:160-165, and its listener-direction
+ * walk reads them), carried over on the device behind prev's analysis.  Same grid, same device; asynchronous like
+ * PvAmdRunAsync (PvAmdSync(s) waits for it; prev's run need not have finished when this is called). */
+PVA_EXPORT int PvAmdRunAsyncAfter(PvAmdSolver* s, PvAmdSolver* prev, float lx, float ly, float lz);
 PVA_EXPORT int PvAmdSync(PvAmdSolver* s);
 /* n (1..8) independent runs -- one per solver, listener i at listenersXYZ[3i..3i+2] -- advanced together by ONE
  * kernel launch per K steps instead of n launches on n streams (the reference would make these n iterations of its

@@ -148,6 +148,7 @@ SYMBOLS = {
     "PvAmdSaveScene": (C.c_int, [_vp, C.c_char_p]),
     "PvAmdRun": (C.c_int, [_vp] + [C.c_float] * 3),
     "PvAmdRunAsync": (C.c_int, [_vp] + [C.c_float] * 3),
+    "PvAmdRunAsyncAfter": (C.c_int, [_vp, _vp] + [C.c_float] * 3),
     "PvAmdSync": (C.c_int, [_vp]),
     "PvAmdRunBatch": (C.c_int, [C.POINTER(_vp), C.c_int, _fp, C.c_int]),
     "PvAmdGetTimings": (C.c_int, [_vp, C.POINTER(PvAmdTimings)]),
@@ -673,6 +674,10 @@ class Solver:
 
     def run_async(self, listener):
         _check(lib().PvAmdRunAsync(self._h, *[float(v) for v in listener]))
+
+    def run_async_after(self, prev, listener):
+        """a run that continues `prev`'s result map (PvAmdRunAsyncAfter: two solvers taking turns on one sequence of iterations)"""
+        _check(lib().PvAmdRunAsyncAfter(self._h, prev._h, *[float(v) for v in listener]))
 
     def sync(self):
         _check(lib().PvAmdSync(self._h))

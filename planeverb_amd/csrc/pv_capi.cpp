@@ -564,6 +564,15 @@ int PvAmdRunAsync(PvAmdSolver* h, float lx, float ly, float lz) {
     return ret(h, h->s->run(lx, ly, lz, false));
 }
 
+int PvAmdRunAsyncAfter(PvAmdSolver* h, PvAmdSolver* prev, float lx, float ly, float lz) {
+    if (!wholeGrid(h) || !ensure(h) || !prev || !wholeGrid(prev) || !ensure(prev)) return -1;
+    if (prev->s->spec().gx != h->s->spec().gx || prev->s->spec().gy != h->s->spec().gy || prev->s->device() != h->s->device()) {
+        g_lastError = "PvAmdRunAsyncAfter: the two solvers must have the same grid and device";
+        return -1;
+    }
+    return ret(h, h->s->run(lx, ly, lz, false, prev->s));
+}
+
 int PvAmdRunBatch(PvAmdSolver* const* hs, int n, const float* listenersXYZ, int wait) {
     if (!hs || !listenersXYZ || n < 1 || n > kBatchMax) {
         g_lastError = "PvAmdRunBatch: 1..8 solvers and their listener positions";

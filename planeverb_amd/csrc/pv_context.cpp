@@ -99,6 +99,18 @@ bool Context::init(const LiveConfig& cfg, std::string* err) {
         return false;
     }
     c->streaming_ = c->solver_->options().streaming;
+    c->lastSolver_ = c->solver_;
+    // Two iterations in flight where an iteration leaves most of the chip idle: the grids the resident kernel serves (the
+    // reference's presets).  PLANEVERB_AMD_LIVE_PIPELINE=1 / 2 forces one / two.
+    int pipeline = (!c->streaming_ && c->solver_->residentKernel()) ? 2 : 1;
+    if (const char* e = std::getenv("PLANEVERB_AMD_LIVE_PIPELINE")) pipeline = std::atoi(e) >= 2 && !c->streaming_ ? 2 : 1;
+    if (pipeline == 2) {
+        c->solver2_ = Solver::create(spec, device, opt, err);
+        if (!c->solver2_) {
+            delete c;
+            return false;
+        }
+    }
     if (c->streaming_)
         std::fprintf(stderr, "[planeverb_amd] %d x %d grid, T = %d: sparse-emitter mode (wet gain / RT60 for the cells of the "
                              "emitters registered at the start of an iteration)\n", spec.gx, spec.gy, c->solver_->T());
@@ -112,7 +124,7 @@ bool Context::init(const LiveConfig& cfg, std::string* err) {
         }
     }
     c->running_.store(true);
-    c->worker_ = std::thread(&Context::workerLoop, c);  // PvContext.cpp:160
+    c->worker_ = std::thread(c->solver2_ ? &Context::workerLoopPipelined : &Context::workerLoop, c);  // PvContext.cpp:160
     g_context.store(c, std::memory_order_seq_cst);
     return true;
 }
@@ -125,6 +137,7 @@ void Context::exit() {
 Context::~Context() {
     running_.store(false);  // PvContext.cpp:166-167
     if (worker_.joinable()) worker_.join();
+    delete solver2_;
     delete solver_;
     for (Slot& s : slots_) Solver::hostFree(s.data);
     std::free(base_.load());
@@ -206,6 +219,84 @@ void Context::workerLoop() {
     iterCv_.notify_all();
 }
 
+void Context::workerLoopPipelined() {
+    float lx, lz, ly = ly_.load();
+    unpackXZ(lxz_.load(), &lx, &lz);
+    std::unique_lock<std::mutex> solverLock(solverMutex_);
+    Solver* const sv[2] = {solver_, solver2_};
+    struct Flight {
+        int k, slot;
+        Solver::WindowBlock win;
+    };
+    std::deque<Flight> flights;
+    auto fail = [&](Solver* s) {
+        std::string e = s->lastError();
+        std::fprintf(stderr, "[planeverb_amd] simulation worker stopped: %s\n", e.c_str());
+        {
+            std::lock_guard<std::mutex> lock(errMutex_);
+            workerErr_ = std::move(e);
+        }
+        failed_.store(true, std::memory_order_release);
+        running_.store(false);
+    };
+    // the oldest iteration in flight: wait for its device work and its block's copy, make it visible
+    auto complete = [&]() -> bool {
+        const Flight f = flights.front();
+        flights.pop_front();
+        if (!(sv[f.k]->sync() && sv[f.k]->waitPublish())) {
+            fail(sv[f.k]);
+            return false;
+        }
+        publishSlot(f.slot, f.win);
+        lastSolver_ = sv[f.k];
+        pushGeometryChanges();            // PvContext.cpp:86: after an iteration's analysis
+        unpackXZ(lxz_.load(), &lx, &lz);  // PvContext.cpp:89
+        ly = ly_.load();
+        return true;
+    };
+    long long started = 0;
+    int prevK = -1;
+    bool ok = true;
+    while (ok && running_.load(std::memory_order_acquire)) {
+        const int k = (int)(started & 1);
+        while (ok && !flights.empty() && (flights.size() >= 2 || flights.front().k == k)) ok = complete();
+        if (!ok) break;
+        applyPending(k);
+        // a slot that is neither readable nor the target of an iteration in flight
+        int slot = 0;
+        for (; slot < 3; ++slot) {
+            bool used = slot == front_.load(std::memory_order_relaxed);
+            for (const Flight& f : flights) used = used || f.slot == slot;
+            if (!used) break;
+        }
+        Flight f{k, slot, {}};
+        if (!(sv[k]->run(lx, ly, lz, /*wait=*/false, prevK >= 0 ? sv[prevK] : nullptr) &&
+              sv[k]->publishWindowAsync(slots_[slot].data, &f.win, false))) {
+            // (the iteration still in flight on the other solver is valid: make it visible first, as the one-solver loop does)
+            while (!flights.empty() && complete()) {
+            }
+            if (!failed_.load()) fail(sv[k]);
+            break;
+        }
+        flights.push_back(f);
+        prevK = k;
+        // (the first iteration runs alone: the reference pushes the geometry its caller added after Init behind it,
+        // PvContext.cpp:80-86)
+        if (started++ == 0) ok = complete();
+        if (ok && solverWaiters_.load(std::memory_order_acquire) > 0) {  // a GetImpulseResponse call wants the solvers
+            while (ok && !flights.empty()) ok = complete();
+            if (!ok) break;
+            solverLock.unlock();
+            while (solverWaiters_.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+            solverLock.lock();
+        }
+    }
+    while (!failed_.load() && !flights.empty() && complete()) {
+    }
+    solverLock.unlock();
+    iterCv_.notify_all();
+}
+
 std::string Context::workerError() {
     std::lock_guard<std::mutex> lock(errMutex_);
     return workerErr_;
@@ -264,10 +355,14 @@ bool Context::beginPublish() {
 bool Context::finishPublish() {
     if (!pendPublish_) return true;
     pendPublish_ = false;
-    const int f = front_.load(std::memory_order_relaxed);
-    const int back = pendBack_;
-    const Solver::WindowBlock w = pendWin_;
     if (!solver_->waitPublish()) return false;
+    publishSlot(pendBack_, pendWin_);
+    return true;
+}
+
+// host part of a publish: the block has landed in slots_[back]
+void Context::publishSlot(const int back, const Solver::WindowBlock& w) {
+    const int f = front_.load(std::memory_order_relaxed);
     if (f >= 0) {
         // Cells of the old block outside the new one keep the old block's values from now on (the reference leaves
         // m_results untouched where an iteration finds no onset, Analyzer.cpp:160-165).  Nobody can be reading these
@@ -282,7 +377,7 @@ bool Context::finishPublish() {
             float* b = base_.load(std::memory_order_relaxed);
             if (!b) {
                 b = static_cast<float*>(std::calloc((size_t)solver_->spec().gx * gy, 32));
-                if (!b) return false;
+                if (!b) std::abort();  // (a map of 32 bytes per cell on the host)
                 base_.store(b, std::memory_order_release);
             }
             for (int r = or0; r < or0 + onr; ++r) {
@@ -315,7 +410,6 @@ bool Context::finishPublish() {
         iterations_.fetch_add(1, std::memory_order_acq_rel);
     }
     iterCv_.notify_all();
-    return true;
 }
 
 Out8 Context::outputAt(int cx, int cy) {
@@ -426,7 +520,7 @@ int Context::impulseResponse(float x, float y, float z, void* cells16, int cap) 
     solverWaiters_.fetch_sub(1, std::memory_order_acq_rel);
     const int T = solver_->T();
     std::vector<char> buf((size_t)T * 16);
-    if (!solver_->impulseResponseCells(cx, cy, buf.data())) return -1;
+    if (!lastSolver_->impulseResponseCells(cx, cy, buf.data())) return -1;
     lock.unlock();
     if (cells16 && cap > 0) std::memcpy(cells16, buf.data(), (size_t)std::min(cap, T) * 16);
     return T;
@@ -473,12 +567,27 @@ void Context::pushGeometryChanges() {
         std::lock_guard<std::mutex> lock(geomMutex_);
         q.swap(changes_);
     }
+    if (solver2_) {  // pipelined: every solver rasterises every change, in queue order, before ITS next iteration
+        for (auto& pend : pending_) pend.insert(pend.end(), q.begin(), q.end());
+        return;
+    }
     for (const Change& c : q) {  // GeometryManager.cpp:123-152, applied in queue order
         if (c.add)
             solver_->rasterAdd(c.box);
         else
             solver_->rasterRemove(c.box);
     }
+}
+
+void Context::applyPending(const int k) {
+    Solver* s = k == 0 ? solver_ : solver2_;
+    for (const Change& c : pending_[k]) {
+        if (c.add)
+            s->rasterAdd(c.box);
+        else
+            s->rasterRemove(c.box);
+    }
+    pending_[k].clear();
 }
 
 }  // namespace pva

@@ -22,6 +22,7 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <cstdint>
 #include <mutex>
 #include <string>
@@ -106,9 +107,18 @@ private:
     Context() = default;
     ~Context();
     void workerLoop();
+    // Pipelined iterations (small grids): TWO solvers, two iterations in flight.  Iteration i + 1 starts -- with the listener
+    // latched and the geometry pushed at that moment, as in the reference's loop (PvContext.cpp:86-89) -- while iteration i is
+    // still running on the other solver: every result still answers the listener its run started with one run time later,
+    // but results arrive twice as often.  What an iteration leaves untouched (cells without an onset keep the previous
+    // iteration's values, Analyzer.cpp:160-165) is carried from the other solver's maps on the device (Solver::run's
+    // carryFrom), so the published records are those of the one-solver loop.
+    void workerLoopPipelined();
     void pushGeometryChanges();
+    void applyPending(int k);
     bool beginPublish();
     bool finishPublish();
+    void publishSlot(int back, const Solver::WindowBlock& w);
     bool pendPublish_ = false;
     int pendBack_ = 0;
     Solver::WindowBlock pendWin_;
@@ -117,6 +127,8 @@ private:
     friend void retireContext(Context*);
 
     Solver* solver_ = nullptr;
+    Solver* solver2_ = nullptr;           // pipelined mode only
+    Solver* lastSolver_ = nullptr;        // the solver that ran the last PUBLISHED iteration (GetImpulseResponse reads it)
     std::thread worker_;
     std::atomic<bool> running_{false};
     std::atomic<bool> retiring_{false};
@@ -158,6 +170,7 @@ private:
     std::vector<Box> geometry_;
     std::vector<int> geometryFree_;
     std::vector<Change> changes_;
+    std::vector<Change> pending_[2];  // pipelined mode: drained from the queue, not yet rasterised into solver k
     std::mutex geomMutex_;
 
     // Published results.  Only the block of the map an iteration can have changed (the history window) crosses PCIe:
@@ -172,7 +185,7 @@ private:
         std::atomic<int> r0{0}, c0{0}, nr{0}, nc{0};
         std::atomic<float> lx{0.f}, lz{0.f};
     };
-    Slot slots_[2];
+    Slot slots_[3];  // one readable + one per iteration in flight
     std::atomic<int> front_{-1};
     std::atomic<uint64_t> pubSeq_{0};
     std::atomic<float*> base_{nullptr};

@@ -2863,7 +2863,7 @@ void launchFillDelay(float* delay, long long n, hipStream_t stream) {
     hipLaunchKernelGGL(pv_fill_delay_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, delay, (int)n);
 }
 
-void launchAnalysis(const AnalyzeArgs& a, hipStream_t stream) {
+void launchAnalysisFar(const AnalyzeArgs& a, hipStream_t stream) {
     const int n = a.gx * a.gy;
     if (a.lazyFar) {
         const int nr = max(a.prevNR, min(a.winRows, a.gx)), nc = max(a.prevNC, min(a.winCols, a.gy));
@@ -2872,6 +2872,10 @@ void launchAnalysis(const AnalyzeArgs& a, hipStream_t stream) {
     } else {
         hipLaunchKernelGGL(pv_far_cells_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a);
     }
+}
+
+void launchAnalysis(const AnalyzeArgs& a, hipStream_t stream) {
+    launchAnalysisFar(a, stream);
     const dim3 grid = analysisWindowGrid(a);
     hipLaunchKernelGGL(pv_encode_kernel, grid, dim3(256), 0, stream, a);
     // wet gain + decay time: sixteen, four or one lane per cell by the number of reachable cells, decided on the device

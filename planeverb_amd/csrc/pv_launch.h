@@ -66,6 +66,10 @@ void launchLaneSelfTest(float* out128, hipStream_t stream);
 void launchAnalysis(const AnalyzeArgs& a, hipStream_t stream);
 // the three phases of launchAnalysis separately (slab groups run the middle one per slab, the others on the whole map)
 void launchFarCells(const AnalyzeArgs& a, hipStream_t stream);
+void launchAnalysisFar(const AnalyzeArgs& a, hipStream_t stream);  // launchAnalysis' first pass (the lazy far frame, or every far cell)
+// no-onset cells of the window take the six persistent result planes (occlusion, wet gain, decay time, lowpass, source
+// direction x / y) from another solver's maps (pv_rt60.hip; Solver::run's carryFrom)
+void launchCarryResults(const AnalyzeArgs& a, const float* srcOut, hipStream_t stream);
 void launchAnalysisCells(const AnalyzeArgs& a, hipStream_t stream);
 void launchAnalysisDirection(const AnalyzeArgs& a, hipStream_t stream);
 // wet gain + decay time, blocked forms (pv_rt60.hip: four lanes / one lane per cell; each launch checks on the device whether it is the one)

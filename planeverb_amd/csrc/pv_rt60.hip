@@ -176,6 +176,31 @@ __global__ __launch_bounds__(256) void pv_rt60_blocked_kernel(const AnalyzeArgs 
 
 }  // namespace
 
+// Live module with two iterations in flight on two solvers (Solver::run's carryFrom): a cell in which this run found no onset
+// keeps what the PREVIOUS iteration left there (the reference never touches m_results[s] then, Analyzer.cpp:160-165) -- the
+// previous iteration ran on the other solver, so its six persistent planes are copied over for exactly those cells
+namespace {
+__global__ __launch_bounds__(256) void pv_carry_results_kernel(const AnalyzeArgs a, const float* __restrict__ src) {
+    const DynParams dyn = *a.dyn;
+    const int wc = blockIdx.x * blockDim.x + threadIdx.x, wr = blockIdx.y;
+    if (wc >= a.winCols) return;
+    const int X = dyn.histRow0 - a.G + wr, Y = dyn.histCol0 - a.G + wc;
+    if (X >= a.gx || Y >= a.gy) return;
+    const long long s = (long long)X * a.gy + Y;
+    if (a.delay[s] != FLT_MAX) return;
+    a.out[s] = src[s];
+    a.out[a.resN + s] = src[a.resN + s];
+    a.out[2 * a.resN + s] = src[2 * a.resN + s];
+    a.out[3 * a.resN + s] = src[3 * a.resN + s];
+    a.out[6 * a.resN + s] = src[6 * a.resN + s];
+    a.out[7 * a.resN + s] = src[7 * a.resN + s];
+}
+}  // namespace
+
+void launchCarryResults(const AnalyzeArgs& a, const float* srcOut, hipStream_t stream) {
+    hipLaunchKernelGGL(pv_carry_results_kernel, dim3((a.winCols + 255) / 256, a.winRows), dim3(256), 0, stream, a, srcOut);
+}
+
 // the blocked form; the sixteen-lane form (pv_rt60_wave_kernel, pv_kernels.hip) is launched beside them by launchAnalysis
 void launchRt60Blocked(const AnalyzeArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL((pv_rt60_blocked_kernel<4, 4>), dim3((a.winCols + 63) / 64, a.winRows), dim3(256), 0, stream, a);

@@ -1142,7 +1142,16 @@ bool Solver::ensureFarDirections() {
 
 // the analysis of the run enqueued on stream_ (history recorded, dynCur_ = its parameters)
 void Solver::enqueueAnalysis(float lx, float lz) {
-    launchAnalysis(analyzeArgs(lx, lz), stream_);
+    const AnalyzeArgs a = analyzeArgs(lx, lz);
+    if (carryFrom_ && carryFrom_ != this && carryFrom_->device_ == device_ && !opt_.streaming && !isSlab()) {
+        launchAnalysisFar(a, stream_);
+        launchAnalysisCells(a, stream_);
+        hipStreamWaitEvent(stream_, carryFrom_->ev_[2], 0);  // the previous iteration's analysis (and its own carry) is complete
+        launchCarryResults(a, carryFrom_->res_, stream_);
+        launchAnalysisDirection(a, stream_);
+    } else {
+        launchAnalysis(a, stream_);
+    }
     if (lazyFar_) {
         farWin_ = curWindow();
         farDirValid_ = false;
@@ -1498,8 +1507,13 @@ bool Solver::runCells(int lcx, int lcy, float lx, float lz, bool wait) {
     return wait ? sync() : true;
 }
 
-bool Solver::run(float lx, float ly, float lz, bool wait) {
+bool Solver::run(float lx, float ly, float lz, bool wait, Solver* carryFrom) {
     (void)ly;  // world y is ignored: grid-x = world x, grid-y = world z (FDTD.cpp:97-98)
+    struct Scope {
+        Solver*& p;
+        ~Scope() { p = nullptr; }
+    } scope{carryFrom_};
+    carryFrom_ = carryFrom;
     if (opt_.edgeTiles) {  // tile class 2 exists only in the batched kernel: a batch of one
         Solver* self = this;
         const float xyz[3] = {lx, ly, lz};

@@ -107,7 +107,12 @@ public:
     void rasterAdd(const Box& b) { mat_.add(b); }
     void rasterRemove(const Box& b) { mat_.remove(b); }
 
-    bool run(float lx, float ly, float lz, bool wait);
+    // carryFrom (live module, two iterations in flight on two solvers): the solver that ran the PREVIOUS iteration.  The cells
+    // in which this run finds no onset take their occlusion / wet gain / decay time / lowpass / source direction from that
+    // solver's maps, on the device, behind that solver's analysis and in front of this run's listener-direction pass -- what one
+    // solver's persistent result map does by itself (Analyzer.cpp:160-165 leaves m_results untouched there, and the direction
+    // walk reads those values, :340-431)
+    bool run(float lx, float ly, float lz, bool wait, Solver* carryFrom = nullptr);
     bool runCells(int lcx, int lcy, float lx, float lz, bool wait);
     bool sync();
     // n <= 8 identically configured solvers of one device: n independent runs (listeners lxyz[3n]) advanced by one
@@ -181,6 +186,7 @@ private:
     FarInfo farInfo() const;
     bool ensureFarDirections();
     void enqueueAnalysis(float lx, float lz);
+    Solver* carryFrom_ = nullptr;  // for the run being enqueued
     bool fail(const std::string& what);
     bool hipOk(hipError_t e, const char* what);
     template <typename Tp>

@@ -72,7 +72,9 @@ public:
     void rasterAdd(const Box& b) { mat_.add(b); }
     void rasterRemove(const Box& b) { mat_.remove(b); }
 
-    bool run(float lx, float, float lz, bool) {
+    bool residentKernel() const { return false; }
+    bool run(float lx, float, float lz, bool, Solver* carryFrom = nullptr) {
+        (void)carryFrom;
         const int fa = failAfterRuns().load();
         if (fa >= 0 && runs_ >= fa) {
             err_ = "fake solver: injected failure";

@@ -292,17 +292,20 @@ def test_batch_policy_helpers():
         assert (o["steps_per_launch"], o["tile_rows"], o["edge_tiles"]) == (k, rows, 1)
 
 
+@pytest.mark.parametrize("pipeline", ["1", "2"])
 @pytest.mark.parametrize("san", ["tsan", "asan"])
-def test_live_module_host_side_under_sanitizers(san, tmp_path):
+def test_live_module_host_side_under_sanitizers(san, pipeline, tmp_path):
     """SURVEY.md section 5 ("run host code under TSan/ASan"): a HIP-less build of pv_core.cpp + pv_context.cpp +
     pv_capi.cpp (Part 1) against tests/host/fake_solver.h, hammered through the C-ABI by 4 threads (GetOutput /
     Emit / UpdateEmission / EndEmission / Add-Update-RemoveGeometry / SetListenerPosition / GetImpulseResponse) while
     the main thread cycles Exit / Init, then a worker failure.  ThreadSanitizer resp. AddressSanitizer + UBSan must stay
-    silent and every record read must come from one iteration and belong to the cell asked for."""
+    silent and every record read must come from one iteration and belong to the cell asked for.
+    pipeline = 2: the worker loop that keeps two iterations in flight on two solvers (three result slots)."""
     out = str(tmp_path / "build")
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "host"), "OUT=" + out, out + "/hammer_" + san],
                           stdout=subprocess.DEVNULL)
-    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66", ASAN_OPTIONS="detect_leaks=1 exitcode=67")
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66", ASAN_OPTIONS="detect_leaks=1 exitcode=67",
+               PLANEVERB_AMD_LIVE_PIPELINE=pipeline)
     r = subprocess.run([out + "/hammer_" + san, "1.5"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
     assert "Sanitizer" not in r.stderr, r.stderr[-4000:]
