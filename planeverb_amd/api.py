@@ -46,6 +46,7 @@ PVA_OPT_STREAM_FUSE = 20
 PVA_OPT_AUX_STREAMS = 21
 PVA_OPT_RESIDENT_KERNEL = 22
 PVA_OPT_RT60_LANES = 23
+PVA_OPT_DEBUG_LOSE_FIRST_CAPTURE = 24
 
 
 class PlaneverbOutput(C.Structure):
@@ -621,7 +622,8 @@ class Solver:
                 "edge_tiles": PVA_OPT_EDGE_TILES, "row_bands": PVA_OPT_ROW_BANDS,
                 "patch_kernel": PVA_OPT_PATCH_KERNEL, "patch_strip": PVA_OPT_PATCH_STRIP,
                 "lazy_far_cells": PVA_OPT_LAZY_FAR_CELLS, "stream_fuse": PVA_OPT_STREAM_FUSE, "aux_streams": PVA_OPT_AUX_STREAMS,
-                "resident_kernel": PVA_OPT_RESIDENT_KERNEL, "rt60_lanes": PVA_OPT_RT60_LANES}
+                "resident_kernel": PVA_OPT_RESIDENT_KERNEL, "rt60_lanes": PVA_OPT_RT60_LANES,
+                "debug_lose_first_capture": PVA_OPT_DEBUG_LOSE_FIRST_CAPTURE}
         for k, v in options.items():
             _check(lib().PvAmdSetOption(self._h, keys[k], int(v)))
         self.info = PvAmdInfo()

@@ -197,10 +197,10 @@ const char* PvAmdLastError(void) {
     // unrelated calls on this thread (batch solver, slabs, communicator) stay readable.  PlaneverbWorkerError() always
     // has the worker's reason.
     {
-        static thread_local const void* reported = nullptr;
+        static thread_local unsigned long long reported = 0;  // (a generation number: addresses are re-used)
         Context::Ref c;
-        if (c && c->failed() && reported != (const void*)c.get()) {
-            reported = c.get();
+        if (c && c->failed() && reported != c->generation()) {
+            reported = c->generation();
             g_lastError = "simulation worker stopped: " + c->workerError();
         }
     }
@@ -459,6 +459,7 @@ int PvAmdSetOption(PvAmdSolver* h, int key, long long value) {
         case PVA_OPT_PATCH_STRIP: h->opt.patchStrip = (int)value; break;
         case PVA_OPT_RESIDENT_KERNEL: h->opt.resident = (int)value; break;
         case PVA_OPT_RT60_LANES: h->opt.rt60Lanes = (int)value; break;
+        case PVA_OPT_DEBUG_LOSE_FIRST_CAPTURE: h->opt.debugLoseFirstCapture = value != 0; break;
         default: g_lastError = "unknown option"; return -1;
     }
     return 0;

@@ -93,6 +93,8 @@ bool Context::init(const LiveConfig& cfg, std::string* err) {
     opt.autoStreaming = true;
     if (const char* e = std::getenv("PLANEVERB_AMD_LIVE_STREAMING")) opt.streaming = std::atoi(e) != 0;
     Context* c = new Context();
+    static std::atomic<unsigned long long> generations{0};
+    c->generation_ = generations.fetch_add(1) + 1;
     c->solver_ = Solver::create(spec, device, opt, err);
     if (!c->solver_) {
         delete c;
@@ -194,7 +196,9 @@ void Context::workerLoop() {
         // Iteration i: enqueue FDTD + analysis; make iteration i - 1 visible (its result block has been travelling to the
         // host on the copy stream since it was packed); queue this iteration's block behind its analysis; wait for the
         // DEVICE work of iteration i -- not for its copy, which overlaps the next iteration's first launches.
-        if (!((!streaming_ || registerEmitters()) && solver_->run(lx, ly, lz, /*wait=*/false) && finishPublish() &&
+        // (sparse-emitter mode: enqueueing a run BLOCKS for the front phase of the run -- the host paces the fused forward sums
+        // -- so the previous iteration is made visible first instead of ~100 ms late)
+        if (!((!streaming_ || (finishPublish() && registerEmitters())) && solver_->run(lx, ly, lz, /*wait=*/false) && finishPublish() &&
               beginPublish() && solver_->sync())) {
             stop();
             break;
@@ -531,6 +535,8 @@ int Context::impulseResponse(float x, float y, float z, void* cells16, int cap) 
 // ----------------------------------------------------------------------------------------------------------------
 
 int Context::addGeometry(const Box& b) {
+    // (a non-finite absorption is refused: NaN marks air in the material and coefficient planes, pv_solver.cpp addBox)
+    if (!std::isfinite(b.R)) return -1;
     std::lock_guard<std::mutex> lock(geomMutex_);
     int id;
     if (geometryFree_.empty()) {  // GeometryManager.cpp:70-79
@@ -554,6 +560,7 @@ void Context::removeGeometry(int id) {
 }
 
 void Context::updateGeometry(int id, const Box& b) {
+    if (!std::isfinite(b.R)) return;
     std::lock_guard<std::mutex> lock(geomMutex_);
     if (id < 0 || id >= (int)geometry_.size()) return;
     changes_.push_back({false, geometry_[(size_t)id]});  // GeometryManager.cpp:112-121

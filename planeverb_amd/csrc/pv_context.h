@@ -94,6 +94,8 @@ public:
     int impulseResponse(float x, float y, float z, void* cells16, int cap);
 
     long long iterations() const { return iterations_.load(std::memory_order_acquire); }
+    // a number no other context of this process has had (a new context can land on a retired one's address)
+    unsigned long long generation() const { return generation_; }
     long long waitIterations(long long count, int timeoutMs);
     const GridSpec& spec() const { return solver_->spec(); }
     // the worker stops for good on a solver error: then this is true, workerError() says why and IsRunning reports 0
@@ -126,6 +128,7 @@ private:
     bool registerEmitters();
     friend void retireContext(Context*);
 
+    unsigned long long generation_ = 0;
     Solver* solver_ = nullptr;
     Solver* solver2_ = nullptr;           // pipelined mode only
     Solver* lastSolver_ = nullptr;        // the solver that ran the last PUBLISHED iteration (GetImpulseResponse reads it)

@@ -2904,9 +2904,12 @@ __global__ __launch_bounds__(256) void pv_stream_accum_kernel(const AnalyzeArgs 
     int X, Y;
     if (a.ringList) {
         // forward sums of the air tiles inside the stencil (pv_stream.h): this pass serves only the listed tiles (walls, grid
-        // edges, listener, registered emitters) -- blockIdx.y = list entry, blockIdx.x = 256-cell chunk of the tile
-        const int t = a.ringList[blockIdx.y];
-        const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+        // edges, listener, registered emitters) -- blockIdx.x = list entry * chunks + 256-cell chunk of the tile (a grid's y
+        // extent stops at 65 535: a 16k^2 scene with many wall tiles has more list entries than that)
+        const int chunks = (a.rxi * a.wi + 255) / 256;
+        const int entry = blockIdx.x / chunks;
+        const int t = a.ringList[entry];
+        const int idx = (blockIdx.x - entry * chunks) * blockDim.x + threadIdx.x;
         if (idx >= a.rxi * a.wi) return;
         const int ti = t / a.nty, r = idx / a.wi;
         X = ti * a.rxi + r;
@@ -3093,7 +3096,7 @@ __global__ void pv_stream_tilegate_kernel(const uint8_t* marks, const uint8_t* h
 void launchStreamAccum(const AnalyzeArgs& a, const uint8_t* hasEmitter, uint8_t* tileOpen, int ntiles,
                        hipStream_t stream) {
     dim3 grid((a.gy + 255) / 256, a.gx);
-    if (a.ringList) grid = dim3((a.rxi * a.wi + 255) / 256, a.numRing > 0 ? a.numRing : 1);
+    if (a.ringList) grid = dim3((unsigned)((a.rxi * a.wi + 255) / 256) * (unsigned)(a.numRing > 0 ? a.numRing : 1), 1);
     hipMemsetAsync(a.tileOpenOut, 0, (size_t)ntiles, stream);
     if (!a.ringList || a.numRing > 0) hipLaunchKernelGGL(pv_stream_accum_kernel, grid, dim3(256), 0, stream, a);
     hipLaunchKernelGGL(pv_stream_tilegate_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, stream, a.tileOpenOut,

@@ -140,9 +140,12 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         const long long wty = std::min(ceilDiv(g_.NY, wi_), ceilDiv(2 * reach + 1, wi_) + 1);
         const long long histBytes = wtx * wty * rxi_ * wi_ * 4 * (long long)T_;
         const long long planeBytes = (long long)(g_.NX + 64) * (g_.NY + 128) * (24 + 2 + 36 + 12);  // fields, codes, maps, scratch
+        // (decided on the device's TOTAL memory: the mode decides which outputs exist -- wet gain / RT60 for registered
+        // emitters only -- and must not flip with what other processes hold at this moment; a history that then does not fit
+        // what is free fails the creation with a message, below)
         size_t freeB = 0, totalB = 0;
         hipMemGetInfo(&freeB, &totalB);
-        if ((unsigned long long)(histBytes + planeBytes) + (2ull << 30) > freeB || wtx * wty * rxi_ * wi_ * 4 > (long long)INT_MAX)
+        if ((unsigned long long)(histBytes + planeBytes) + (8ull << 30) > totalB || wtx * wty * rxi_ * wi_ * 4 > (long long)INT_MAX)
             opt_.streaming = true;
     }
     if (opt_.streaming && opt_.edgeTiles) opt_.edgeTiles = false;
@@ -180,7 +183,9 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     geo_.rows = kGuard + geo_.ntx * rxi_ + kGuard;
     geo_.pitch = roundUp(kGuard + geo_.nty * wi_ + kGuard, 64);
     const size_t plane = (size_t)geo_.rows * geo_.pitch;
-    if (plane * 4 > (size_t)INT_MAX) return fail("grid too large for 32-bit plane offsets");
+    // (the face-coefficient plane is 12 B per cell and is reached through one buffer descriptor with 32-bit offsets, like the
+    // three-plane span of the segment and patch kernels: ~13 400^2 padded cells)
+    if (plane * 12 > (size_t)INT_MAX) return fail("grid too large for 32-bit plane offsets (12 bytes per cell of face coefficients)");
     const int ntiles = geo_.ntx * geo_.nty;
 
     // lane-shift self test: the stencil relies on DPP wave shifts moving data by exactly one lane
@@ -468,7 +473,16 @@ Solver::~Solver() {
 // geometry
 // ----------------------------------------------------------------------------------------------------------------
 
+// A box whose absorption is not finite is refused: NaN is what marks an air cell in the material plane and an air|air face
+// in the coefficient plane, so such a wall would silently become air (the reference would spread NaN through its fields
+// instead, FDTD.cpp:150-168: neither is a result).
+static bool finiteBox(const Box& b) { return std::isfinite(b.R); }
+
 int Solver::addBox(const Box& b) {
+    if (!finiteBox(b)) {
+        err_ = "geometry with a non-finite absorption";
+        return -1;
+    }
     int id;
     if (boxFree_.empty()) {
         id = (int)boxTable_.size();
@@ -487,6 +501,7 @@ int Solver::addBox(const Box& b) {
 
 bool Solver::updateBox(int id, const Box& b) {
     if (id < 0 || id >= (int)boxTable_.size()) return fail("invalid geometry id");
+    if (!finiteBox(b)) return fail("geometry with a non-finite absorption");
     mat_.remove(boxTable_[(size_t)id]);  // UpdateObject = Remove(old) then Add(new), GeometryManager.cpp:112-121
     boxTable_[(size_t)id] = b;
     mat_.add(b);
@@ -1394,7 +1409,7 @@ bool Solver::buildGraph(int cap) {
     hipGraph_t g = nullptr;
     const hipError_t e = hipStreamEndCapture(stream_, &g);
     // test hook (tests/test_gpu_parity.py::test_run_survives_a_lost_graph_capture): the solver's first capture counts as lost
-    if (!captureLossInjected_ && std::getenv("PVA_DEBUG_LOSE_FIRST_CAPTURE")) {
+    if (!captureLossInjected_ && opt_.debugLoseFirstCapture) {
         captureLossInjected_ = true;
         ok = false;
     }

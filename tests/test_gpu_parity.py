@@ -347,8 +347,8 @@ def test_run_survives_a_lost_graph_capture(pvlib, monkeypatch):
     solver's stream is capturing invalidates the capture (seen with the live module's worker beside a test thread): the run
     then goes out as plain launches and the next run captures again -- same records either way."""
     g = golden("g71_smallroom")
-    monkeypatch.setenv("PVA_DEBUG_LOSE_FIRST_CAPTURE", "1")
-    with pvlib.Solver(float(g["size"]), float(g["size"]), int(g["res"])) as s:
+    # (resident_kernel=2: the replayed graph of tile-kernel launches, which the resident kernel otherwise replaces at this size)
+    with pvlib.Solver(float(g["size"]), float(g["size"]), int(g["res"]), resident_kernel=2, debug_lose_first_capture=1) as s:
         for b in g["boxes"]:
             s.add_geometry(b)
         for attempt in ("capture lost: plain launches", "captured", "replayed"):
