@@ -207,6 +207,24 @@ def lib():
     return _lib
 
 
+def variant(lib_path):
+    """This module once more, bound to ANOTHER build of the library -- e.g. libplaneverb_amd_exp.so, the experimental build
+    (make EXTRA=-DPV_EXPERIMENTAL) that carries the kernel arms and tile configurations the product library leaves out.
+    Both libraries can be used side by side in one process (each has its own state)."""
+    import importlib.util
+    import sys
+    name = "%s_variant_%s" % (__name__, os.path.splitext(os.path.basename(lib_path))[0])
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, __file__)
+    mod = importlib.util.module_from_spec(spec)
+    mod.__package__ = __package__
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    mod.LIB_PATH = lib_path
+    return mod
+
+
 def last_error():
     e = lib().PvAmdLastError()
     return e.decode() if e else ""

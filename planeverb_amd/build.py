@@ -22,11 +22,20 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def build(force=False, jobs=4):
-    """Compile every HIP/C++ source of the package for gfx950.  Works without a GPU (cross-compile)."""
+EXP_LIB_PATH = os.path.join(PKG_DIR, "libplaneverb_amd_exp.so")
+
+
+def build(force=False, jobs=4, experimental=True):
+    """Compile every HIP/C++ source of the package for gfx950.  Works without a GPU (cross-compile).
+    experimental: also the EXPERIMENTAL build (libplaneverb_amd_exp.so, -DPV_EXPERIMENTAL): the product's sources plus the
+    arms that were built, measured and switched off (row-streaming segments, patch kernel, stacked tiles) and the tuning
+    tiles of rounds 1-3 -- what their equivalence tests load (tests/conftest.py pvlib_exp); nothing else uses it."""
     if force:
         subprocess.check_call(["make", "-C", CSRC, "clean"], stdout=subprocess.DEVNULL)
     subprocess.check_call(["make", "-C", CSRC, "-j%d" % jobs], stdout=subprocess.DEVNULL)
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("build finished but %s is missing" % LIB_PATH)
+    if experimental and not os.environ.get("PLANEVERB_AMD_LIB"):
+        subprocess.check_call(["make", "-C", CSRC, "-j%d" % jobs, "BUILD=build_exp", "OUT=../libplaneverb_amd_exp.so",
+                               "EXTRA=-DPV_EXPERIMENTAL"], stdout=subprocess.DEVNULL)
     return LIB_PATH

@@ -1701,8 +1701,14 @@ __device__ __forceinline__ bool deadTileSkippable(const StepArgs& a, int tile) {
 }
 
 }  // namespace pva
+// The arms that were built, shown bit-exact, measured and switched off -- row-streaming air segments (pv_seg.h), the
+// persistent patch kernel (pv_patch.h), stacked tiles (PV_STACK_CONFIGS) -- are compiled only into the EXPERIMENTAL build
+// of the library (make EXTRA=-DPV_EXPERIMENTAL BUILD=build_exp OUT=../libplaneverb_amd_exp.so), which their equivalence
+// tests load; the product library carries the kernels its defaults and tuning options can reach.
+#ifdef PV_EXPERIMENTAL
 #include "pv_seg.h"
 #include "pv_patch.h"
+#endif
 #include "pv_stream.h"
 namespace pva {
 
@@ -1739,6 +1745,7 @@ void launchStepOpen(int K, int rxi, const StepArgs& a, const OpenArgs& o, hipStr
 #undef X
 }
 
+#ifdef PV_EXPERIMENTAL
 // configurations with a persistent patch kernel (pv_patch.h): the large-grid tile
 #define PV_PATCH_CONFIGS(X) X(12, 36)
 
@@ -1824,6 +1831,14 @@ void launchStepSeg(int K, int rxi, const StepArgs& a, hipStream_t stream) {
 #undef X
 }
 
+#else  // product build: the experimental arms do not exist
+bool patchConfigOk(int, int) { return false; }
+void launchStepPatch(int, int, const StepArgs&, int, hipStream_t) {}
+int segConfigColumns(int, int) { return 0; }
+int segConfigMaxTileColumns(int, int) { return 0; }
+void launchStepSeg(int, int, const StepArgs&, hipStream_t) {}
+#endif
+
 // positions an XCD's band needs under the chosen order (sub-bands are padded to whole multiples of H rows)
 static int bandPositions(const StepArgs& a) {
     if (a.tileOrder <= 1) return (a.ntiles + 7) / 8;
@@ -1883,21 +1898,26 @@ static void launchStackT(const StepArgs& a, hipStream_t stream) {
 }
 
 // (K steps per launch, interior rows per tile, waves/SIMD bound of the air kernel, rows per general-tile slice)
-#ifdef PV_DEV_FAST  // development builds: two configurations only (make EXTRA=-DPV_DEV_FAST)
-#define PV_STEP_CONFIGS(X) X(8, 24, 3, 12) X(12, 36, 2, 9) X(8, 40, 2, 10) X(12, 12, 3, 6) X(10, 20, 3, 10)
-#define PV_STACK_CONFIGS(X)
-#define PV_BATCH_CONFIGS(X) X(8, 24, 3, 12) X(12, 36, 2, 9) X(8, 40, 2, 10) X(12, 12, 3, 6) X(10, 20, 3, 10)
-#else
+// (K steps per launch, interior rows per tile, waves per SIMD, rows per slice of the two-kernel form's general tiles).  The
+// PRODUCT library carries the tiles its defaults choose by grid size (pv_solver.cpp: (12, 36), (10, 36), (8, 24), (10, 20),
+// (12, 12)) and the batched launches' tile (8, 40); every other (K, rows) -- tuning experiments of rounds 1-3, all bit-exact
+// -- and the stacked tiles live in the experimental build only.
+#define PV_PRODUCT_STEP_CONFIGS(X) X(8, 24, 3, 12) X(10, 36, 2, 9) X(12, 36, 2, 9) X(8, 40, 2, 10) X(12, 12, 3, 6) X(10, 20, 3, 10)
+#ifdef PV_EXPERIMENTAL
 #define PV_STEP_CONFIGS(X) \
-    X(4, 32, 3, 8) X(4, 24, 4, 6) X(2, 28, 4, 7) X(1, 30, 4, 15) X(8, 24, 3, 12) X(6, 28, 3, 14) X(3, 26, 4, 13) \
-    X(8, 48, 2, 12) X(12, 40, 2, 10) X(8, 40, 2, 10) X(12, 32, 2, 8) X(10, 36, 2, 9) X(8, 44, 2, 11) X(10, 40, 2, 10) X(12, 36, 2, 9) \
-    X(9, 42, 2, 14) X(11, 36, 2, 9) X(9, 40, 2, 10) \
-    X(12, 12, 3, 6) X(10, 20, 3, 10) /* round 3: deep K on small tiles for launch-bound grids (profiles/r03_small_tiles.txt) */
-
+    PV_PRODUCT_STEP_CONFIGS(X) \
+    X(4, 32, 3, 8) X(4, 24, 4, 6) X(2, 28, 4, 7) X(1, 30, 4, 15) X(6, 28, 3, 14) X(3, 26, 4, 13) \
+    X(8, 48, 2, 12) X(12, 40, 2, 10) X(12, 32, 2, 8) X(8, 44, 2, 11) X(10, 40, 2, 10) \
+    X(9, 42, 2, 14) X(11, 36, 2, 9) X(9, 40, 2, 10)
 // stacked tiles (K steps per launch, row pairs per wave, interior rows per tile, rows per general-tile slice); the
 // tile's interior height doubles as the configuration's `rxi`
 #define PV_STACK_CONFIGS(X) \
     X(12, 28, 196, 7) X(12, 30, 210, 10)
+#define PV_BATCH_CONFIGS(X) PV_PRODUCT_STEP_CONFIGS(X) X(6, 28, 3, 14)
+#else
+#define PV_STEP_CONFIGS(X) PV_PRODUCT_STEP_CONFIGS(X)
+#define PV_STACK_CONFIGS(X)
+#define PV_BATCH_CONFIGS(X) PV_PRODUCT_STEP_CONFIGS(X)
 #endif
 
 void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream, int which, hipStream_t stream2) {
@@ -1913,9 +1933,6 @@ void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream, int which
 
 // configurations with a batched kernel: the defaults of every grid-size class (pv_solver.cpp) and the other
 // merged-launch tiles of the tuning sweeps
-#ifndef PV_DEV_FAST
-#define PV_BATCH_CONFIGS(X) X(8, 24, 3, 12) X(6, 28, 3, 14) X(10, 36, 2, 9) X(12, 36, 2, 9) X(8, 40, 2, 10) X(12, 12, 3, 6) X(10, 20, 3, 10)
-#endif
 
 bool batchConfigOk(int K, int rxi) {
 #define X(k, r, w, sub) \

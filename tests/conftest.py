@@ -76,6 +76,27 @@ def pvlib():
     return api
 
 
+# tiles of the PRODUCT library (csrc/pv_kernels.hip PV_PRODUCT_STEP_CONFIGS); everything else -- other (K, rows), stacked tiles,
+# row-streaming segments, the patch kernel -- exists in the experimental build only
+PRODUCT_TILES = {(8, 24), (10, 36), (12, 36), (8, 40), (12, 12), (10, 20)}
+
+
+def needs_experimental(opts):
+    k, r = opts.get("steps_per_launch", 0), opts.get("tile_rows", 0)
+    if (k or r) and (k or 8, r or 24) not in PRODUCT_TILES:
+        return True
+    return bool(opts.get("stream_rows") or opts.get("patch_kernel", 0) > 0)
+
+
+@pytest.fixture(scope="session")
+def pvlib_exp(pvlib):
+    """planeverb_amd.api bound to the EXPERIMENTAL build of the library (libplaneverb_amd_exp.so)"""
+    from planeverb_amd.build import EXP_LIB_PATH
+    if not os.path.exists(EXP_LIB_PATH):
+        pytest.skip("experimental build of the library not present")
+    return pvlib.variant(EXP_LIB_PATH)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import pvoracle

@@ -53,11 +53,11 @@ def test_config4_hugeroom_4096_all_listeners(pvlib):
 
 
 @pytest.mark.parametrize("K,rows,nseg", [(8, 40, 2048), (12, 36, 1024)])
-def test_config4_hugeroom_4096_row_streaming_segments(pvlib, K, rows, nseg):
+def test_config4_hugeroom_4096_row_streaming_segments(pvlib_exp, K, rows, nseg):
     """BASELINE config 4 at full size through the row-streaming segment kernels (PVA_OPT_STREAM_ROWS, pv_seg.h): three of
     the listeners, both emitters each and the 25 m block of every map against the reference's vectors"""
     g = golden("g71_hugeroom_cfg4")
-    with pvlib.Solver(mode_a_size(4096), mode_a_size(4096), 275, steps_per_launch=K, tile_rows=rows,
+    with pvlib_exp.Solver(mode_a_size(4096), mode_a_size(4096), 275, steps_per_launch=K, tile_rows=rows,
                       stream_rows=nseg) as s:
         s.load_scene(os.path.join(SCENES, "HugeRoom.pv"))
         for i in (0, 3, 7):

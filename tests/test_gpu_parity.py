@@ -15,7 +15,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import SCENES, golden, rel_err, same_bits, valid_mask
+from conftest import SCENES, golden, needs_experimental, rel_err, same_bits, valid_mask
 
 pytestmark = pytest.mark.gpu
 
@@ -96,11 +96,13 @@ def test_golden_small(pvlib, name):
                                   dict(dense_history=1), dict(use_graph=1), dict(use_graph=2),
                                   dict(small_grid_kernel=1), dict(small_grid_kernel=2), dict(small_grid_kernel=2, use_graph=2), dict(small_grid_kernel=2, packed_math=0), dict(small_grid_kernel=2, merged_launch=0),
                                   dict(small_grid_kernel=2, merged_launch=0, use_graph=2)])
-def test_every_kernel_configuration(pvlib, opts):
-    """every compiled (K, rows) instantiation and the dense-history mode produce the same bits"""
+def test_every_kernel_configuration(pvlib, request, opts):
+    """every compiled (K, rows) instantiation and the dense-history mode produce the same bits (tiles outside the product
+    library's set run on the experimental build, conftest.PRODUCT_TILES)"""
     g = golden("g71_smallroom")
     gx, gy, T, fs = (int(v) for v in g["dims"])
-    with pvlib.Solver(25.0, 25.0, 275, **opts) as s:
+    lib = request.getfixturevalue("pvlib_exp") if needs_experimental(opts) else pvlib
+    with lib.Solver(25.0, 25.0, 275, **opts) as s:
         for b in g["boxes"]:
             s.add_geometry(b)
         s.run(g["listener"])
@@ -154,12 +156,12 @@ STACKED = [dict(steps_per_launch=12, tile_rows=196), dict(steps_per_launch=12, t
 
 
 @pytest.mark.parametrize("opts", STACKED)
-def test_stacked_tiles_golden_512(pvlib, opts):
+def test_stacked_tiles_golden_512(pvlib_exp, opts):
     """stacked air tiles (4 waves share one tall tile, boundary faces exchanged through LDS every step) against the
     reference's vectors for BASELINE config 2 (Mode A): the pulse crosses several stacked tiles in x and y"""
     g = golden("g512A_shoebox")
     gx, gy, T, fs = (int(v) for v in g["dims"])
-    with pvlib.Solver(float(g["size"]), float(g["size"]), 275, **opts) as s:
+    with pvlib_exp.Solver(float(g["size"]), float(g["size"]), 275, **opts) as s:
         assert s.info.tileRows == opts["tile_rows"]
         for b in g["boxes"]:
             s.add_geometry(b)
@@ -173,7 +175,7 @@ def test_stacked_tiles_golden_512(pvlib, opts):
 
 
 @pytest.mark.parametrize("opts", STACKED)
-def test_stacked_tiles_match_single_wave_tiles_1024(pvlib, opts):
+def test_stacked_tiles_match_single_wave_tiles_1024(pvlib_exp, opts):
     """same bits as the single-wave tile kernel on every cell of a 1024^2 grid: final fields, recorded planes, delay
     and result maps (walls inside the pulse's reach, listener near a stacked tile's corner)"""
     dx = np.float32(343.21) / np.float32(275) / np.float32(3.5)
@@ -181,8 +183,8 @@ def test_stacked_tiles_match_single_wave_tiles_1024(pvlib, opts):
     L = ((196 * 2 + 0.5) * float(dx), 0.0, (40 * 9 + 1.5) * float(dx))
     boxes = [[L[0] + 20.0, L[2] + 9.0, 30.0, 1.0, 0.85], [L[0] - 33.0, L[2] - 4.0, 1.2, 55.0, 0.5],
              [L[0] + 3.0, L[2] - 60.0, 44.0, 2.0, 0.969536]]
-    with pvlib.Solver(size, size, 275, steps_per_launch=8, tile_rows=24) as a, \
-            pvlib.Solver(size, size, 275, **opts) as b:
+    with pvlib_exp.Solver(size, size, 275, steps_per_launch=8, tile_rows=24) as a, \
+            pvlib_exp.Solver(size, size, 275, **opts) as b:
         for s in (a, b):
             for box in boxes:
                 s.add_geometry(box)
@@ -515,7 +517,7 @@ def test_dead_tiles_thick_walls_vs_oracle(pvlib, oracle):
         assert check(s, [bar, late], (30.0, 0.0, 70.0)) > 5000        # and a run after that starts clean again
 
 
-def test_step_composition_and_zero_fixed_point(pvlib):
+def test_step_composition_and_zero_fixed_point(pvlib, pvlib_exp):
     """raw stencil properties: 2n steps == n steps twice (any K), and an all-zero field stays all-zero"""
     rng = np.random.default_rng(11)
     boxes = random_scene(rng, 25.0, 8)
@@ -523,7 +525,7 @@ def test_step_composition_and_zero_fixed_point(pvlib):
     outs = []
     for opts in (dict(steps_per_launch=4, tile_rows=32), dict(steps_per_launch=1, tile_rows=30),
                  dict(steps_per_launch=8, tile_rows=24)):
-        with pvlib.Solver(25.0, 25.0, 275, no_free_grid=1, **opts) as s:
+        with (pvlib_exp if needs_experimental(opts) else pvlib).Solver(25.0, 25.0, 275, no_free_grid=1, **opts) as s:
             for b in boxes:
                 s.add_geometry(b)
             s.set_fields(*init)
@@ -920,7 +922,7 @@ def test_listener_outside_grid_and_api_misc(pvlib):
 
 
 @pytest.mark.parametrize("K,rows,nseg", [(8, 40, 40), (8, 40, 300), (12, 36, 64), (12, 36, 1000)])
-def test_row_streaming_segments_equivalence(pvlib, K, rows, nseg):
+def test_row_streaming_segments_equivalence(pvlib_exp, K, rows, nseg):
     """PVA_OPT_STREAM_ROWS (row-streaming air segments, pv_seg.h): same bits as the tile kernels -- the raw stencil from
     dense random fields with walls, a closed-room run and an open-field run whose pulse crosses many segments (history
     planes, activity flags, every result member)"""
@@ -933,7 +935,7 @@ def test_row_streaming_segments_equivalence(pvlib, K, rows, nseg):
     cfg = dict(steps_per_launch=K, tile_rows=rows, use_graph=2)
     outs = []
     for m in (0, nseg):
-        with pvlib.Solver(size, size, 275, no_free_grid=1, stream_rows=m, **cfg) as s:
+        with pvlib_exp.Solver(size, size, 275, no_free_grid=1, stream_rows=m, **cfg) as s:
             for w in walls:
                 s.add_geometry(w)
             s.set_fields(*init)
@@ -943,7 +945,7 @@ def test_row_streaming_segments_equivalence(pvlib, K, rows, nseg):
     for scene, listener in (("HugeRoom.pv", (100.0, 0.0, 90.0)), (None, (150.0, 0.0, 170.0))):
         res = []
         for m in (0, nseg):
-            with pvlib.Solver(size, size, 275, stream_rows=m, **cfg) as s:
+            with pvlib_exp.Solver(size, size, 275, stream_rows=m, **cfg) as s:
                 if scene:
                     s.load_scene(os.path.join(SCENES, scene))
                 s.run(listener)
@@ -955,7 +957,7 @@ def test_row_streaming_segments_equivalence(pvlib, K, rows, nseg):
 
 
 @pytest.mark.parametrize("n,strip", [(900, 3), (1250, 1), (1250, 5)])
-def test_patch_kernel_equivalence(pvlib, n, strip):
+def test_patch_kernel_equivalence(pvlib_exp, n, strip):
     """PVA_OPT_PATCH_KERNEL (persistent per-CU air-tile kernel with LDS-DMA run-ahead, pv_patch.h): same bits as the
     one-wave-per-tile kernel -- the raw stencil from dense random fields with walls (every tile non-zero, ragged last
     patch: tile columns not a multiple of 4), a closed-room run and an open-field run (history planes, activity flags,
@@ -969,7 +971,7 @@ def test_patch_kernel_equivalence(pvlib, n, strip):
     cfg = dict(steps_per_launch=12, tile_rows=36, use_graph=2)
     outs = []
     for m in (0, 1):
-        with pvlib.Solver(size, size, 275, no_free_grid=1, patch_kernel=m, patch_strip=strip, **cfg) as s:
+        with pvlib_exp.Solver(size, size, 275, no_free_grid=1, patch_kernel=m, patch_strip=strip, **cfg) as s:
             for w in walls:
                 s.add_geometry(w)
             s.set_fields(*init)
@@ -979,7 +981,7 @@ def test_patch_kernel_equivalence(pvlib, n, strip):
     for scene, listener in (("HugeRoom.pv", (100.0, 0.0, 90.0)), (None, (150.0, 0.0, 170.0))):
         res = []
         for m in (0, 1):
-            with pvlib.Solver(size, size, 275, patch_kernel=m, patch_strip=strip, **cfg) as s:
+            with pvlib_exp.Solver(size, size, 275, patch_kernel=m, patch_strip=strip, **cfg) as s:
                 if scene:
                     s.load_scene(os.path.join(SCENES, scene))
                 s.run(listener)
