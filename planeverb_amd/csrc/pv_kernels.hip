@@ -2224,6 +2224,13 @@ __device__ __forceinline__ int analysisWindowIndex(const AnalyzeArgs& a, const D
     return (r - (dyn.histRow0 - a.G)) * a.winCols + (c - (dyn.histCol0 - a.G));
 }
 
+// samples per memory round trip of the forward pass (three planes each) and of the pre-scan for an audible sample
+#ifndef PV_ENCODE_CH
+#define PV_ENCODE_CH 8
+#endif
+#ifndef PV_ENCODE_SC
+#define PV_ENCODE_SC 16
+#endif
 __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
     const DynParams dyn = *a.dyn;
     int X, Y;
@@ -2264,7 +2271,7 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
     // Every loop below walks the history in chunks of CH samples: the CH loads are issued together (they do not
     // depend on the running sums), then consumed strictly in sample order, so the float32 accumulation order is the
     // reference's while the memory latency is paid once per chunk instead of once per sample.
-    constexpr int CH = 8;
+    constexpr int CH = PV_ENCODE_CH;
 
     // Is there an onset at all?  Walls (beta = 0: pr is identically zero, FDTD.cpp:139) have none.  In a room (few
     // reachable cells, the kernel's duration is that of its slowest thread) the cell's own pressure is scanned first, 16
@@ -2277,7 +2284,7 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
     }
     const bool roomRegime = *a.activeCount < kRt60WaveMaxCells;  // few reachable cells: see pv_rt60_wave_kernel
     if (roomRegime) {
-        constexpr int SC = 16;
+        constexpr int SC = PV_ENCODE_SC;
         bool audible = false;
         for (int t0 = tFirst; t0 < T && !audible; t0 += SC) {
             float pc[SC];
