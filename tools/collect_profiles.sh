@@ -45,4 +45,14 @@ python tools/modeb_probe.py 2009 8034 16067 32134 > $O/modeB_streaming.txt 2>&1
 # round 3 additions: the reference's resolution presets, 1-rank RCCL self-test of bench.py's distributed path, patch-kernel A/B
 python tools/gpu_presets.py > $O/presets.txt 2>&1
 PV_BENCH_FORCE_DIST=1 python bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/bench_force_dist.json 2> $O/bench_force_dist.err
-python tools/gpu_patch.py 4096 3 > $O/patch_ab.txt 2>&1
+# (the patch kernel lives in the experimental build: PLANEVERB_AMD_LIB=$PWD/planeverb_amd/libplaneverb_amd_exp.so python tools/gpu_patch.py 4096 3)
+# round 4 additions: the all-cells-reached analysis workload (kernel stats + the two HBM PMC passes), the presets through the resident
+# kernel (table + kernel trace), live module with one / two iterations in flight, the decay-time forms
+python tools/gpu_analysis_workload.py 6 > $O/analysis_workload.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_ana -o a -- python tools/gpu_analysis_workload.py 6 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_ana -o f -- python tools/gpu_analysis_workload.py 3 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_ana -o w -- python tools/gpu_analysis_workload.py 3 > /dev/null 2>&1
+python tools/gpu_resident.py 275 375 500 750 1000 stress=10 > $O/presets.txt 2>&1
+for r in 275 750; do rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_presets_$r -o p -- python tools/gpu_presets.py $r use_graph=0 > /dev/null 2>&1; done
+(for p in 1 2; do echo "== PLANEVERB_AMD_LIVE_PIPELINE=$p"; PLANEVERB_AMD_LIVE_PIPELINE=$p python tools/gpu_presets.py 275 375 500 750 1000 2>&1 | grep -v "^#"; done) > $O/live_pipeline.txt 2>&1
+python tools/gpu_rt60.py 275 500 750 1000 1500 2009 > $O/rt60.txt 2>&1

@@ -95,6 +95,52 @@ for tag, fd, wd in (("4096", "pmc_fetch", "pmc_write"), ("8192", "pmc_fetch8k", 
             traffic[tag] = {"bytes_per_launch": rb + wb, "read_bytes": rb, "write_bytes": wb, "kernel": short}
     out["grids"][tag] = g
     lines.append("")
+# the analysis half of the metric: bytes of the analysis chain per RUN (sum over its kernels' launches / runs), for the bench's
+# grid (from the bench passes above) and for the all-cells-reached workload (tools/gpu_analysis_workload.py)
+ANALYSIS = ("pv_far_frame_kernel", "pv_far_cells_kernel", "pv_encode_kernel", "pv_rt60_wave_kernel", "pv_rt60_blocked_kernel",
+            "pv_direction_kernel", "pv_dir_init_kernel", "pv_dir_jump_kernel", "pv_dir_final_kernel", "pv_carry_results_kernel")
+
+
+def analysis_bytes(fp, wp):
+    if not (os.path.exists(fp) and os.path.exists(wp)):
+        return None
+    F, W = counters(fp), counters(wp)
+    runs = max([len(v) for k, v in F.items() if "pv_encode_kernel" in k] + [0])
+    if not runs:
+        return None
+    per = {}
+    for k in sorted(F):
+        if not any(a in k for a in ANALYSIS):
+            continue
+        short = k.split("(")[0].replace("void pva::", "").replace("pva::", "").replace("(anonymous namespace)::", "")
+        rb = sum(F[k]) * 1024 * fetch_corr / runs
+        wb = sum(W.get(k, [0.0])) * 1024 * write_corr / runs
+        per[short] = {"launches_per_run": len(F[k]) / runs, "read_bytes_per_run": rb, "write_bytes_per_run": wb}
+    tot = sum(v["read_bytes_per_run"] + v["write_bytes_per_run"] for v in per.values())
+    return {"runs_profiled": runs, "bytes_per_run": tot, "kernels": per,
+            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 corrections calibrated on the box "
+                      "(profiles/%s_analysis_pmc.md)" % R}
+
+
+alines = ["# HBM-side traffic of the analysis chain per run (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes, corrected as in "
+          "%s_hbm_pmc.md)" % R, ""]
+for tag, fd, wd, what in (("analysis_4096", "pmc_fetch", "pmc_write", "bench workload: HugeRoom.pv in a 4096^2 grid, T = 435 (a closed room: ~4 400 reached cells)"),
+                          ("analysis_512B", "pmc_fetch_ana", "pmc_write_ana", "all-cells-reached workload: Shoebox.pv 25 m at 512^2, T = 3179 (tools/gpu_analysis_workload.py)")):
+    ab = analysis_bytes(os.path.join(SRC, fd, "f_counter_collection.csv"), os.path.join(SRC, wd, "w_counter_collection.csv"))
+    if ab is None:
+        continue
+    traffic[tag] = ab
+    alines += ["## %s" % what, "", "| kernel | launches per run | read MB per run | written MB per run |", "|---|---|---|---|"]
+    for k, v in ab["kernels"].items():
+        alines.append("| %s | %.1f | %.2f | %.2f |" % (k, v["launches_per_run"], v["read_bytes_per_run"] / 1e6, v["write_bytes_per_run"] / 1e6))
+    alines += ["", "total %.2f MB per run (%d runs profiled)" % (ab["bytes_per_run"] / 1e6, ab["runs_profiled"]), ""]
+for f in ("analysis_workload.txt", "trace_ana/a_kernel_stats.csv"):
+    pth = os.path.join(SRC, f)
+    if os.path.exists(pth):
+        alines += ["## %s" % f, "", "```", open(pth).read().strip(), "```", ""]
+if len(alines) > 2:
+    open(os.path.join(DST, R + "_analysis_pmc.md"), "w").write("\n".join(alines) + "\n")
+
 # stamp: which device code these counters belong to (bench.py quotes them only for the same kernel sources)
 sys.path.insert(0, ROOT)
 from planeverb_amd.build import kernel_source_hash  # noqa: E402
@@ -129,6 +175,14 @@ for w in ("zero1", "random1"):
                  "valu_busy_single_launch": m.get("SQ_ACTIVE_INST_VALU", 0) * 4.0 / 1024.0 / (m.get("GRBM_GUI_ACTIVE", 1) / 8.0)}
 for t in traffic.values():
     t.update(stamp)
+for f in ("presets.txt", "live_pipeline.txt", "rt60.txt", "inflight.txt"):
+    pth = os.path.join(SRC, f)
+    if os.path.exists(pth):
+        shutil.copy(pth, os.path.join(DST, R + "_" + f))
+for res in ("275", "750"):
+    pth = os.path.join(SRC, "trace_presets_" + res, "p_kernel_stats.csv")
+    if os.path.exists(pth):
+        shutil.copy(pth, os.path.join(DST, R + "_presets_%s_kernel_stats.csv" % res))
 if sq:
     traffic["sq_4096"] = dict(sq, **stamp)
 out["stamp"] = stamp
