@@ -190,7 +190,9 @@ struct ResidentArgs {
     int* tileFirst;        // per tile: first step block in which the tile was non-zero (reset to INT_MAX before the launch)
     const DynParams* dyn;
     int* errFlag;          // 3 = a block gave up waiting for a neighbour (every block then leaves: the run failed)
-    unsigned* flags;       // ntiles epoch counters + 1 abort word, zeroed before every launch
+    unsigned* flags;       // ntiles epoch counters + 1 abort word + 1 claim counter (one-XCD mode), zeroed before every launch
+    int xcdMode;           // 1: the blocks that run on XCD xcdTarget claim the tiles; hand-off through that XCD's L2
+    int xcdTarget;
     long long histPlane;   // floats per recorded step
     long long planeBytes;  // bytes of one padded float plane
     int pitch, G;

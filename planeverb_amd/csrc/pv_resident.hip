@@ -16,6 +16,14 @@
 //     dispatch, XCD placement & inter-workgroup visibility") -- no grid-wide barrier, no kernel boundary;
 //   * two buffer sets suffice: a block overwrites set s (epoch e + 2) only after every neighbour has raised its flag to
 //     e + 1, i.e. after that neighbour has finished reading epoch e from set s.
+// ONE-XCD MODE (a.xcdMode, grids of up to 32 tiles: the Sandbox's 71^2, 95^2): the hand-off above is two dependent trips
+// through the fabric (flag, then data) plus the producer's drain, ~3 us per epoch, because sc1 stores leave the XCD's L2.
+// Inside ONE XCD the L2 is the coherence point: plain stores stay in it, L1-bypassing loads are served from it.  The launch
+// then has 8 x ntiles blocks; every block reads the XCD it actually runs on (HW_REG_XCC_ID), the blocks on XCD
+// a.xcdTarget claim the tiles through a counter, the others leave.  Correctness never depends on where the hardware put a
+// block -- only blocks that ARE on the target XCD take part -- and if fewer than ntiles of them turn up there (another
+// dispatch pattern or partition mode) the claim check below gives the run up within milliseconds (errFlag 4) and the host
+// repeats it in the placement-independent mode.
 // No assumption about dispatch order or workgroup -> XCD placement is made; all blocks must be co-resident (the host caps
 // the grid and keeps a per-device budget), and every wait is bounded: a block that waits longer than ~2 s raises the abort
 // word, every other block leaves at its next wait, and the run fails with an error instead of hanging the device.
@@ -202,9 +210,15 @@ __device__ __forceinline__ void publishRows(const int wave, const ResidentArgs& 
                                             const int pitchB) {
     if constexpr (WV < W) {
         if (wave == WV) {
-            storeRows<K, RXI, W, WV, kSc1>(pr, makeRsrc(a.pr[set], a.planeBytes), voff, soff0, pitchB);
-            storeRows<K, RXI, W, WV, kSc1>(vx, makeRsrc(a.vx[set], a.planeBytes), voff, soff0, pitchB);
-            storeRows<K, RXI, W, WV, kSc1>(vy, makeRsrc(a.vy[set], a.planeBytes), voff, soff0, pitchB);
+            if (a.xcdMode) {  // (one XCD: plain stores stay in the L2 every taking-part block shares)
+                storeRows<K, RXI, W, WV, 0>(pr, makeRsrc(a.pr[set], a.planeBytes), voff, soff0, pitchB);
+                storeRows<K, RXI, W, WV, 0>(vx, makeRsrc(a.vx[set], a.planeBytes), voff, soff0, pitchB);
+                storeRows<K, RXI, W, WV, 0>(vy, makeRsrc(a.vy[set], a.planeBytes), voff, soff0, pitchB);
+            } else {
+                storeRows<K, RXI, W, WV, kSc1>(pr, makeRsrc(a.pr[set], a.planeBytes), voff, soff0, pitchB);
+                storeRows<K, RXI, W, WV, kSc1>(vx, makeRsrc(a.vx[set], a.planeBytes), voff, soff0, pitchB);
+                storeRows<K, RXI, W, WV, kSc1>(vy, makeRsrc(a.vy[set], a.planeBytes), voff, soff0, pitchB);
+            }
         } else {
             publishRows<K, RXI, W, WV + 1>(wave, a, set, pr, vx, vy, voff, soff0, pitchB);
         }
@@ -243,7 +257,36 @@ __global__ __launch_bounds__(64 * W) void pv_resident_kernel(const ResidentArgs 
     __shared__ ResShared<W> sh;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int tile = blockIdx.x;
+    int tile = blockIdx.x;
+    if (a.xcdMode) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u;  // HW_REG_XCC_ID[3:0]
+        if ((int)xcc != a.xcdTarget) return;
+        if (threadIdx.x == 0) sh.abort = (int)atomicAdd(a.flags + a.ntiles + 1, 1u);  // claim a tile
+        __syncthreads();
+        tile = sh.abort;
+        __syncthreads();
+        if (tile >= a.ntiles) return;
+        // every tile must have found a block on this XCD before anybody waits for a neighbour: ~2 ms, then give the run up
+        if (wave == 0) {
+            bool bad = false;
+            for (unsigned spins = 0;; ++spins) {
+                const unsigned got = __hip_atomic_load(a.flags + a.ntiles + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (got >= (unsigned)a.ntiles) break;
+                if (spins > 2000u || __hip_atomic_load(a.flags + a.ntiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    if (lane == 0) {
+                        __hip_atomic_store(a.flags + a.ntiles, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        atomicExch(a.errFlag, 4);
+                    }
+                    bad = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (lane == 0) sh.abort = bad ? 1 : 0;
+        }
+        __syncthreads();
+        if (sh.abort) return;
+    }
     const int ti = tile / a.nty;
     const int tj = tile - ti * a.nty;
     const int ws = wave * (R - 2);  // first row of this wave's window, in loaded-tile rows
@@ -379,7 +422,12 @@ __global__ __launch_bounds__(64 * W) void pv_resident_kernel(const ResidentArgs 
         if (e + 1 < nEpochs) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains its write-through stores ...
             __syncthreads();                                   // ... before ONE lane raises the block's flag
-            if (threadIdx.x == 0) __hip_atomic_store(myFlag, (unsigned)(e + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x == 0) {
+                if (a.xcdMode)  // (a plain store: the flag stays in the XCD's L2, where the neighbours' L1-bypassing polls find it)
+                    __hip_atomic_store(myFlag, (unsigned)(e + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else
+                    __hip_atomic_store(myFlag, (unsigned)(e + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         PV_STAMP(5);
     }
@@ -436,7 +484,7 @@ int residentMaxBlocks(int K, int rxi, int device) {
 void launchResident(int K, int rxi, const ResidentArgs& a, hipStream_t stream) {
 #define X(k, r, w) \
     if (K == k && rxi == r) { \
-        hipLaunchKernelGGL((pv_resident_kernel<k, r, w>), dim3(a.ntiles), dim3(64 * w), 0, stream, a); \
+        hipLaunchKernelGGL((pv_resident_kernel<k, r, w>), dim3(a.xcdMode ? 8 * a.ntiles : a.ntiles), dim3(64 * w), 0, stream, a); \
         return; \
     }
     PV_RESIDENT_CONFIGS(X)

@@ -28,6 +28,11 @@ inline int floorDiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b
 
 // resident kernel (pv_resident.hip): blocks of runs in flight per device, all solvers of the process
 static constexpr int kResidentMaxTiles = 512;
+static int kResidentXcdMaxTiles = 32;  // one workgroup per CU of one XCD (PLANEVERB_AMD_RESIDENT_XCD=N: N > 1 sets it, measurements)
+static std::atomic<int>& residentXcdInFlight(int device, int xcd) {
+    static std::atomic<int> n[64][8];
+    return n[device & 63][xcd & 7];
+}
 static std::atomic<int>& residentInFlight(int device) {
     static std::atomic<int> n[64];
     return n[device & 63];
@@ -36,6 +41,8 @@ static std::atomic<int>& residentInFlight(int device) {
 void Solver::releaseResident() {
     if (residentHeld_ > 0) residentInFlight(device_).fetch_sub(residentHeld_);
     residentHeld_ = 0;
+    if (xcdHeld_ > 0) residentXcdInFlight(device_, xcdTarget_).fetch_sub(xcdHeld_);
+    xcdHeld_ = 0;
 }
 
 bool Solver::fail(const std::string& what) {
@@ -366,7 +373,17 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
             const int cap = residentMaxBlocks(K_, rxi_, device_);
             if (ntiles > std::min(cap / 2, kResidentMaxTiles)) useResident_ = false;
         }
-        if (useResident_ && !dalloc(&resFlags_, (size_t)ntiles + 1, true)) return false;
+        if (useResident_ && !dalloc(&resFlags_, (size_t)ntiles + 2, true)) return false;
+        if (useResident_) {
+            static std::atomic<int> turn{0};
+            xcdTarget_ = turn.fetch_add(1) & 7;
+            // (validation: an XCD that does not exist -- the first run is then given up by the claim check and repeated)
+            if (const char* e = std::getenv("PLANEVERB_AMD_RESIDENT_XCD_TARGET")) xcdTarget_ = std::atoi(e);
+            if (const char* e = std::getenv("PLANEVERB_AMD_RESIDENT_XCD")) {  // 0: never the one-XCD mode
+                xcdOk_ = std::atoi(e) != 0;
+                if (std::atoi(e) > 1) kResidentXcdMaxTiles = std::min(std::atoi(e), 64);
+            }
+        }
     }
 
     warnIfPulseDiffers();
@@ -1289,8 +1306,21 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
         }
     }
     if (resident) {
+        // one-XCD mode where the grid fits one XCD's CUs and that XCD is not taken by another solver's run
+        bool xcd = xcdOk_ && ntiles <= kResidentXcdMaxTiles;
+        if (xcd) {
+            std::atomic<int>& onXcd = residentXcdInFlight(device_, xcdTarget_);
+            if (onXcd.fetch_add(ntiles) + ntiles > kResidentXcdMaxTiles) {
+                onXcd.fetch_sub(ntiles);
+                xcd = false;
+            } else {
+                xcdHeld_ = ntiles;
+            }
+        }
+        lastLcx_ = lcx;
+        lastLcy_ = lcy;
         enqueueBeginRun(true);
-        if (!hipOk(hipMemsetAsync(resFlags_, 0, sizeof(unsigned) * ((size_t)ntiles + 1), stream_), "resident flags"))
+        if (!hipOk(hipMemsetAsync(resFlags_, 0, sizeof(unsigned) * ((size_t)ntiles + 2), stream_), "resident flags"))
             return false;
         ResidentArgs ra{};
         for (int i = 0; i < 2; ++i) {
@@ -1305,6 +1335,9 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
         ra.dyn = dynDev_;
         ra.errFlag = errFlag_;
         ra.flags = resFlags_;
+        ra.xcdMode = xcd ? 1 : 0;
+        ra.xcdTarget = xcdTarget_;
+        lastRunXcd_ = xcd;
         ra.histPlane = histPlane_;
         ra.planeBytes = (long long)geo_.rows * geo_.pitch * 4;
         ra.pitch = geo_.pitch;
@@ -1578,7 +1611,26 @@ bool Solver::sync() {
             !hipOk(hipStreamSynchronize(fs), "errFlag sync"))
             return false;
         tim_.reachedCells = counts[1];
-        if (flag == 3) return fail("resident kernel: a workgroup gave up waiting for its neighbours (run aborted)");
+        if (lastRunXcd_) {
+            // one-XCD mode: did every tile find a workgroup on this solver's XCD?  (If NONE of the launch's blocks ran there --
+            // a partition mode in which every block reports the same XCD -- nobody could even raise the error flag.)
+            lastRunXcd_ = false;
+            unsigned claims = 0;
+            if (!hipOk(hipMemcpyAsync(&claims, resFlags_ + geo_.ntx * geo_.nty + 1, sizeof(unsigned), hipMemcpyDeviceToHost, fs),
+                       "claim copy") || !hipOk(hipStreamSynchronize(fs), "claim sync"))
+                return false;
+            if (claims < (unsigned)(geo_.ntx * geo_.nty) && flag == 0) flag = 4;
+        }
+        if (flag == 4 && xcdOk_) {
+            // one-XCD mode: fewer workgroups than tiles turned up on this solver's XCD (another dispatch pattern / partition
+            // mode than the one observed).  Nothing was computed; from now on the placement-independent hand-off, and the run
+            // is repeated in it.
+            xcdOk_ = false;
+            std::fprintf(stderr, "[planeverb_amd] resident kernel: one-XCD mode not available on this device (workgroups are "
+                                 "not spread over the XCDs as expected); using the placement-independent hand-off\n");
+            return enqueueRun(lastLcx_, lastLcy_, lastLx_, lastLz_) && sync();
+        }
+        if (flag == 3 || flag == 4) return fail("resident kernel: a workgroup gave up waiting for its neighbours (run aborted)");
         if (flag) return fail("pressure history window overflow (a tile outside the window became non-zero)");
     }
     return true;

@@ -287,6 +287,12 @@ private:
     bool useResident_ = false;
     unsigned* resFlags_ = nullptr;     // ntiles epoch counters + 1 abort word
     int residentHeld_ = 0;             // blocks of the device's resident budget held by the run in flight
+    // one-XCD mode of the resident kernel (grids of up to kResidentXcdMaxTiles tiles): hand-off through one XCD's L2
+    bool xcdOk_ = true;                // false once a launch found fewer blocks on its XCD than tiles (errFlag 4)
+    int xcdTarget_ = 0;                // this solver's XCD (solvers take turns, so that pipelined solvers do not share one)
+    int xcdHeld_ = 0;                  // blocks of that XCD's budget held by the run in flight
+    bool lastRunXcd_ = false;          // the run in flight went out in the one-XCD mode
+    int lastLcx_ = 0, lastLcy_ = 0;    // (a run given up by the claim check is repeated in the placement-independent mode)
     void releaseResident();
     float* scratch_ = nullptr;  // max(3T, NX*NY) floats
     size_t scratchCount_ = 0;

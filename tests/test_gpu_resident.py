@@ -82,6 +82,28 @@ def test_resident_kernel_equals_tile_kernel_graph(pvlib, res, scene):
             maps_equal(r, g, "listener %r" % (L,))
 
 
+@pytest.mark.parametrize("env", [{"PLANEVERB_AMD_RESIDENT_XCD": "0"}, {"PLANEVERB_AMD_RESIDENT_XCD_TARGET": "9"}])
+def test_resident_kernel_hand_off_modes(pvlib, monkeypatch, env):
+    """Grids of up to 32 tiles hand their tiles over through ONE XCD's L2 (the blocks that run on the solver's XCD claim the
+    tiles).  PLANEVERB_AMD_RESIDENT_XCD=0: the placement-independent hand-off at the same size.  ..._XCD_TARGET=9: an XCD that
+    does not exist -- no block claims a tile, the host sees it, repeats the run in the placement-independent mode and stays
+    there.  Same vectors either way."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    g = golden("g71_smallroom")
+    gx, gy, T, fs = (int(v) for v in g["dims"])
+    with pvlib.Solver(float(g["size"]), float(g["size"]), int(g["res"])) as s:
+        assert s.info.residentKernel == 1
+        for b in g["boxes"]:
+            s.add_geometry(b)
+        for rep in range(3):
+            s.run(g["listener"])
+            res, delay = s.results()
+            compare_maps(res, delay, g["results"], g["delay"], T, fs, "%r run %d" % (env, rep))
+            for i, t in enumerate(g["snap_ts"]):
+                assert same_bits(s.history_plane(int(t)), g["snaps"][i][0]).all(), "recorded pr, step %d" % t
+
+
 def test_resident_kernel_random_scenes_vs_oracle(pvlib, oracle):
     """seeded random box scenes at 70^2 ... 140^2, resident kernel against the pinned oracle"""
     rng = np.random.default_rng(2024)
