@@ -157,6 +157,8 @@ struct BeginArgs {
     const DynParams* dynBandsHost;  // pinned, nbands entries (NULL when the run is not banded)
     DynParams* dynBands;
     int nbands;
+    unsigned* zeroWords;   // words to clear (the resident kernel's flags: no memset node beside the launch), or NULL / 0
+    int nZero;
 };
 
 // whole-grid-resident kernel for grids that fit one CU's LDS (pv_small_grid_kernel)

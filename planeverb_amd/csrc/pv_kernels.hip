@@ -2024,6 +2024,7 @@ __global__ void pv_begin_run_kernel(BeginArgs a) {
         *a.errFlag = 0;
     }
     if (i < a.nbands) a.dynBands[i] = a.dynBandsHost[i];
+    if (i < a.nZero) a.zeroWords[i] = 0u;
     if (a.tileFirst && i < a.ntiles) {
         a.tileFirst[i] = a.tileFirstInit;
         a.nz0[i] = 0;
@@ -2044,6 +2045,7 @@ void launchZero(float* p, long long n, hipStream_t stream) {
 void launchBeginRun(const BeginArgs& a, hipStream_t stream) {
     int n = a.ntiles > a.listCap ? a.ntiles : a.listCap;
     if (a.segHost && a.segCap > n) n = a.segCap;
+    if (a.nZero > n) n = a.nZero;
     hipLaunchKernelGGL(pv_begin_run_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, a);
 }
 

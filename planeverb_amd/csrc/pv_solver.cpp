@@ -813,6 +813,8 @@ void Solver::enqueueBeginRun(bool resetTiles) {
     b.dynBandsHost = bandedRun_ ? dynBandsHost_ : nullptr;
     b.dynBands = dynBandsDev_;
     b.nbands = bandedRun_ ? nb_ : 0;
+    b.zeroWords = resFlags_;
+    b.nZero = resFlags_ ? geo_.ntx * geo_.nty + 2 : 0;
     launchBeginRun(b, stream_);
 }
 
@@ -1319,9 +1321,7 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
         }
         lastLcx_ = lcx;
         lastLcy_ = lcy;
-        enqueueBeginRun(true);
-        if (!hipOk(hipMemsetAsync(resFlags_, 0, sizeof(unsigned) * ((size_t)ntiles + 2), stream_), "resident flags"))
-            return false;
+        enqueueBeginRun(true);  // (also clears the flag words)
         ResidentArgs ra{};
         for (int i = 0; i < 2; ++i) {
             ra.pr[i] = pr_[i];
