@@ -301,6 +301,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     }
     if (!hipOk(hipHostMalloc((void**)&dynHost_, sizeof(DynParams)), "hipHostMalloc")) return false;
     if (!hipOk(hipHostMalloc((void**)&outHost_, 8 * sizeof(float)), "hipHostMalloc")) return false;
+    if (!hipOk(hipHostMalloc((void**)&statusHost_, 4 * sizeof(int)), "hipHostMalloc")) return false;
     if (!hipOk(hipHostMalloc((void**)&qCellsHost_, kMaxQueries * sizeof(long long)), "hipHostMalloc")) return false;
     if (!hipOk(hipHostMalloc((void**)&qOutHost_, kMaxQueries * 8 * sizeof(float)), "hipHostMalloc")) return false;
     if (!hipOk(hipHostMalloc((void**)&listHost_, sizeof(int) * (size_t)listCap_), "hipHostMalloc")) return false;
@@ -467,6 +468,7 @@ Solver::~Solver() {
     if (dynBandsHost_) hipHostFree(dynBandsHost_);
     if (dynHost_) hipHostFree(dynHost_);
     if (outHost_) hipHostFree(outHost_);
+    if (statusHost_) hipHostFree(statusHost_);
     if (qCellsHost_) hipHostFree(qCellsHost_);
     if (qOutHost_) hipHostFree(qOutHost_);
     if (listHost_) hipHostFree(listHost_);
@@ -1404,6 +1406,7 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
     hipEventRecord(ev_[2], stream_);
     lastRunBatched_ = false;
     enqueueQueries();
+    enqueueRunStatus();
     pendingTimings_ = true;
     return hipOk(hipGetLastError(), "run launch");
 }
@@ -1538,6 +1541,7 @@ bool Solver::runBatch(Solver* const* s, int n, const float* lxyz, bool wait, std
         hipEventRecord(v.ev_[2], v.stream_);
         v.lastRunBatched_ = n > 1;
         v.enqueueQueries();
+        v.enqueueRunStatus();
         v.pendingTimings_ = true;
     }
     if (hipGetLastError() != hipSuccess) return bad("batched run launch failed");
@@ -1599,28 +1603,27 @@ bool Solver::sync() {
             tim_.airLaunches = n;
             tim_.generalLaunches = numGeneral_ > 0 ? n : 0;
         }
-        // The error flag, never through the legacy stream (applyGeometry).  WHICH stream was measured on MI355X / ROCm 7.0
-        // (profiles/r03_ab_errflag.txt): read behind stream_, the batched launches of a batch member's NEXT step loop take twice as
-        // long (63 instead of 33 us at 512^2: 2.2e11 instead of 3.7e11 cell-updates/s); with one more stream per solver for it, four
-        // pipelined runs of a 512^2 grid lose 11 % (the streams of a process share a handful of hardware queues by creation
-        // order).  So: by the kind of run, and through the solver's second stream, which the batched mode does not use.
         int flag = 0, counts[2] = {0, 0};
-        hipStream_t fs = lastRunBatched_ ? stream2_ : stream_;  // (stream2_ is idle in the batched mode)
-        if (!hipOk(hipMemcpyAsync(&flag, errFlag_, sizeof(int), hipMemcpyDeviceToHost, fs), "errFlag copy") ||
-            !hipOk(hipMemcpyAsync(counts, activeCount_, sizeof(counts), hipMemcpyDeviceToHost, fs), "count copy") ||
-            !hipOk(hipStreamSynchronize(fs), "errFlag sync"))
-            return false;
-        tim_.reachedCells = counts[1];
-        if (lastRunXcd_) {
-            // one-XCD mode: did every tile find a workgroup on this solver's XCD?  (If NONE of the launch's blocks ran there --
-            // a partition mode in which every block reports the same XCD -- nobody could even raise the error flag.)
+        if (statusQueued_) {
+            // the run's last kernel left its status words in pinned memory: no copy, no second synchronisation
+            statusQueued_ = false;
+            flag = statusHost_[0];
+            counts[0] = statusHost_[1];
+            counts[1] = statusHost_[2];
+            if (lastRunXcd_ && statusHost_[3] >= 0 && statusHost_[3] < geo_.ntx * geo_.nty && flag == 0) flag = 4;
             lastRunXcd_ = false;
-            unsigned claims = 0;
-            if (!hipOk(hipMemcpyAsync(&claims, resFlags_ + geo_.ntx * geo_.nty + 1, sizeof(unsigned), hipMemcpyDeviceToHost, fs),
-                       "claim copy") || !hipOk(hipStreamSynchronize(fs), "claim sync"))
+        } else {
+            // (raw stepping: no status kernel.)  The error flag, never through the legacy stream (applyGeometry), and by the kind
+            // of run -- read behind stream_, the batched launches of a batch member's NEXT step loop took twice as long
+            // (profiles/r03_ab_errflag.txt) -- through the solver's second stream, which the batched mode does not use.
+            lastRunXcd_ = false;
+            hipStream_t fs = lastRunBatched_ ? stream2_ : stream_;  // (stream2_ is idle in the batched mode)
+            if (!hipOk(hipMemcpyAsync(&flag, errFlag_, sizeof(int), hipMemcpyDeviceToHost, fs), "errFlag copy") ||
+                !hipOk(hipMemcpyAsync(counts, activeCount_, sizeof(counts), hipMemcpyDeviceToHost, fs), "count copy") ||
+                !hipOk(hipStreamSynchronize(fs), "errFlag sync"))
                 return false;
-            if (claims < (unsigned)(geo_.ntx * geo_.nty) && flag == 0) flag = 4;
         }
+        tim_.reachedCells = counts[1];
         if (flag == 4 && xcdOk_) {
             // one-XCD mode: fewer workgroups than tiles turned up on this solver's XCD (another dispatch pattern / partition
             // mode than the one observed).  Nothing was computed; from now on the placement-independent hand-off, and the run
@@ -1685,6 +1688,12 @@ bool Solver::setOutputQueries(const float* xyz, int n) {
     }
     numQueries_ = n;
     return true;
+}
+
+// last kernel of a run: its status words into pinned memory (sync() then needs no copy and no second synchronisation)
+void Solver::enqueueRunStatus() {
+    launchRunStatus(errFlag_, activeCount_, lastRunXcd_ ? resFlags_ + geo_.ntx * geo_.nty + 1 : nullptr, statusHost_, stream_);
+    statusQueued_ = true;
 }
 
 void Solver::enqueueQueries() {

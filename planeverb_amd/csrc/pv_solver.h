@@ -300,6 +300,9 @@ private:
     // pinned host staging
     DynParams* dynHost_ = nullptr;
     float* outHost_ = nullptr;  // 8 floats the output-gather kernel writes straight into host memory
+    int* statusHost_ = nullptr; // 4 ints the last kernel of a run leaves here: error flag, two cell counts, resident claims
+    bool statusQueued_ = false; // ... for the run in flight (else sync() copies them back)
+    void enqueueRunStatus();
     long long* qCellsHost_ = nullptr;  // kMaxQueries result-cell indices (-1 = outside the map), device-visible
     float* qOutHost_ = nullptr;        // kMaxQueries x 8 floats
     int numQueries_ = 0;
