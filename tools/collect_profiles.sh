@@ -56,3 +56,6 @@ python tools/gpu_resident.py 275 375 500 750 1000 stress=10 > $O/presets.txt 2>&
 for r in 275 750; do rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_presets_$r -o p -- python tools/gpu_presets.py $r use_graph=0 > /dev/null 2>&1; done
 (for p in 1 2; do echo "== PLANEVERB_AMD_LIVE_PIPELINE=$p"; PLANEVERB_AMD_LIVE_PIPELINE=$p python tools/gpu_presets.py 275 375 500 750 1000 2>&1 | grep -v "^#"; done) > $O/live_pipeline.txt 2>&1
 python tools/gpu_rt60.py 275 500 750 1000 1500 2009 > $O/rt60.txt 2>&1
+python tools/gpu_run_times.py > $O/run_times.txt 2>&1
+# phase stamps of the resident kernel (needs the trace build, made HERE before the call: see tools/gpu_resident_trace.py)
+if [ -f planeverb_amd/libplaneverb_amd_trace.so ]; then PLANEVERB_AMD_LIB=$PWD/planeverb_amd/libplaneverb_amd_trace.so python tools/gpu_resident_trace.py 275 750 > $O/resident_trace.txt 2>&1; fi

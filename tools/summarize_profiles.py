@@ -175,7 +175,7 @@ for w in ("zero1", "random1"):
                  "valu_busy_single_launch": m.get("SQ_ACTIVE_INST_VALU", 0) * 4.0 / 1024.0 / (m.get("GRBM_GUI_ACTIVE", 1) / 8.0)}
 for t in traffic.values():
     t.update(stamp)
-for f in ("presets.txt", "live_pipeline.txt", "rt60.txt", "inflight.txt"):
+for f in ("presets.txt", "live_pipeline.txt", "rt60.txt", "inflight.txt", "run_times.txt", "resident_trace.txt"):
     pth = os.path.join(SRC, f)
     if os.path.exists(pth):
         shutil.copy(pth, os.path.join(DST, R + "_" + f))
