@@ -298,6 +298,12 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
                             !hipOk(hipHostMalloc((void**)&ringHost_, sizeof(int) * (size_t)ntiles), "hipHostMalloc") ||
                             !hipOk(hipHostMalloc((void**)&idleHost_, 2 * sizeof(int)), "hipHostMalloc")))
             return false;
+        const char* os = getenv("PLANEVERB_AMD_OPEN_STREAM");  // development knob: 0 = the open half tiles behind the merged launch
+        if (streamFuse_ && !(os && atoi(os) == 0)) {
+            if (!hipOk(hipStreamCreateWithFlags(&openStream_, hipStreamNonBlocking), "hipStreamCreate")) return false;
+            for (auto& e : openEv_)
+                if (!hipOk(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate")) return false;
+        }
     }
     if (!hipOk(hipHostMalloc((void**)&dynHost_, sizeof(DynParams)), "hipHostMalloc")) return false;
     if (!hipOk(hipHostMalloc((void**)&outHost_, 8 * sizeof(float)), "hipHostMalloc")) return false;
@@ -484,6 +490,9 @@ Solver::~Solver() {
     for (auto& e : genDone_) hipEventDestroy(e);
     if (forkEv_) hipEventDestroy(forkEv_);
     for (hipStream_t x : auxStreams_) hipStreamDestroy(x);
+    for (hipEvent_t e : openEv_)
+        if (e) hipEventDestroy(e);
+    if (openStream_) hipStreamDestroy(openStream_);
     if (stream2_) hipStreamDestroy(stream2_);
     if (stream_) hipStreamDestroy(stream_);
 }
@@ -986,8 +995,16 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
             } else if (streamFuse_ && record && !fuseIdle_) {
                 // sparse-emitter mode, forward sums inside the stencil (pv_stream.h): classify, the merged launch without
                 // the open air tiles, the open half tiles
+                // The open half tiles go out on a stream of their own, beside the merged launch of the same sweep (they touch
+                // disjoint tiles of the same buffer sets): behind it they are one to four rounds of 246-register waves with
+                // nothing to cover their load and store phases.  The next sweep's classify pass waits for them.
                 const ClassifyArgs c = classifyArgs(a, li, withPulse);
+                if (openPending_) joinOpen(li - 1);
                 launchStreamClassify(c, stream_);
+                if (openStream_) {
+                    hipEventRecord(openEv_[li & 1], stream_);
+                    hipStreamWaitEvent(openStream_, openEv_[li & 1], 0);
+                }
                 StepArgs a2 = a;
                 a2.tileClass = classStream_;
                 a2.tileOpen = ringOpen_;
@@ -1005,7 +1022,11 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
                 o.nDry = g_.nDry;
                 o.gxRes = g_.gx;
                 o.gyRes = g_.gy;
-                launchStepOpen(K_, rxi_, a2, o, stream_);
+                launchStepOpen(K_, rxi_, a2, o, openStream_ ? openStream_ : stream_);
+                if (openStream_) {
+                    hipEventRecord(openEv_[2 + (li & 1)], openStream_);
+                    openPending_ = true;
+                }
             } else if (usePatch_) {
                 // general tiles in their 4-wave blocks, then the air tiles by the resident workgroups (disjoint tiles of
                 // the same output set; neither reads what the other writes)
@@ -1049,7 +1070,14 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
         ++tim_.stepLaunches;
     }
     if (two) hipStreamWaitEvent(stream_, genDone_[(size_t)li - 1], 0);  // join
+    if (openPending_) joinOpen(li - 1);  // the last sweep's open half tiles
     return hipOk(hipGetLastError(), "step launch");
+}
+
+// the stream of the merged launches waits for sweep li's open half tiles
+void Solver::joinOpen(int li) {
+    hipStreamWaitEvent(stream_, openEv_[2 + (li & 1)], 0);
+    openPending_ = false;
 }
 
 ClassifyArgs Solver::classifyArgs(const StepArgs& a, int li, bool withPulse) const {

@@ -261,6 +261,10 @@ private:
     int ring_ = 0;             // history planes allocated (T_ when not streaming)
     int halfRing_ = 0;         // streaming: steps per accumulate pass (the ring holds two such halves)
     hipEvent_t streamEv_[4] = {nullptr, nullptr, nullptr, nullptr};  // stepDone[2], accDone[2]
+    hipStream_t openStream_ = nullptr;  // sparse-emitter mode: the open half tiles of a sweep, beside the merged launch
+    hipEvent_t openEv_[4] = {nullptr, nullptr, nullptr, nullptr};  // classified[2], openDone[2] (alternating sweeps)
+    bool openPending_ = false;
+    void joinOpen(int li);
     int* sOnset_ = nullptr;
     float* sState_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // Edry, fluxX, fluxY, vx, vy
     uint8_t* tileOpen_ = nullptr;   // per tile: history still wanted (streaming mode)
