@@ -142,6 +142,10 @@ typedef struct PvAmdTimings {
                                0 when the run was replayed from a hipGraph */
     int reachedCells;       /* cells with an onset in the last run's analysis (Analyzer.cpp:146-165): the impulse responses that
                                were actually analysed -- the others leave at once */
+    int activeCells;        /* cells of the history window's tiles that ever held a non-zero value: what the analysis kernels
+                               look at (an upper bound of reachedCells) */
+    int silentCells;        /* air cells among them whose whole history stayed below the audible threshold (no onset: Analyzer.cpp:160-165);
+                               many of them make the next run's analysis look for an audible sample before anything else */
 } PvAmdTimings;
 
 /* option keys for PvAmdSetOption (must be set before the first run) */

@@ -85,7 +85,7 @@ class PvAmdSlabInfo(C.Structure):
 class PvAmdTimings(C.Structure):
     _fields_ = [("fdtdMs", C.c_float), ("analysisMs", C.c_float), ("geometryMs", C.c_float),
                 ("stepKernelMs", C.c_float), ("stepLaunches", C.c_int), ("airKernelMs", C.c_float), ("generalKernelMs", C.c_float), ("airLaunches", C.c_int),
-                ("generalLaunches", C.c_int), ("stepLoopMs", C.c_float), ("reachedCells", C.c_int)]
+                ("generalLaunches", C.c_int), ("stepLoopMs", C.c_float), ("reachedCells", C.c_int), ("activeCells", C.c_int), ("silentCells", C.c_int)]
 
 
 # every symbol include/planeverb_amd.h declares: name -> (restype, argtypes)

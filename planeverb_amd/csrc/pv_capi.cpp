@@ -617,6 +617,8 @@ int PvAmdGetTimings(PvAmdSolver* h, PvAmdTimings* out) {
     out->generalLaunches = t.generalLaunches;
     out->stepLoopMs = t.stepLoopMs;
     out->reachedCells = t.reachedCells;
+    out->activeCells = t.activeCells;
+    out->silentCells = t.silentCells;
     return 0;
 }
 

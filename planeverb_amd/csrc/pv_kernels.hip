@@ -2233,6 +2233,12 @@ __device__ __forceinline__ int analysisWindowIndex(const AnalyzeArgs& a, const D
 #ifndef PV_ENCODE_SC
 #define PV_ENCODE_SC 16
 #endif
+// an air cell of an active tile whose whole history stayed below the audible threshold (one atomic per wave and exit)
+__device__ __forceinline__ void countSilentCell(const AnalyzeArgs& a) {
+    const unsigned long long m = __ballot(1);
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(a.activeCount + 3, __popcll(m));
+}
+
 __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
     const DynParams dyn = *a.dyn;
     int X, Y;
@@ -2284,7 +2290,13 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
         a.delay[s] = FLT_MAX;
         return;
     }
-    const bool roomRegime = *a.activeCount < kRt60WaveMaxCells;  // few reachable cells: see pv_rt60_wave_kernel
+    // ... and so is a scene in which the PREVIOUS run found many SILENT cells -- air cells of active tiles whose whole history
+    // stays below the threshold (a room much larger than the audible radius): without the pre-scan each of them walks three
+    // planes for all T samples to find that out, with it one plane.  Shoebox.pv at 25 m / 512^2 (T = 3179): analysis 1.67 ->
+    // 1.06 ms; where every cell has an onset the pre-scan costs 3-7 % (one more pass over the samples before the onset):
+    // profiles/r04_rt60.txt.  The kernel lasts as long as its slowest thread, so a percent or two of silent cells is enough:
+    // the hint is written by the run's last kernel (pv_run_status_kernel: silent > reached / 64; Shoebox has 5470 of 104 410).
+    const bool roomRegime = *a.activeCount < kRt60WaveMaxCells || a.activeCount[2] != 0;  // few reachable cells: see pv_rt60_wave_kernel
     if (roomRegime) {
         constexpr int SC = PV_ENCODE_SC;
         bool audible = false;
@@ -2297,6 +2309,7 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
         }
         if (!audible) {
             a.delay[s] = FLT_MAX;
+            countSilentCell(a);
             return;
         }
     }
@@ -2348,6 +2361,7 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
     }
     if (onset < 0) {
         a.delay[s] = FLT_MAX;
+        countSilentCell(a);
         return;
     }
     a.delay[s] = (float)onset;
@@ -2508,6 +2522,7 @@ __device__ __forceinline__ void countActiveCells(const AnalyzeArgs& a) {
     if (threadIdx.x == 0) {
         a.activeCount[0] = part[0];
         a.activeCount[1] = 0;
+        a.activeCount[3] = 0;
     }
 }
 

@@ -54,7 +54,7 @@ void launchResident(int K, int rxi, const ResidentArgs& a, hipStream_t stream);
 // shader clock of the moment (pv_probe.hip): MHz by a timed s_sleep, or 0
 float clockProbeMHz(int device, float* byMemtime);
 // error flag, {cells of non-zero tiles, cells with an onset}, resident claim counter (or NULL) -> 4 ints of pinned host memory
-void launchRunStatus(const int* err, const int* counts, const unsigned* claims, int* outHost, hipStream_t stream);
+void launchRunStatus(const int* err, int* counts, const unsigned* claims, int* outHost, hipStream_t stream);
 #ifdef PV_RESIDENT_TRACE
 void residentDumpTrace();  // development builds: the phase stamps of the last launch to stderr
 #endif

@@ -21,17 +21,22 @@ __global__ void pv_clock_probe_kernel(unsigned long long* out) {
 // pinned host memory by the LAST kernel of the run, so that Solver::sync() reads them after its one stream synchronisation
 // instead of copying them back and synchronising a second time (~25-40 us of host latency per run: a tenth of a 70^2 run).
 namespace {
-__global__ void pv_run_status_kernel(const int* err, const int* counts, const unsigned* claims, int* out) {
+__global__ void pv_run_status_kernel(const int* err, int* counts, const unsigned* claims, int* out) {
     if (threadIdx.x == 0) {
         out[0] = *err;
         out[1] = counts[0];
         out[2] = counts[1];
         out[3] = claims ? (int)*claims : -1;
+        // hint for the next run's pv_encode_kernel: many silent cells (counts[3]) -> look for an audible sample first
+        // (the kernel lasts as long as its slowest thread: a silent cell's walk over all T samples of three planes -- a percent
+        // or two of such cells is enough)
+        counts[2] = (long long)counts[3] * 64 > (long long)counts[1] ? 1 : 0;
+        out[4] = counts[3];
     }
 }
 }  // namespace
 
-void launchRunStatus(const int* err, const int* counts, const unsigned* claims, int* outHost, hipStream_t stream) {
+void launchRunStatus(const int* err, int* counts, const unsigned* claims, int* outHost, hipStream_t stream) {
     hipLaunchKernelGGL(pv_run_status_kernel, dim3(1), dim3(64), 0, stream, err, counts, claims, outHost);
 }
 

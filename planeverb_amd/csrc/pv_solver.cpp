@@ -230,7 +230,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     if (!dalloc(&generalCount_, 1, true)) return false;
     if (!dalloc(&dynDev_, 1, true)) return false;
     if (!dalloc(&errFlag_, 1, true)) return false;
-    if (!dalloc(&activeCount_, 2, true)) return false;
+    if (!dalloc(&activeCount_, 4, true)) return false;  // [0] cells of non-zero tiles, [1] cells with an onset, [2] the encode kernel's pre-scan hint, [3] silent air cells
     if (!dalloc(&res_, (size_t)std::max(lgx_, 1) * g_.gy * 8, true)) return false;  // zeroed pool: PvContext.cpp:132
     if (!dalloc(&delay_, (size_t)std::max(lgx_, 1) * g_.gy, true)) return false;
     // far cells lazily: whole grids with a windowed history (a slab group / the streaming mode run their own passes)
@@ -307,7 +307,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     }
     if (!hipOk(hipHostMalloc((void**)&dynHost_, sizeof(DynParams)), "hipHostMalloc")) return false;
     if (!hipOk(hipHostMalloc((void**)&outHost_, 8 * sizeof(float)), "hipHostMalloc")) return false;
-    if (!hipOk(hipHostMalloc((void**)&statusHost_, 4 * sizeof(int)), "hipHostMalloc")) return false;
+    if (!hipOk(hipHostMalloc((void**)&statusHost_, 8 * sizeof(int)), "hipHostMalloc")) return false;
     if (!hipOk(hipHostMalloc((void**)&qCellsHost_, kMaxQueries * sizeof(long long)), "hipHostMalloc")) return false;
     if (!hipOk(hipHostMalloc((void**)&qOutHost_, kMaxQueries * 8 * sizeof(float)), "hipHostMalloc")) return false;
     if (!hipOk(hipHostMalloc((void**)&listHost_, sizeof(int) * (size_t)listCap_), "hipHostMalloc")) return false;
@@ -1638,6 +1638,7 @@ bool Solver::sync() {
             flag = statusHost_[0];
             counts[0] = statusHost_[1];
             counts[1] = statusHost_[2];
+            tim_.silentCells = statusHost_[4];
             if (lastRunXcd_ && statusHost_[3] >= 0 && statusHost_[3] < geo_.ntx * geo_.nty && flag == 0) flag = 4;
             lastRunXcd_ = false;
         } else {
@@ -1652,6 +1653,7 @@ bool Solver::sync() {
                 return false;
         }
         tim_.reachedCells = counts[1];
+        tim_.activeCells = counts[0];
         if (flag == 4 && xcdOk_) {
             // one-XCD mode: fewer workgroups than tiles turned up on this solver's XCD (another dispatch pattern / partition
             // mode than the one observed).  Nothing was computed; from now on the placement-independent hand-off, and the run

@@ -67,6 +67,8 @@ struct SolverTimings {
     int airLaunches = 0, generalLaunches = 0;
     int stepLaunches = 0;
     int reachedCells = 0;  // cells with an onset in the last analysed run (whole grids, full-history analysis)
+    int activeCells = 0;   // cells of the window's ever-non-zero tiles
+    int silentCells = 0;   // air cells among them whose whole history stayed below the audible threshold
 };
 
 class SlabGroup;
@@ -304,7 +306,7 @@ private:
     // pinned host staging
     DynParams* dynHost_ = nullptr;
     float* outHost_ = nullptr;  // 8 floats the output-gather kernel writes straight into host memory
-    int* statusHost_ = nullptr; // 4 ints the last kernel of a run leaves here: error flag, two cell counts, resident claims
+    int* statusHost_ = nullptr; // the words the last kernel of a run leaves here: error flag, two cell counts, resident claims, silent cells
     bool statusQueued_ = false; // ... for the run in flight (else sync() copies them back)
     void enqueueRunStatus();
     long long* qCellsHost_ = nullptr;  // kMaxQueries result-cell indices (-1 = outside the map), device-visible

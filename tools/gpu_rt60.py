@@ -32,11 +32,12 @@ def same(a, b):
 
 
 print("# %g m, %s; analysis ms of a run (far frame + encode + wet / decay time + direction), run ms" % (size, scene))
-print("# res  grid     T   reached |  lanes 16        4     auto | bit-identical")
+LANES = [int(x) for x in os.environ.get("LANES", "16,4,0").split(",")]
+print("# res  grid     T   reached |  lanes %s (0 = auto) | bit-identical" % LANES)
 bad = 0
 for res in presets or [275, 500, 750, 1000, 1500, 2009]:
     row, ref, ok = [], None, True
-    for lanes in (16, 4, 0):
+    for lanes in LANES:
         with pv.Solver(size, size, res, rt60_lanes=lanes) as s:
             if scene:
                 s.load_scene(scene)
