@@ -203,6 +203,15 @@ struct ResidentArgs {
     float courant;
 };
 
+// slab decomposition, neighbours on one device: words in device memory instead of cross-queue events (pv_halo_push_kernel)
+struct HaloHandoff {
+    unsigned* count;           // blocks of this slab's push launches that have finished, since the run began (NULL: hand-off by events)
+    unsigned* raise[2];        // the words the upper / lower neighbour waits on (NULL: no such neighbour, or it is on another device)
+    const unsigned* await[2];  // this slab's own words, raised by the upper / lower neighbour
+    unsigned seq;              // sweep index + 1
+    int* err;                  // this slab's error flag (5 = a neighbour's halo never arrived)
+};
+
 // sparse-emitter mode with the forward sums inside the stencil (pv_stream.h)
 struct OpenArgs {
     int* sOnset;            // per result cell: onset step, -1 = none yet

@@ -2856,23 +2856,65 @@ struct HaloPushArgs {
     const float* src[6];
     float* dst[6];
     long long n;  // floats per block
+    HaloHandoff h;
 };
+// Device-side hand-off between slabs on ONE device (HaloHandoff, pv_device.h).  A cross-queue event wait per slab and sweep
+// costs ~50 us on this runtime (the waiting queue is parked until the command processor looks at it again: a 2048^2 run with two
+// slabs took 95 us per sweep for 37 us of stencil, profiles/r04_slabs.txt); a word in memory costs 2-3 us.  So the push kernel
+// of sweep li (a) copies its rows, (b) fence + count: the block that completes the count raises the words its neighbours
+// look at to li + 1, (c) that same block then waits until the slab's own words -- raised by the neighbours' pushes of the
+// same sweep -- have reached li + 1.  The slab's next step launch follows in stream order: behind the neighbours' halos,
+// without an event.  (Write-after-read: a neighbour's push of sweep li comes behind its step li, which came behind its wait
+// for THIS slab's push li - 1, which came behind this slab's step li - 1 -- the last reader of the guard rows it overwrites.)
+// One wave spins, bounded; the others leave: the neighbours' kernels never lack a place to run.
 __global__ __launch_bounds__(256) void pv_halo_push_kernel(const HaloPushArgs h) {
+    typedef unsigned int v4u __attribute__((__vector_size__(16)));
     const int b = blockIdx.y;
-    if (!h.dst[b]) return;
-    const float4* s = reinterpret_cast<const float4*>(h.src[b]);
-    float4* d = reinterpret_cast<float4*>(h.dst[b]);
-    const long long n4 = h.n >> 2;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) d[i] = s[i];
+    const bool hand = h.h.count != nullptr;
+    if (h.dst[b]) {
+        // (with the hand-off the rows are written THROUGH to memory -- sc1 -- so that nothing has to be flushed before the word
+        // is raised: a release fence here writes back and invalidates the whole L2 under the other slab's running step kernel,
+        // measured 65 us per sweep)
+        const rsrc_t rs = makeRsrc(h.src[b], h.n * 4), rd = makeRsrc(h.dst[b], h.n * 4);
+        const int n4 = (int)(h.n >> 2);
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) {
+            const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, i * 16, 0, 0);
+            if (hand)
+                __builtin_amdgcn_raw_buffer_store_b128(v, rd, i * 16, 0, 16 /* sc1 */);
+            else
+                __builtin_amdgcn_raw_buffer_store_b128(v, rd, i * 16, 0, 0);
+        }
+    }
+    if (!hand) return;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this thread's rows are in memory
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const unsigned nblocks = gridDim.x * gridDim.y;
+    if (__hip_atomic_fetch_add(h.h.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u != h.h.seq * nblocks) return;
+    for (int i = 0; i < 2; ++i)
+        if (h.h.raise[i]) __hip_atomic_store(h.h.raise[i], h.h.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = 0; i < 2; ++i) {
+        if (!h.h.await[i]) continue;
+        int spins = 0;
+        while (__hip_atomic_load(h.h.await[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < h.h.seq) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1 << 19)) {  // (~0.5 s: a neighbour whose launches do not run beside this one must not hang the device;
+                                        // SlabGroup::run then repeats the run with events)
+                atomicExch(h.h.err, 5);
+                return;
+            }
+        }
+    }
 }
 
-void launchHaloPush(const float* const src[6], float* const dst[6], long long n, hipStream_t stream) {
+void launchHaloPush(const float* const src[6], float* const dst[6], long long n, const HaloHandoff& hand, hipStream_t stream) {
     HaloPushArgs h;
     for (int i = 0; i < 6; ++i) {
         h.src[i] = src[i];
         h.dst[i] = dst[i];
     }
     h.n = n;
+    h.h = hand;
     const unsigned bx = (unsigned)std::min<long long>(64, (n / 4 + 255) / 256);
     hipLaunchKernelGGL(pv_halo_push_kernel, dim3(bx, 6), dim3(256), 0, stream, h);
 }

@@ -77,7 +77,7 @@ void launchAnalysisDirection(const AnalyzeArgs& a, hipStream_t stream);
 // wet gain + decay time, blocked forms (pv_rt60.hip: four lanes / one lane per cell; each launch checks on the device whether it is the one)
 void launchRt60Blocked(const AnalyzeArgs& a, hipStream_t stream);
 // slab halos: src[i] -> dst[i] for up to six blocks of n floats (n % 4 == 0, 16-byte aligned); dst[i] = NULL skips a block
-void launchHaloPush(const float* const src[6], float* const dst[6], long long n, hipStream_t stream);
+void launchHaloPush(const float* const src[6], float* const dst[6], long long n, const HaloHandoff& hand, hipStream_t stream);
 void launchHistRow(const AnalyzeArgs& a, int X, float* outTxPitch, hipStream_t stream);
 void launchCopyBlock(const float* src, long long sstride, int spitch, int sr0, int sc0, float* dst, long long dstride,
                      int dpitch, int dr0, int dc0, int nr, int nc, int nplanes, const int* srcPlanesDev,

@@ -1,6 +1,8 @@
 // pv_slabs.cpp -- see pv_slabs.h
 #include "pv_slabs.h"
 
+#include <cstdio>
+
 #include <algorithm>
 #include <climits>
 #include <cstring>
@@ -88,6 +90,17 @@ bool SlabGroup::init(const GridSpec& spec, const std::vector<int>& devices, cons
         if (!hipOk(hipEventCreateWithFlags(&miscEv_[(size_t)s], hipEventDisableTiming), "hipEventCreate")) return false;
     }
     hipSetDevice(rootDevice_);
+    {
+        // hand-off words for neighbours that share a device (PLANEVERB_AMD_SLAB_HANDOFF=0: events everywhere, as in round 3)
+        bool any = false;
+        for (int s = 0; s + 1 < S; ++s) any = any || devices_[(size_t)s] == devices_[(size_t)s + 1];
+        bool oneDev = true;  // (the words live on the root's device: groups that span devices keep their events)
+        for (int s = 0; s < S; ++s) oneDev = oneDev && devices_[(size_t)s] == rootDevice_;
+        const char* e = getenv("PLANEVERB_AMD_SLAB_HANDOFF");
+        if (any && oneDev && pushHalos_ && !(e && atoi(e) == 0) &&
+            !hipOk(hipMalloc((void**)&handoff_, sizeof(unsigned) * 3 * (size_t)S), "hipMalloc"))
+            return false;
+    }
     const size_t n = (size_t)g_.gx * g_.gy;
     winRows_ = a.histTilesXG_ * rxi_;
     winCols_ = a.histTilesY_ * wi_;
@@ -128,7 +141,7 @@ SlabGroup::~SlabGroup() {
         if (e) hipEventDestroy(e);
     hipSetDevice(rootDevice_);
     if (rootStream_) hipStreamSynchronize(rootStream_);
-    for (void* p : {(void*)res_, (void*)res8_, (void*)delay_, (void*)dirScratch_, (void*)planesDev_, (void*)dynDev_})
+    for (void* p : {(void*)res_, (void*)res8_, (void*)delay_, (void*)dirScratch_, (void*)planesDev_, (void*)dynDev_, (void*)handoff_})
         if (p) hipFree(p);
     if (dynHost_) hipHostFree(dynHost_);
     if (outHost_) hipHostFree(outHost_);
@@ -201,6 +214,7 @@ bool SlabGroup::run(float lx, float ly, float lz) {
     int lcx, lcy;
     listenerCell(g_, lx, lz, &lcx, &lcy);
     hipSetDevice(rootDevice_);
+    if (handoff_ && !hipOk(hipMemsetAsync(handoff_, 0, sizeof(unsigned) * 3 * (size_t)S, rootStream_), "hand-off words")) return false;
     hipEventRecord(rootEv_[0], rootStream_);
     DynParams d{};  // the WHOLE grid's history window (filled in below, once slab 0 has placed the columns)
     for (int s = 0; s < S; ++s) {
@@ -245,9 +259,12 @@ bool SlabGroup::run(float lx, float ly, float lz) {
             for (int s = 0; s < S; ++s) {
                 Solver& v = *slabs_[(size_t)s];
                 hipSetDevice(v.device_);
+                // (neighbours on the same device hand over through words in memory, inside the push kernel: sameDev)
+                const bool upSame = s > 0 && handoff_ && devices_[(size_t)s - 1] == devices_[(size_t)s];
+                const bool downSame = s + 1 < S && handoff_ && devices_[(size_t)s + 1] == devices_[(size_t)s];
                 if (li > 0) {
-                    if (s > 0) hipStreamWaitEvent(v.stream_, stepEv_[(size_t)2 * (s - 1) + ((li - 1) & 1)], 0);
-                    if (s + 1 < S) hipStreamWaitEvent(v.stream_, stepEv_[(size_t)2 * (s + 1) + ((li - 1) & 1)], 0);
+                    if (s > 0 && !upSame) hipStreamWaitEvent(v.stream_, stepEv_[(size_t)2 * (s - 1) + ((li - 1) & 1)], 0);
+                    if (s + 1 < S && !downSame) hipStreamWaitEvent(v.stream_, stepEv_[(size_t)2 * (s + 1) + ((li - 1) & 1)], 0);
                 }
                 if (!v.enqueueSteps(li * K_, k, true, true, li == 0)) return slabFailed(s);
                 const int set = v.cur_;  // the set launch li wrote (enqueueSteps has toggled cur_)
@@ -273,8 +290,24 @@ bool SlabGroup::run(float lx, float ly, float lz) {
                         dst[3 + f] = theirs[f] + (G - K_) * pitch;
                     }
                 }
-                launchHaloPush(src, dst, (long long)haloFloats, v.stream_);
-                hipEventRecord(stepEv_[(size_t)2 * s + (li & 1)], v.stream_);
+                // words of slab s: [3 s] count, [3 s + 1] raised by the upper neighbour, [3 s + 2] raised by the lower neighbour
+                HaloHandoff hand{};
+                if (upSame || downSame) {
+                    hand.count = handoff_ + 3 * s;
+                    hand.seq = (unsigned)li + 1u;
+                    hand.err = v.errFlag_;
+                    if (upSame) {
+                        hand.raise[0] = handoff_ + 3 * (s - 1) + 2;
+                        hand.await[0] = handoff_ + 3 * s + 1;
+                    }
+                    if (downSame) {
+                        hand.raise[1] = handoff_ + 3 * (s + 1) + 1;
+                        hand.await[1] = handoff_ + 3 * s + 2;
+                    }
+                }
+                launchHaloPush(src, dst, (long long)haloFloats, hand, v.stream_);
+                // (the event: cross-device neighbours, and the root's join behind the last launch)
+                if (li == nl - 1 || (s > 0 && !upSame) || (s + 1 < S && !downSame)) hipEventRecord(stepEv_[(size_t)2 * s + (li & 1)], v.stream_);
             }
         }
     } else {
@@ -353,6 +386,7 @@ bool SlabGroup::run(float lx, float ly, float lz) {
         launchFarCells(a, v.stream_);
         launchAnalysisCells(a, v.stream_);
         hipEventRecord(miscEv_[(size_t)s], v.stream_);
+        v.enqueueRunStatus();  // (the slab's error flag into pinned memory: read below without a copy and a second synchronisation)
     }
     // ... the window block of each slab's maps goes into the whole-grid maps, where the direction descent runs once
     hipSetDevice(rootDevice_);
@@ -393,10 +427,23 @@ bool SlabGroup::run(float lx, float ly, float lz) {
         hipSetDevice(v.device_);
         v.pendingTimings_ = false;
         if (!hipOk(hipStreamSynchronize(v.stream_), "slab sync")) return false;
-        int flag = 0;
-        if (!hipOk(hipMemcpyAsync(&flag, v.errFlag_, sizeof(int), hipMemcpyDeviceToHost, v.stream_), "errFlag copy") ||
-            !hipOk(hipStreamSynchronize(v.stream_), "errFlag sync"))
-            return false;
+        const int flag = v.statusHost_[0];
+        v.statusQueued_ = false;
+        if (flag == 5 && handoff_) {
+            // A push kernel gave up waiting for a neighbour's word: the neighbour's launches did not run beside it (streams that
+            // share one hardware queue can be serialised by the runtime).  From now on the cross-queue events of round 3; the run
+            // is repeated with them.  (Every slab's stream is drained first; the begin-run kernels clear the flags.)
+            for (int t = 0; t < S; ++t) {
+                hipSetDevice(slabs_[(size_t)t]->device_);
+                hipStreamSynchronize(slabs_[(size_t)t]->stream_);
+            }
+            hipSetDevice(rootDevice_);
+            hipFree(handoff_);
+            handoff_ = nullptr;
+            std::fprintf(stderr, "[planeverb_amd] slab group: hand-off words not usable on this device / runtime (a halo push waited "
+                                 "in vain); falling back to stream events\n");
+            return run(lx, ly, lz);
+        }
         if (flag) return fail("slab " + std::to_string(s) + ": pressure history window overflow");
     }
     hipSetDevice(rootDevice_);

@@ -87,6 +87,7 @@ private:
     int* dirScratch_ = nullptr;
     int* planesDev_ = nullptr;  // {0, 1, 2, 3, 6, 7}: everything a slab computes (the direction is the root's)
     DynParams* dynDev_ = nullptr;
+    unsigned* handoff_ = nullptr;  // 3 words per slab: device-side hand-off between slabs of one device (pv_halo_push_kernel)
     DynParams* dynHost_ = nullptr;  // pinned
     float* outHost_ = nullptr;      // pinned, 8 floats
     int winRows_ = 0, winCols_ = 0;

@@ -1664,6 +1664,7 @@ bool Solver::sync() {
             return enqueueRun(lastLcx_, lastLcy_, lastLx_, lastLz_) && sync();
         }
         if (flag == 3 || flag == 4) return fail("resident kernel: a workgroup gave up waiting for its neighbours (run aborted)");
+        if (flag == 5) return fail("slab decomposition: a neighbour's halo rows never arrived (run aborted)");
         if (flag) return fail("pressure history window overflow (a tile outside the window became non-zero)");
     }
     return true;
