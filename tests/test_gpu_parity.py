@@ -844,6 +844,71 @@ def test_streaming_equals_full_history_2048_long(pvlib, fuse):
             assert same_bits(st.get_output(e).as_array(), full.get_output(e).as_array()).all()
 
 
+def test_streaming_open_tiles_beside_or_behind_the_merged_launch(pvlib, monkeypatch):
+    """Round 4: the open half tiles of a sweep go out on a stream of their own beside the merged launch (Solver::joinOpen);
+    PLANEVERB_AMD_OPEN_STREAM=0 keeps them behind it.  Same fields, maps and emitter records, and the same as the ring form."""
+    dx = np.float32(343.21) / np.float32(275) / np.float32(3.5)
+    size = float((1024 + 0.5) * dx)
+    L = (150.0, 0.0, 170.0)
+    E = [(160.0, 0.0, 180.0), (240.0, 0.0, 90.0)]
+    walls = [[170.0, 175.0, 3.0, 40.0, 0.9], [120.0, 150.0, 50.0, 2.0, 0.7]]
+    T = 1500
+    got = {}
+    for key, fuse, env in (("beside", 1, "1"), ("behind", 1, "0"), ("ring", 0, "1")):
+        monkeypatch.setenv("PLANEVERB_AMD_OPEN_STREAM", env)
+        with pvlib.Solver(size, size, 275, num_steps=T, streaming_analysis=1, **fuse_opts(fuse)) as st:
+            assert st.info.streamFuse == fuse
+            for wbox in walls:
+                st.add_geometry(wbox)
+            st.set_emitters(E)
+            for _ in range(2):  # (twice: the events and the pending flag are per run)
+                st.run(L)
+            r, d = st.results()
+            got[key] = (r.copy(), d.copy(), [f.copy() for f in st.fields()], [st.get_output(e).as_array().copy() for e in E])
+    for key in ("behind", "ring"):
+        assert same_bits(got["beside"][1], got[key][1]).all(), "delay map vs " + key
+        for k in range(8):
+            assert same_bits(got["beside"][0][..., k], got[key][0][..., k]).all(), "result plane %d vs %s" % (k, key)
+        for fa, fb in zip(got["beside"][2], got[key][2]):
+            assert same_bits(fa, fb).all(), "final fields vs " + key
+        for oa, ob in zip(got["beside"][3], got[key][3]):
+            assert same_bits(oa, ob).all(), "emitter record vs " + key
+
+
+def test_encode_prescan_hint_changes_no_bit(pvlib):
+    """Round 4: when a run finds silent cells -- air cells of active tiles whose whole history stays below the audible threshold --
+    the NEXT run's pv_encode_kernel looks for an audible sample before anything else, also outside the room regime (the hint is
+    written by the run's last kernel).  BASELINE config 2 / Mode B (Shoebox.pv 25 m at 512^2, T = 3179: 132 000 active cells,
+    5 470 of them silent): run 1 (no hint) and runs 2, 3 (hint) give the same maps, the reference's vectors at the fixture's
+    cells, and the timings report the cells."""
+    g = golden("g512B_shoebox")
+    gx, gy, T, fs = (int(v) for v in g["dims"])
+    c = g["cells"]
+    X, Y = c[:, 0], c[:, 1]
+    valid = valid_mask(g["cell_delay"], T, fs)
+    with pvlib.Solver(float(g["size"]), float(g["size"]), int(g["res"])) as s:
+        for b in g["boxes"]:
+            s.add_geometry(b)
+        maps = []
+        for i in range(3):
+            s.run(g["listener"])
+            r, d = s.results()
+            maps.append((r.copy(), d.copy()))
+            t = s.timings()
+            assert t.reachedCells == int((d < 1e30).sum())
+            assert t.activeCells >= 65536, "outside the room regime: only the hint switches the pre-scan on"
+            assert t.activeCells >= t.reachedCells + t.silentCells
+            assert t.silentCells * 64 > t.reachedCells, "the scene is meant to raise the hint"
+            assert same_bits(d[X, Y], g["cell_delay"]).all()
+            for k, nm in enumerate(NAMES):
+                m = valid if k not in (4, 5) else np.ones_like(valid)
+                assert same_bits(r[X, Y, k][m], g["cell_results"][:, k][m]).all(), "run %d %s" % (i, nm)
+        for r, d in maps[1:]:
+            assert same_bits(maps[0][1], d).all()
+            for k in range(8):
+                assert same_bits(maps[0][0][..., k], r[..., k]).all()
+
+
 @pytest.mark.parametrize("size,res,scene", [(10.0, 500, "ExampleProject.pv"), (10.0, 750, "SmallRoom.pv"),
                                             (3.0, 275, None), (6.5, 375, "SmallRoom.pv")])
 def test_resolution_presets_and_tiny_grids_vs_oracle(pvlib, oracle, size, res, scene):
