@@ -1715,6 +1715,15 @@ namespace pva {
 // configurations whose sparse-emitter mode advances the forward sums inside the stencil (pv_stream.h)
 #define PV_OPEN_CONFIGS(X) X(12, 36) X(10, 36) X(8, 24)
 
+// the unpacked air kernel (PVA_OPT_PACKED_MATH = 0) is a validation form: experimental build only
+bool unpackedAirOk() {
+#ifdef PV_EXPERIMENTAL
+    return true;
+#else
+    return false;
+#endif
+}
+
 bool openConfigOk(int K, int rxi) {
 #define X(k, r) \
     if (K == k && rxi == r) return true;
@@ -1864,10 +1873,12 @@ static void launchStepT(const StepArgs& a, hipStream_t stream, int which, hipStr
     }
     if (which & 1) {
         const int blocks = a.tileOrder == 0 ? (a.ntiles + 3) / 4 : 8 * ((bandPositions(a) + 3) / 4);
-        if (a.packed)
-            hipLaunchKernelGGL((pv_step_air_kernel<K, RXI, WPS, true>), dim3(blocks), dim3(256), 0, stream, a);
-        else
+#ifdef PV_EXPERIMENTAL
+        if (!a.packed)  // (the unpacked form: PVA_OPT_PACKED_MATH = 0, refused by Solver::init in the product build)
             hipLaunchKernelGGL((pv_step_air_kernel<K, RXI, WPS, false>), dim3(blocks), dim3(256), 0, stream, a);
+        else
+#endif
+            hipLaunchKernelGGL((pv_step_air_kernel<K, RXI, WPS, true>), dim3(blocks), dim3(256), 0, stream, a);
     }
     if ((which & 2) && a.numGeneral > 0) {
         const int gblocks = (a.numGeneral * (RXI / SUB) + 3) / 4;

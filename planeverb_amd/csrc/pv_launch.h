@@ -27,6 +27,7 @@ void launchStepPatch(int K, int rxi, const StepArgs& a, int blocks, hipStream_t 
 // sparse-emitter mode with the forward sums inside the stencil (pv_stream.h): per K-step launch the classify pass, the merged
 // launch with the per-launch tile classes, and the open half tiles
 bool openConfigOk(int K, int rxi);
+bool unpackedAirOk();
 void launchStreamClassify(const ClassifyArgs& c, hipStream_t stream);
 void launchStreamIdle(const ClassifyArgs& c, int* idleHost, hipStream_t stream);
 void launchStepOpen(int K, int rxi, const StepArgs& a, const OpenArgs& o, hipStream_t stream);

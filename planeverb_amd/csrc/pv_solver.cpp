@@ -133,6 +133,8 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     if (!stepConfigSupported(K_, rxi_)) return fail("unsupported (stepsPerLaunch, tileRows) configuration");
     if (opt_.tileOrder < 0) opt_.tileOrder = tiles36 >= 4500 ? 3 : 1;  // (measured: profiles/r02_tile_order.txt)
     // edge tiles are an "allow": only the batched kernels of the mirror-pair tiles have that arm
+    if (!opt_.packed && !unpackedAirOk())
+        return fail("PVA_OPT_PACKED_MATH = 0 (the unpacked air kernel) is a validation form of the experimental build of the library");
     if (opt_.edgeTiles && !(edgeConfigOk(K_, rxi_) && opt_.packed && opt_.merged == 1 && !opt_.streaming &&
                             opt_.timeKernels == 0))
         opt_.edgeTiles = false;

@@ -77,13 +77,15 @@ def pvlib():
 
 
 # tiles of the PRODUCT library (csrc/pv_kernels.hip PV_PRODUCT_STEP_CONFIGS); everything else -- other (K, rows), stacked tiles,
-# row-streaming segments, the patch kernel -- exists in the experimental build only
+# row-streaming segments, the patch kernel, the unpacked air kernel -- exists in the experimental build only
 PRODUCT_TILES = {(8, 24), (10, 36), (12, 36), (8, 40), (12, 12), (10, 20)}
 
 
 def needs_experimental(opts):
     k, r = opts.get("steps_per_launch", 0), opts.get("tile_rows", 0)
     if (k or r) and (k or 8, r or 24) not in PRODUCT_TILES:
+        return True
+    if opts.get("packed_math", 1) == 0:  # (the unpacked air kernel: a validation form)
         return True
     return bool(opts.get("stream_rows") or opts.get("patch_kernel", 0) > 0)
 

@@ -30,3 +30,11 @@ for i in range(0, len(ms), 50):
     if not any(a <= int(r["Start_Timestamp"]) <= b for _, r in ops) and i > 100:
         print("(no open-tile launches from here on)")
         break
+acc = [r for r in rows if "pv_stream_accum_kernel" in r["Kernel_Name"]]
+if acc:
+    print("accumulate passes: %d, %.1f ms in total; mean us per block of 20 passes: %s" % (
+        len(acc), sum(map(d, acc)) / 1e3, " ".join("%.0f" % (sum(map(d, acc[i:i + 20])) / len(acc[i:i + 20])) for i in range(0, len(acc), 20))))
+for nm in ("pv_stream_trace_kernel", "pv_stream_tilegate_kernel", "pv_stream_idle_kernel", "fillBuffer"):
+    rs = [r for r in rows if nm in r["Kernel_Name"]]
+    if rs:
+        print("%s: %d launches, %.1f ms" % (nm, len(rs), sum(map(d, rs)) / 1e3))
