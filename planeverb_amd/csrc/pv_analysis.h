@@ -10,6 +10,9 @@
 
 namespace pva {
 
+// (slab groups: see AnalyzeArgs::abortWord)
+__device__ __forceinline__ bool analysisAborted(const AnalyzeArgs& a) { return a.abortWord && *a.abortWord != 0u; }
+
 struct CellHistory {
     const float* h;     // this cell, step 0
     long long plane;

@@ -210,6 +210,7 @@ struct HaloHandoff {
     const unsigned* await[2];  // this slab's own words, raised by the upper / lower neighbour
     unsigned seq;              // sweep index + 1
     int* err;                  // this slab's error flag (5 = a neighbour's halo never arrived)
+    unsigned* abortWord;       // the group's abort word (AnalyzeArgs::abortWord), raised together with err
 };
 
 // sparse-emitter mode with the forward sums inside the stencil (pv_stream.h)
@@ -251,6 +252,10 @@ struct FarInfo {
 };
 
 struct AnalyzeArgs {
+    // slab groups with hand-off words: raised by a push kernel that waited for a neighbour in vain -- the run's fields are
+    // not a run's fields then, and the analysis must leave the result maps (whose no-onset cells carry over to later runs) as
+    // they are; SlabGroup::run repeats the run with stream events.  NULL everywhere else
+    const unsigned* abortWord;
     const float* hist;
     const FaceCoef* coef;
     const int* tileFirst;

@@ -2251,6 +2251,7 @@ __device__ __forceinline__ void countSilentCell(const AnalyzeArgs& a) {
 }
 
 __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
+    if (analysisAborted(a)) return;
     const DynParams dyn = *a.dyn;
     int X, Y;
     if (!analysisWindowCell(a, dyn, &X, &Y)) return;
@@ -2428,6 +2429,7 @@ __device__ __forceinline__ void rowChains(float (&acc)[NCH], const float (&add)[
 }
 
 __global__ __launch_bounds__(256) void pv_rt60_wave_kernel(const AnalyzeArgs a) {
+    if (analysisAborted(a)) return;
     if (rt60LanesPerCell(a, *a.activeCount) != 16) return;  // (more cells: the blocked forms of pv_rt60.hip)
     const DynParams dyn = *a.dyn;
     // 16 cells per 256-thread block along the window's columns, one window row per blockIdx.y
@@ -2538,6 +2540,7 @@ __device__ __forceinline__ void countActiveCells(const AnalyzeArgs& a) {
 }
 
 __global__ __launch_bounds__(256) void pv_far_cells_kernel(const AnalyzeArgs a) {
+    if (analysisAborted(a)) return;  // (grid-uniform)
     if (blockIdx.x == 0 && a.tileFirst) countActiveCells(a);  // (before any thread leaves: the reduction has barriers)
     const int index = blockIdx.x * blockDim.x + threadIdx.x;
     if (index >= a.gx * a.gy) return;
@@ -2550,6 +2553,7 @@ __global__ __launch_bounds__(256) void pv_far_cells_kernel(const AnalyzeArgs a) 
 // run's reached cells.  All other cells of the map keep delay = FLT_MAX from the solver's creation / their own last reset,
 // and their direction is made on demand (pv_far_dir_kernel, farDirectionOf).
 __global__ __launch_bounds__(256) void pv_far_frame_kernel(const AnalyzeArgs a) {
+    if (analysisAborted(a)) return;
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && a.tileFirst) countActiveCells(a);
     const DynParams dyn = *a.dyn;
     int r0, c0, nr, nc;
@@ -2603,6 +2607,7 @@ void launchFarDirections(float* res, long long n, const FarInfo& f, hipStream_t 
 void launchFillDelay(float* delay, long long n, hipStream_t stream);
 
 __global__ __launch_bounds__(256) void pv_direction_kernel(const AnalyzeArgs a) {
+    if (analysisAborted(a)) return;
     const DynParams dyn = *a.dyn;
     int X, Y;
     if (!analysisWindowCell(a, dyn, &X, &Y)) return;
@@ -2680,6 +2685,7 @@ __device__ __forceinline__ bool dirLineOfSight(const AnalyzeArgs& a, int cell, f
 // J is indexed by window-local cell; its entries are GRID cell indices (| kDirFinal).  A hop always lands on a
 // reached cell (finite delay), i.e. inside the window.
 __global__ __launch_bounds__(256) void pv_dir_init_kernel(const AnalyzeArgs a, int* J) {
+    if (analysisAborted(a)) return;
     const DynParams dyn = *a.dyn;
     int X, Y;
     if (!analysisWindowCell(a, dyn, &X, &Y)) return;
@@ -2701,6 +2707,7 @@ __global__ __launch_bounds__(256) void pv_dir_init_kernel(const AnalyzeArgs a, i
 // a run is a chain of dependent launches, and beside another run's stencil each one waits for its turn).
 constexpr int kDirHops = 20;
 __global__ __launch_bounds__(256) void pv_dir_jump_kernel(const AnalyzeArgs a, int* J) {
+    if (analysisAborted(a)) return;
     const DynParams dyn = *a.dyn;
     int X, Y;
     if (!analysisWindowCell(a, dyn, &X, &Y)) return;
@@ -2713,6 +2720,7 @@ __global__ __launch_bounds__(256) void pv_dir_jump_kernel(const AnalyzeArgs a, i
 }
 
 __global__ __launch_bounds__(256) void pv_dir_final_kernel(const AnalyzeArgs a, const int* J) {
+    if (analysisAborted(a)) return;
     const DynParams dyn = *a.dyn;
     int X, Y;
     if (!analysisWindowCell(a, dyn, &X, &Y)) return;
@@ -2842,7 +2850,8 @@ void launchHistRow(const AnalyzeArgs& a, int X, float* out, hipStream_t stream) 
 // (dr0, dc0) of dst planes -- a slab's part of the history window into the whole grid's result / delay maps
 __global__ void pv_copy_block_kernel(const float* __restrict__ src, long long sstride, int spitch, int sr0, int sc0,
                                      float* __restrict__ dst, long long dstride, int dpitch, int dr0, int dc0, int nr,
-                                     int nc, const int* srcPlanes, const int* dstPlanes) {
+                                     int nc, const int* srcPlanes, const int* dstPlanes, const unsigned* abortWord) {
+    if (abortWord && *abortWord != 0u) return;  // (AnalyzeArgs::abortWord)
     const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
     const int ks = srcPlanes ? srcPlanes[blockIdx.z] : blockIdx.z, kd = dstPlanes ? dstPlanes[blockIdx.z] : blockIdx.z;
     if (c >= nc || r >= nr) return;
@@ -2851,11 +2860,11 @@ __global__ void pv_copy_block_kernel(const float* __restrict__ src, long long ss
 
 void launchCopyBlock(const float* src, long long sstride, int spitch, int sr0, int sc0, float* dst, long long dstride,
                      int dpitch, int dr0, int dc0, int nr, int nc, int nplanes, const int* srcPlanesDev,
-                     const int* dstPlanesDev, hipStream_t stream) {
+                     const int* dstPlanesDev, hipStream_t stream, const unsigned* abortWord) {
     if (nr <= 0 || nc <= 0) return;
     hipLaunchKernelGGL(pv_copy_block_kernel, dim3((unsigned)((nc + 255) / 256), (unsigned)nr, (unsigned)nplanes), dim3(256),
                        0, stream, src, sstride, spitch, sr0, sc0, dst, dstride, dpitch, dr0, dc0, nr, nc, srcPlanesDev,
-                       dstPlanesDev);
+                       dstPlanesDev, abortWord);
 }
 
 // Slab decomposition (pv_slabs.cpp): after a K-step launch a slab PUSHES the K rows next to each of its boundaries into the
@@ -2910,8 +2919,10 @@ __global__ __launch_bounds__(256) void pv_halo_push_kernel(const HaloPushArgs h)
         while (__hip_atomic_load(h.h.await[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < h.h.seq) {
             __builtin_amdgcn_s_sleep(2);
             if (++spins > (1 << 19)) {  // (~0.5 s: a neighbour whose launches do not run beside this one must not hang the device;
-                                        // SlabGroup::run then repeats the run with events)
+                                        // SlabGroup::run then repeats the run with events -- the abort word keeps this run's
+                                        // analysis away from the result maps)
                 atomicExch(h.h.err, 5);
+                if (h.h.abortWord) __hip_atomic_store(h.h.abortWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return;
             }
         }

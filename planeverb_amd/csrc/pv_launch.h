@@ -82,7 +82,7 @@ void launchHaloPush(const float* const src[6], float* const dst[6], long long n,
 void launchHistRow(const AnalyzeArgs& a, int X, float* outTxPitch, hipStream_t stream);
 void launchCopyBlock(const float* src, long long sstride, int spitch, int sr0, int sc0, float* dst, long long dstride,
                      int dpitch, int dr0, int dc0, int nr, int nc, int nplanes, const int* srcPlanesDev,
-                     const int* dstPlanesDev, hipStream_t stream);  // plane maps: NULL = identity
+                     const int* dstPlanesDev, hipStream_t stream, const unsigned* abortWord = nullptr);  // plane maps: NULL = identity
 // (far: where the last run's far cells begin -- their listener direction is computed, not read: pv_device.h FarInfo)
 void launchGatherQueries(const float* res, long long n, const long long* cellsHost, int nq, float* outHost, const FarInfo& far,
                          hipStream_t stream);  // nq <= 64

@@ -77,6 +77,7 @@ __device__ __forceinline__ void groupChain(float& acc, const float (&add)[S], co
 template <int L, int S>
 __global__ __launch_bounds__(256) void pv_rt60_blocked_kernel(const AnalyzeArgs a) {
     __shared__ double tab[32];
+    if (analysisAborted(a)) return;
     if (rt60LanesPerCell(a, *a.activeCount) != L) return;  // (grid-uniform: the other instantiations' launches do the work)
     if (threadIdx.x < 32) {
         double invc, logc;

@@ -96,10 +96,22 @@ bool SlabGroup::init(const GridSpec& spec, const std::vector<int>& devices, cons
         for (int s = 0; s + 1 < S; ++s) any = any || devices_[(size_t)s] == devices_[(size_t)s + 1];
         bool oneDev = true;  // (the words live on the root's device: groups that span devices keep their events)
         for (int s = 0; s < S; ++s) oneDev = oneDev && devices_[(size_t)s] == rootDevice_;
+        // A push kernel WAITS for its neighbours' pushes: every slab's stream needs a hardware queue to itself -- the runtime
+        // multiplexes a process's streams on GPU_MAX_HW_QUEUES (default 4) of them by creation order, and a waiting kernel
+        // parks whatever sits behind it in its queue (the neighbour's launches, if they share it: the wait then ends in its
+        // time-out).  So: only with S slab streams + the root stream <= that number, and only after a dry run of the hand-off
+        // on this group's own streams has come through (probeHandoff).
         const char* e = getenv("PLANEVERB_AMD_SLAB_HANDOFF");
-        if (any && oneDev && pushHalos_ && !(e && atoi(e) == 0) &&
-            !hipOk(hipMalloc((void**)&handoff_, sizeof(unsigned) * 3 * (size_t)S), "hipMalloc"))
-            return false;
+        const char* q = getenv("GPU_MAX_HW_QUEUES");
+        const int queues = q && atoi(q) > 0 ? atoi(q) : 4;
+        const bool forced = e && atoi(e) == 2;  // (2: whatever the queue count says -- the stress tests of the fallback)
+        if (any && oneDev && pushHalos_ && !(e && atoi(e) == 0) && (S + 1 <= queues || forced)) {
+            if (!hipOk(hipMalloc((void**)&handoff_, sizeof(unsigned) * (3 * (size_t)S + 1)), "hipMalloc")) return false;
+            if (!forced && !probeHandoff()) {
+                hipFree(handoff_);
+                handoff_ = nullptr;
+            }
+        }
     }
     const size_t n = (size_t)g_.gx * g_.gy;
     winRows_ = a.histTilesXG_ * rxi_;
@@ -131,6 +143,42 @@ bool SlabGroup::init(const GridSpec& spec, const std::vector<int>& devices, cons
     }
     for (Solver* sv : slabs_) sv->efree_ = efree_;
     return true;
+}
+
+// Dry run of the hand-off on the group's own streams: three sweeps of push kernels that move no rows.  False if a wait timed
+// out (the slabs' streams do not run beside each other here): the group then keeps round 3's stream events.
+bool SlabGroup::probeHandoff() {
+    const int S = (int)slabs_.size();
+    hipSetDevice(rootDevice_);
+    if (hipMemsetAsync(handoff_, 0, sizeof(unsigned) * (3 * (size_t)S + 1), rootStream_) != hipSuccess ||
+        hipStreamSynchronize(rootStream_) != hipSuccess)
+        return false;
+    const float* src[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    float* dst[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int li = 0; li < 3; ++li)
+        for (int s = 0; s < S; ++s) {
+            Solver& v = *slabs_[(size_t)s];
+            HaloHandoff hand{};
+            hand.count = handoff_ + 3 * s;
+            hand.seq = (unsigned)li + 1u;
+            hand.err = reinterpret_cast<int*>(handoff_ + 3 * S);  // (the probe's only error word: the abort word itself)
+            hand.abortWord = handoff_ + 3 * S;
+            if (s > 0) {
+                hand.raise[0] = handoff_ + 3 * (s - 1) + 2;
+                hand.await[0] = handoff_ + 3 * s + 1;
+            }
+            if (s + 1 < S) {
+                hand.raise[1] = handoff_ + 3 * (s + 1) + 1;
+                hand.await[1] = handoff_ + 3 * s + 2;
+            }
+            launchHaloPush(src, dst, 1024, hand, v.stream_);
+        }
+    bool ok = hipGetLastError() == hipSuccess;
+    for (int s = 0; s < S; ++s) ok = (hipStreamSynchronize(slabs_[(size_t)s]->stream_) == hipSuccess) && ok;
+    unsigned word = 1;  // (never the legacy stream: see Solver::applyGeometry)
+    ok = ok && hipMemcpyAsync(&word, handoff_ + 3 * S, sizeof(word), hipMemcpyDeviceToHost, rootStream_) == hipSuccess &&
+         hipStreamSynchronize(rootStream_) == hipSuccess && word == 0u;
+    return ok;
 }
 
 SlabGroup::~SlabGroup() {
@@ -214,7 +262,7 @@ bool SlabGroup::run(float lx, float ly, float lz) {
     int lcx, lcy;
     listenerCell(g_, lx, lz, &lcx, &lcy);
     hipSetDevice(rootDevice_);
-    if (handoff_ && !hipOk(hipMemsetAsync(handoff_, 0, sizeof(unsigned) * 3 * (size_t)S, rootStream_), "hand-off words")) return false;
+    if (handoff_ && !hipOk(hipMemsetAsync(handoff_, 0, sizeof(unsigned) * (3 * (size_t)S + 1), rootStream_), "hand-off words")) return false;
     hipEventRecord(rootEv_[0], rootStream_);
     DynParams d{};  // the WHOLE grid's history window (filled in below, once slab 0 has placed the columns)
     for (int s = 0; s < S; ++s) {
@@ -296,6 +344,7 @@ bool SlabGroup::run(float lx, float ly, float lz) {
                     hand.count = handoff_ + 3 * s;
                     hand.seq = (unsigned)li + 1u;
                     hand.err = v.errFlag_;
+                    hand.abortWord = handoff_ + 3 * S;
                     if (upSame) {
                         hand.raise[0] = handoff_ + 3 * (s - 1) + 2;
                         hand.await[0] = handoff_ + 3 * s + 1;
@@ -376,13 +425,15 @@ bool SlabGroup::run(float lx, float ly, float lz) {
     }
     // whole-grid maps: delay = FLT_MAX and the default direction everywhere (Analyzer.cpp:64-68,415-428) ...
     hipSetDevice(rootDevice_);
-    const AnalyzeArgs ra = rootArgs(lx, lz);
+    AnalyzeArgs ra = rootArgs(lx, lz);
+    ra.abortWord = handoff_ ? handoff_ + 3 * S : nullptr;
     launchFarCells(ra, rootStream_);
     // ... every slab analyses its own cells ...
     for (int s = 0; s < S; ++s) {
         Solver& v = *slabs_[(size_t)s];
         hipSetDevice(v.device_);
-        const AnalyzeArgs a = v.analyzeArgs(lx, lz);
+        AnalyzeArgs a = v.analyzeArgs(lx, lz);
+        a.abortWord = handoff_ ? handoff_ + 3 * S : nullptr;
         launchFarCells(a, v.stream_);
         launchAnalysisCells(a, v.stream_);
         hipEventRecord(miscEv_[(size_t)s], v.stream_);
@@ -401,9 +452,9 @@ bool SlabGroup::run(float lx, float ly, float lz) {
         const long long lresN = (long long)std::max(v.lgx_, 1) * g_.gy;
         if (v.device_ == rootDevice_) {
             launchCopyBlock(v.res_, lresN, g_.gy, lr0, c0, res_, ra.resN, g_.gy, lr0 + v.x0_, c0, nr, nc, 6, planesDev_,
-                            planesDev_, rootStream_);
+                            planesDev_, rootStream_, ra.abortWord);
             launchCopyBlock(v.delay_, 0, g_.gy, lr0, c0, delay_, 0, g_.gy, lr0 + v.x0_, c0, nr, nc, 1, nullptr, nullptr,
-                            rootStream_);
+                            rootStream_, ra.abortWord);
         } else {
             const int planes[6] = {0, 1, 2, 3, 6, 7};
             for (int k : planes)

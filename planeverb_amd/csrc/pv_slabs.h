@@ -64,6 +64,7 @@ private:
     bool hipOk(hipError_t e, const char* what);
     bool slabFailed(int s);
     AnalyzeArgs rootArgs(float lx, float lz) const;
+    bool probeHandoff();
 
     GridSpec g_;
     std::vector<Solver*> slabs_;
