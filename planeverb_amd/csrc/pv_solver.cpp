@@ -380,7 +380,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
                        histTilesY_ == geo_.nty && kGuard >= K_ + residentExtraRows(K_, rxi_) && T_ >= 1;
         if (useResident_) {
             const int cap = residentMaxBlocks(K_, rxi_, device_);
-            if (ntiles > std::min(cap / 2, kResidentMaxTiles)) useResident_ = false;
+            if (ntiles > std::min(cap * 3 / 4, kResidentMaxTiles)) useResident_ = false;  // (= the run-time budget of enqueueRun)
         }
         if (useResident_ && !dalloc(&resFlags_, (size_t)ntiles + 2, true)) return false;
         if (useResident_) {
