@@ -52,7 +52,7 @@ python tools/gpu_analysis_workload.py 6 > $O/analysis_workload.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_ana -o a -- python tools/gpu_analysis_workload.py 6 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_ana -o f -- python tools/gpu_analysis_workload.py 3 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_ana -o w -- python tools/gpu_analysis_workload.py 3 > /dev/null 2>&1
-python tools/gpu_resident.py 275 375 500 750 1000 stress=10 > $O/presets.txt 2>&1
+python tools/gpu_resident.py 275 375 500 750 1000 1250 1500 stress=10 > $O/presets.txt 2>&1
 for r in 275 750; do rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_presets_$r -o p -- python tools/gpu_presets.py $r use_graph=0 > /dev/null 2>&1; done
 (for p in 1 2; do echo "== PLANEVERB_AMD_LIVE_PIPELINE=$p"; PLANEVERB_AMD_LIVE_PIPELINE=$p python tools/gpu_presets.py 275 375 500 750 1000 2>&1 | grep -v "^#"; done) > $O/live_pipeline.txt 2>&1
 python tools/gpu_rt60.py 275 500 750 1000 1500 2009 > $O/rt60.txt 2>&1
