@@ -85,7 +85,18 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         return fail("no HIP device: libplaneverb_amd has no CPU path");
     if (device < 0 || device >= ndev) return fail("HIP device index out of range");
     if (!hipOk(hipSetDevice(device), "hipSetDevice")) return false;
-    if (!hipOk(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate")) return false;
+    {
+        // (slab groups: the odd slabs' streams get the high priority -- streams of different priorities never share a hardware
+        // queue, and two neighbouring slabs whose streams do share one run their launches one after the other:
+        // PLANEVERB_AMD_SLAB_PRIORITY=0 switches it off, profiles/r04_slabs.txt)
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const char* e = getenv("PLANEVERB_AMD_SLAB_PRIORITY");
+        const bool high = opt.slabCount > 1 && (opt.slabIndex & 1) && !(e && atoi(e) == 0);
+        if (!hipOk(high ? hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, hi)
+                        : hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate"))
+            return false;
+    }
     {
         int lo = 0, hi = 0;  // numerically lowest = highest priority
         hipDeviceGetStreamPriorityRange(&lo, &hi);
