@@ -92,7 +92,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         int lo = 0, hi = 0;
         hipDeviceGetStreamPriorityRange(&lo, &hi);
         const char* e = getenv("PLANEVERB_AMD_SLAB_PRIORITY");
-        const bool high = opt.slabCount > 1 && (opt.slabIndex & 1) && !(e && atoi(e) == 0);
+        const bool high = opt.streamPriority > 0 || (opt.slabCount > 1 && (opt.slabIndex & 1) && !(e && atoi(e) == 0));
         if (!hipOk(high ? hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, hi)
                         : hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate"))
             return false;

@@ -51,6 +51,7 @@ struct SolverOptions {
     bool lazyFar = true;  // far cells of the result map lazily (see Solver::lazyFar_)
     int patch = -1;       // air tiles by the persistent patch kernel (pv_patch.h): -1 = default of the configuration, 0 off, 1 on
     int patchStrip = 3;   // patch columns per strip of its walk
+    int streamPriority = 0;  // PVA_OPT_STREAM_PRIORITY: 1 = main stream on the highest priority (a hardware queue apart from the default-priority streams)
     bool debugLoseFirstCapture = false;  // PVA_OPT_DEBUG_LOSE_FIRST_CAPTURE: the solver's first graph capture counts as lost
     int rt60Lanes = 0;    // decay-time pass: lanes per cell (pv_rt60.hip): 0 = by the number of reachable cells, 16 / 4 / 1 = forced
     int resident = 0;     // resident kernel (pv_resident.hip: one launch per run, every tile a workgroup that stays on its CU for
