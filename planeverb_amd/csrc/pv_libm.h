@@ -89,8 +89,23 @@ PV_HD inline float pvLog10f(float x) {
 // (the table fetch is a functor: the RT60 kernels of pv_rt60.hip keep the 16 entries in LDS -- a per-lane index into a
 // constant array is a global load whose latency sits at the head of every evaluation's dependent chain -- and the host
 // check of tools/libm_check.cpp runs the very same arithmetic through pvLog10fNonNeg below)
+// FUSED multiply-adds.  The reference's libm evaluates logf's polynomial in double and rounds once to float; whether the five
+// multiply-add pairs of that evaluation are fused or not changes no float result for ANY argument log10f can hand to logf (the
+// normalised mantissas: exponent fields 0x7e / 0x7f, 2^24 values -- checked exhaustively, tools/libm_fma_check.cpp, each pair
+// alone and all together: 0 of 16 777 216 differ; glibc's own x86-64 build selects an FMA variant of logf at run time for the
+// same reason).  So the branch-free form below fuses them: 10 double operations per logarithm instead of 15 -- and y0 = logc +
+// kk ln2 (kk in {-1, 0, 1}) comes out of the table functor, which may hold the 48 values ready-made (pv_rt60.hip: LDS): 8.
+// The decay-time kernels are bound by exactly these operations (profiles/r04_rt60.txt).
+PV_HD inline double pvFma(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fma(a, b, c);
+#else
+    return __builtin_fma(a, b, c);  // (host: libm's fma where the target has no instruction -- correct either way)
+#endif
+}
+
 struct PvLogTabConst {
-    PV_HD void operator()(int i, double* invc, double* logc) const {
+    PV_HD void operator()(int i, int kk, double* invc, double* y0) const {
         constexpr double T[16][2] = {
             {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2},
             {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2},  {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3},
@@ -101,7 +116,7 @@ struct PvLogTabConst {
             {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3},
             {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},  {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
         *invc = T[i][0];
-        *logc = T[i][1];
+        *y0 = pvFma((double)kk, 0x1.62e42fefa39efp-1, T[i][1]);
     }
 };
 
@@ -125,15 +140,14 @@ PV_HD inline float pvLog10fNonNegT(float x, const TabF& tab) {
     const int i = (int)((tmp >> 19) & 15u);
     const int kk = (int)tmp >> 23;
     const uint32_t iz = ix - (tmp & (0x1ffu << 23));
-    double invc, logc;
-    tab(i, &invc, &logc);
+    double invc, y0;
+    tab(i, kk, &invc, &y0);  // y0 = logc + kk ln2
     const double z = (double)pvFloatBits(iz);
-    const double r = z * invc - 1.0;
-    const double y0 = logc + (double)kk * 0x1.62e42fefa39efp-1;
+    const double r = pvFma(z, invc, -1.0);
     const double r2 = r * r;
-    double y = 0x1.5575b0be00b6ap-2 * r + -0x1.ffffef20a4123p-2;
-    y = -0x1.00ea348b88334p-2 * r2 + y;
-    y = y * r2 + (y0 + r);
+    double y = pvFma(0x1.5575b0be00b6ap-2, r, -0x1.ffffef20a4123p-2);
+    y = pvFma(-0x1.00ea348b88334p-2, r2, y);
+    y = pvFma(y, r2, y0 + r);
     const float lm = ix == 0x3f800000u ? 0.f : (float)y;
     const float zf = yk * log10_2lo + ivln10 * lm;
     const float res = zf + yk * log10_2hi;

@@ -33,10 +33,11 @@ namespace pva {
 namespace {
 
 struct LogTabLds {
-    const double* t;  // 16 x {invc, logc} in LDS
-    __device__ __forceinline__ void operator()(int i, double* invc, double* logc) const {
-        *invc = t[2 * i];
-        *logc = t[2 * i + 1];
+    const double* t;  // 48 x {invc, logc + kk ln2} in LDS, entry (kk + 1) * 16 + i
+    __device__ __forceinline__ void operator()(int i, int kk, double* invc, double* y0) const {
+        const int e = (kk + 1) * 16 + i;
+        *invc = t[2 * e];
+        *y0 = t[2 * e + 1];
     }
 };
 
@@ -76,13 +77,14 @@ __device__ __forceinline__ void groupChain(float& acc, const float (&add)[S], co
 
 template <int L, int S>
 __global__ __launch_bounds__(256) void pv_rt60_blocked_kernel(const AnalyzeArgs a) {
-    __shared__ double tab[32];
+    __shared__ double tab[96];
     if (analysisAborted(a)) return;
     if (rt60LanesPerCell(a, *a.activeCount) != L) return;  // (grid-uniform: the other instantiations' launches do the work)
-    if (threadIdx.x < 32) {
-        double invc, logc;
-        PvLogTabConst{}((int)threadIdx.x >> 1, &invc, &logc);
-        tab[threadIdx.x] = (threadIdx.x & 1) ? logc : invc;
+    if (threadIdx.x < 96) {
+        double invc, y0;
+        const int e = (int)threadIdx.x >> 1;
+        PvLogTabConst{}(e & 15, (e >> 4) - 1, &invc, &y0);
+        tab[threadIdx.x] = (threadIdx.x & 1) ? y0 : invc;
     }
     __syncthreads();
     const LogTabLds ltab{tab};
