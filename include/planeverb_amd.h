@@ -172,6 +172,7 @@ enum {
     PVA_OPT_RESIDENT_KERNEL = 22, /* the resident kernel (csrc/pv_resident.hip): ONE launch per run, every tile a workgroup that stays on its CU for all T steps and hands its interior to its neighbours every K steps through write-through stores + one flag word per tile (no kernel boundary, no grid barrier) -- for the grids the reference ships (its 275 ... 750 Hz presets on a 25 m scene: 70^2 ... 191^2) and everything else whose history window is the whole grid and whose tiles fit the chip at once.  0 (default) = auto: where the solver runs its default tile for launch-bound grids; 1 = also with an explicitly chosen (steps per launch, tile rows) = (12, 12); 2 = never (the replayed graph of tile-kernel launches) */
     PVA_OPT_RT60_LANES = 23,   /* wet gain + decay time (Analyzer.cpp:235-247,282-327): lanes that share a cell -- 16 (DPP row: few cells, parallel logarithms) or 4 (blocked form of csrc/pv_rt60.hip: fewer instructions per sample); same bits in every form.  0 (default) = chosen on the device from the number of reachable cells */
     PVA_OPT_STREAM_PRIORITY = 25, /* 1 = the solver's main stream is created with the device's highest priority.  Streams of different priorities never share a hardware queue (the runtime multiplexes the streams of a process on a handful of them, and launches of streams that share one run one after the other): give every other solver of a group that is meant to run side by side -- two runs in flight on one GPU -- this option.  Results do not depend on it.  Default 0 */
+    PVA_OPT_ALTERNATE_SWEEPS = 26, /* tile order 3 only: 1 = odd launches of a run walk every XCD's strip of tiles from its last tile row to its first, so that a launch reads first what the previous launch wrote last (still in the 256 MiB Infinity Cache) instead of streaming through the cache in the order that evicts everything before it is read again.  Results do not depend on it.  -1 = default, 0 = off */
     PVA_OPT_DEBUG_LOSE_FIRST_CAPTURE = 24, /* validation: 1 = the solver's first run-graph capture counts as lost (what a legacy-stream operation of another host thread does to it): that run goes out as plain launches, the next one captures again (tests/test_gpu_parity.py) */
     PVA_OPT_PATCH_STRIP = 18,  /* patch columns per strip of the patch kernel's walk over the grid (development; default 3) */
     PVA_OPT_EDGE_TILES = 15    /* 1 = tiles whose only non-air faces are the grid's absorbing edges run the air-tile code + edge overrides (tile class 2) instead of the general path.  Only the batched kernels of the mirror-pair tiles (K, rows = (8,40), (10,36), (12,36)) have that arm -- inside the merged kernel it slows the air tiles by 25-40 %, DESIGN.md 8.4 -- so every run of such a solver goes through PvAmdRunBatch's kernel (PvAmdRun = a batch of one) and PvAmdRunSteps is refused; ignored for other configurations.  Default 0 */

@@ -627,6 +627,12 @@ __device__ __forceinline__ void leapfrogStepMirror(v2f (&pr)[NP], v2f (&vx)[NP],
 #ifndef PV_LATE_ARGS
 #define PV_LATE_ARGS 0
 #endif
+#ifndef PV_AIR_LOAD_AUX
+#define PV_AIR_LOAD_AUX 0   // cache-policy word of the mirror-pair air tile's field loads / stores (measurement builds)
+#endif
+#ifndef PV_AIR_STORE_AUX
+#define PV_AIR_STORE_AUX 0
+#endif
 
 // Edge tiles (tile class 2): tiles of an otherwise EMPTY region that touch the grid's x = 0, y = 0 or y = gy edge.
 // Their only non-air faces are the absorbing edge itself (FDTD.cpp:201-223; face coefficients -1 / +1, i.e.
@@ -734,16 +740,16 @@ __device__ __forceinline__ void stepTileAirMirror(const StepArgs& a, const int t
         vx[i] = v2f{vxS * 5.f + i, vxS * 7.f - i};
     }
 #else
-    float vxS = bufLoadF(rVxIn, voff, soff0 + NP * pitchB);
+    float vxS = bufLoadFA<PV_AIR_LOAD_AUX>(rVxIn, voff, soff0 + NP * pitchB);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int soT = soff0 + i * pitchB, soB = soff0 + (ROWS - 1 - i) * pitchB;
-        pr[i].x = bufLoadF(rPrIn, voff, soT);
-        pr[i].y = bufLoadF(rPrIn, voff, soB);
-        vy[i].x = bufLoadF(rVyIn, voff, soT);
-        vy[i].y = bufLoadF(rVyIn, voff, soB);
-        vx[i].x = bufLoadF(rVxIn, voff, soT);
-        vx[i].y = (i > 0) ? -bufLoadF(rVxIn, voff, soB + pitchB) : 0.f;  // face ROWS-i; face ROWS is not in the tile
+        pr[i].x = bufLoadFA<PV_AIR_LOAD_AUX>(rPrIn, voff, soT);
+        pr[i].y = bufLoadFA<PV_AIR_LOAD_AUX>(rPrIn, voff, soB);
+        vy[i].x = bufLoadFA<PV_AIR_LOAD_AUX>(rVyIn, voff, soT);
+        vy[i].y = bufLoadFA<PV_AIR_LOAD_AUX>(rVyIn, voff, soB);
+        vx[i].x = bufLoadFA<PV_AIR_LOAD_AUX>(rVxIn, voff, soT);
+        vx[i].y = (i > 0) ? -bufLoadFA<PV_AIR_LOAD_AUX>(rVxIn, voff, soB + pitchB) : 0.f;  // face ROWS-i; face ROWS is not in the tile
     }
 #endif
     // All 3*ROWS loads are in flight before anything consumes one.  Without this fence the schedule depends on what
@@ -815,9 +821,9 @@ __device__ __forceinline__ void stepTileAirMirror(const StepArgs& a, const int t
             const float p = r < NP ? pr[r].x : pr[ROWS - 1 - r].y;
             const float x = r < NP ? vx[r].x : (r == NP ? vxS : -vx[ROWS - r].y);
             const float y = r < NP ? vy[r].x : vy[ROWS - 1 - r].y;
-            bufStoreF(outP ? 0.f : p, rPrOut, voff, so);
-            bufStoreF(outX ? 0.f : x, rVxOut, voff, so);
-            bufStoreF(outP ? 0.f : y, rVyOut, voff, so);
+            bufStoreFA<PV_AIR_STORE_AUX>(outP ? 0.f : p, rPrOut, voff, so);
+            bufStoreFA<PV_AIR_STORE_AUX>(outX ? 0.f : x, rVxOut, voff, so);
+            bufStoreFA<PV_AIR_STORE_AUX>(outP ? 0.f : y, rVyOut, voff, so);
         }
     }
 }
@@ -1426,7 +1432,7 @@ __device__ __forceinline__ bool xcdTileAt(const StepArgs& a, int xcd, int q, int
         if (w <= 0) return false;
         const int r = q / w;
         if (r >= a.ntx) return false;
-        *ti = r;
+        *ti = a.sweepReverse ? a.ntx - 1 - r : r;
         *tj = c0 + (q - r * w);
         return true;
     }

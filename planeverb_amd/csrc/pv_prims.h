@@ -82,5 +82,14 @@ __device__ __forceinline__ float bufLoadF(rsrc_t r, int voff, int soff) {
 __device__ __forceinline__ void bufStoreF(float v, rsrc_t r, int voff, int soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
 }
+// with a cache-policy word (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
+template <int AUX>
+__device__ __forceinline__ float bufLoadFA(rsrc_t r, int voff, int soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, AUX));
+}
+template <int AUX>
+__device__ __forceinline__ void bufStoreFA(float v, rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, AUX);
+}
 
 }  // namespace pva

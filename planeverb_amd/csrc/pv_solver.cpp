@@ -143,6 +143,9 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     }
     if (!stepConfigSupported(K_, rxi_)) return fail("unsupported (stepsPerLaunch, tileRows) configuration");
     if (opt_.tileOrder < 0) opt_.tileOrder = tiles36 >= 4500 ? 3 : 1;  // (measured: profiles/r02_tile_order.txt)
+    // odd launches walk the strips backwards: what the previous launch wrote last is read first, out of the Infinity Cache
+    // (4096^2: +2 % with two runs in flight, +4-5 % with one; profiles/r04_alternate_sweeps.txt)
+    if (opt_.alternateSweeps < 0) opt_.alternateSweeps = opt_.tileOrder == 3 ? 1 : 0;
     // edge tiles are an "allow": only the batched kernels of the mirror-pair tiles have that arm
     if (!opt_.packed && !unpackedAirOk())
         return fail("PVA_OPT_PACKED_MATH = 0 (the unpacked air kernel) is a validation form of the experimental build of the library");
@@ -896,6 +899,7 @@ void Solver::setLaunchArgs(StepArgs& a, int t0, int k, bool firstOfRun, int li) 
     a.inBytes = firstOfRun ? 0 : (int)a.planeBytes;
     a.nzIn = nz_[li & 1];
     a.nzOut = nz_[(li & 1) ^ 1];
+    a.sweepReverse = (opt_.alternateSweeps == 1 && opt_.tileOrder == 3) ? (li & 1) : 0;
 }
 
 bool Solver::bandsActive() const { return bandedRun_; }
