@@ -10,6 +10,7 @@
 // order 3).   hipcc --offload-arch=gfx950 -O3 tools/tile_major_probe.hip -o /tmp/tmp_probe && /tmp/tmp_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 
 constexpr int K = 12, RXI = 36, WI = 40, ROWS = RXI + 2 * K, NTX = 114, NTY = 103;
 constexpr int G = 16, PITCH = 4160, PROWS = G + NTX * RXI + G + 32;
@@ -46,7 +47,11 @@ __device__ __forceinline__ bool tileOf(int order, int b, int wave, int* ti, int*
     return true;
 }
 
-template <int LAYOUT>  // 0 = row-major padded planes, 1 = tile-major
+// LORDER (row-major planes only): 0 = the compiler's schedule of the 180 loads; 1 = rows top to bottom, pinned (a scheduling barrier
+// per row); 2 = pinned and ALIGNED between vertical neighbours: a tile shares its first 2K rows with the tile above and its last 2K with
+// the tile below, so odd tile rows load their last third first and their first third last -- both sharers of a row then ask for it at
+// the same point of their load phases (does the XCD's 4 MiB L2 still have it?  11.8 MB of tiles are in flight per XCD)
+template <int LAYOUT, int LORDER = 0>  // 0 = row-major padded planes, 1 = tile-major
 __global__ __launch_bounds__(256, 2) void probe(const float* __restrict__ in, float* __restrict__ out, int order, int work,
                                                 float seed) {
     const int lane = threadIdx.x & 63;
@@ -64,10 +69,22 @@ __global__ __launch_bounds__(256, 2) void probe(const float* __restrict__ in, fl
     if (LAYOUT == 0) {
         const int row0 = G - K + ti * RXI, col0 = G - K + tj * WI;
         const int so0 = (row0 * PITCH + col0) * 4;
+        if (LORDER == 2 && (ti & 1)) {
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r)
+            for (int k = 0; k < ROWS; ++k) {
+                const int r = k < 2 * K ? ROWS - 2 * K + k : (k < ROWS - 2 * K ? k : k - (ROWS - 2 * K));
 #pragma unroll
-            for (int p = 0; p < 3; ++p) f[p][r] = bufLoadF(rin[p], lane * 4, so0 + r * PITCH * 4);
+                for (int p = 0; p < 3; ++p) f[p][r] = bufLoadF(rin[p], lane * 4, so0 + r * PITCH * 4);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) f[p][r] = bufLoadF(rin[p], lane * 4, so0 + r * PITCH * 4);
+                if (LORDER) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     } else {
         const int col = lane - K, dtj = col < 0 ? -1 : (col >= WI ? 1 : 0);
         const int lanePart = (dtj * TILE + (col - WI * dtj)) * 4;  // per-lane constant (may be negative: soffset covers it)
@@ -112,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void probe(const float* __restrict__ in, fl
     }
 }
 
-int main() {
+int main(int argc, char** argv) {
     const long long n = (PLANE_RM > PLANE_TM ? PLANE_RM : PLANE_TM) * 3;
     float *a, *b;
     hipMalloc(&a, n * 4);
@@ -123,18 +140,27 @@ int main() {
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const dim3 blk(256);
+    const int only = argc > 1 ? atoi(argv[1]) : -1;  // >= 0: one variant only, 4 launches (for rocprofv3 --pmc)
     for (int order : {0, 3}) {
         const int blocks = order == 0 ? (NTX * NTY + 3) / 4 : 8 * ((NTX * ((NTY + 7) / 8) + 3) / 4);
         for (int work : {0, 12, 22}) {
-            for (int layout : {0, 1}) {
+            for (int variant : {0, 1, 2, 3}) {  // row-major, tile-major, row-major pinned top-down, row-major pinned + aligned
+                if (only >= 0 && (variant != only || order != 3 || work != 22)) continue;
+                if (variant >= 2 && order != 3) continue;
                 float best = 1e9f;
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < (only >= 0 ? 2 : 8); ++i) {
                     hipEventRecord(e0);
                     for (int rep = 0; rep < 4; ++rep) {  // ping-pong like the solver
-                        if (layout == 0)
-                            hipLaunchKernelGGL(probe<0>, dim3(blocks), blk, 0, 0, rep & 1 ? b : a, rep & 1 ? a : b, order, work, 0.f);
+                        const float* in = rep & 1 ? b : a;
+                        float* out = rep & 1 ? a : b;
+                        if (variant == 0)
+                            hipLaunchKernelGGL((probe<0, 0>), dim3(blocks), blk, 0, 0, in, out, order, work, 0.f);
+                        else if (variant == 1)
+                            hipLaunchKernelGGL((probe<1, 0>), dim3(blocks), blk, 0, 0, in, out, order, work, 0.f);
+                        else if (variant == 2)
+                            hipLaunchKernelGGL((probe<0, 1>), dim3(blocks), blk, 0, 0, in, out, order, work, 0.f);
                         else
-                            hipLaunchKernelGGL(probe<1>, dim3(blocks), blk, 0, 0, rep & 1 ? b : a, rep & 1 ? a : b, order, work, 0.f);
+                            hipLaunchKernelGGL((probe<0, 2>), dim3(blocks), blk, 0, 0, in, out, order, work, 0.f);
                     }
                     hipEventRecord(e1);
                     hipEventSynchronize(e1);
@@ -142,8 +168,9 @@ int main() {
                     hipEventElapsedTime(&ms, e0, e1);
                     if (i && ms / 4 < best) best = ms / 4;
                 }
-                printf("tile order %d, work %2d rounds (%4d fma per wave), %s planes: %.1f us per sweep of 11742 tiles\n", order, work,
-                       work * 180, layout == 0 ? "row-major " : "tile-major", best * 1e3);
+                static const char* names[] = {"row-major planes", "tile-major planes", "row-major, loads pinned top-down", "row-major, loads pinned + aligned between vertical neighbours"};
+                printf("tile order %d, work %2d rounds (%4d fma per wave), %s: %.1f us per sweep of 11742 tiles\n", order, work, work * 180,
+                       names[variant], best * 1e3);
             }
         }
     }
