@@ -14,6 +14,19 @@ namespace pva {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// The s_nop in front of the inline-asm DPP subtracts (subLanePrev2).  The product build's kernels never need it -- the pressure
+// rows a vy sweep shifts were written a whole vx sweep earlier -- and tools/check_dpp_hazard.py (run by tests/test_host_cpu.py on
+// the generated assembly of every kernel source) PROVES that for the build at hand; 273 s_nop fewer per air tile are worth ~3 % at
+// 4096^2 (profiles/r04_load_order.txt).  The experimental build keeps it: three of its instantiations do read a register written
+// one wait state earlier.
+#ifndef PV_DPP_ASM_NOP
+#ifdef PV_EXPERIMENTAL
+#define PV_DPP_ASM_NOP "s_nop 1\n\t"
+#else
+#define PV_DPP_ASM_NOP ""
+#endif
+#endif
+
 // The pressure history is TILE-MAJOR: plane[t][window tile][row in tile][column in tile], RXI x WI floats per tile, no
 // padding.  A step kernel records a tile's RXI x WI block of one sub-step as ONE contiguous chunk (5.76 KB for the 36 x 40
 // tile) instead of RXI segments of 160 B that sit a whole plane row apart: 5.2 instead of 3.2 TB/s of history writes on
@@ -50,11 +63,12 @@ __device__ __forceinline__ float lanePrev(float v) {
 // src1 - dpp(src0), the lane shift rides on the subtract.  The compiler folds laneNext(v) - v like this by itself
 // but leaves this operand order as shift + subtract, hence the asm.  gfx9-family ISAs need 2 wait states between a
 // VALU write of a VGPR and a DPP read of it, and the compiler's hazard recogniser cannot see into inline asm: the
-// leading s_nop 1 covers the inputs, and the outputs are early-clobber so they never alias a later input.
+// leading PV_DPP_ASM_NOP (above) covers the inputs where they need it, and the outputs are early-clobber so they never alias a
+// later input.
 __device__ __forceinline__ void subLanePrev2(const v2f a, const v2f b, v2f& ta, v2f& tb) {
 #if PV_USE_DPP
     float t0, t1, t2, t3;
-    asm("s_nop 1\n\t"
+    asm(PV_DPP_ASM_NOP
         "v_subrev_f32_dpp %0, %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_subrev_f32_dpp %1, %5, %5 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
         "v_subrev_f32_dpp %2, %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
