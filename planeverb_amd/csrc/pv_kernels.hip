@@ -628,8 +628,8 @@ __device__ __forceinline__ void leapfrogStepMirror(v2f (&pr)[NP], v2f (&vx)[NP],
 #define PV_LATE_ARGS 0
 #endif
 #ifndef PV_LOAD_PIN
-#define PV_LOAD_PIN 2  // issue order of the mirror-pair air tile's loads: 0 = the compiler's (grouped by plane), 1 = pinned pair by pair
-                       // (outside-in), 2 = pinned row by row, top to bottom: 4-5 % faster at 4096^2 (profiles/r04_load_order.txt)
+#define PV_LOAD_PIN 2  // issue order of the mirror-pair air tile's loads: 0 = the compiler's (grouped by plane), 2 = pinned row by row,
+                       // top to bottom: 4-5 % faster at 4096^2, 6-9 % at 8192^2 (profiles/r04_load_order.txt)
 #endif
 #ifndef PV_LOAD_PIN_ROWS
 #define PV_LOAD_PIN_ROWS 2  // rows per scheduling barrier of the pinned row order
@@ -748,50 +748,30 @@ __device__ __forceinline__ void stepTileAirMirror(const StepArgs& a, const int t
     }
 #else
 #if PV_LOAD_PIN >= 2
-    // rows top to bottom, one scheduling barrier per row: the order the loads are ISSUED in (the compiler otherwise groups them by
+    // rows top to bottom, a scheduling barrier every PV_LOAD_PIN_ROWS rows: the order the loads are ISSUED in (the compiler otherwise groups them by
     // plane; measured with tools/tile_major_probe.hip: the pinned row order is 5-7 % faster on the same bytes)
-    // (measurement builds: 3 = plane by plane, 5 = bottom to top, 4 = 2 + stores pinned row by row)
+    // (plane by plane, bottom to top, pair by pair outside-in, the planes a third of the tile apart, stores pinned as well: all
+    // measured, none better -- profiles/r04_load_order.txt)
     float vxS = 0.f;
-    auto loadRow = [&](const int r, const int which) {  // which: bit 0 pr, bit 1 vy, bit 2 vx
+    auto loadRow = [&](const int r) {
         const int so = soff0 + r * pitchB;
         if (r < NP) {
-            if (which & 1) pr[r].x = bufLoadFA<PV_AIR_LOAD_AUX>(rPrIn, voff, so);
-            if (which & 2) vy[r].x = bufLoadFA<PV_AIR_LOAD_AUX>(rVyIn, voff, so);
-            if (which & 4) vx[r].x = bufLoadFA<PV_AIR_LOAD_AUX>(rVxIn, voff, so);
+            pr[r].x = bufLoadFA<PV_AIR_LOAD_AUX>(rPrIn, voff, so);
+            vy[r].x = bufLoadFA<PV_AIR_LOAD_AUX>(rVyIn, voff, so);
+            vx[r].x = bufLoadFA<PV_AIR_LOAD_AUX>(rVxIn, voff, so);
         } else {
             const int i = ROWS - 1 - r;
-            if (which & 1) pr[i].y = bufLoadFA<PV_AIR_LOAD_AUX>(rPrIn, voff, so);
-            if (which & 2) vy[i].y = bufLoadFA<PV_AIR_LOAD_AUX>(rVyIn, voff, so);
-            if (which & 4) {
-                if (r == NP)
-                    vxS = bufLoadFA<PV_AIR_LOAD_AUX>(rVxIn, voff, so);
-                else
-                    vx[i + 1].y = bufLoadFA<PV_AIR_LOAD_AUX>(rVxIn, voff, so);  // face r belongs to pair ROWS - r (negated below)
-            }
+            pr[i].y = bufLoadFA<PV_AIR_LOAD_AUX>(rPrIn, voff, so);
+            vy[i].y = bufLoadFA<PV_AIR_LOAD_AUX>(rVyIn, voff, so);
+            if (r == NP)
+                vxS = bufLoadFA<PV_AIR_LOAD_AUX>(rVxIn, voff, so);
+            else
+                vx[i + 1].y = bufLoadFA<PV_AIR_LOAD_AUX>(rVxIn, voff, so);  // face r belongs to pair ROWS - r (negated below)
         }
         if (r % PV_LOAD_PIN_ROWS == PV_LOAD_PIN_ROWS - 1) __builtin_amdgcn_sched_barrier(0);
     };
-#if PV_LOAD_PIN == 3
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) loadRow(r, 1);
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) loadRow(r, 2);
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) loadRow(r, 4);
-#elif PV_LOAD_PIN == 5
-#pragma unroll
-    for (int r = ROWS - 1; r >= 0; --r) loadRow(r, 7);
-#elif PV_LOAD_PIN == 7
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-        loadRow(r, 1);
-        loadRow((r + ROWS / 3) % ROWS, 2);
-        loadRow((r + 2 * ROWS / 3) % ROWS, 4);
-    }
-#else
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) loadRow(r, 7);
-#endif
+    for (int r = 0; r < ROWS; ++r) loadRow(r);
     vx[0].y = 0.f;  // face ROWS is not in the tile
 #pragma unroll
     for (int i = 1; i < NP; ++i) vx[i].y = -vx[i].y;
@@ -805,17 +785,8 @@ __device__ __forceinline__ void stepTileAirMirror(const StepArgs& a, const int t
         vy[i].x = bufLoadFA<PV_AIR_LOAD_AUX>(rVyIn, voff, soT);
         vy[i].y = bufLoadFA<PV_AIR_LOAD_AUX>(rVyIn, voff, soB);
         vx[i].x = bufLoadFA<PV_AIR_LOAD_AUX>(rVxIn, voff, soT);
-#if PV_LOAD_PIN == 1
-        vx[i].y = (i > 0) ? bufLoadFA<PV_AIR_LOAD_AUX>(rVxIn, voff, soB + pitchB) : 0.f;  // (negated below)
-        __builtin_amdgcn_sched_barrier(0);  // the loads are issued pair by pair, outside-in
-#else
         vx[i].y = (i > 0) ? -bufLoadFA<PV_AIR_LOAD_AUX>(rVxIn, voff, soB + pitchB) : 0.f;  // face ROWS-i; face ROWS is not in the tile
-#endif
     }
-#if PV_LOAD_PIN == 1
-#pragma unroll
-    for (int i = 1; i < NP; ++i) vx[i].y = -vx[i].y;
-#endif
 #endif
 #endif
     // All 3*ROWS loads are in flight before anything consumes one.  Without this fence the schedule depends on what
@@ -890,9 +861,6 @@ __device__ __forceinline__ void stepTileAirMirror(const StepArgs& a, const int t
             bufStoreFA<PV_AIR_STORE_AUX>(outP ? 0.f : p, rPrOut, voff, so);
             bufStoreFA<PV_AIR_STORE_AUX>(outX ? 0.f : x, rVxOut, voff, so);
             bufStoreFA<PV_AIR_STORE_AUX>(outP ? 0.f : y, rVyOut, voff, so);
-#if PV_LOAD_PIN == 4
-            __builtin_amdgcn_sched_barrier(0);
-#endif
         }
     }
 }
