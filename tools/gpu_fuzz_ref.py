@@ -68,8 +68,13 @@ def one(seed):
             for e in rng.uniform(0.3, size - 0.3, (6, 3)).astype(np.float32):
                 want = r.output(e)
                 got = s.get_output(e).as_array()
+                # Q6: a position in the last cell row / column maps to an index PAST the reference's result array --
+                # it returns whatever the heap holds there (seed 210131: FLT_MAX in all eight fields, which is finite); this
+                # library answers with the sentinel.  Such positions are skipped (host_cells: no result cell).
+                if pv.host_cells(size, size, res, e[0], e[2])[1] is None:
+                    assert got[0] == -1.0, "sentinel outside the result map"
+                    continue
                 if want is not None and np.isfinite(want).all():
-                    d = rdelay[pv.host_cells(size, size, res, e[0], e[2])[1]] if False else None
                     assert same_bits(got[[0, 4, 5, 6, 7]], want[[0, 4, 5, 6, 7]]).all() or not np.isfinite(got).all(), "GetOutput"
         k, rows, resident = s.info.stepsPerLaunch, s.info.tileRows, s.info.residentKernel
     r.close()
