@@ -241,6 +241,7 @@ def main(argv=None, hooks=None):
                     help="PVA_OPT_EDGE_TILES: 1 = grid-border tiles on the air path (every run then goes through the "
                          "batched kernel, also with --batch 1)")
     ap.add_argument("--tile-order", type=int, default=-1, help="PVA_OPT_TILE_ORDER (development: block -> tile map)")
+    ap.add_argument("--xcd-regions", type=int, default=-1, help="PVA_OPT_XCD_REGIONS (development: 2 x 4 regions / 8 strips)")
     ap.add_argument("--alternate-sweeps", type=int, default=-1,
                     help="PVA_OPT_ALTERNATE_SWEEPS (development: odd launches walk the tiles backwards)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -307,6 +308,8 @@ def main(argv=None, hooks=None):
         opts["edge_tiles"] = args.edge_tiles
     if args.alternate_sweeps >= 0:
         opts["alternate_sweeps"] = args.alternate_sweeps
+    if args.xcd_regions >= 0:
+        opts["xcd_regions"] = args.xcd_regions
     if args.batch == 0:  # auto: batched launches pay for launch-bound grids only
         args.batch = 8 if args.grid <= 1536 else 1
     NB = max(1, min(args.batch, 8))  # runs per batched launch

@@ -173,6 +173,7 @@ enum {
     PVA_OPT_RT60_LANES = 23,   /* wet gain + decay time (Analyzer.cpp:235-247,282-327): lanes that share a cell -- 16 (DPP row: few cells, parallel logarithms) or 4 (blocked form of csrc/pv_rt60.hip: fewer instructions per sample); same bits in every form.  0 (default) = chosen on the device from the number of reachable cells */
     PVA_OPT_STREAM_PRIORITY = 25, /* 1 = the solver's main stream is created with the device's highest priority.  Streams of different priorities never share a hardware queue (the runtime multiplexes the streams of a process on a handful of them, and launches of streams that share one run one after the other): give every other solver of a group that is meant to run side by side -- two runs in flight on one GPU -- this option.  Results do not depend on it.  Default 0 */
     PVA_OPT_ALTERNATE_SWEEPS = 26, /* tile order 3 only: 1 = odd launches of a run walk every XCD's strip of tiles from its last tile row to its first, so that a launch reads first what the previous launch wrote last (still in the 256 MiB Infinity Cache) instead of streaming through the cache in the order that evicts everything before it is read again.  Results do not depend on it.  -1 = default, 0 = off */
+    PVA_OPT_XCD_REGIONS = 27, /* tile order 3 only: 1 = every XCD owns one of 2 x 4 regions of the grid (walked row-major) instead of one of 8 strips of tile columns: a region is twice as wide, so half as many cache lines on its sides are fetched by two XCDs, and a tile's vertical neighbours are still close enough for the XCD's L2.  Results do not depend on it.  -1 = default (on), 0 = strips */
     PVA_OPT_DEBUG_LOSE_FIRST_CAPTURE = 24, /* validation: 1 = the solver's first run-graph capture counts as lost (what a legacy-stream operation of another host thread does to it): that run goes out as plain launches, the next one captures again (tests/test_gpu_parity.py) */
     PVA_OPT_PATCH_STRIP = 18,  /* patch columns per strip of the patch kernel's walk over the grid (development; default 3) */
     PVA_OPT_EDGE_TILES = 15    /* 1 = tiles whose only non-air faces are the grid's absorbing edges run the air-tile code + edge overrides (tile class 2) instead of the general path.  Only the batched kernels of the mirror-pair tiles (K, rows = (8,40), (10,36), (12,36)) have that arm -- inside the merged kernel it slows the air tiles by 25-40 %, DESIGN.md 8.4 -- so every run of such a solver goes through PvAmdRunBatch's kernel (PvAmdRun = a batch of one) and PvAmdRunSteps is refused; ignored for other configurations.  Default 0 */

@@ -462,6 +462,7 @@ int PvAmdSetOption(PvAmdSolver* h, int key, long long value) {
         case PVA_OPT_DEBUG_LOSE_FIRST_CAPTURE: h->opt.debugLoseFirstCapture = value != 0; break;
         case PVA_OPT_STREAM_PRIORITY: h->opt.streamPriority = (int)value; break;
         case PVA_OPT_ALTERNATE_SWEEPS: h->opt.alternateSweeps = (int)value; break;
+        case PVA_OPT_XCD_REGIONS: h->opt.xcdRegions = (int)value; break;
         default: g_lastError = "unknown option"; return -1;
     }
     return 0;

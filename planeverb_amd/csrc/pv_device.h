@@ -123,9 +123,10 @@ struct StepArgs {
     int inBytes;           // extent of the INPUT planes' buffer descriptors: planeBytes, or 0 for the first launch of a
                            // run -- every field load is then out of range and returns 0 without touching memory,
                            // which is the run's zero initial state (no reset pass over the planes)
-    int sweepReverse;      // tile order 3 only: 1 = the XCD's strip is walked from its last tile row to its first.  Odd launches of
-                           // a run set it (PVA_OPT_ALTERNATE_SWEEPS): a launch then reads first what the previous launch wrote
-                           // last, i.e. what is still in the 256 MiB Infinity Cache, instead of streaming through it
+    int sweepReverse;      // tile order 3 only.  bit 0: the XCD's tiles are walked from its last tile row to its first -- odd launches of
+                           // a run set it (PVA_OPT_ALTERNATE_SWEEPS): a launch then reads first what the previous launch wrote last,
+                           // i.e. what is still in the 256 MiB Infinity Cache, instead of streaming through it.  bit 1: 2 x 4 regions
+                           // instead of 8 strips of tile columns (PVA_OPT_XCD_REGIONS)
 };
 
 // Batched launch (pv_step_batch_kernel): up to kBatchMax independent runs of identically configured solvers advance

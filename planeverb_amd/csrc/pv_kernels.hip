@@ -1464,12 +1464,27 @@ __device__ __forceinline__ bool bandPosition(const StepArgs& a, int q, int bandR
 __device__ __forceinline__ bool xcdTileAt(const StepArgs& a, int xcd, int q, int* ti, int* tj) {
     if (a.tileOrder == 3) {  // column strips: XCD x owns tile columns [x*cw, (x+1)*cw) and walks its strip row-major, so
                              // that a tile's vertical neighbours are cw tiles -- not a whole tile row of the grid -- away
+        if (a.sweepReverse & 2) {
+            // 2 x 4 regions instead of 8 strips (PVA_OPT_XCD_REGIONS): XCD x owns tile rows [x / 4 * rh, ...) x tile columns
+            // [x % 4 * cw, ...) and walks its region row-major.  Twice as wide, a region has half as many lines on its sides that
+            // the neighbouring XCD fetches too (11 % of all reads with strips of 13 tiles), and a vertical neighbour is still only
+            // 26 tiles away: 4096^2 +0.5-4 %, 8192^2 +2 % (profiles/r04_xcd_regions.txt; 4 x 2 regions: slower)
+            const int cw = (a.nty + 3) >> 2, rh = (a.ntx + 1) >> 1;
+            const int c0 = (xcd & 3) * cw, w = min(cw, a.nty - c0);
+            const int r0 = (xcd >> 2) * rh, h = min(rh, a.ntx - r0);
+            if (w <= 0 || h <= 0) return false;
+            const int r = q / w;
+            if (r >= h) return false;
+            *ti = r0 + ((a.sweepReverse & 1) ? h - 1 - r : r);
+            *tj = c0 + (q - r * w);
+            return true;
+        }
         const int cw = (a.nty + 7) >> 3;
         const int c0 = xcd * cw, w = min(cw, a.nty - c0);
         if (w <= 0) return false;
         const int r = q / w;
         if (r >= a.ntx) return false;
-        *ti = a.sweepReverse ? a.ntx - 1 - r : r;
+        *ti = (a.sweepReverse & 1) ? a.ntx - 1 - r : r;
         *tj = c0 + (q - r * w);
         return true;
     }
@@ -1894,7 +1909,7 @@ void launchStepSeg(int, int, const StepArgs&, hipStream_t) {}
 // positions an XCD's band needs under the chosen order (sub-bands are padded to whole multiples of H rows)
 static int bandPositions(const StepArgs& a) {
     if (a.tileOrder <= 1) return (a.ntiles + 7) / 8;
-    if (a.tileOrder == 3) return a.ntx * ((a.nty + 7) / 8);
+    if (a.tileOrder == 3) return max(a.ntx * ((a.nty + 7) / 8), ((a.ntx + 1) / 2) * ((a.nty + 3) / 4));  // (8 strips / 2 x 4 regions)
     if (a.tileOrder < 4) return a.bandRows * a.nty;
     const int H = a.tileOrder;
     return ((a.bandRows + H - 1) / H) * H * a.nty;

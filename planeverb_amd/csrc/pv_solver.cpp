@@ -146,6 +146,9 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     // odd launches walk the strips backwards: what the previous launch wrote last is read first, out of the Infinity Cache
     // (4096^2: +2 % with two runs in flight, +4-5 % with one; profiles/r04_alternate_sweeps.txt)
     if (opt_.alternateSweeps < 0) opt_.alternateSweeps = opt_.tileOrder == 3 ? 1 : 0;
+    // tile order 3: 2 x 4 regions instead of 8 strips of tile columns (xcdTileAt; profiles/r04_xcd_regions.txt)
+    // (where the strips are narrow: 4096^2 has 13 tile columns per strip, 3072^2 10: +2-4 %; 8192^2 has 26 and loses 1-2 %)
+    if (opt_.xcdRegions < 0) opt_.xcdRegions = (opt_.tileOrder == 3 && ceilDiv(ceilDiv(g_.NY, 64 - 2 * K_), 8) < 20) ? 1 : 0;
     // edge tiles are an "allow": only the batched kernels of the mirror-pair tiles have that arm
     if (!opt_.packed && !unpackedAirOk())
         return fail("PVA_OPT_PACKED_MATH = 0 (the unpacked air kernel) is a validation form of the experimental build of the library");
@@ -899,7 +902,8 @@ void Solver::setLaunchArgs(StepArgs& a, int t0, int k, bool firstOfRun, int li) 
     a.inBytes = firstOfRun ? 0 : (int)a.planeBytes;
     a.nzIn = nz_[li & 1];
     a.nzOut = nz_[(li & 1) ^ 1];
-    a.sweepReverse = (opt_.alternateSweeps == 1 && opt_.tileOrder == 3) ? (li & 1) : 0;
+    // bit 0: this launch walks the XCDs' tiles backwards (odd launches of a run); bit 1: 2 x 4 regions instead of 8 strips
+    a.sweepReverse = opt_.tileOrder == 3 ? (((opt_.alternateSweeps == 1) ? (li & 1) : 0) | (opt_.xcdRegions == 1 ? 2 : 0)) : 0;
 }
 
 bool Solver::bandsActive() const { return bandedRun_; }

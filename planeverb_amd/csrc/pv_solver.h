@@ -57,6 +57,8 @@ struct SolverOptions {
     int resident = 0;     // resident kernel (pv_resident.hip: one launch per run, every tile a workgroup that stays on its CU for
                           // all T steps): 0 = auto (default tile of the launch-bound grids, whole-grid history window, all
                           // blocks co-resident), 1 = also with an explicitly chosen tile, 2 = never
+    int xcdRegions = -1;       // tile order 3: 1 = every XCD owns one of 2 x 4 regions of the grid instead of one of 8 strips of tile
+                               // columns (half as many boundary lines fetched by two XCDs); -1 = default (on), 0 = strips
     int alternateSweeps = -1;  // tile order 3: odd launches of a run walk the XCD strips backwards (StepArgs::sweepReverse):
                                // -1 = default, 0 = off, 1 = on
     int rowBands = 0;     // B > 1: each sweep = B launches (bands of tile rows, one stream each) with 3-point

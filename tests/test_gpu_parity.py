@@ -1069,9 +1069,10 @@ def test_tile_orders_cover_every_tile(pvlib):
     init = [rng.standard_normal((n + 1, n + 1)).astype(np.float32) for _ in range(3)]
     ref = None
     # (order, PVA_OPT_ALTERNATE_SWEEPS): order 3 with its odd launches walking the strips backwards (the default) and not
-    for order, alt in ((1, -1), (0, -1), (2, -1), (3, 0), (3, 1), (3, -1), (5, -1)):
+    # PVA_OPT_XCD_REGIONS): order 3 as strips and as 2 x 4 regions
+    for order, alt, reg in ((1, -1, -1), (0, -1, -1), (2, -1, -1), (3, 0, 0), (3, 1, 0), (3, 0, 1), (3, 1, 1), (3, -1, -1), (5, -1, -1)):
         with pvlib.Solver(size, size, 275, no_free_grid=1, steps_per_launch=12, tile_rows=36, use_graph=2,
-                          tile_order=order, alternate_sweeps=alt) as s:
+                          tile_order=order, alternate_sweeps=alt, xcd_regions=reg) as s:
             s.add_geometry([200, 170, 30, 2, 0.8])
             s.set_fields(*init)
             s.run_steps(40)
@@ -1079,7 +1080,7 @@ def test_tile_orders_cover_every_tile(pvlib):
         if ref is None:
             ref = f
         else:
-            assert all(same_bits(a, b).all() for a, b in zip(f, ref)), (order, alt)
+            assert all(same_bits(a, b).all() for a, b in zip(f, ref)), (order, alt, reg)
 
 
 def test_history_that_cannot_fit_fails_loudly(pvlib):

@@ -27,6 +27,7 @@ ap.add_argument("--tile-order", type=int, default=-1)
 ap.add_argument("--k", type=int, default=0)
 ap.add_argument("--rows", type=int, default=0)
 ap.add_argument("--alt", type=int, default=-1)  # PVA_OPT_ALTERNATE_SWEEPS
+ap.add_argument("--regions", type=int, default=-1)  # PVA_OPT_XCD_REGIONS
 ap.add_argument("--segments", type=int, default=0)  # PVA_OPT_STREAM_ROWS: row-streaming air segments (-1 = tile kernels)
 a = ap.parse_args()
 
@@ -37,6 +38,8 @@ if a.tile_order >= 0:
     kw["tile_order"] = a.tile_order
 if a.alt >= 0:
     kw["alternate_sweeps"] = a.alt
+if a.regions >= 0:
+    kw["xcd_regions"] = a.regions
 solvers = [pv.Solver(size, size, 275, no_free_grid=1, stream_rows=a.segments, **kw) for _ in range(a.inflight)]
 rng = np.random.default_rng(1)
 for s in solvers:
