@@ -31,6 +31,18 @@ def test_library_exports_every_declared_symbol(pvlib):
     assert sorted(pvlib.SYMBOLS) == names
 
 
+def test_python_option_keys_match_the_header(pvlib):
+    """every PVA_OPT_* of include/planeverb_amd.h has the same value in planeverb_amd/api.py (the ctypes mirror passes the numbers),
+    and no two options share one"""
+    src = open(os.path.join(ROOT, "include", "planeverb_amd.h")).read()
+    header = dict((k, int(v)) for k, v in re.findall(r"\b(PVA_OPT_\w+)\s*=\s*(\d+)", src))
+    assert len(header) >= 27 and len(set(header.values())) == len(header)
+    for k, v in header.items():
+        assert getattr(pvlib, k) == v, k
+    mirrored = [k for k in dir(pvlib) if k.startswith("PVA_OPT_")]
+    assert sorted(mirrored) == sorted(header), set(mirrored) ^ set(header)
+
+
 def test_reference_abi_names_present(pvlib):
     """the 11 functions + 2 Unity hooks of PlaneverbUnity.cpp:12-135"""
     for n in ["PlaneverbInit", "PlaneverbExit", "PlaneverbEmit", "PlaneverbUpdateEmission", "PlaneverbEndEmission",
