@@ -19,6 +19,32 @@ struct CellHistory {
     __device__ __forceinline__ float at(int t) const { return h[(long long)t * plane]; }
 };
 
+// The history planes are tile-major without padding (pv_prims.h histOffset), so an OFFSET g inside a plane names a window cell:
+// tile g / (rxi wi), row and column inside it.  Analysis kernels whose lanes run along g read 256 contiguous bytes of one
+// plane per load instruction and wave, and every line of the history is fetched by exactly one workgroup (lanes along WINDOW
+// columns read 160-192-byte pieces of tile rows that are not line-aligned: 2.7 x the bytes, profiles/r04_analysis_pmc.md).
+struct PlaneCell {
+    bool inGrid;   // a result cell (X < gx, Y < gy)
+    int X, Y;      // array cell (row of a slab: local)
+    int tile;      // grid tile index ti * nty + tj
+    int row, col;  // inside the tile
+};
+__device__ __forceinline__ PlaneCell planeCell(const AnalyzeArgs& a, const DynParams& dyn, long long g) {
+    PlaneCell c{false, 0, 0, 0, 0, 0};
+    if (g >= a.histPlane) return c;
+    const int gi = (int)g, tileCells = a.rxi * a.wi;
+    const int wt = gi / tileCells, f = gi - wt * tileCells;
+    c.row = f / a.wi;
+    c.col = f - c.row * a.wi;
+    const int hti = wt / dyn.histTilesY, htj = wt - hti * dyn.histTilesY;
+    const int ti = dyn.histTileX0 + hti, tj = dyn.histTileY0 + htj;
+    c.tile = ti * a.nty + tj;
+    c.X = ti * a.rxi + c.row;
+    c.Y = tj * a.wi + c.col;
+    c.inGrid = c.X < a.gx && c.Y < a.gy;
+    return c;
+}
+
 // FreeGrid::GetEFreePerR, FreeGrid.cpp:41-59
 __device__ __forceinline__ float efreePerR(float efree, float dx, int lX, int lY, int eX, int eY) {
     const float lx = (float)lX * dx, ly = (float)lY * dx;
@@ -38,7 +64,9 @@ __device__ __forceinline__ float efreePerR(float efree, float dx, int lX, int lY
 constexpr int kRt60WaveMaxCells = 65536;  // below this a window counts as "a room" (pv_encode_kernel's pre-scan for an audible sample)
 __device__ __forceinline__ int rt60LanesPerCell(const AnalyzeArgs& a, int activeCells) {
     if (a.rt60Lanes) return a.rt60Lanes;  // (PVA_OPT_RT60_LANES: validation / measurement)
-    return activeCells <= 8192 ? 16 : 4;  // (measured on MI355X, profiles/r04_rt60.txt: 70^2 0.093 / 0.098 ms, 127^2 0.156 / 0.148 ms)
+    // (measured on MI355X, profiles/r04_rt60.txt: 70^2 0.093 / 0.098 ms, 127^2 0.156 / 0.148 ms for sixteen / four lanes; round 5:
+    // one lane per cell over the tile-major history replaces the four-lane form, profiles/r05_rt60.txt)
+    return activeCells <= 8192 ? 16 : 1;
 }
 
 struct Rt60Cell {

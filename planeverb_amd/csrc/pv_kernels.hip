@@ -2295,35 +2295,88 @@ __device__ __forceinline__ int analysisWindowIndex(const AnalyzeArgs& a, const D
     return (r - (dyn.histRow0 - a.G)) * a.winCols + (c - (dyn.histCol0 - a.G));
 }
 
-// samples per memory round trip of the forward pass (three planes each) and of the pre-scan for an audible sample
+// samples per memory round trip of the forward pass (three planes each)
 #ifndef PV_ENCODE_CH
 #define PV_ENCODE_CH 8
 #endif
-#ifndef PV_ENCODE_SC
-#define PV_ENCODE_SC 16
-#endif
-// an air cell of an active tile whose whole history stayed below the audible threshold (one atomic per wave and exit)
-__device__ __forceinline__ void countSilentCell(const AnalyzeArgs& a) {
-    const unsigned long long m = __ballot(1);
-    if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(a.activeCount + 3, __popcll(m));
+
+// Onset of every window cell (Analyzer.cpp:146-165: first sample whose |pressure| exceeds the audible threshold), round 5.
+// Rounds 1-4 found it inside pv_encode_kernel, one thread per cell walking forward through time: the kernel lasted as long as
+// its slowest thread, and the slowest threads were the SILENT cells -- air cells of a reached tile that never become audible
+// (the air outside a closed room, in the tiles its walls cross): all T samples, 16 per memory round trip, 280 us of a 370 us
+// kernel at 512^2 / T = 3179 -- and the decay-time pass could only start behind it.  Here the search is parallel IN TIME: a
+// block is 64 consecutive cells of the tile-major plane (planeCell: one coalesced 256-byte read per plane) x 16 waves, wave w
+// scans the samples t = tBeg + (16 j + w) 16 + k; the earliest hit per cell is kept with an LDS minimum, and a wave stops once
+// no cell of the block can improve.  A silent cell costs T / 256 round trips instead of T / 16.  pv_encode_kernel and the
+// decay-time kernels read the onset from the delay map, side by side on two streams.
+constexpr int kOnsetWaves = 16, kOnsetSC = 16;
+__global__ __launch_bounds__(64 * kOnsetWaves) void pv_onset_kernel(const AnalyzeArgs a) {
+    __shared__ int found[64];
+    if (analysisAborted(a)) return;
+    const DynParams dyn = *a.dyn;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long g = (long long)blockIdx.x * 64 + lane;
+    const PlaneCell c = planeCell(a, dyn, g);
+    const int T = a.T;
+    int tF = INT_MAX;
+    bool live = c.inGrid;
+    if (live) {
+        tF = a.tileFirst[c.tile];
+        // never reached by the pulse, or a wall (beta = 0: pr is identically zero, FDTD.cpp:139): no onset
+        live = tF < T && a.coef[(size_t)(c.X + a.G) * a.pitch + (c.Y + a.G)].beta != 0.f;
+    }
+    if (wave == 0) found[lane] = INT_MAX;
+    __syncthreads();
+    if (__ballot(live) == 0ull) return;  // (the same lanes in every wave of the block: block-uniform)
+    int tBeg = live ? tF : INT_MAX;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) tBeg = min(tBeg, __shfl_xor(tBeg, off));
+    const int voff = (int)g * 4;
+    const int planeBytes = (int)(a.histPlane * 4);
+    constexpr int SC = kOnsetSC;
+#pragma unroll 1
+    for (int t = tBeg + wave * SC; t < T; t += kOnsetWaves * SC) {
+        const int best = found[lane];
+        if (__ballot(live && best > t) == 0ull) break;  // nothing at or after t can be the first
+        float pc[SC];
+#pragma unroll
+        for (int k = 0; k < SC; ++k) {
+            const int tt = t + k;
+            const bool want = live && tt >= tF && tt < T && tt < best;  // (a tile's history starts at its first recorded step)
+            pc[k] = bufLoadF(makeRsrc(a.hist + (long long)min(tt, T - 1) * a.histPlane, planeBytes), want ? voff : 0x7fffffff, 0);
+        }
+        int hit = INT_MAX;
+#pragma unroll
+        for (int k = SC - 1; k >= 0; --k) hit = fabsf(pc[k]) > kAudibleThresholdDev ? t + k : hit;
+        if (hit != INT_MAX) atomicMin(&found[lane], hit);
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const int onset = found[lane];
+    if (live && onset != INT_MAX) a.delay[c.X * a.gy + c.Y] = (float)onset;
+    // reached cells of this run (bench / PvAmdTimings.reachedCells) and silent ones: one atomic each per block
+    const unsigned long long mr = __ballot(live && onset != INT_MAX), ms = __ballot(live && onset == INT_MAX);
+    if (lane == 0) {
+        if (mr) atomicAdd(a.activeCount + 1, __popcll(mr));
+        if (ms) atomicAdd(a.activeCount + 3, __popcll(ms));
+    }
 }
 
+// One thread per window cell, lanes along the tile-major plane (planeCell), behind pv_onset_kernel: dry energy, flux,
+// obstruction gain, source directivity, low-pass cutoff of the cells that have an onset.
 __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
     if (analysisAborted(a)) return;
     const DynParams dyn = *a.dyn;
-    int X, Y;
-    if (!analysisWindowCell(a, dyn, &X, &Y)) return;
+    const PlaneCell pc0 = planeCell(a, dyn, (long long)blockIdx.x * 256 + threadIdx.x);
+    if (!pc0.inGrid) return;
+    const int X = pc0.X, Y = pc0.Y;
     const int s = X * a.gy + Y;
+    const float delay = a.delay[s];
+    if (delay == FLT_MAX) return;  // no onset (Analyzer.cpp:160-165): the result record stays as it is
+    const int onset = (int)delay;
+    const int tFirst = a.tileFirst[pc0.tile];
 
-    const int tile = (X / a.rxi) * a.nty + (Y / a.wi);
     const int prow = X + a.G, pcol = Y + a.G;
-    const int hti = X / a.rxi - dyn.histTileX0, htj = Y / a.wi - dyn.histTileY0;
-    const bool inWin = hti >= 0 && hti < dyn.histTilesX && htj >= 0 && htj < dyn.histTilesY;
-    const int tFirst = inWin ? a.tileFirst[tile] : INT_MAX;
-    if (tFirst == INT_MAX || tFirst >= a.T) {  // never reached by the pulse: no onset (Analyzer.cpp:160-165)
-        a.delay[s] = FLT_MAX;
-        return;
-    }
     const int T = a.T;
     const int hr = prow - dyn.histRow0, hcol = pcol - dyn.histCol0;
     const long long hoff = histOffset(hr, hcol, a.rxi, a.wi, dyn.histTilesY);
@@ -2346,49 +2399,17 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
     const bool airX = kx != kx, airY = ky != ky;
     const float C = a.courant;
 
-    // Every loop below walks the history in chunks of CH samples: the CH loads are issued together (they do not
-    // depend on the running sums), then consumed strictly in sample order, so the float32 accumulation order is the
-    // reference's while the memory latency is paid once per chunk instead of once per sample.
+    // The loop walks the history in chunks of CH samples: the CH loads are issued together (they do not depend on the
+    // running sums), then consumed strictly in sample order, so the float32 accumulation order is the reference's while the
+    // memory latency is paid once per chunk instead of once per sample.
     constexpr int CH = PV_ENCODE_CH;
 
-    // Is there an onset at all?  Walls (beta = 0: pr is identically zero, FDTD.cpp:139) have none.  In a room (few
-    // reachable cells, the kernel's duration is that of its slowest thread) the cell's own pressure is scanned first, 16
-    // samples per memory round trip: the air cells outside a closed room but inside an active tile leave here; through
-    // the recurrence below each of them walked three planes for all T - tFirst samples, 8 at a time (100 of 112 us at
-    // 512^2).  An open field has next to no such cells and is bandwidth-bound: no second pass there.
-    if (fc.beta == 0.f) {
-        a.delay[s] = FLT_MAX;
-        return;
-    }
-    // ... and so is a scene in which the PREVIOUS run found many SILENT cells -- air cells of active tiles whose whole history
-    // stays below the threshold (a room much larger than the audible radius): without the pre-scan each of them walks three
-    // planes for all T samples to find that out, with it one plane.  Shoebox.pv at 25 m / 512^2 (T = 3179): analysis 1.67 ->
-    // 1.06 ms; where every cell has an onset the pre-scan costs 3-7 % (one more pass over the samples before the onset):
-    // profiles/r04_rt60.txt.  The kernel lasts as long as its slowest thread, so a percent or two of silent cells is enough:
-    // the hint is written by the run's last kernel (pv_run_status_kernel: silent > reached / 64; Shoebox has 5470 of 104 410).
-    const bool roomRegime = *a.activeCount < kRt60WaveMaxCells || a.activeCount[2] != 0;  // few reachable cells: see pv_rt60_wave_kernel
-    if (roomRegime) {
-        constexpr int SC = PV_ENCODE_SC;
-        bool audible = false;
-        for (int t0 = tFirst; t0 < T && !audible; t0 += SC) {
-            float pc[SC];
-#pragma unroll
-            for (int k = 0; k < SC; ++k) pc[k] = hc.at(min(t0 + k, T - 1));
-#pragma unroll
-            for (int k = 0; k < SC; ++k) audible = audible || fabsf(pc[k]) > kAudibleThresholdDev;
-        }
-        if (!audible) {
-            a.delay[s] = FLT_MAX;
-            countSilentCell(a);
-            return;
-        }
-    }
-
-    // onset + dry energy + flux, Analyzer.cpp:146-195 (sums run from sample 0; samples before tFirst are zero)
-    int onset = -1, sourceDirEnd = INT_MAX, directEnd = INT_MAX;
+    // dry energy + flux, Analyzer.cpp:170-195: both sums run from sample 0 (samples before tFirst are zero) to the end of
+    // their windows behind the onset; vx / vy by the stencil's own recurrence as long as the flux needs them
+    const int sourceDirEnd = onset + a.nDir, directEnd = min(onset + a.nDry, T);
     float Edry = 0.f, fluxX = 0.f, fluxY = 0.f, vx = 0.f, vy = 0.f;
-    bool done = false;
-    for (int t0 = tFirst; t0 < T && !done; t0 += CH) {
+#pragma unroll 1
+    for (int t0 = tFirst; t0 < directEnd; t0 += CH) {
         float pc[CH], pxc[CH], pyc[CH];
         const bool needVChunk = t0 < sourceDirEnd;
 #pragma unroll
@@ -2401,10 +2422,7 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
             const int t = t0 + k;
-            if (done || t >= T || t >= directEnd) {
-                done = true;
-                continue;
-            }
+            if (t >= directEnd) continue;
             const float p = pc[k];
             if (t < sourceDirEnd) {
                 const float pxn = pxc[k], pyn = pyc[k];
@@ -2413,31 +2431,12 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
                 vx = airX ? ax : wx;
                 vy = airY ? ay : wy;
             }
-            if (onset < 0 && fabsf(p) > kAudibleThresholdDev) {
-                onset = t;
-                sourceDirEnd = t + a.nDir;
-                directEnd = t + a.nDry;
-                if (t >= directEnd) {
-                    done = true;
-                    continue;
-                }
-            }
             Edry += p * p;
             if (t < sourceDirEnd) {
                 fluxX += p * vx;
                 fluxY += p * vy;
             }
         }
-    }
-    if (onset < 0) {
-        a.delay[s] = FLT_MAX;
-        countSilentCell(a);
-        return;
-    }
-    a.delay[s] = (float)onset;
-    {  // reached cells of this run (bench / PvAmdTimings.reachedCells): one atomic per wave
-        const unsigned long long m = __ballot(1);
-        if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(a.activeCount + 1, __popcll(m));
     }
 
     // obstruction gain + source directivity, Analyzer.cpp:197-220
@@ -2451,8 +2450,7 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
     const float rr = 1.0f / ((0.001f < occ) ? occ : 0.001f);
     const float lowpass = -147.f + (18390.f) / (1.f + pvPowf(rr / 12.f, 0.8f));
 
-
-    // (wet gain and decay time: pv_rt60_wave_kernel / pv_rt60_blocked_kernel, by the number of reachable cells)
+    // (wet gain and decay time: pv_rt60_wave_kernel / pv_rt60_tile_kernel, by the number of reachable cells)
     a.out[s] = occ;
     a.out[3 * a.resN + s] = lowpass;
     a.out[6 * a.resN + s] = sdx;
@@ -3007,11 +3005,24 @@ void launchFarCells(const AnalyzeArgs& a, hipStream_t stream) {
 
 // onset, dry gain, source directivity, lowpass, wet gain, decay time of the window's cells (everything but the listener
 // direction, which needs the delay / occlusion maps of the WHOLE window: launchAnalysisDirection)
-void launchAnalysisCells(const AnalyzeArgs& a, hipStream_t stream) {
-    const dim3 grid = analysisWindowGrid(a);
-    hipLaunchKernelGGL(pv_encode_kernel, grid, dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(pv_rt60_wave_kernel, dim3((a.winCols + 15) / 16, a.winRows), dim3(256), 0, stream, a);
+void launchOnset(const AnalyzeArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(pv_onset_kernel, dim3((unsigned)((a.histPlane + 63) / 64)), dim3(64 * kOnsetWaves), 0, stream, a);
+}
+void launchEncode(const AnalyzeArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(pv_encode_kernel, dim3((unsigned)((a.histPlane + 255) / 256)), dim3(256), 0, stream, a);
+}
+// wet gain + decay time: sixteen lanes per cell or one by the number of reachable cells, decided on the device (the launch
+// of the other form leaves at once; a forced form, PVA_OPT_RT60_LANES, launches only itself)
+void launchRt60(const AnalyzeArgs& a, hipStream_t stream) {
+    if (a.rt60Lanes == 0 || a.rt60Lanes == 16)
+        hipLaunchKernelGGL(pv_rt60_wave_kernel, dim3((a.winCols + 15) / 16, a.winRows), dim3(256), 0, stream, a);
     launchRt60Blocked(a, stream);
+}
+
+void launchAnalysisCells(const AnalyzeArgs& a, hipStream_t stream) {
+    launchOnset(a, stream);
+    launchEncode(a, stream);
+    launchRt60(a, stream);
 }
 
 void launchAnalysisDirection(const AnalyzeArgs& a, hipStream_t stream) {
@@ -3039,12 +3050,8 @@ void launchAnalysisFar(const AnalyzeArgs& a, hipStream_t stream) {
 
 void launchAnalysis(const AnalyzeArgs& a, hipStream_t stream) {
     launchAnalysisFar(a, stream);
+    launchAnalysisCells(a, stream);
     const dim3 grid = analysisWindowGrid(a);
-    hipLaunchKernelGGL(pv_encode_kernel, grid, dim3(256), 0, stream, a);
-    // wet gain + decay time: sixteen, four or one lane per cell by the number of reachable cells, decided on the device
-    // (the launches of the other forms leave at once)
-    hipLaunchKernelGGL(pv_rt60_wave_kernel, dim3((a.winCols + 15) / 16, a.winRows), dim3(256), 0, stream, a);
-    launchRt60Blocked(a, stream);
     // listener direction: the plain walk where walks are short (small windows: rooms, the sandbox's grids), pointer
     // jumping where a window is wide enough for hundreds of steps (a dozen tiny launches, path-length independent)
     if (a.dirJump)

@@ -73,7 +73,10 @@ void launchAnalysisFar(const AnalyzeArgs& a, hipStream_t stream);  // launchAnal
 // no-onset cells of the window take the six persistent result planes (occlusion, wet gain, decay time, lowpass, source
 // direction x / y) from another solver's maps (pv_rt60.hip; Solver::run's carryFrom)
 void launchCarryResults(const AnalyzeArgs& a, const float* srcOut, hipStream_t stream);
-void launchAnalysisCells(const AnalyzeArgs& a, hipStream_t stream);
+void launchAnalysisCells(const AnalyzeArgs& a, hipStream_t stream);  // = the three below, one after the other
+void launchOnset(const AnalyzeArgs& a, hipStream_t stream);   // onsets of the window's cells into the delay map
+void launchEncode(const AnalyzeArgs& a, hipStream_t stream);  // dry gain, source direction, low-pass (reads the onsets)
+void launchRt60(const AnalyzeArgs& a, hipStream_t stream);    // wet gain, decay time (reads the onsets)
 void launchAnalysisDirection(const AnalyzeArgs& a, hipStream_t stream);
 // wet gain + decay time, blocked forms (pv_rt60.hip: four lanes / one lane per cell; each launch checks on the device whether it is the one)
 void launchRt60Blocked(const AnalyzeArgs& a, hipStream_t stream);

@@ -156,6 +156,41 @@ PV_HD inline float pvLog10fNonNegT(float x, const TabF& tab) {
 
 PV_HD inline float pvLog10fNonNeg(float x) { return pvLog10fNonNegT(x, PvLogTabConst{}); }
 
+// ... and for a positive NORMAL finite argument only (0x00800000 <= bits < 0x7f800000): the selects for zero, subnormals,
+// inf and NaN are gone, and so is logf's early return for a mantissa of exactly 1 -- table entry 9 is {1, 0}, so the
+// polynomial gives r = 0 and y = y0 = +0 there by itself.  This is what the lane-per-cell decay-time kernel (pv_rt60.hip)
+// evaluates per sample; a wave whose running energy is not normal in some lane (it is a sum of squares: zero before the
+// first non-zero sample, subnormal for a few samples after it) takes pvLog10fNonNegT for that chunk instead.  Bit-identical
+// to pvLog10f on its whole domain (tools/libm_check.cpp, every normal float).
+PV_HD inline bool pvIsNormalPositive(float x) { return pvBitsF(x) - 0x00800000u < 0x7f000000u; }
+
+template <class TabF>
+PV_HD inline float pvLog10fNormalT(float x, const TabF& tab) {
+    const float ivln10 = 4.3429449201e-01f, log10_2hi = 3.0102920532e-01f, log10_2lo = 7.9034151668e-07f;
+    const int hx = (int)pvBitsF(x);
+    const int k = (hx >> 23) - 127;
+    const int i10 = (int)((unsigned)k >> 31);
+    const uint32_t ix = ((uint32_t)hx & 0x007fffffu) | ((uint32_t)(0x7f - i10) << 23);
+    const float yk = (float)(k + i10);
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> 19) & 15u);
+    const int kk = (int)tmp >> 23;
+    const uint32_t iz = ix - (tmp & (0x1ffu << 23));
+    double invc, y0;
+    tab(i, kk, &invc, &y0);
+    const double z = (double)pvFloatBits(iz);
+    const double r = pvFma(z, invc, -1.0);
+    const double r2 = r * r;
+    double y = pvFma(0x1.5575b0be00b6ap-2, r, -0x1.ffffef20a4123p-2);
+    y = pvFma(-0x1.00ea348b88334p-2, r2, y);
+    y = pvFma(y, r2, y0 + r);
+    const float lm = (float)y;
+    const float zf = yk * log10_2lo + ivln10 * lm;
+    return zf + yk * log10_2hi;
+}
+
+PV_HD inline float pvLog10fNormal(float x) { return pvLog10fNormalT(x, PvLogTabConst{}); }
+
 // powf for x >= 0 (zero, subnormal, inf and NaN included) and a positive finite y with |y * log2(x)| < 126 -- the
 // analysis calls it with y = 0.8f, for which the overflow / underflow branches of glibc's powf cannot be taken.
 PV_HD inline float pvPowf(float x, float y) {

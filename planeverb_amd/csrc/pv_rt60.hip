@@ -28,6 +28,10 @@
 #include "pv_libm.h"
 #include "pv_prims.h"
 
+#ifndef PV_RT60_TILE_S
+#define PV_RT60_TILE_S 8  // samples per chunk of the lane-per-cell form
+#endif
+
 namespace pva {
 
 namespace {
@@ -177,6 +181,175 @@ __global__ __launch_bounds__(256) void pv_rt60_blocked_kernel(const AnalyzeArgs 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Lane-per-cell form over the TILE-MAJOR history (round 5): the form for everything above a few thousand cells.
+// ---------------------------------------------------------------------------------------------------------------
+// The blocked form above is bound by bytes it should not read (profiles/r04_analysis_pmc.md: 3 564 MB for a 1 328 MB
+// history at 4.8 TB/s): its lanes run along WINDOW columns, so one load instruction touches four time planes x 16 floats,
+// i.e. 64-byte pieces of 128-byte lines of tile rows that are 160-192 bytes long and not line-aligned -- the other halves
+// arrive later, by other waves on other XCDs.  Here a lane's cell is its OFFSET g inside a history plane
+// (plane[t][tile][row][col] is tile-major without padding, so hist + t * histPlane + g is the cell's sample t): the 64 lanes
+// of a wave read 256 contiguous bytes of one plane per load instruction, every line is fetched by exactly one workgroup.
+// One lane per cell also means no lane runs another lane's chain steps: per sample one multiply, three dependent adds and
+// one logarithm (~45 instructions) instead of ~58 per sample and 64 lanes.
+// Like pv_encode_kernel it reads the onset from the delay map (pv_onset_kernel) and nothing else of that kernel's, so the two
+// run BESIDE each other on two streams -- the encode pass is bound by memory latency, this one by its instructions.
+// Segments of the backward pass (Analyzer.cpp:300-318), all wave-uniform: [endPoint, T) energy only; [max of the wave's
+// starting points, endPoint) every live lane regresses every sample -- no masks, branch-free logarithm for normal arguments
+// (pvLog10fNormalT; a chunk in which some lane's running energy is zero, subnormal or not finite takes the general form);
+// the rest masked per lane.  Lanes out of range load through an out-of-range buffer offset: the load returns 0 without
+// touching memory, and adding 0 * 0 leaves a non-negative sum as it is, bit for bit.
+template <int S>
+__global__ __launch_bounds__(256) void pv_rt60_tile_kernel(const AnalyzeArgs a) {
+    __shared__ double tab[96];
+    if (analysisAborted(a)) return;
+    if (rt60LanesPerCell(a, *a.activeCount) != 1) return;  // (grid-uniform)
+    if (threadIdx.x < 96) {
+        double invc, y0;
+        const int e = (int)threadIdx.x >> 1;
+        PvLogTabConst{}(e & 15, (e >> 4) - 1, &invc, &y0);
+        tab[threadIdx.x] = (threadIdx.x & 1) ? y0 : invc;
+    }
+    __syncthreads();
+    const LogTabLds ltab{tab};
+    const DynParams dyn = *a.dyn;
+    const int T = a.T;
+    constexpr int kOut = 0x7fffffff;  // >= every descriptor's extent: the load returns 0
+    const long long plane = a.histPlane;
+    const int planeBytes = (int)(plane * 4);
+
+    // which cell: offset in a history plane -> window tile, row and column in the tile -> grid cell; its onset from the delay map
+    const long long gl = (long long)blockIdx.x * 256 + threadIdx.x;
+    const PlaneCell pc = planeCell(a, dyn, gl);
+    const int cell = pc.X * a.gy + pc.Y;
+    const float delay = pc.inGrid ? a.delay[cell] : FLT_MAX;
+    const bool live = delay != FLT_MAX;
+    if (__ballot(live) == 0ull) return;
+    const int onset = live ? (int)delay : 0;
+    const int voff = (int)gl * 4;
+    auto planeRsrc = [&](int t) { return makeRsrc(a.hist + (long long)t * plane, planeBytes); };
+
+    const int endPoint = T - a.nCut;
+    const int sp = onset + a.nDry + 1;  // startingPoint (live lanes)
+    int spMax = live ? sp : INT_MIN, spMin = live ? sp : INT_MAX;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        spMax = max(spMax, __shfl_xor(spMax, off));
+        spMin = min(spMin, __shfl_xor(spMin, off));
+    }
+    const int lvoff = live ? voff : kOut;
+    // dead lanes carry an energy of 1 through the unmasked segment (their loads return 0): a normal argument for the logarithm
+    float edc = live ? 0.f : 1.f, xysum = 0.f, ysum = 0.f;
+
+    // ---- [endPoint, T): energy only ----
+    const int e0 = max(endPoint, 0);
+#pragma unroll 1
+    for (int i = T - 1; i >= e0; i -= S) {
+        float p[S];
+#pragma unroll
+        for (int k = 0; k < S; ++k) p[k] = bufLoadF(planeRsrc(max(i - k, 0)), (i - k >= e0) ? lvoff : kOut, 0);
+#pragma unroll
+        for (int k = 0; k < S; ++k) edc = edc + p[k] * p[k];
+    }
+
+    // ---- [spMax, endPoint): whole chunks, every live lane in range ----
+    int i = min(endPoint, T) - 1;
+    {
+        const int nfull = max(i - max(spMax, 0) + 1, 0) / S;
+        float xf = (float)(i - sp);  // (float)(i - startingPoint), counted down: exact (integers below 2^24)
+        float pN[S];
+        if (nfull > 0) {
+#pragma unroll
+            for (int k = 0; k < S; ++k) pN[k] = bufLoadF(planeRsrc(i - k), lvoff, 0);
+        }
+#pragma unroll 1
+        for (int c = 0; c < nfull; ++c, i -= S) {
+            float e[S], y[S];
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                edc = edc + pN[k] * pN[k];
+                e[k] = edc;
+            }
+            if (c + 1 < nfull) {  // the next chunk's loads are in flight while this chunk's logarithms run
+#pragma unroll
+                for (int k = 0; k < S; ++k) pN[k] = bufLoadF(planeRsrc(i - S - k), lvoff, 0);
+            }
+            // the energy only grows: normal at both ends of the chunk = normal throughout (NaN fails the test)
+            if (__ballot(!(pvIsNormalPositive(e[0]) && pvIsNormalPositive(e[S - 1]))) == 0ull) {
+#pragma unroll
+                for (int k = 0; k < S; ++k) y[k] = 10.f * pvLog10fNormalT(e[k], ltab);
+            } else {
+#pragma unroll
+                for (int k = 0; k < S; ++k) y[k] = 10.f * pvLog10fNonNegT(e[k], ltab);
+            }
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                xysum = xysum + y[k] * xf;
+                ysum = ysum + y[k];
+                xf = xf - 1.f;
+            }
+        }
+    }
+
+    // ---- the rest, down to the wave's lowest starting point: masked per lane ----
+    {
+        const int lo = max(spMin, 0);
+#pragma unroll 1
+        for (; i >= lo; i -= S) {
+            float p[S], e[S];
+#pragma unroll
+            for (int k = 0; k < S; ++k)
+                p[k] = bufLoadF(planeRsrc(max(i - k, 0)), (live && i - k >= sp) ? voff : kOut, 0);
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                edc = edc + p[k] * p[k];  // + 0 out of range
+                e[k] = edc;
+            }
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                const bool regress = live && i - k >= sp;  // (i - k < endPoint holds for the whole segment)
+                const float y = 10.f * pvLog10fNonNegT(regress ? e[k] : 1.f, ltab);
+                xysum = regress ? xysum + y * (float)(i - k - sp) : xysum;
+                ysum = regress ? ysum + y : ysum;
+            }
+        }
+    }
+
+    // ---- wet gain (Analyzer.cpp:235-247): forwards over [startingPoint, startingPoint + N_wet) ^ [0, T) ----
+    float wet = 0.f;
+    {
+        const int wetEnd = live ? min(sp + a.nWet, T) : 0;
+        int wetEndMax = wetEnd;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) wetEndMax = max(wetEndMax, __shfl_xor(wetEndMax, off));
+        float pN[S];
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            const int t = spMin + k;
+            pN[k] = bufLoadF(planeRsrc(min(t, T - 1)), (live && t >= sp && t < wetEnd) ? voff : kOut, 0);
+        }
+#pragma unroll 1
+        for (int t0 = spMin; t0 < wetEndMax; t0 += S) {
+            float p[S];
+#pragma unroll
+            for (int k = 0; k < S; ++k) p[k] = pN[k];
+            if (t0 + S < wetEndMax) {
+#pragma unroll
+                for (int k = 0; k < S; ++k) {
+                    const int t = t0 + S + k;
+                    pN[k] = bufLoadF(planeRsrc(min(t, T - 1)), (live && t >= sp && t < wetEnd) ? voff : kOut, 0);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < S; ++k) wet = wet + p[k] * p[k];  // + 0 out of range
+        }
+    }
+    if (live) {
+        a.out[a.resN + cell] = sqrtf(wet / a.efree);
+        a.out[2 * a.resN + cell] = rt60FromSums(a, sp, xysum, ysum);
+    }
+}
+
 }  // namespace
 
 // Live module with two iterations in flight on two solvers (Solver::run's carryFrom): a cell in which this run found no onset
@@ -204,11 +377,17 @@ void launchCarryResults(const AnalyzeArgs& a, const float* srcOut, hipStream_t s
     hipLaunchKernelGGL(pv_carry_results_kernel, dim3((a.winCols + 255) / 256, a.winRows), dim3(256), 0, stream, a, srcOut);
 }
 
-// the blocked form; the sixteen-lane form (pv_rt60_wave_kernel, pv_kernels.hip) is launched beside them by launchAnalysis
+// the forms above; the sixteen-lane form (pv_rt60_wave_kernel, pv_kernels.hip) is launched beside them by launchAnalysis.  Which
+// one does the work is decided on the device (rt60LanesPerCell); a forced form (PVA_OPT_RT60_LANES) launches only itself.
 void launchRt60Blocked(const AnalyzeArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL((pv_rt60_blocked_kernel<4, 4>), dim3((a.winCols + 63) / 64, a.winRows), dim3(256), 0, stream, a);
-    // (one lane per cell -- <1, 4>, <1, 8> -- was measured too: slower than four lanes at every size, 0.27 vs 0.15 ms at 127^2,
-    // 1.93 vs 1.70 ms at 512^2 / T = 3179; <4, 8> and <4, 2> are within 3 % of <4, 4>: profiles/r04_rt60.txt)
+    if (a.rt60Lanes == 4) {
+        hipLaunchKernelGGL((pv_rt60_blocked_kernel<4, 4>), dim3((a.winCols + 63) / 64, a.winRows), dim3(256), 0, stream, a);
+        // (one lane per cell ALONG WINDOW COLUMNS -- <1, 4>, <1, 8> -- was measured in round 4: slower than four lanes at every
+        // size, 0.27 vs 0.15 ms at 127^2, 1.93 vs 1.70 ms at 512^2 / T = 3179; <4, 8> and <4, 2> within 3 % of <4, 4>:
+        // profiles/r04_rt60.txt)
+    } else if (a.rt60Lanes != 16) {
+        hipLaunchKernelGGL((pv_rt60_tile_kernel<PV_RT60_TILE_S>), dim3((unsigned)((a.histPlane + 255) / 256)), dim3(256), 0, stream, a);
+    }
 }
 
 }  // namespace pva

@@ -20,6 +20,7 @@ namespace {
 // two cross-stream event waits per band and sweep cost more than the chip-wide drain they remove.
 constexpr int kAutoRowBands = 1;
 constexpr int kDefaultPatch = 0;  // persistent patch kernel for the (12, 36) tile: off until measured faster (PVA_OPT_PATCH_KERNEL)
+constexpr long long kAnalysisForkCells = 32768;  // window cells from which the decay-time pass runs beside the encode pass (enqueueAnalysis)
 constexpr int kMinGuard = 8;  // guard width = max(this, K): a tile's halo never leaves the allocation
 inline int roundUp(int v, int m) { return (v + m - 1) / m * m; }
 inline int ceilDiv(int a, int b) { return (a + b - 1) / b; }
@@ -108,6 +109,8 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         auxStreams_.push_back(x);
     }
     if (!hipOk(hipEventCreateWithFlags(&forkEv_, hipEventDisableTiming), "hipEventCreate")) return false;
+    for (auto& e : anaEv_)
+        if (!hipOk(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate")) return false;
     for (auto& e : ev_)
         if (!hipOk(hipEventCreate(&e), "hipEventCreate")) return false;
 
@@ -508,6 +511,8 @@ Solver::~Solver() {
     for (auto& e : airDone_) hipEventDestroy(e);
     for (auto& e : genDone_) hipEventDestroy(e);
     if (forkEv_) hipEventDestroy(forkEv_);
+    for (auto& e : anaEv_)
+        if (e) hipEventDestroy(e);
     for (hipStream_t x : auxStreams_) hipStreamDestroy(x);
     for (hipEvent_t e : openEv_)
         if (e) hipEventDestroy(e);
@@ -1156,7 +1161,7 @@ AnalyzeArgs Solver::analyzeArgs(float lx, float lz) const {
     // so does the dense-history (validation) mode.
     const bool smallWindow = a.winRows <= 256 && a.winCols <= 256;
     a.dirJump = (!opt_.denseHistory && !(smallWindow && geo_.ntx * geo_.nty > 4096)) ? 1 : 0;
-    a.rt60Lanes = (opt_.rt60Lanes == 16 || opt_.rt60Lanes == 4) ? opt_.rt60Lanes : 0;
+    a.rt60Lanes = (opt_.rt60Lanes == 16 || opt_.rt60Lanes == 4 || opt_.rt60Lanes == 1) ? opt_.rt60Lanes : 0;
     a.T = T_;
     a.nDir = g_.nDir;
     a.nDry = g_.nDry;
@@ -1228,15 +1233,28 @@ bool Solver::ensureFarDirections() {
 // the analysis of the run enqueued on stream_ (history recorded, dynCur_ = its parameters)
 void Solver::enqueueAnalysis(float lx, float lz) {
     const AnalyzeArgs a = analyzeArgs(lx, lz);
-    if (carryFrom_ && carryFrom_ != this && carryFrom_->device_ == device_ && !opt_.streaming && !isSlab()) {
-        launchAnalysisFar(a, stream_);
-        launchAnalysisCells(a, stream_);
-        hipStreamWaitEvent(stream_, carryFrom_->ev_[2], 0);  // the previous iteration's analysis (and its own carry) is complete
-        launchCarryResults(a, carryFrom_->res_, stream_);
-        launchAnalysisDirection(a, stream_);
+    const bool carry = carryFrom_ && carryFrom_ != this && carryFrom_->device_ == device_ && !opt_.streaming && !isSlab();
+    // Two iterations in flight on two solvers: the OTHER solver's iteration reads this solver's result maps in its carry pass,
+    // so nothing of this analysis may write them before that iteration's analysis (and its own carry) is complete
+    if (carry) hipStreamWaitEvent(stream_, carryFrom_->ev_[2], 0);
+    launchAnalysisFar(a, stream_);
+    launchOnset(a, stream_);
+    // wet gain / decay time beside the encode pass: both only read the onsets and the history, and write different planes.
+    // Worth two cross-stream waits where the decay-time pass is long (windows of tens of thousands of cells)
+    const bool fork = histPlane_ >= kAnalysisForkCells && opt_.analysisFork != 0;
+    if (fork) {
+        hipEventRecord(anaEv_[0], stream_);
+        hipStreamWaitEvent(stream2_, anaEv_[0], 0);
+        launchRt60(a, stream2_);
+        hipEventRecord(anaEv_[1], stream2_);
+        launchEncode(a, stream_);
+        hipStreamWaitEvent(stream_, anaEv_[1], 0);
     } else {
-        launchAnalysis(a, stream_);
+        launchEncode(a, stream_);
+        launchRt60(a, stream_);
     }
+    if (carry) launchCarryResults(a, carryFrom_->res_, stream_);
+    launchAnalysisDirection(a, stream_);
     if (lazyFar_) {
         farWin_ = curWindow();
         farDirValid_ = false;

@@ -53,6 +53,7 @@ struct SolverOptions {
     int patchStrip = 3;   // patch columns per strip of its walk
     int streamPriority = 0;  // PVA_OPT_STREAM_PRIORITY: 1 = main stream on the highest priority (a hardware queue apart from the default-priority streams)
     bool debugLoseFirstCapture = false;  // PVA_OPT_DEBUG_LOSE_FIRST_CAPTURE: the solver's first graph capture counts as lost
+    int analysisFork = 1; // 0: wet gain / decay time behind the encode pass instead of beside it (measurements)
     int rt60Lanes = 0;    // decay-time pass: lanes per cell (pv_rt60.hip): 0 = by the number of reachable cells, 16 / 4 / 1 = forced
     int resident = 0;     // resident kernel (pv_resident.hip: one launch per run, every tile a workgroup that stays on its CU for
                           // all T steps): 0 = auto (default tile of the launch-bound grids, whole-grid history window, all
@@ -222,6 +223,7 @@ private:
     std::vector<hipStream_t> auxStreams_;  // PVA_OPT_AUX_STREAMS
     std::vector<hipEvent_t> airDone_, genDone_;  // per-launch cross-stream dependencies (no timing)
     hipEvent_t forkEv_ = nullptr;
+    hipEvent_t anaEv_[2] = {nullptr, nullptr};  // enqueueAnalysis: onsets known -> stream2_, decay times done -> stream_
     // captured launch schedule of one run (reset + all step launches on both streams), replayed per run
     hipGraph_t graph_ = nullptr;
     hipGraphExec_t graphExec_ = nullptr;

@@ -167,9 +167,9 @@ def test_resident_kernel_concurrent_solvers_and_budget(pvlib):
 
 
 @pytest.mark.parametrize("name", ["g71_smallroom", "g71_floorplan", "g96_smallroom_res375"])
-@pytest.mark.parametrize("lanes", [16, 4])
+@pytest.mark.parametrize("lanes", [16, 4, 1])
 def test_decay_time_forms_golden(pvlib, name, lanes):
-    """both forms of the wet gain / decay time pass reproduce the reference's vectors (the choice is made on the device by
+    """all forms of the wet gain / decay time pass reproduce the reference's vectors (the choice is made on the device by
     the number of reachable cells; PVA_OPT_RT60_LANES forces one)"""
     g = golden(name)
     gx, gy, T, fs = (int(v) for v in g["dims"])
@@ -183,12 +183,13 @@ def test_decay_time_forms_golden(pvlib, name, lanes):
 
 def test_decay_time_forms_agree_512_mode_b(pvlib):
     """BASELINE config 2 / Mode B (512^2, T = 3179: every cell of the room is reached, ~100 000 impulse responses): the
-    four-lane form (the device's choice here) against the reference's vectors and against the sixteen-lane form"""
+    lane-per-cell form (the device's choice here), beside and behind the encode pass, against the reference's vectors and against
+    the sixteen- and the four-lane form"""
     g = golden("g512B_shoebox")
     gx, gy, T, fs = (int(v) for v in g["dims"])
     maps = []
-    for lanes in (0, 16):
-        with pvlib.Solver(float(g["size"]), float(g["size"]), int(g["res"]), rt60_lanes=lanes) as s:
+    for lanes, fork in ((0, 1), (16, 1), (4, 1), (1, 0)):
+        with pvlib.Solver(float(g["size"]), float(g["size"]), int(g["res"]), rt60_lanes=lanes, analysis_fork=fork) as s:
             for b in g["boxes"]:
                 s.add_geometry(b)
             s.run(g["listener"])
@@ -205,8 +206,10 @@ def test_decay_time_forms_agree_512_mode_b(pvlib):
             maps.append((res, delay))
             if lanes == 0:
                 assert s.timings().reachedCells == int((delay < 1e30).sum()) > 100000
-    for k, nm in enumerate(NAMES):
-        assert same_bits(maps[0][0][..., k], maps[1][0][..., k]).all(), nm
+    for other in maps[1:]:
+        assert same_bits(maps[0][1], other[1]).all()
+        for k, nm in enumerate(NAMES):
+            assert same_bits(maps[0][0][..., k], other[0][..., k]).all(), nm
 
 
 def test_two_solvers_taking_turns_equal_one_solver(pvlib):

@@ -14,6 +14,11 @@ int main(int argc, char** argv) {
         const float x = pva::pvFloatBits((uint32_t)u);
         if (u >= 1 && u < 0x7f800000ull && pva::pvBitsF(pva::pvLog10f(x)) != pva::pvBitsF(std::log10(x))) ++badLog;
         if (u >= 1 && u < 0x7f800000ull && pva::pvBitsF(pva::pvLog10fNonNeg(x)) != pva::pvBitsF(std::log10(x))) ++badLog;
+        // the fast form's domain: positive normal finite floats (pv_rt60.hip's lane-per-cell kernel)
+        if (u >= 0x00800000ull && u < 0x7f800000ull &&
+            (!pva::pvIsNormalPositive(x) || pva::pvBitsF(pva::pvLog10fNormal(x)) != pva::pvBitsF(std::log10(x))))
+            ++badLog;
+        if (u < 0x00800000ull && pva::pvIsNormalPositive(x)) ++badLog;
         if (pva::pvBitsF(pva::pvPowf(x, 0.8f)) != pva::pvBitsF(std::pow(x, 0.8f))) ++badPow;
         ++n;
     }
@@ -23,6 +28,9 @@ int main(int argc, char** argv) {
         const float a = pva::pvLog10f(s), b = std::log10(s);
         if (!((a != a && b != b) || pva::pvBitsF(a) == pva::pvBitsF(b))) ++badLog;
     }
+    if (pva::pvIsNormalPositive(INFINITY) || pva::pvIsNormalPositive(NAN) || pva::pvIsNormalPositive(-1.f) ||
+        pva::pvIsNormalPositive(0.f) || !pva::pvIsNormalPositive(1.f) || !pva::pvIsNormalPositive(1.17549435e-38f))
+        ++badLog;
     const float nonneg[] = {0.f, INFINITY, NAN, 1.f, 1.17549435e-38f, 1e-45f};  // the branch-free form's domain
     for (float s : nonneg) {
         const float a = pva::pvLog10fNonNeg(s), b = std::log10(s);
