@@ -66,7 +66,8 @@ __device__ __forceinline__ int rt60LanesPerCell(const AnalyzeArgs& a, int active
     if (a.rt60Lanes) return a.rt60Lanes;  // (PVA_OPT_RT60_LANES: validation / measurement)
     // (measured on MI355X, profiles/r04_rt60.txt: 70^2 0.093 / 0.098 ms, 127^2 0.156 / 0.148 ms for sixteen / four lanes; round 5:
     // one lane per cell over the tile-major history replaces the four-lane form, profiles/r05_rt60.txt)
-    return activeCells <= 8192 ? 16 : 1;
+    if (activeCells <= 8192) return 16;
+    return a.histPlane * 4 * 16 < (1ll << 31) ? 1 : 4;  // (the lane-per-cell form reaches a chunk's planes through one descriptor and scalar offsets)
 }
 
 struct Rt60Cell {

@@ -276,8 +276,12 @@ struct AnalyzeArgs {
     int rxi, wi, nty;
     int winRows, winCols;  // extent of the history window in cells: the analysis kernels' launch grid
     int* activeCount;      // [0]: cells of the window's ever-non-zero tiles (an upper bound of the reached cells: chooses the
-                           // decay-time form on the device), [1]: cells with an onset (counted by pv_encode_kernel; both reset by
-                           // the first launch of the analysis)
+                           // decay-time form on the device), [1]: cells with an onset, [3]: silent air cells, [4]: entries of
+                           // unitList (all counted by pv_onset_kernel and reset by the first launch of the analysis)
+    int* unitList;         // the 64-cell groups of the history plane (group u = plane offsets 64 u .. 64 u + 63) that hold a cell
+                           // with an onset, in no particular order: what pv_encode_kernel and pv_rt60_tile_kernel work on, one
+                           // wave per entry -- consecutive workgroups then hold equal amounts of work wherever the reached cells
+                           // lie in the plane (launched over the plane, a third of the SIMDs got three waves of it, most one)
     int* dirScratch;       // winRows x winCols ints for the listener-direction pointer jumping
     int dirJump;           // listener direction by pointer jumping (wide windows) instead of the plain walk
     int rt60Lanes;         // 0 = by the number of reachable cells (rt60LanesPerCell); 16 / 4 / 1 = that form of the decay-time pass

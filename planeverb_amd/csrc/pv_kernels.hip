@@ -2309,7 +2309,13 @@ __device__ __forceinline__ int analysisWindowIndex(const AnalyzeArgs& a, const D
 // scans the samples t = tBeg + (16 j + w) 16 + k; the earliest hit per cell is kept with an LDS minimum, and a wave stops once
 // no cell of the block can improve.  A silent cell costs T / 256 round trips instead of T / 16.  pv_encode_kernel and the
 // decay-time kernels read the onset from the delay map, side by side on two streams.
-constexpr int kOnsetWaves = 16, kOnsetSC = 16;
+#ifndef PV_ONSET_WAVES
+#define PV_ONSET_WAVES 4
+#endif
+#ifndef PV_ONSET_SC
+#define PV_ONSET_SC 32
+#endif
+constexpr int kOnsetWaves = PV_ONSET_WAVES, kOnsetSC = PV_ONSET_SC;
 __global__ __launch_bounds__(64 * kOnsetWaves) void pv_onset_kernel(const AnalyzeArgs a) {
     __shared__ int found[64];
     if (analysisAborted(a)) return;
@@ -2328,9 +2334,16 @@ __global__ __launch_bounds__(64 * kOnsetWaves) void pv_onset_kernel(const Analyz
     if (wave == 0) found[lane] = INT_MAX;
     __syncthreads();
     if (__ballot(live) == 0ull) return;  // (the same lanes in every wave of the block: block-uniform)
-    int tBeg = live ? tF : INT_MAX;
+    // A run starts from zero fields and the stencil moves a value by one cell per step along one axis (FDTD.cpp:124-199): the
+    // recorded pressure of a cell at Manhattan distance m from the listener is exactly zero up to and including step m,
+    // whatever the geometry.  The search starts there (cells far from the listener: half the samples between the tile's first
+    // recorded step and the onset).  No listener in the grid: no pulse, no onset.
+    const int m = abs(c.X - (dyn.lrow - a.G)) + abs(c.Y - (dyn.lcol - a.G));
+    const int tS = live ? min(max(tF, m), T) : INT_MAX;
+    int tBeg = tS;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) tBeg = min(tBeg, __shfl_xor(tBeg, off));
+    tBeg = __builtin_amdgcn_readfirstlane(tBeg);  // (wave-uniform by value: scalar loop counter, scalar descriptors)
     const int voff = (int)g * 4;
     const int planeBytes = (int)(a.histPlane * 4);
     constexpr int SC = kOnsetSC;
@@ -2342,7 +2355,7 @@ __global__ __launch_bounds__(64 * kOnsetWaves) void pv_onset_kernel(const Analyz
 #pragma unroll
         for (int k = 0; k < SC; ++k) {
             const int tt = t + k;
-            const bool want = live && tt >= tF && tt < T && tt < best;  // (a tile's history starts at its first recorded step)
+            const bool want = live && tt >= tS && tt < T && tt < best;  // (a tile's history starts at its first recorded step)
             pc[k] = bufLoadF(makeRsrc(a.hist + (long long)min(tt, T - 1) * a.histPlane, planeBytes), want ? voff : 0x7fffffff, 0);
         }
         int hit = INT_MAX;
@@ -2357,44 +2370,65 @@ __global__ __launch_bounds__(64 * kOnsetWaves) void pv_onset_kernel(const Analyz
     // reached cells of this run (bench / PvAmdTimings.reachedCells) and silent ones: one atomic each per block
     const unsigned long long mr = __ballot(live && onset != INT_MAX), ms = __ballot(live && onset == INT_MAX);
     if (lane == 0) {
-        if (mr) atomicAdd(a.activeCount + 1, __popcll(mr));
+        if (mr) {
+            atomicAdd(a.activeCount + 1, __popcll(mr));
+            a.unitList[atomicAdd(a.activeCount + 4, 1)] = (int)blockIdx.x;  // this group of 64 cells has work for the passes behind
+        }
         if (ms) atomicAdd(a.activeCount + 3, __popcll(ms));
     }
 }
 
 // One thread per window cell, lanes along the tile-major plane (planeCell), behind pv_onset_kernel: dry energy, flux,
 // obstruction gain, source directivity, low-pass cutoff of the cells that have an onset.
+// TIME is wave-uniform: every load instruction reads ONE plane (the wave's 256 contiguous bytes of it), from the earliest
+// first sample of the wave's cells to the latest last one, and a lane whose own window has not begun or is over loads nothing
+// and adds nothing.  (Per-lane start and end times -- each lane walking its own [first, onset + N) -- put up to 64 planes
+// into one load instruction: 0.65 ms instead of 0.07 for the 104 000 cells of the 512^2 / T = 3179 room.)
+__device__ __forceinline__ int waveMin(int v) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) v = min(v, __shfl_xor(v, off));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ int waveMax(int v) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) v = max(v, __shfl_xor(v, off));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
 __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
     if (analysisAborted(a)) return;
     const DynParams dyn = *a.dyn;
-    const PlaneCell pc0 = planeCell(a, dyn, (long long)blockIdx.x * 256 + threadIdx.x);
-    if (!pc0.inGrid) return;
+    const int unit = blockIdx.x * 4 + (int)(threadIdx.x >> 6);  // one wave per entry of the list of groups with work
+    if (unit >= a.activeCount[4]) return;
+    const PlaneCell pc0 = planeCell(a, dyn, (long long)a.unitList[unit] * 64 + (threadIdx.x & 63));
     const int X = pc0.X, Y = pc0.Y;
     const int s = X * a.gy + Y;
-    const float delay = a.delay[s];
-    if (delay == FLT_MAX) return;  // no onset (Analyzer.cpp:160-165): the result record stays as it is
-    const int onset = (int)delay;
-    const int tFirst = a.tileFirst[pc0.tile];
+    const float delay = pc0.inGrid ? a.delay[s] : FLT_MAX;
+    const bool live = delay != FLT_MAX;  // no onset (Analyzer.cpp:160-165): the result record stays as it is
+    if (__ballot(live) == 0ull) return;
+    const int onset = live ? (int)delay : 0;
+    const int T = a.T;
+    const int tFirst = live ? a.tileFirst[pc0.tile] : T;
 
     const int prow = X + a.G, pcol = Y + a.G;
-    const int T = a.T;
     const int hr = prow - dyn.histRow0, hcol = pcol - dyn.histCol0;
-    const long long hoff = histOffset(hr, hcol, a.rxi, a.wi, dyn.histTilesY);
+    const long long hoff = live ? histOffset(hr, hcol, a.rxi, a.wi, dyn.histTilesY) : 0;
     CellHistory hc{a.hist + hoff, a.histPlane};
     // neighbours for the velocity recurrence; a neighbour tile that became active later (or never) has
     // unwritten history that is exactly zero by causality
     int tFx = INT_MAX, tFy = INT_MAX;
-    if (X > 0 && prow - 1 >= dyn.histRow0) tFx = a.tileFirst[((X - 1) / a.rxi) * a.nty + (Y / a.wi)];
-    if (Y > 0 && pcol - 1 >= dyn.histCol0) tFy = a.tileFirst[(X / a.rxi) * a.nty + ((Y - 1) / a.wi)];
+    if (live && X > 0 && prow - 1 >= dyn.histRow0) tFx = a.tileFirst[((X - 1) / a.rxi) * a.nty + (Y / a.wi)];
+    if (live && Y > 0 && pcol - 1 >= dyn.histCol0) tFy = a.tileFirst[(X / a.rxi) * a.nty + ((Y - 1) / a.wi)];
     // (the neighbours' offsets are only formed where they are read: tFx / tFy stay INT_MAX otherwise)
     CellHistory hx{a.hist + (tFx != INT_MAX ? histOffset(hr - 1, hcol, a.rxi, a.wi, dyn.histTilesY) : hoff), a.histPlane};
     CellHistory hy{a.hist + (tFy != INT_MAX ? histOffset(hr, hcol - 1, a.rxi, a.wi, dyn.histTilesY) : hoff), a.histPlane};
-    if (X == 0 && a.histAbove) {  // first row of a slab: the row above lives in the neighbouring slab
+    if (live && X == 0 && a.histAbove) {  // first row of a slab: the row above lives in the neighbouring slab
         hx = CellHistory{a.histAbove + (pcol - dyn.histCol0), a.histPitch};
         tFx = 0;
     }
 
-    const FaceCoef fc = a.coef[(size_t)prow * a.pitch + pcol];
+    FaceCoef fc{0.f, 0.f, 0.f};
+    if (live) fc = a.coef[(size_t)prow * a.pitch + pcol];
     const float kx = fc.kx, ky = fc.ky;
     const bool airX = kx != kx, airY = ky != ky;
     const float C = a.courant;
@@ -2406,23 +2440,30 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
 
     // dry energy + flux, Analyzer.cpp:170-195: both sums run from sample 0 (samples before tFirst are zero) to the end of
     // their windows behind the onset; vx / vy by the stencil's own recurrence as long as the flux needs them
-    const int sourceDirEnd = onset + a.nDir, directEnd = min(onset + a.nDry, T);
+    const int sourceDirEnd = live ? onset + a.nDir : 0, directEnd = live ? min(onset + a.nDry, T) : 0;
+    // (first sample that can be non-zero: the tile's first recorded step, and never before the pulse can have arrived through
+    // the stencil -- one cell per step along one axis, so this cell's pressure is exactly zero up to step m and its neighbours'
+    // up to step m - 1: pv_onset_kernel)
+    const int m = abs(X - (dyn.lrow - a.G)) + abs(Y - (dyn.lcol - a.G));
+    const int tBegin = max(tFirst, m - 1);
+    const int tLo = waveMin(live ? tBegin : INT_MAX), tHi = waveMax(directEnd), tVHi = waveMax(sourceDirEnd);
     float Edry = 0.f, fluxX = 0.f, fluxY = 0.f, vx = 0.f, vy = 0.f;
 #pragma unroll 1
-    for (int t0 = tFirst; t0 < directEnd; t0 += CH) {
+    for (int t0 = tLo; t0 < tHi; t0 += CH) {
         float pc[CH], pxc[CH], pyc[CH];
-        const bool needVChunk = t0 < sourceDirEnd;
+        const bool needVChunk = t0 < tVHi;  // (wave-uniform)
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
-            const int tt = min(t0 + k, T - 1);
-            pc[k] = hc.at(tt);
-            pxc[k] = (needVChunk && tt >= tFx) ? hx.at(tt) : 0.f;
-            pyc[k] = (needVChunk && tt >= tFy) ? hy.at(tt) : 0.f;
+            const int t = t0 + k, tt = min(t, T - 1);
+            const bool mine = t >= tBegin && t < directEnd, mineV = mine && t < sourceDirEnd;
+            pc[k] = mine ? hc.at(tt) : 0.f;
+            pxc[k] = (needVChunk && mineV && tt >= tFx) ? hx.at(tt) : 0.f;
+            pyc[k] = (needVChunk && mineV && tt >= tFy) ? hy.at(tt) : 0.f;
         }
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
             const int t = t0 + k;
-            if (t >= directEnd) continue;
+            if (t < tBegin || t >= directEnd) continue;
             const float p = pc[k];
             if (t < sourceDirEnd) {
                 const float pxn = pxc[k], pyn = pyc[k];
@@ -2439,6 +2480,25 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
         }
     }
 
+    // wet gain, Analyzer.cpp:235-247: forwards over [onset + N_dry + 1, + N_wet) ^ [0, T).  Only beside the lane-per-cell form of
+    // the decay-time pass (pv_rt60_tile_kernel, which is the backward walk alone); the sixteen- and four-lane forms do their own
+    const bool withWet = rt60LanesPerCell(a, *a.activeCount) == 1;
+    float wet = 0.f;
+    if (withWet) {
+        constexpr int WCH = 32;  // one plane per sample: more of them per memory round trip
+        const int wetBegin = live ? onset + a.nDry + 1 : INT_MAX, wetEnd = live ? min(wetBegin + a.nWet, T) : 0;
+        const int wLo = waveMin(wetBegin), wHi = waveMax(wetEnd);
+#pragma unroll 1
+        for (int t0 = wLo; t0 < wHi; t0 += WCH) {
+            float pw[WCH];
+#pragma unroll
+            for (int k = 0; k < WCH; ++k) pw[k] = (t0 + k >= wetBegin && t0 + k < wetEnd) ? hc.at(t0 + k) : 0.f;
+#pragma unroll
+            for (int k = 0; k < WCH; ++k) wet = wet + pw[k] * pw[k];  // + 0 outside the lane's window
+        }
+    }
+    if (!live) return;
+
     // obstruction gain + source directivity, Analyzer.cpp:197-220
     const float EfreePr = efreePerR(a.efree, a.dx, a.lcx, a.lcy, X + a.x0, Y);
     const float occ = sqrtf(Edry / EfreePr);
@@ -2450,8 +2510,9 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
     const float rr = 1.0f / ((0.001f < occ) ? occ : 0.001f);
     const float lowpass = -147.f + (18390.f) / (1.f + pvPowf(rr / 12.f, 0.8f));
 
-    // (wet gain and decay time: pv_rt60_wave_kernel / pv_rt60_tile_kernel, by the number of reachable cells)
+    // (decay time: pv_rt60_wave_kernel / pv_rt60_tile_kernel, by the number of reachable cells)
     a.out[s] = occ;
+    if (withWet) a.out[a.resN + s] = sqrtf(wet / a.efree);
     a.out[3 * a.resN + s] = lowpass;
     a.out[6 * a.resN + s] = sdx;
     a.out[7 * a.resN + s] = sdy;
@@ -2592,6 +2653,7 @@ __device__ __forceinline__ void countActiveCells(const AnalyzeArgs& a) {
         a.activeCount[0] = part[0];
         a.activeCount[1] = 0;
         a.activeCount[3] = 0;
+        a.activeCount[4] = 0;
     }
 }
 

@@ -31,6 +31,12 @@
 #ifndef PV_RT60_TILE_S
 #define PV_RT60_TILE_S 8  // samples per chunk of the lane-per-cell form
 #endif
+#ifndef PV_RT60_TILE_NB
+#define PV_RT60_TILE_NB 4  // chunks of loads in flight per wave
+#endif
+#ifndef PV_RT60_TILE_BLOCK
+#define PV_RT60_TILE_BLOCK 256  // threads per workgroup of the lane-per-cell form
+#endif
 
 namespace pva {
 
@@ -194,21 +200,22 @@ __global__ __launch_bounds__(256) void pv_rt60_blocked_kernel(const AnalyzeArgs 
 // one logarithm (~45 instructions) instead of ~58 per sample and 64 lanes.
 // Like pv_encode_kernel it reads the onset from the delay map (pv_onset_kernel) and nothing else of that kernel's, so the two
 // run BESIDE each other on two streams -- the encode pass is bound by memory latency, this one by its instructions.
-// Segments of the backward pass (Analyzer.cpp:300-318), all wave-uniform: [endPoint, T) energy only; [max of the wave's
-// starting points, endPoint) every live lane regresses every sample -- no masks, branch-free logarithm for normal arguments
-// (pvLog10fNormalT; a chunk in which some lane's running energy is zero, subnormal or not finite takes the general form);
-// the rest masked per lane.  Lanes out of range load through an out-of-range buffer offset: the load returns 0 without
-// touching memory, and adding 0 * 0 leaves a non-negative sum as it is, bit for bit.
-template <int S>
-__global__ __launch_bounds__(256) void pv_rt60_tile_kernel(const AnalyzeArgs a) {
+// Chunks of the backward pass (Analyzer.cpp:300-318) are of three wave-uniform kinds: in [endPoint, T) energy only; in [max of
+// the wave's starting points, endPoint) every live lane regresses every sample -- no masks, branch-free logarithm for normal
+// arguments (pvLog10fNormalT; a chunk in which some lane's running energy is zero, subnormal or not finite takes the general
+// form); the rest masked per lane.  Lanes out of range load through an out-of-range buffer offset: the load returns 0
+// without touching memory, and adding 0 * 0 leaves a non-negative sum as it is, bit for bit.  The wet gain of this form's
+// cells is pv_encode_kernel's (a forward walk, like its dry gain).
+template <int S, int NB>
+__global__ __launch_bounds__(PV_RT60_TILE_BLOCK) void pv_rt60_tile_kernel(const AnalyzeArgs a) {
     __shared__ double tab[96];
     if (analysisAborted(a)) return;
     if (rt60LanesPerCell(a, *a.activeCount) != 1) return;  // (grid-uniform)
-    if (threadIdx.x < 96) {
+    for (int w = threadIdx.x; w < 96; w += PV_RT60_TILE_BLOCK) {
         double invc, y0;
-        const int e = (int)threadIdx.x >> 1;
+        const int e = w >> 1;
         PvLogTabConst{}(e & 15, (e >> 4) - 1, &invc, &y0);
-        tab[threadIdx.x] = (threadIdx.x & 1) ? y0 : invc;
+        tab[w] = (w & 1) ? y0 : invc;
     }
     __syncthreads();
     const LogTabLds ltab{tab};
@@ -219,7 +226,9 @@ __global__ __launch_bounds__(256) void pv_rt60_tile_kernel(const AnalyzeArgs a) 
     const int planeBytes = (int)(plane * 4);
 
     // which cell: offset in a history plane -> window tile, row and column in the tile -> grid cell; its onset from the delay map
-    const long long gl = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int unit = blockIdx.x * (PV_RT60_TILE_BLOCK / 64) + (int)(threadIdx.x >> 6);  // one wave per group of 64 cells with work
+    if (unit >= a.activeCount[4]) return;
+    const long long gl = (long long)a.unitList[unit] * 64 + (threadIdx.x & 63);
     const PlaneCell pc = planeCell(a, dyn, gl);
     const int cell = pc.X * a.gy + pc.Y;
     const float delay = pc.inGrid ? a.delay[cell] : FLT_MAX;
@@ -228,6 +237,13 @@ __global__ __launch_bounds__(256) void pv_rt60_tile_kernel(const AnalyzeArgs a) 
     const int onset = live ? (int)delay : 0;
     const int voff = (int)gl * 4;
     auto planeRsrc = [&](int t) { return makeRsrc(a.hist + (long long)t * plane, planeBytes); };
+    // a chunk's S planes through ONE descriptor (base = the chunk's lowest plane) and S scalar offsets that never change: a
+    // descriptor per load is a 64-bit multiply-add and two merges on the scalar unit, 12 scalar instructions per load and a third
+    // as many as the kernel's vector instructions (profiles/r05_rt60.txt).  The bounds check of a raw buffer is on vector +
+    // scalar offset, so the descriptor's extent is the chunk's S planes, and lanes out of range still load through kOut
+    // (S planes must stay below 2^31 bytes for that: rt60LanesPerCell).
+    auto chunkRsrc = [&](int iTop) { return makeRsrc(a.hist + (long long)(iTop - S + 1) * plane, (long long)S * planeBytes); };
+    auto chunkOff = [&](int k) { return (int)((unsigned)(S - 1 - k) * (unsigned)planeBytes); };
 
     const int endPoint = T - a.nCut;
     const int sp = onset + a.nDry + 1;  // startingPoint (live lanes)
@@ -237,117 +253,115 @@ __global__ __launch_bounds__(256) void pv_rt60_tile_kernel(const AnalyzeArgs a) 
         spMax = max(spMax, __shfl_xor(spMax, off));
         spMin = min(spMin, __shfl_xor(spMin, off));
     }
+    // (wave-uniform by value; said so to the compiler: the loops below then run on scalar counters and scalar descriptors)
+    spMax = __builtin_amdgcn_readfirstlane(spMax);
+    spMin = __builtin_amdgcn_readfirstlane(spMin);
     const int lvoff = live ? voff : kOut;
-    // dead lanes carry an energy of 1 through the unmasked segment (their loads return 0): a normal argument for the logarithm
+    // dead lanes carry an energy of 1 through the unmasked chunks (their loads return 0): a normal argument for the logarithm
     float edc = live ? 0.f : 1.f, xysum = 0.f, ysum = 0.f;
 
-    // ---- [endPoint, T): energy only ----
-    const int e0 = max(endPoint, 0);
-#pragma unroll 1
-    for (int i = T - 1; i >= e0; i -= S) {
-        float p[S];
-#pragma unroll
-        for (int k = 0; k < S; ++k) p[k] = bufLoadF(planeRsrc(max(i - k, 0)), (i - k >= e0) ? lvoff : kOut, 0);
-#pragma unroll
-        for (int k = 0; k < S; ++k) edc = edc + p[k] * p[k];
-    }
-
-    // ---- [spMax, endPoint): whole chunks, every live lane in range ----
-    int i = min(endPoint, T) - 1;
+    // A software-pipelined loop over chunks of S samples, backwards from T - 1 (chunk c: samples i0 = T - 1 - c S ... i0 - S + 1).
+    // NB chunks of loads are in flight per wave: a ring of NB x S registers, the loop unrolled NB times so that every slot is a
+    // fixed set of registers, loads issued in consumption order everywhere (the compiler's wait-count bookkeeping joins
+    // prologue and loop at the loop header; a reordered prologue made every pass through the header wait for ALL loads).
+    // This many cells leave one or two waves per SIMD: with one chunk ahead the kernel waited a memory round trip per chunk
+    // (2.1 TB/s, 0.68 ms where its instructions take 0.3: profiles/r05_rt60.txt).  Every chunk issues and consumes its S loads
+    // whatever it is (the counts are the same on every path); what a chunk does with the energies is wave-uniform:
+    //   entirely in [endPoint, T)      nothing (energy only);
+    //   entirely in [spMax, endPoint)  every live lane regresses every sample: no masks, pvLog10fNormalT;
+    //   otherwise                      masked per lane and sample, the general logarithm.
+    const int lowest = live ? max(min(sp, endPoint), 0) : INT_MAX;  // this lane's energy integral covers [lowest, T)
+    const int hiAll = max(min(spMax, endPoint), 0);                  // from here up every live lane is inside its integral
+    const int lo = max(min(spMin, endPoint), 0);                     // nothing below is anybody's
+    const int n1 = max(T - hiAll, 0) / S;                            // chunks that lie entirely in [hiAll, T): loads without masks
+    int i0 = T - 1;                                                  // first sample of the chunk being consumed
     {
-        const int nfull = max(i - max(spMax, 0) + 1, 0) / S;
-        float xf = (float)(i - sp);  // (float)(i - startingPoint), counted down: exact (integers below 2^24)
-        float pN[S];
-        if (nfull > 0) {
+        float ring[NB][S];
 #pragma unroll
-            for (int k = 0; k < S; ++k) pN[k] = bufLoadF(planeRsrc(i - k), lvoff, 0);
+        for (int b = 0; b < NB; ++b) {
+            const int vo = (b < n1) ? lvoff : kOut;
+            const rsrc_t rs = chunkRsrc(i0 - b * S);
+#pragma unroll
+            for (int k = 0; k < S; ++k) ring[b][k] = bufLoadF(rs, vo, chunkOff(k));
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll 1
-        for (int c = 0; c < nfull; ++c, i -= S) {
-            float e[S], y[S];
+        for (int c0 = 0; c0 < n1; c0 += NB) {
 #pragma unroll
-            for (int k = 0; k < S; ++k) {
-                edc = edc + pN[k] * pN[k];
-                e[k] = edc;
-            }
-            if (c + 1 < nfull) {  // the next chunk's loads are in flight while this chunk's logarithms run
-#pragma unroll
-                for (int k = 0; k < S; ++k) pN[k] = bufLoadF(planeRsrc(i - S - k), lvoff, 0);
-            }
-            // the energy only grows: normal at both ends of the chunk = normal throughout (NaN fails the test)
-            if (__ballot(!(pvIsNormalPositive(e[0]) && pvIsNormalPositive(e[S - 1]))) == 0ull) {
-#pragma unroll
-                for (int k = 0; k < S; ++k) y[k] = 10.f * pvLog10fNormalT(e[k], ltab);
-            } else {
-#pragma unroll
-                for (int k = 0; k < S; ++k) y[k] = 10.f * pvLog10fNonNegT(e[k], ltab);
-            }
-#pragma unroll
-            for (int k = 0; k < S; ++k) {
-                xysum = xysum + y[k] * xf;
-                ysum = ysum + y[k];
-                xf = xf - 1.f;
-            }
-        }
-    }
-
-    // ---- the rest, down to the wave's lowest starting point: masked per lane ----
-    {
-        const int lo = max(spMin, 0);
-#pragma unroll 1
-        for (; i >= lo; i -= S) {
-            float p[S], e[S];
-#pragma unroll
-            for (int k = 0; k < S; ++k)
-                p[k] = bufLoadF(planeRsrc(max(i - k, 0)), (live && i - k >= sp) ? voff : kOut, 0);
-#pragma unroll
-            for (int k = 0; k < S; ++k) {
-                edc = edc + p[k] * p[k];  // + 0 out of range
-                e[k] = edc;
-            }
-#pragma unroll
-            for (int k = 0; k < S; ++k) {
-                const bool regress = live && i - k >= sp;  // (i - k < endPoint holds for the whole segment)
-                const float y = 10.f * pvLog10fNonNegT(regress ? e[k] : 1.f, ltab);
-                xysum = regress ? xysum + y * (float)(i - k - sp) : xysum;
-                ysum = regress ? ysum + y : ysum;
-            }
-        }
-    }
-
-    // ---- wet gain (Analyzer.cpp:235-247): forwards over [startingPoint, startingPoint + N_wet) ^ [0, T) ----
-    float wet = 0.f;
-    {
-        const int wetEnd = live ? min(sp + a.nWet, T) : 0;
-        int wetEndMax = wetEnd;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) wetEndMax = max(wetEndMax, __shfl_xor(wetEndMax, off));
-        float pN[S];
-#pragma unroll
-        for (int k = 0; k < S; ++k) {
-            const int t = spMin + k;
-            pN[k] = bufLoadF(planeRsrc(min(t, T - 1)), (live && t >= sp && t < wetEnd) ? voff : kOut, 0);
-        }
-#pragma unroll 1
-        for (int t0 = spMin; t0 < wetEndMax; t0 += S) {
-            float p[S];
-#pragma unroll
-            for (int k = 0; k < S; ++k) p[k] = pN[k];
-            if (t0 + S < wetEndMax) {
+            for (int b = 0; b < NB; ++b, i0 -= S) {
+                float e[S];
 #pragma unroll
                 for (int k = 0; k < S; ++k) {
-                    const int t = t0 + S + k;
-                    pN[k] = bufLoadF(planeRsrc(min(t, T - 1)), (live && t >= sp && t < wetEnd) ? voff : kOut, 0);
+                    edc = edc + ring[b][k] * ring[b][k];  // (+ 0 past the last chunk: those loads returned 0)
+                    e[k] = edc;
+                }
+                {  // the slot's next occupant: chunk c0 + b + NB (past the last one: loads that return 0 untouched)
+                    const int vo = (c0 + b + NB < n1) ? lvoff : kOut;
+                    const rsrc_t rs = chunkRsrc(i0 - NB * S);
+#pragma unroll
+                    for (int k = 0; k < S; ++k) ring[b][k] = bufLoadF(rs, vo, chunkOff(k));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (c0 + b < n1 && i0 < endPoint && i0 - S + 1 >= spMax) {
+                    float y[S];
+                    // the energy only grows: normal at both ends of the chunk = normal throughout (NaN fails the test)
+#ifdef PV_RT60_PROBE_NOLOG  // timing probe only: what the kernel takes without its logarithms
+                    if (true) {
+#pragma unroll
+                        for (int k = 0; k < S; ++k) y[k] = 10.f * e[k];
+                    } else
+#endif
+                    if (__ballot(!(pvIsNormalPositive(e[0]) && pvIsNormalPositive(e[S - 1]))) == 0ull) {
+                        pvLog10fNormalBatch(e, y, ltab);
+#pragma unroll
+                        for (int k = 0; k < S; ++k) y[k] = 10.f * y[k];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < S; ++k) y[k] = 10.f * pvLog10fNonNegT(e[k], ltab);
+                    }
+                    float xf = (float)(i0 - sp);  // (float)(i - startingPoint), counted down: exact (integers below 2^24)
+#pragma unroll
+                    for (int k = 0; k < S; ++k) {
+                        xysum = xysum + y[k] * xf;
+                        ysum = ysum + y[k];
+                        xf = xf - 1.f;
+                    }
+                } else if (c0 + b < n1 && i0 - S + 1 < endPoint) {  // (the chunk that holds endPoint; late-onset waves)
+#pragma unroll
+                    for (int k = 0; k < S; ++k) {
+                        const int ii = i0 - k;
+                        const bool regress = live && ii >= sp && ii < endPoint;
+                        const float y = 10.f * pvLog10fNonNegT(regress ? e[k] : 1.f, ltab);
+                        xysum = regress ? xysum + y * (float)(ii - sp) : xysum;
+                        ysum = regress ? ysum + y : ysum;
+                    }
                 }
             }
+        }
+        i0 = T - 1 - n1 * S;  // (the unrolled loop may have counted past the last chunk)
+    }
+    // ---- the rest, down to the wave's lowest starting point: masked per lane (a few chunks) ----
+#pragma unroll 1
+    for (; i0 >= lo; i0 -= S) {
+        float p[S], e[S];
 #pragma unroll
-            for (int k = 0; k < S; ++k) wet = wet + p[k] * p[k];  // + 0 out of range
+        for (int k = 0; k < S; ++k) p[k] = bufLoadF(planeRsrc(max(i0 - k, 0)), (i0 - k >= lowest) ? voff : kOut, 0);
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            edc = edc + p[k] * p[k];  // + 0 outside the lane's integral
+            e[k] = edc;
+        }
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            const int ii = i0 - k;
+            const bool regress = live && ii >= sp && ii < endPoint;
+            const float y = 10.f * pvLog10fNonNegT(regress ? e[k] : 1.f, ltab);
+            xysum = regress ? xysum + y * (float)(ii - sp) : xysum;
+            ysum = regress ? ysum + y : ysum;
         }
     }
-    if (live) {
-        a.out[a.resN + cell] = sqrtf(wet / a.efree);
-        a.out[2 * a.resN + cell] = rt60FromSums(a, sp, xysum, ysum);
-    }
+    // (wet gain, Analyzer.cpp:235-247: a forward walk like the dry gain's -- in this form pv_encode_kernel continues into it)
+    if (live) a.out[2 * a.resN + cell] = rt60FromSums(a, sp, xysum, ysum);
 }
 
 }  // namespace
@@ -386,7 +400,7 @@ void launchRt60Blocked(const AnalyzeArgs& a, hipStream_t stream) {
         // size, 0.27 vs 0.15 ms at 127^2, 1.93 vs 1.70 ms at 512^2 / T = 3179; <4, 8> and <4, 2> within 3 % of <4, 4>:
         // profiles/r04_rt60.txt)
     } else if (a.rt60Lanes != 16) {
-        hipLaunchKernelGGL((pv_rt60_tile_kernel<PV_RT60_TILE_S>), dim3((unsigned)((a.histPlane + 255) / 256)), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((pv_rt60_tile_kernel<PV_RT60_TILE_S, PV_RT60_TILE_NB>), dim3((unsigned)((a.histPlane + PV_RT60_TILE_BLOCK - 1) / PV_RT60_TILE_BLOCK)), dim3(PV_RT60_TILE_BLOCK), 0, stream, a);
     }
 }
 

@@ -252,7 +252,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     if (!dalloc(&generalCount_, 1, true)) return false;
     if (!dalloc(&dynDev_, 1, true)) return false;
     if (!dalloc(&errFlag_, 1, true)) return false;
-    if (!dalloc(&activeCount_, 4, true)) return false;  // [0] cells of non-zero tiles, [1] cells with an onset, [2] the encode kernel's pre-scan hint, [3] silent air cells
+    if (!dalloc(&activeCount_, 8, true)) return false;  // AnalyzeArgs::activeCount
     if (!dalloc(&res_, (size_t)std::max(lgx_, 1) * g_.gy * 8, true)) return false;  // zeroed pool: PvContext.cpp:132
     if (!dalloc(&delay_, (size_t)std::max(lgx_, 1) * g_.gy, true)) return false;
     // far cells lazily: whole grids with a windowed history (a slab group / the streaming mode run their own passes)
@@ -294,6 +294,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
                         "(PVA_OPT_STREAMING_ANALYSIS + PvAmdSetEmitters), which keeps a 64-step ring instead");
         if (!hipOk(hipMalloc((void**)&hist_, (size_t)bytes), "hipMalloc history")) return false;
         deviceBytes_ += bytes;
+        if (!dalloc(&unitList_, (size_t)(histPlane_ / 64 + 1), true)) return false;
         if (isSlab()) {
             if (opt_.slabIndex > 0 && !dalloc(&histAbove_, (size_t)T_ * histPitch_, true)) return false;
             if (opt_.slabIndex + 1 < opt_.slabCount && !dalloc(&histEdge_, (size_t)T_ * histPitch_, true)) return false;
@@ -479,7 +480,7 @@ Solver::~Solver() {
     if (emCells_) hipFree(emCells_);
     if (emTrace_) hipFree(emTrace_);
     void* ptrs[] = {coef_,      matDev_, pulseDev_, hist_,  tileFirst_, tileClass_, generalList_,
-                    generalCount_, dynDev_, errFlag_, res8_,     delay_, scratch_, res_, activeCount_, win8_,
+                    generalCount_, dynDev_, errFlag_, res8_,     delay_, scratch_, res_, activeCount_, win8_, unitList_,
                     histAbove_, histEdge_, tileDead_, deadCount_};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -1153,6 +1154,7 @@ AnalyzeArgs Solver::analyzeArgs(float lx, float lz) const {
     a.winRows = histTilesX_ * rxi_;
     a.winCols = histTilesY_ * wi_;
     a.activeCount = activeCount_;
+    a.unitList = unitList_;
     a.dirScratch = reinterpret_cast<int*>(scratch_);
     // Listener direction: pointer jumping (six tiny launches at T = 1187, path-length independent) wherever a walk can be
     // long or launches are cheap -- wide windows, and every grid small enough to run as one replayed graph, where the plain

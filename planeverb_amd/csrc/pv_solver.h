@@ -260,6 +260,7 @@ private:
     int* generalCount_ = nullptr;
     DynParams* dynDev_ = nullptr;
     int* errFlag_ = nullptr;
+    int* unitList_ = nullptr;     // AnalyzeArgs::unitList: histPlane / 64 + 1 ints
     int* activeCount_ = nullptr;  // cells with an onset in the last analysis (chooses the RT60 kernel on the device)
     float* res_ = nullptr;   // 8 SoA result planes (see AnalyzeArgs::res)
     float* res8_ = nullptr;  // AoS copy for whole-map read-backs, allocated and packed on demand

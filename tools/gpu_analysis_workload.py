@@ -8,7 +8,11 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import planeverb_amd.api as pv
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-with pv.Solver(25.0, 25.0, 2009, rt60_lanes=int(os.environ.get("LANES", "0"))) as s:
+res = 2009
+for a in sys.argv[2:]:
+    if a.startswith("res="):
+        res = int(a[4:])
+with pv.Solver(25.0, 25.0, res, rt60_lanes=int(os.environ.get("LANES", "0")), analysis_fork=int(os.environ.get("FORK", "1"))) as s:
     s.load_scene(os.path.join(ROOT, "tests", "scenes", "Shoebox.pv"))
     ana, fd = [], []
     for _ in range(n):

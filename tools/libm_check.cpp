@@ -31,6 +31,15 @@ int main(int argc, char** argv) {
     if (pva::pvIsNormalPositive(INFINITY) || pva::pvIsNormalPositive(NAN) || pva::pvIsNormalPositive(-1.f) ||
         pva::pvIsNormalPositive(0.f) || !pva::pvIsNormalPositive(1.f) || !pva::pvIsNormalPositive(1.17549435e-38f))
         ++badLog;
+    {  // the staged batch form = the scalar form (same operations): a sample of normal floats through both
+        for (unsigned long long u = 0x00800000ull; u + 8 * 4099 < 0x7f800000ull; u += 7919ull * stride) {
+            float in[8], o[8];
+            for (int n = 0; n < 8; ++n) in[n] = pva::pvFloatBits((uint32_t)(u + 4099ull * n));
+            pva::pvLog10fNormalBatch(in, o, pva::PvLogTabConst{});
+            for (int n = 0; n < 8; ++n)
+                if (pva::pvBitsF(o[n]) != pva::pvBitsF(std::log10(in[n]))) ++badLog;
+        }
+    }
     const float nonneg[] = {0.f, INFINITY, NAN, 1.f, 1.17549435e-38f, 1e-45f};  // the branch-free form's domain
     for (float s : nonneg) {
         const float a = pva::pvLog10fNonNeg(s), b = std::log10(s);
