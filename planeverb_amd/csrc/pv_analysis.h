@@ -61,12 +61,15 @@ __device__ __forceinline__ float efreePerR(float efree, float dx, int lX, int lY
 // differ in how many LANES share a cell (pv_rt60.hip).  Which one runs is decided on the device from the number of cells
 // of the window's ever-non-zero tiles (an upper bound of the reached cells, counted by block 0 of the far-cells pass):
 // few cells -> sixteen lanes per cell (parallelism), more -> four (fewer instructions per sample).
-constexpr int kRt60WaveMaxCells = 65536;  // below this a window counts as "a room" (pv_encode_kernel's pre-scan for an audible sample)
+constexpr int kRt60TileMinCells = 98304;
 __device__ __forceinline__ int rt60LanesPerCell(const AnalyzeArgs& a, int activeCells) {
     if (a.rt60Lanes) return a.rt60Lanes;  // (PVA_OPT_RT60_LANES: validation / measurement)
     // (measured on MI355X, profiles/r04_rt60.txt: 70^2 0.093 / 0.098 ms, 127^2 0.156 / 0.148 ms for sixteen / four lanes; round 5:
     // one lane per cell over the tile-major history replaces the four-lane form, profiles/r05_rt60.txt)
+    // sixteen lanes per cell for a few thousand cells (parallelism), one lane per cell over the tile-major plane from ~100 000 (fewest
+    // instructions and bytes per sample; it needs two waves per SIMD worth of cells), four in between: profiles/r05_rt60.txt
     if (activeCells <= 8192) return 16;
+    if (activeCells <= kRt60TileMinCells) return 4;
     return a.histPlane * 4 * 16 < (1ll << 31) ? 1 : 4;  // (the lane-per-cell form reaches a chunk's planes through one descriptor and scalar offsets)
 }
 

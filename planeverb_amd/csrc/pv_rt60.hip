@@ -394,13 +394,16 @@ void launchCarryResults(const AnalyzeArgs& a, const float* srcOut, hipStream_t s
 // the forms above; the sixteen-lane form (pv_rt60_wave_kernel, pv_kernels.hip) is launched beside them by launchAnalysis.  Which
 // one does the work is decided on the device (rt60LanesPerCell); a forced form (PVA_OPT_RT60_LANES) launches only itself.
 void launchRt60Blocked(const AnalyzeArgs& a, hipStream_t stream) {
-    if (a.rt60Lanes == 4) {
+    // (the number of cells with work is known on the device only; the window's size bounds it: no launch for a form it rules out)
+    if (a.rt60Lanes == 4 || (a.rt60Lanes == 0 && a.histPlane > 8192)) {
         hipLaunchKernelGGL((pv_rt60_blocked_kernel<4, 4>), dim3((a.winCols + 63) / 64, a.winRows), dim3(256), 0, stream, a);
         // (one lane per cell ALONG WINDOW COLUMNS -- <1, 4>, <1, 8> -- was measured in round 4: slower than four lanes at every
         // size, 0.27 vs 0.15 ms at 127^2, 1.93 vs 1.70 ms at 512^2 / T = 3179; <4, 8> and <4, 2> within 3 % of <4, 4>:
         // profiles/r04_rt60.txt)
-    } else if (a.rt60Lanes != 16) {
-        hipLaunchKernelGGL((pv_rt60_tile_kernel<PV_RT60_TILE_S, PV_RT60_TILE_NB>), dim3((unsigned)((a.histPlane + PV_RT60_TILE_BLOCK - 1) / PV_RT60_TILE_BLOCK)), dim3(PV_RT60_TILE_BLOCK), 0, stream, a);
+    }
+    if (a.rt60Lanes == 1 || (a.rt60Lanes == 0 && a.histPlane > kRt60TileMinCells)) {
+        hipLaunchKernelGGL((pv_rt60_tile_kernel<PV_RT60_TILE_S, PV_RT60_TILE_NB>),
+                           dim3((unsigned)((a.histPlane + PV_RT60_TILE_BLOCK - 1) / PV_RT60_TILE_BLOCK)), dim3(PV_RT60_TILE_BLOCK), 0, stream, a);
     }
 }
 
