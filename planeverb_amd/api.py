@@ -51,6 +51,7 @@ PVA_OPT_STREAM_PRIORITY = 25
 PVA_OPT_ALTERNATE_SWEEPS = 26
 PVA_OPT_XCD_REGIONS = 27
 PVA_OPT_ANALYSIS_FORK = 28
+PVA_OPT_FUSED_ANALYSIS = 29
 
 
 class PlaneverbOutput(C.Structure):
@@ -647,7 +648,7 @@ class Solver:
                 "resident_kernel": PVA_OPT_RESIDENT_KERNEL, "rt60_lanes": PVA_OPT_RT60_LANES,
                 "debug_lose_first_capture": PVA_OPT_DEBUG_LOSE_FIRST_CAPTURE, "stream_priority": PVA_OPT_STREAM_PRIORITY,
                 "alternate_sweeps": PVA_OPT_ALTERNATE_SWEEPS, "xcd_regions": PVA_OPT_XCD_REGIONS,
-                "analysis_fork": PVA_OPT_ANALYSIS_FORK}
+                "analysis_fork": PVA_OPT_ANALYSIS_FORK, "fused_analysis": PVA_OPT_FUSED_ANALYSIS}
         for k, v in options.items():
             _check(lib().PvAmdSetOption(self._h, keys[k], int(v)))
         self.info = PvAmdInfo()

@@ -8,7 +8,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.environ.get("PLANEVERB_AMD_LIB") or os.path.join(PKG_DIR, "libplaneverb_amd.so")
 
 
-KERNEL_SOURCES = ["pv_kernels.hip", "pv_resident.hip", "pv_rt60.hip", "pv_probe.hip", "pv_stream.h", "pv_seg.h", "pv_device.h", "pv_libm.h", "pv_prims.h", "pv_analysis.h", "Makefile"]
+KERNEL_SOURCES = ["pv_kernels.hip", "pv_resident.hip", "pv_rt60.hip", "pv_fused.hip", "pv_analysis_dev.h", "pv_probe.hip", "pv_stream.h", "pv_seg.h", "pv_device.h", "pv_libm.h", "pv_prims.h", "pv_analysis.h", "Makefile"]
 
 
 def kernel_source_hash():

@@ -460,6 +460,7 @@ int PvAmdSetOption(PvAmdSolver* h, int key, long long value) {
         case PVA_OPT_RESIDENT_KERNEL: h->opt.resident = (int)value; break;
         case PVA_OPT_RT60_LANES: h->opt.rt60Lanes = (int)value; break;
         case PVA_OPT_ANALYSIS_FORK: h->opt.analysisFork = (int)value; break;
+        case PVA_OPT_FUSED_ANALYSIS: h->opt.fusedAnalysis = (int)value; break;
         case PVA_OPT_DEBUG_LOSE_FIRST_CAPTURE: h->opt.debugLoseFirstCapture = value != 0; break;
         case PVA_OPT_STREAM_PRIORITY: h->opt.streamPriority = (int)value; break;
         case PVA_OPT_ALTERNATE_SWEEPS: h->opt.alternateSweeps = (int)value; break;

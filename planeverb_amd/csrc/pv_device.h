@@ -327,4 +327,13 @@ struct AnalyzeArgs {
     int numEmitters;
 };
 
+// fused analysis of the small grids (pv_fused.hip)
+constexpr int kFusedCtlWords = 16;  // ticket, one counter per phase, the workers that have left
+struct FusedArgs {
+    AnalyzeArgs a;
+    unsigned* ctl;          // kFusedCtlWords words, zero before the launch (the launch leaves them at zero)
+    const float* carrySrc;  // two iterations in flight: the other solver's result planes (no-onset cells take their record), or NULL
+    int* errFlag;           // 6 = a worker waited for a phase in vain
+};
+
 }  // namespace pva

@@ -33,6 +33,7 @@
 #include "pv_libm.h"
 #include "pv_prims.h"
 #include "pv_analysis.h"
+#include "pv_analysis_dev.h"
 
 namespace pva {
 
@@ -2289,16 +2290,6 @@ __device__ __forceinline__ bool analysisWindowCell(const AnalyzeArgs& a, const D
     *Y = dyn.histCol0 - a.G + wc;
     return *X < a.gx && *Y < a.gy;
 }
-// window-local index of grid cell `cell` (= X*gy + Y), for the per-cell scratch of the direction kernels
-__device__ __forceinline__ int analysisWindowIndex(const AnalyzeArgs& a, const DynParams& dyn, int cell) {
-    const int r = cell / a.gy, c = cell - r * a.gy;
-    return (r - (dyn.histRow0 - a.G)) * a.winCols + (c - (dyn.histCol0 - a.G));
-}
-
-// samples per memory round trip of the forward pass (three planes each)
-#ifndef PV_ENCODE_CH
-#define PV_ENCODE_CH 8
-#endif
 
 // Onset of every window cell (Analyzer.cpp:146-165: first sample whose |pressure| exceeds the audible threshold), round 5.
 // Rounds 1-4 found it inside pv_encode_kernel, one thread per cell walking forward through time: the kernel lasted as long as
@@ -2378,176 +2369,24 @@ __global__ __launch_bounds__(64 * kOnsetWaves) void pv_onset_kernel(const Analyz
     }
 }
 
-// One thread per window cell, lanes along the tile-major plane (planeCell), behind pv_onset_kernel: dry energy, flux,
-// obstruction gain, source directivity, low-pass cutoff of the cells that have an onset.
-// TIME is wave-uniform: every load instruction reads ONE plane (the wave's 256 contiguous bytes of it), from the earliest
-// first sample of the wave's cells to the latest last one, and a lane whose own window has not begun or is over loads nothing
-// and adds nothing.  (Per-lane start and end times -- each lane walking its own [first, onset + N) -- put up to 64 planes
-// into one load instruction: 0.65 ms instead of 0.07 for the 104 000 cells of the 512^2 / T = 3179 room.)
-__device__ __forceinline__ int waveMin(int v) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) v = min(v, __shfl_xor(v, off));
-    return __builtin_amdgcn_readfirstlane(v);
-}
-__device__ __forceinline__ int waveMax(int v) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) v = max(v, __shfl_xor(v, off));
-    return __builtin_amdgcn_readfirstlane(v);
-}
-
+// dry gain, source directivity, low-pass cutoff (+ wet gain beside the lane-per-cell decay-time form) of the cells that have an
+// onset, behind pv_onset_kernel: one wave per entry of the list of 64-cell groups with work (encodeWave, pv_analysis_dev.h)
 __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
     if (analysisAborted(a)) return;
     const DynParams dyn = *a.dyn;
-    const int unit = blockIdx.x * 4 + (int)(threadIdx.x >> 6);  // one wave per entry of the list of groups with work
+    const int unit = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     if (unit >= a.activeCount[4]) return;
     const PlaneCell pc0 = planeCell(a, dyn, (long long)a.unitList[unit] * 64 + (threadIdx.x & 63));
-    const int X = pc0.X, Y = pc0.Y;
-    const int s = X * a.gy + Y;
-    const float delay = pc0.inGrid ? a.delay[s] : FLT_MAX;
+    const float delay = pc0.inGrid ? a.delay[pc0.X * a.gy + pc0.Y] : FLT_MAX;
     const bool live = delay != FLT_MAX;  // no onset (Analyzer.cpp:160-165): the result record stays as it is
     if (__ballot(live) == 0ull) return;
-    const int onset = live ? (int)delay : 0;
-    const int T = a.T;
-    const int tFirst = live ? a.tileFirst[pc0.tile] : T;
-
-    const int prow = X + a.G, pcol = Y + a.G;
-    const int hr = prow - dyn.histRow0, hcol = pcol - dyn.histCol0;
-    const long long hoff = live ? histOffset(hr, hcol, a.rxi, a.wi, dyn.histTilesY) : 0;
-    CellHistory hc{a.hist + hoff, a.histPlane};
-    // neighbours for the velocity recurrence; a neighbour tile that became active later (or never) has
-    // unwritten history that is exactly zero by causality
-    int tFx = INT_MAX, tFy = INT_MAX;
-    if (live && X > 0 && prow - 1 >= dyn.histRow0) tFx = a.tileFirst[((X - 1) / a.rxi) * a.nty + (Y / a.wi)];
-    if (live && Y > 0 && pcol - 1 >= dyn.histCol0) tFy = a.tileFirst[(X / a.rxi) * a.nty + ((Y - 1) / a.wi)];
-    // (the neighbours' offsets are only formed where they are read: tFx / tFy stay INT_MAX otherwise)
-    CellHistory hx{a.hist + (tFx != INT_MAX ? histOffset(hr - 1, hcol, a.rxi, a.wi, dyn.histTilesY) : hoff), a.histPlane};
-    CellHistory hy{a.hist + (tFy != INT_MAX ? histOffset(hr, hcol - 1, a.rxi, a.wi, dyn.histTilesY) : hoff), a.histPlane};
-    if (live && X == 0 && a.histAbove) {  // first row of a slab: the row above lives in the neighbouring slab
-        hx = CellHistory{a.histAbove + (pcol - dyn.histCol0), a.histPitch};
-        tFx = 0;
-    }
-
-    FaceCoef fc{0.f, 0.f, 0.f};
-    if (live) fc = a.coef[(size_t)prow * a.pitch + pcol];
-    const float kx = fc.kx, ky = fc.ky;
-    const bool airX = kx != kx, airY = ky != ky;
-    const float C = a.courant;
-
-    // The loop walks the history in chunks of CH samples: the CH loads are issued together (they do not depend on the
-    // running sums), then consumed strictly in sample order, so the float32 accumulation order is the reference's while the
-    // memory latency is paid once per chunk instead of once per sample.
-    constexpr int CH = PV_ENCODE_CH;
-
-    // dry energy + flux, Analyzer.cpp:170-195: both sums run from sample 0 (samples before tFirst are zero) to the end of
-    // their windows behind the onset; vx / vy by the stencil's own recurrence as long as the flux needs them
-    const int sourceDirEnd = live ? onset + a.nDir : 0, directEnd = live ? min(onset + a.nDry, T) : 0;
-    // (first sample that can be non-zero: the tile's first recorded step, and never before the pulse can have arrived through
-    // the stencil -- one cell per step along one axis, so this cell's pressure is exactly zero up to step m and its neighbours'
-    // up to step m - 1: pv_onset_kernel)
-    const int m = abs(X - (dyn.lrow - a.G)) + abs(Y - (dyn.lcol - a.G));
-    const int tBegin = max(tFirst, m - 1);
-    const int tLo = waveMin(live ? tBegin : INT_MAX), tHi = waveMax(directEnd), tVHi = waveMax(sourceDirEnd);
-    float Edry = 0.f, fluxX = 0.f, fluxY = 0.f, vx = 0.f, vy = 0.f;
-#pragma unroll 1
-    for (int t0 = tLo; t0 < tHi; t0 += CH) {
-        float pc[CH], pxc[CH], pyc[CH];
-        const bool needVChunk = t0 < tVHi;  // (wave-uniform)
-#pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            const int t = t0 + k, tt = min(t, T - 1);
-            const bool mine = t >= tBegin && t < directEnd, mineV = mine && t < sourceDirEnd;
-            pc[k] = mine ? hc.at(tt) : 0.f;
-            pxc[k] = (needVChunk && mineV && tt >= tFx) ? hx.at(tt) : 0.f;
-            pyc[k] = (needVChunk && mineV && tt >= tFy) ? hy.at(tt) : 0.f;
-        }
-#pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            const int t = t0 + k;
-            if (t < tBegin || t >= directEnd) continue;
-            const float p = pc[k];
-            if (t < sourceDirEnd) {
-                const float pxn = pxc[k], pyn = pyc[k];
-                const float ax = vx - C * (p - pxn), wx = kx * (p + pxn);
-                const float ay = vy - C * (p - pyn), wy = ky * (p + pyn);
-                vx = airX ? ax : wx;
-                vy = airY ? ay : wy;
-            }
-            Edry += p * p;
-            if (t < sourceDirEnd) {
-                fluxX += p * vx;
-                fluxY += p * vy;
-            }
-        }
-    }
-
-    // wet gain, Analyzer.cpp:235-247: forwards over [onset + N_dry + 1, + N_wet) ^ [0, T).  Only beside the lane-per-cell form of
-    // the decay-time pass (pv_rt60_tile_kernel, which is the backward walk alone); the sixteen- and four-lane forms do their own
-    const bool withWet = rt60LanesPerCell(a, *a.activeCount) == 1;
-    float wet = 0.f;
-    if (withWet) {
-        constexpr int WCH = 32;  // one plane per sample: more of them per memory round trip
-        const int wetBegin = live ? onset + a.nDry + 1 : INT_MAX, wetEnd = live ? min(wetBegin + a.nWet, T) : 0;
-        const int wLo = waveMin(wetBegin), wHi = waveMax(wetEnd);
-#pragma unroll 1
-        for (int t0 = wLo; t0 < wHi; t0 += WCH) {
-            float pw[WCH];
-#pragma unroll
-            for (int k = 0; k < WCH; ++k) pw[k] = (t0 + k >= wetBegin && t0 + k < wetEnd) ? hc.at(t0 + k) : 0.f;
-#pragma unroll
-            for (int k = 0; k < WCH; ++k) wet = wet + pw[k] * pw[k];  // + 0 outside the lane's window
-        }
-    }
-    if (!live) return;
-
-    // obstruction gain + source directivity, Analyzer.cpp:197-220
-    const float EfreePr = efreePerR(a.efree, a.dx, a.lcx, a.lcy, X + a.x0, Y);
-    const float occ = sqrtf(Edry / EfreePr);
-    float norm = sqrtf(fluxX * fluxX + fluxY * fluxY);
-    norm = -1.0f / (norm > 0.0f ? norm : 1.0f);
-    const float sdx = norm * fluxX, sdy = norm * fluxY;
-
-    // low-pass cutoff, Analyzer.cpp:227-230 (std::max(0.001f, g) == (0.001f < g) ? g : 0.001f)
-    const float rr = 1.0f / ((0.001f < occ) ? occ : 0.001f);
-    const float lowpass = -147.f + (18390.f) / (1.f + pvPowf(rr / 12.f, 0.8f));
-
-    // (decay time: pv_rt60_wave_kernel / pv_rt60_tile_kernel, by the number of reachable cells)
-    a.out[s] = occ;
-    if (withWet) a.out[a.resN + s] = sqrtf(wet / a.efree);
-    a.out[3 * a.resN + s] = lowpass;
-    a.out[6 * a.resN + s] = sdx;
-    a.out[7 * a.resN + s] = sdy;
+    encodeWave<false>(a, dyn, pc0, live, live ? (int)delay : 0, rt60LanesPerCell(a, *a.activeCount) == 1);
 }
 
-// Wave form: SIXTEEN lanes (one DPP row) per cell, four cells per wave.  Lane j of a row holds sample i0 - j of a
-// 16-sample chunk, walking backwards from T - 1; the chunk's 16 loads are one instruction and its 16 log10f
-// evaluations run side by side.  The three running sums stay strictly sequential, in the reference's order: each is a
-// chain of 16 steps per chunk in which lane j adds its addend to the value of lane j - 1, fetched by a DPP row
-// rotation riding on the add (v_add_f32 row_ror:1); lane 0 thereby reads lane 15, which still holds the chain's value
-// at the end of the previous chunk, so the carry between chunks needs no broadcast.  Lanes outside the regression
-// range add +0.0f, which leaves a non-negative-zero float sum unchanged bit for bit.  Sixteen times the threads of
-// the cell form, a sixteenth of its dependent work per thread: the form for the few thousand cells of a closed room,
-// which leave the cell form with 80 waves on 1024 SIMDs, each paying a memory round trip per 8 samples.
-__device__ __forceinline__ float rowRor1Add(float acc, float addend) {  // acc[lane - 1 in its row of 16] + addend
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x121, 0xf, 0xf,
-                                                                  false)) + addend;
-}
-
-template <int NCH>
-__device__ __forceinline__ void rowChains(float (&acc)[NCH], const float (&add)[NCH], const int sub) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const bool mine = sub == j;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const float t = rowRor1Add(acc[c], add[c]);
-            acc[c] = mine ? t : acc[c];
-        }
-    }
-}
-
+// wet gain + decay time, sixteen lanes per cell (rt60WaveBody, pv_analysis_dev.h): the few thousand cells of a closed room
 __global__ __launch_bounds__(256) void pv_rt60_wave_kernel(const AnalyzeArgs a) {
     if (analysisAborted(a)) return;
-    if (rt60LanesPerCell(a, *a.activeCount) != 16) return;  // (more cells: the blocked forms of pv_rt60.hip)
+    if (rt60LanesPerCell(a, *a.activeCount) != 16) return;  // (more cells: the forms of pv_rt60.hip)
     const DynParams dyn = *a.dyn;
     // 16 cells per 256-thread block along the window's columns, one window row per blockIdx.y
     const int sub = threadIdx.x & 15;
@@ -2557,76 +2396,7 @@ __global__ __launch_bounds__(256) void pv_rt60_wave_kernel(const AnalyzeArgs a) 
     // a wave leaves only when none of its four cells has work: the DPP chains need whole rows, not whole waves, but
     // keeping the wave together costs nothing
     if (__ballot(c.s >= 0) == 0ull) return;
-    const bool live = c.s >= 0;
-    const int T = a.T;
-    const int endPoint = T - a.nCut;
-    const int startingPoint = live ? c.startingPoint : T;  // dead rows: no sample is in range
-    const int lowest = min(startingPoint, endPoint);         // the pre-sum over [endPoint, T) is not bounded by the onset
-    // wave-uniform trip count: the longest of the four cells
-    int n = max(T - lowest, 0);
-#pragma unroll
-    for (int off = 16; off < 64; off <<= 1) n = max(n, __shfl_xor(n, off));
-    float acc[3] = {0.f, 0.f, 0.f};  // edc, xysum, ysum: lane 15 of the row carries them from chunk to chunk
-    float pNext = 0.f;
-    {
-        const int i = T - 1 - sub;
-        pNext = (live && i >= lowest && i >= 0) ? c.hc.at(i) : 0.f;
-    }
-    for (int n0 = 0; n0 < n; n0 += 16) {
-        const int i = T - 1 - n0 - sub;
-        const float p = pNext;
-        {  // the next chunk's load is in flight while this chunk's chains run
-            const int in = i - 16;
-            pNext = (live && n0 + 16 < n && in >= lowest && in >= 0) ? c.hc.at(in) : 0.f;
-        }
-        float e[1] = {acc[0]};
-        const float q[1] = {p * p};  // 0 outside [lowest, T): edc + 0 = edc
-        rowChains<1>(e, q, sub);
-        acc[0] = e[0];
-        const bool regress = i >= startingPoint && i < endPoint;
-        const float y = 10.f * pvLog10fNonNeg(regress ? e[0] : 1.f);
-        const float add[2] = {regress ? y * (float)(i - startingPoint) : 0.f, regress ? y : 0.f};
-        float sums[2] = {acc[1], acc[2]};
-        rowChains<2>(sums, add, sub);
-        acc[1] = sums[0];
-        acc[2] = sums[1];
-    }
-    // wet gain (Analyzer.cpp:235-247): the same chain, forwards over [startingPoint, startingPoint + N_wet) ^ [0, T)
-    const int wetEnd = min(startingPoint + a.nWet, T);
-    int nw = max(wetEnd - startingPoint, 0);
-#pragma unroll
-    for (int off = 16; off < 64; off <<= 1) nw = max(nw, __shfl_xor(nw, off));
-    float wetAcc[1] = {0.f};
-    pNext = (live && startingPoint + sub < wetEnd) ? c.hc.at(startingPoint + sub) : 0.f;
-    for (int j0 = 0; j0 < nw; j0 += 16) {
-        const float p = pNext;
-        const int jn = startingPoint + j0 + 16 + sub;
-        pNext = (live && j0 + 16 < nw && jn < wetEnd) ? c.hc.at(jn) : 0.f;
-        const float q[1] = {p * p};
-        rowChains<1>(wetAcc, q, sub);
-    }
-    if (live && sub == 15) {
-        a.out[a.resN + c.s] = sqrtf(wetAcc[0] / a.efree);
-        a.out[2 * a.resN + c.s] = rt60FromSums(a, c.startingPoint, acc[1], acc[2]);
-    }
-}
-
-// Analyzer.cpp:332-337
-__device__ const int kNeighbors[8][2] = {{-1, -1}, {-1, 0}, {-1, 1}, {0, -1}, {0, 1}, {1, -1}, {1, 0}, {1, 1}};
-
-// Analyzer::EncodeListenerDirection, Analyzer.cpp:340-431: walk down the delay map towards the listener until
-// the path is in line of sight; one thread per result cell.
-__device__ __forceinline__ void storeDirection(const AnalyzeArgs& a, int index, int fin) {
-    const int r = fin / a.gy, c = fin - r * a.gy;
-    float ox = (float)r * a.dx - a.lx, oy = (float)c * a.dx - a.lz;
-    float len = (ox * ox) + (oy * oy);
-    if (len != 0.f) {
-        len = sqrtf(len);
-        ox /= len;
-        oy /= len;
-    }
-    a.out[4 * a.resN + index] = ox;
-    a.out[5 * a.resN + index] = oy;
+    rt60WaveBody(a, sub, c.s >= 0, c.s, c.hc, c.startingPoint);
 }
 
 // every cell of the map: no onset (Analyzer.cpp:64-68), listener direction = towards the cell itself (a walk that
@@ -2741,7 +2511,7 @@ __global__ __launch_bounds__(256) void pv_direction_kernel(const AnalyzeArgs a) 
         const int r = cur / a.gy, c = cur - r * a.gy;
         float bestLoud = 0.f, bestDelay = FLT_MAX;
         for (int i = 0; i < 8; ++i) {
-            const int nr = r + kNeighbors[i][0], nc = c + kNeighbors[i][1];
+            const int nr = r + neighbourDr(i), nc = c + neighbourDc(i);
             if (nr < 0 || nc < 0 || nr >= a.gx || nc >= a.gy) continue;
             const int ni = nr * a.gy + nc;
             const float occ = a.out[ni];
@@ -2766,75 +2536,21 @@ __global__ __launch_bounds__(256) void pv_direction_kernel(const AnalyzeArgs a) 
     storeDirection(a, index, cur);
 }
 
-// The same walk by pointer jumping: its cost per cell grows with the path length (an open field at T = 435: up to
-// 435 steps of 8 neighbour reads for each of 0.6 M cells; a 25 m room at 4096^2 cells: 191 ms), but where a walk
-// goes from a cell does not depend on where it started, so "one step from here" is a functional graph and
-// ceil(log2 T) rounds of J[p] = J[J[p]] resolve every walk.  kDirFinal marks entries that are already terminal.
-constexpr int kDirFinal = (int)0x80000000;
-
-__device__ __forceinline__ int dirBestNeighbour(const AnalyzeArgs& a, int cell, float* bestDelay) {
-    const int r = cell / a.gy, c = cell - r * a.gy;
-    int best = -1;
-    float bd = FLT_MAX;
-    for (int i = 0; i < 8; ++i) {
-        const int nr = r + kNeighbors[i][0], nc = c + kNeighbors[i][1];
-        if (nr < 0 || nc < 0 || nr >= a.gx || nc >= a.gy) continue;
-        const int ni = nr * a.gy + nc;
-        const float occ = a.out[ni];
-        const float d = a.delay[ni];
-        if (occ == 0.f) continue;
-        if (d < bd && occ > 0.f) {
-            best = ni;
-            bd = d;
-        }
-    }
-    *bestDelay = bd;
-    return best;
-}
-
-__device__ __forceinline__ bool dirLineOfSight(const AnalyzeArgs& a, int cell, float d) {
-    const float geodesic = kCDev * d / (float)a.fs;
-    const int r = cell / a.gy, c = cell - r * a.gy;
-    const float tx = (float)r * a.dx - a.lx, ty = (float)c * a.dx - a.lz;
-    const float euclid = sqrtf((tx * tx) + (ty * ty));
-    return fabsf(geodesic - euclid) < 0.3f * (kCDev / (float)a.res);
-}
-
-// J is indexed by window-local cell; its entries are GRID cell indices (| kDirFinal).  A hop always lands on a
-// reached cell (finite delay), i.e. inside the window.
+// listener direction by pointer jumping: the per-cell steps are dirInitCell / dirJumpCell / dirFinalCell (pv_analysis_dev.h)
 __global__ __launch_bounds__(256) void pv_dir_init_kernel(const AnalyzeArgs a, int* J) {
     if (analysisAborted(a)) return;
     const DynParams dyn = *a.dyn;
     int X, Y;
     if (!analysisWindowCell(a, dyn, &X, &Y)) return;
-    const int p = X * a.gy + Y;
-    const float d = a.delay[p], o = a.out[p];
-    int hop = p | kDirFinal;
-    if (d > kDelayCloseDev && o < kDistanceGainDev) {
-        float nd;
-        const int n = dirBestNeighbour(a, p, &nd);
-        if (n >= 0) hop = (nd >= d || dirLineOfSight(a, n, nd)) ? (n | kDirFinal) : n;
-    }
-    J[analysisWindowIndex(a, dyn, p)] = hop;
+    dirInitCell<false>(a, dyn, J, X * a.gy + Y);
 }
 
-// One launch follows every unfinished walk for kDirHops hops through the CURRENT table: each hop reads either the
-// old or an already-updated entry of the cell it stands on -- both lie further down the same walk -- so a launch
-// multiplies the distance an entry spans by at least kDirHops + 1 whatever the interleaving of the threads, and
-// ceil(log_{kDirHops+1} T) launches resolve every walk (2 at T = 435 instead of the 9 of hop-doubling: the analysis of
-// a run is a chain of dependent launches, and beside another run's stencil each one waits for its turn).
-constexpr int kDirHops = 20;
 __global__ __launch_bounds__(256) void pv_dir_jump_kernel(const AnalyzeArgs a, int* J) {
     if (analysisAborted(a)) return;
     const DynParams dyn = *a.dyn;
     int X, Y;
     if (!analysisWindowCell(a, dyn, &X, &Y)) return;
-    const int wp = analysisWindowIndex(a, dyn, X * a.gy + Y);
-    int h = J[wp];
-    if (h < 0) return;  // final
-#pragma unroll 1
-    for (int i = 0; i < kDirHops && h >= 0; ++i) h = J[analysisWindowIndex(a, dyn, h)];
-    J[wp] = h;
+    dirJumpCell<false>(a, dyn, J, X * a.gy + Y);
 }
 
 __global__ __launch_bounds__(256) void pv_dir_final_kernel(const AnalyzeArgs a, const int* J) {
@@ -2842,14 +2558,7 @@ __global__ __launch_bounds__(256) void pv_dir_final_kernel(const AnalyzeArgs a, 
     const DynParams dyn = *a.dyn;
     int X, Y;
     if (!analysisWindowCell(a, dyn, &X, &Y)) return;
-    const int index = X * a.gy + Y;
-    int fin = index;
-    if (a.out[index] < kDistanceGainDev) {  // first iteration: delay = FLT_MAX, so only the loudness test applies
-        float nd;
-        const int n = dirBestNeighbour(a, index, &nd);
-        if (n >= 0) fin = dirLineOfSight(a, n, nd) ? n : (J[analysisWindowIndex(a, dyn, n)] & ~kDirFinal);
-    }
-    storeDirection(a, index, fin);
+    dirFinalCell<false>(a, dyn, J, X * a.gy + Y);
 }
 
 static dim3 analysisWindowGrid(const AnalyzeArgs& a) { return dim3((a.winCols + 255) / 256, a.winRows); }
@@ -2857,9 +2566,7 @@ static dim3 analysisWindowGrid(const AnalyzeArgs& a) { return dim3((a.winCols + 
 static void launchDirectionJump(const AnalyzeArgs& a, int* J, hipStream_t stream) {
     const dim3 grid = analysisWindowGrid(a), block(256);
     hipLaunchKernelGGL(pv_dir_init_kernel, grid, block, 0, stream, a, J);
-    int rounds = 1;  // chains are shorter than T (delays are distinct integers < T)
-    for (long long span = kDirHops + 1; span < a.T + 2; span *= kDirHops + 1) ++rounds;
-    for (int i = 0; i < rounds + 1; ++i) hipLaunchKernelGGL(pv_dir_jump_kernel, grid, block, 0, stream, a, J);
+    for (int i = 0; i < dirJumpPasses(a.T); ++i) hipLaunchKernelGGL(pv_dir_jump_kernel, grid, block, 0, stream, a, J);
     hipLaunchKernelGGL(pv_dir_final_kernel, grid, block, 0, stream, a, J);
 }
 

@@ -78,6 +78,12 @@ void launchOnset(const AnalyzeArgs& a, hipStream_t stream);   // onsets of the w
 void launchEncode(const AnalyzeArgs& a, hipStream_t stream);  // dry gain, source direction, low-pass (reads the onsets)
 void launchRt60(const AnalyzeArgs& a, hipStream_t stream);    // wet gain, decay time (reads the onsets)
 void launchAnalysisDirection(const AnalyzeArgs& a, hipStream_t stream);
+// the whole analysis of a grid whose history window is the grid, in one launch (pv_fused.hip); fusedAnalysisOk: its phase
+// counters fit; launchRunFinish: a run's output queries + status words in one launch (last kernel of a run)
+bool fusedAnalysisOk(const AnalyzeArgs& a);
+void launchAnalysisFused(const FusedArgs& f, hipStream_t stream);
+void launchRunFinish(const float* res, long long n, const long long* cellsHost, int nq, float* outHost, const FarInfo& far,
+                     const int* err, int* counts, const unsigned* claims, int* statusHost, hipStream_t stream);
 // wet gain + decay time, blocked forms (pv_rt60.hip: four lanes / one lane per cell; each launch checks on the device whether it is the one)
 void launchRt60Blocked(const AnalyzeArgs& a, hipStream_t stream);
 // slab halos: src[i] -> dst[i] for up to six blocks of n floats (n % 4 == 0, 16-byte aligned); dst[i] = NULL skips a block

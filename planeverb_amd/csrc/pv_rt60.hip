@@ -23,6 +23,7 @@
 #include <cstdint>
 
 #include "pv_analysis.h"
+#include "pv_analysis_dev.h"
 #include "pv_device.h"
 #include "pv_launch.h"
 #include "pv_libm.h"
@@ -42,60 +43,12 @@ namespace pva {
 
 namespace {
 
-struct LogTabLds {
-    const double* t;  // 48 x {invc, logc + kk ln2} in LDS, entry (kk + 1) * 16 + i
-    __device__ __forceinline__ void operator()(int i, int kk, double* invc, double* y0) const {
-        const int e = (kk + 1) * 16 + i;
-        *invc = t[2 * e];
-        *y0 = t[2 * e + 1];
-    }
-};
-
-// value of lane j - 1 of this lane's group of L (lane 0 reads lane L - 1)
-template <int L>
-__device__ __forceinline__ float prevInGroup(float v) {
-    if constexpr (L == 16)  // DPP row_ror:1
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
-    else if constexpr (L == 4)  // DPP quad_perm:[3,0,1,2]
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x93, 0xf, 0xf, false));
-    else
-        return v;
-}
-
-// One chunk of a sequential sum shared by the L lanes of a group: acc = (...((acc + add_0[0]) + add_0[1]) ... + add_{L-1}[S-1]),
-// lane j's addends after lane j-1's.  Every lane runs every step (SIMD), lane j keeps step j; the value a chunk ends with
-// stays in lane L-1, which is where lane 0 of the next chunk fetches it from.  KEEP: also the S partial sums of the own step.
-template <int L, int S, bool KEEP>
-__device__ __forceinline__ void groupChain(float& acc, const float (&add)[S], const int sub, float (&part)[S]) {
-#pragma unroll
-    for (int j = 0; j < L; ++j) {
-        float t = prevInGroup<L>(acc);
-        float tmp[S];
-#pragma unroll
-        for (int k = 0; k < S; ++k) {
-            t = t + add[k];
-            tmp[k] = t;
-        }
-        const bool mine = (L == 1) || sub == j;
-        acc = mine ? t : acc;
-        if (KEEP) {
-#pragma unroll
-            for (int k = 0; k < S; ++k) part[k] = mine ? tmp[k] : part[k];
-        }
-    }
-}
-
 template <int L, int S>
 __global__ __launch_bounds__(256) void pv_rt60_blocked_kernel(const AnalyzeArgs a) {
     __shared__ double tab[96];
     if (analysisAborted(a)) return;
-    if (rt60LanesPerCell(a, *a.activeCount) != L) return;  // (grid-uniform: the other instantiations' launches do the work)
-    if (threadIdx.x < 96) {
-        double invc, y0;
-        const int e = (int)threadIdx.x >> 1;
-        PvLogTabConst{}(e & 15, (e >> 4) - 1, &invc, &y0);
-        tab[threadIdx.x] = (threadIdx.x & 1) ? y0 : invc;
-    }
+    if (rt60LanesPerCell(a, *a.activeCount) != L) return;  // (grid-uniform: the other forms' launches do the work)
+    fillLogTab(tab, threadIdx.x, 256);
     __syncthreads();
     const LogTabLds ltab{tab};
     const DynParams dyn = *a.dyn;
@@ -105,86 +58,7 @@ __global__ __launch_bounds__(256) void pv_rt60_blocked_kernel(const AnalyzeArgs 
     Rt60Cell c{-1, {nullptr, 0}, 0};
     if (wc < a.winCols) c = rt60Cell(a, dyn, dyn.histRow0 - a.G + wr, dyn.histCol0 - a.G + wc);
     if (__ballot(c.s >= 0) == 0ull) return;  // a wave leaves only when none of its cells has work
-    const bool live = c.s >= 0;
-    const int T = a.T;
-    const int endPoint = T - a.nCut;
-    const int startingPoint = live ? c.startingPoint : T;  // dead lanes: no sample is in range
-    const int lowest = min(startingPoint, endPoint);         // the pre-sum over [endPoint, T) is not bounded by the onset
-    const long long plane = a.histPlane;
-    const float* const h0 = live ? c.hc.h : a.hist;
-
-    // ---- decay time: backwards from T - 1; wave-uniform trip count = the longest of the wave's cells ----
-    int n = T - lowest;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) n = max(n, __shfl_xor(n, off));
-    float edc = 0.f, xysum = 0.f, ysum = 0.f;
-    float pNext[S];
-#pragma unroll
-    for (int k = 0; k < S; ++k) {
-        const int i = T - 1 - sub * S - k;
-        pNext[k] = (live && i >= lowest && i >= 0) ? h0[(long long)i * plane] : 0.f;
-    }
-#pragma unroll 1
-    for (int n0 = 0; n0 < n; n0 += L * S) {
-        const int iTop = T - 1 - n0 - sub * S;  // this lane's samples: iTop - k
-        float q[S];
-#pragma unroll
-        for (int k = 0; k < S; ++k) q[k] = pNext[k] * pNext[k];  // 0 outside [lowest, T): edc + 0 = edc
-        if (n0 + L * S < n) {  // the next chunk's loads are in flight while this chunk's chains and logarithms run
-#pragma unroll
-            for (int k = 0; k < S; ++k) {
-                const int i = iTop - L * S - k;
-                pNext[k] = (live && i >= lowest && i >= 0) ? h0[(long long)i * plane] : 0.f;
-            }
-        }
-        float e[S];
-#pragma unroll
-        for (int k = 0; k < S; ++k) e[k] = 0.f;
-        groupChain<L, S, true>(edc, q, sub, e);
-        float ax[S], ay[S];
-#pragma unroll
-        for (int k = 0; k < S; ++k) {
-            const int i = iTop - k;
-            const bool regress = i >= startingPoint && i < endPoint;
-            const float y = 10.f * pvLog10fNonNegT(regress ? e[k] : 1.f, ltab);
-            ax[k] = regress ? y * (float)(i - startingPoint) : 0.f;
-            ay[k] = regress ? y : 0.f;
-        }
-        float unused[S];
-        groupChain<L, S, false>(xysum, ax, sub, unused);
-        groupChain<L, S, false>(ysum, ay, sub, unused);
-    }
-
-    // ---- wet gain (Analyzer.cpp:235-247): the same chain, forwards over [startingPoint, startingPoint + N_wet) ^ [0, T) ----
-    const int wetEnd = min(startingPoint + a.nWet, T);
-    int nw = max(wetEnd - startingPoint, 0);
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) nw = max(nw, __shfl_xor(nw, off));
-    float wet = 0.f;
-#pragma unroll
-    for (int k = 0; k < S; ++k) {
-        const int j = startingPoint + sub * S + k;
-        pNext[k] = (live && j < wetEnd) ? h0[(long long)j * plane] : 0.f;
-    }
-#pragma unroll 1
-    for (int j0 = 0; j0 < nw; j0 += L * S) {
-        float q[S];
-#pragma unroll
-        for (int k = 0; k < S; ++k) q[k] = pNext[k] * pNext[k];
-        if (j0 + L * S < nw) {
-#pragma unroll
-            for (int k = 0; k < S; ++k) {
-                const int j = startingPoint + j0 + L * S + sub * S + k;
-                pNext[k] = (live && j < wetEnd) ? h0[(long long)j * plane] : 0.f;
-            }
-        }
-        float unused[S];
-        groupChain<L, S, false>(wet, q, sub, unused);
-    }
-    if (live && sub == L - 1) {
-        a.out[a.resN + c.s] = sqrtf(wet / a.efree);
-        a.out[2 * a.resN + c.s] = rt60FromSums(a, c.startingPoint, xysum, ysum);
-    }
+    rt60BlockedBody<L, S>(a, ltab, sub, c.s >= 0, c.s, c.hc.h, c.startingPoint);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -211,12 +85,7 @@ __global__ __launch_bounds__(PV_RT60_TILE_BLOCK) void pv_rt60_tile_kernel(const 
     __shared__ double tab[96];
     if (analysisAborted(a)) return;
     if (rt60LanesPerCell(a, *a.activeCount) != 1) return;  // (grid-uniform)
-    for (int w = threadIdx.x; w < 96; w += PV_RT60_TILE_BLOCK) {
-        double invc, y0;
-        const int e = w >> 1;
-        PvLogTabConst{}(e & 15, (e >> 4) - 1, &invc, &y0);
-        tab[w] = (w & 1) ? y0 : invc;
-    }
+    fillLogTab(tab, threadIdx.x, PV_RT60_TILE_BLOCK);
     __syncthreads();
     const LogTabLds ltab{tab};
     const DynParams dyn = *a.dyn;

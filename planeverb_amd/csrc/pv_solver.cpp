@@ -1,6 +1,8 @@
 // pv_solver.cpp -- see pv_solver.h
 #include "pv_solver.h"
 
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -416,6 +418,16 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         }
     }
 
+    // Fused analysis (pv_fused.hip): the grids whose history window is the whole grid, up to the cell count the four-lane
+    // decay-time form serves
+    {
+        const bool wanted = opt_.fusedAnalysis != 0;
+        useFused_ = wanted && !opt_.streaming && !isSlab() && !opt_.denseHistory && histTilesX_ == geo_.ntx &&
+                    histTilesY_ == geo_.nty && histPlane_ <= 98304 && (opt_.rt60Lanes == 0 || opt_.rt60Lanes == 16 || opt_.rt60Lanes == 4) &&
+                    fusedAnalysisOk(analyzeArgs(0.f, 0.f));
+        if (useFused_ && !dalloc(&fusedCtl_, (size_t)kFusedCtlWords, true)) return false;
+    }
+
     warnIfPulseDiffers();
     pulse_ = gaussianPulse(g_);
     pulse_.resize((size_t)std::max(T_, g_.T), 0.f);  // an extended run (numSteps > T) injects nothing after T
@@ -480,7 +492,7 @@ Solver::~Solver() {
     if (emCells_) hipFree(emCells_);
     if (emTrace_) hipFree(emTrace_);
     void* ptrs[] = {coef_,      matDev_, pulseDev_, hist_,  tileFirst_, tileClass_, generalList_,
-                    generalCount_, dynDev_, errFlag_, res8_,     delay_, scratch_, res_, activeCount_, win8_, unitList_,
+                    generalCount_, dynDev_, errFlag_, res8_,     delay_, scratch_, res_, activeCount_, win8_, unitList_, fusedCtl_,
                     histAbove_, histEdge_, tileDead_, deadCount_};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -1239,6 +1251,19 @@ void Solver::enqueueAnalysis(float lx, float lz) {
     // Two iterations in flight on two solvers: the OTHER solver's iteration reads this solver's result maps in its carry pass,
     // so nothing of this analysis may write them before that iteration's analysis (and its own carry) is complete
     if (carry) hipStreamWaitEvent(stream_, carryFrom_->ev_[2], 0);
+    if (useFused_) {
+        FusedArgs f{};
+        f.a = a;
+        f.ctl = fusedCtl_;
+        f.carrySrc = carry ? carryFrom_->res_ : nullptr;
+        f.errFlag = errFlag_;
+        launchAnalysisFused(f, stream_);
+        if (lazyFar_) {
+            farWin_ = curWindow();
+            farDirValid_ = false;
+        }
+        return;
+    }
     launchAnalysisFar(a, stream_);
     launchOnset(a, stream_);
     // wet gain / decay time beside the encode pass: both only read the onsets and the history, and write different planes.
@@ -1474,8 +1499,10 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
     if (!opt_.skipAnalysis) enqueueAnalysis(lx, lz);
     hipEventRecord(ev_[2], stream_);
     lastRunBatched_ = false;
-    enqueueQueries();
-    enqueueRunStatus();
+    // last kernel of the run: the registered queries' outputs and the status words, both into pinned memory
+    launchRunFinish(res_, (long long)g_.gx * g_.gy, qCellsHost_, opt_.skipAnalysis ? 0 : numQueries_, qOutHost_, farInfo(), errFlag_,
+                    activeCount_, lastRunXcd_ ? resFlags_ + geo_.ntx * geo_.nty + 1 : nullptr, statusHost_, stream_);
+    statusQueued_ = true;
     pendingTimings_ = true;
     return hipOk(hipGetLastError(), "run launch");
 }
@@ -1649,6 +1676,20 @@ bool Solver::run(float lx, float ly, float lz, bool wait, Solver* carryFrom) {
 
 bool Solver::sync() {
     if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
+    if (useFused_ && std::getenv("PLANEVERB_AMD_FUSED_DEBUG")) {  // development aid: a run that does not end within 3 s
+        for (int i = 0; i < 3000 && hipStreamQuery(stream_) == hipErrorNotReady; ++i) usleep(1000);
+        if (hipStreamQuery(stream_) == hipErrorNotReady) {
+            unsigned w[kFusedCtlWords] = {};
+            hipStream_t s2;
+            hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+            hipMemcpyAsync(w, fusedCtl_, sizeof(w), hipMemcpyDeviceToHost, s2);
+            hipStreamSynchronize(s2);
+            std::fprintf(stderr, "[planeverb_amd] fused analysis stuck; control words:");
+            for (unsigned v : w) std::fprintf(stderr, " %u", v);
+            std::fprintf(stderr, "\n");
+            _exit(3);
+        }
+    }
     if (!hipOk(hipStreamSynchronize(stream_), "stream sync")) return false;
     releaseResident();
     if (pendingTimings_) {
@@ -1706,6 +1747,18 @@ bool Solver::sync() {
         }
         if (flag == 3 || flag == 4) return fail("resident kernel: a workgroup gave up waiting for its neighbours (run aborted)");
         if (flag == 5) return fail("slab decomposition: a neighbour's halo rows never arrived (run aborted)");
+        if (flag == 6) {
+            unsigned w[kFusedCtlWords] = {};
+            if (fusedCtl_) {
+                hipMemcpy(w, fusedCtl_, sizeof(w), hipMemcpyDeviceToHost);
+                hipMemset(fusedCtl_, 0, sizeof(w));
+            }
+            std::string m = "fused analysis: a worker waited for a phase in vain (run aborted); ticket and phase counters:";
+            for (unsigned v : w) m += " " + std::to_string(v);
+            int zero = 0;
+            hipMemcpy(errFlag_, &zero, sizeof(int), hipMemcpyHostToDevice);
+            return fail(m);
+        }
         if (flag) return fail("pressure history window overflow (a tile outside the window became non-zero)");
     }
     return true;
