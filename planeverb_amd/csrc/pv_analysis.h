@@ -28,15 +28,20 @@ struct PlaneCell {
     int X, Y;      // array cell (row of a slab: local)
     int tile;      // grid tile index ti * nty + tj
     int row, col;  // inside the tile
+    int g;         // the offset itself
+    int hti, htj;  // the tile's place in the window
 };
 __device__ __forceinline__ PlaneCell planeCell(const AnalyzeArgs& a, const DynParams& dyn, long long g) {
-    PlaneCell c{false, 0, 0, 0, 0, 0};
+    PlaneCell c{false, 0, 0, 0, 0, 0, 0, 0, 0};
     if (g >= a.histPlane) return c;
     const int gi = (int)g, tileCells = a.rxi * a.wi;
     const int wt = gi / tileCells, f = gi - wt * tileCells;
     c.row = f / a.wi;
     c.col = f - c.row * a.wi;
     const int hti = wt / dyn.histTilesY, htj = wt - hti * dyn.histTilesY;
+    c.g = gi;
+    c.hti = hti;
+    c.htj = htj;
     const int ti = dyn.histTileX0 + hti, tj = dyn.histTileY0 + htj;
     c.tile = ti * a.nty + tj;
     c.X = ti * a.rxi + c.row;

@@ -79,35 +79,43 @@ __device__ __forceinline__ void encodeWave(const AnalyzeArgs& a, const DynParams
     const int s = X * a.gy + Y;
     const int onset = live ? onsetIn : 0;
     const int T = a.T;
-    const int tFirst = live ? a.tileFirst[pc0.tile] : T;
-
+    constexpr int kOut = 0x7fffffff;  // a buffer offset beyond every extent: the load returns 0 without touching memory
     const int prow = X + a.G, pcol = Y + a.G;
-    const int hr = prow - dyn.histRow0, hcol = pcol - dyn.histCol0;
-    const long long hoff = live ? histOffset(hr, hcol, a.rxi, a.wi, dyn.histTilesY) : 0;
-    CellHistory hc{a.hist + hoff, a.histPlane};
-    // neighbours for the velocity recurrence; a neighbour tile that became active later (or never) has
-    // unwritten history that is exactly zero by causality
-    int tFx = INT_MAX, tFy = INT_MAX;
-    if (live && X > 0 && prow - 1 >= dyn.histRow0) tFx = a.tileFirst[((X - 1) / a.rxi) * a.nty + (Y / a.wi)];
-    if (live && Y > 0 && pcol - 1 >= dyn.histCol0) tFy = a.tileFirst[(X / a.rxi) * a.nty + ((Y - 1) / a.wi)];
-    // (the neighbours' offsets are only formed where they are read: tFx / tFy stay INT_MAX otherwise)
-    CellHistory hx{a.hist + (tFx != INT_MAX ? histOffset(hr - 1, hcol, a.rxi, a.wi, dyn.histTilesY) : hoff), a.histPlane};
-    CellHistory hy{a.hist + (tFy != INT_MAX ? histOffset(hr, hcol - 1, a.rxi, a.wi, dyn.histTilesY) : hoff), a.histPlane};
-    if (live && X == 0 && a.histAbove) {  // first row of a slab: the row above lives in the neighbouring slab
-        hx = CellHistory{a.histAbove + (pcol - dyn.histCol0), a.histPitch};
-        tFx = 0;
-    }
 
+    // The cell's own samples and those of its neighbours (X - 1, Y) and (X, Y - 1), for the velocity recurrence, are plane
+    // offsets: inside a tile one row / one cell back, across a tile's first row / column into the tile above / to the left.  A
+    // neighbour tile that became active later (or never) has unwritten history that is exactly zero by causality, and so has a
+    // neighbour outside the window.  (Everything here is loads that do not depend on each other and a handful of compares: the
+    // first version of this pass went through histOffset's divisions three times and four dependent round trips before its
+    // first sample -- a third of the 36 us the kernel took at 70^2.)
+    const int tileCells = a.rxi * a.wi;
+    const bool hasX = pc0.hti > 0 || pc0.row > 0, hasY = pc0.htj > 0 || pc0.col > 0;
+    const int gX = pc0.row > 0 ? pc0.g - a.wi : pc0.g - dyn.histTilesY * tileCells + (a.rxi - 1) * a.wi;
+    const int gY = pc0.col > 0 ? pc0.g - 1 : pc0.g - tileCells + (a.wi - 1);
+    const int tileX = pc0.row > 0 ? pc0.tile : pc0.tile - a.nty, tileY = pc0.col > 0 ? pc0.tile : pc0.tile - 1;
+    int tFirst = T, tFx = INT_MAX, tFy = INT_MAX;
     FaceCoef fc{0.f, 0.f, 0.f};
-    if (live) fc = a.coef[(size_t)prow * a.pitch + pcol];
+    if (live) {
+        tFirst = a.tileFirst[pc0.tile];
+        if (hasX) tFx = a.tileFirst[tileX];
+        if (hasY) tFy = a.tileFirst[tileY];
+        fc = a.coef[(size_t)prow * a.pitch + pcol];
+    }
+    // first row of a slab: the row above lives in the neighbouring slab, as a dense [T][histPitch] array
+    const bool above = live && X == 0 && a.histAbove != nullptr;
+    if (above) tFx = 0;
     const float kx = fc.kx, ky = fc.ky;
     const bool airX = kx != kx, airY = ky != ky;
     const float C = a.courant;
 
     // The loop walks the history in chunks of CH samples: the CH loads are issued together (they do not depend on the
     // running sums), then consumed strictly in sample order, so the float32 accumulation order is the reference's while the
-    // memory latency is paid once per chunk instead of once per sample.
+    // memory latency is paid once per chunk instead of once per sample.  Loads are buffer loads, one descriptor per plane built
+    // on the scalar unit; a lane whose window does not hold the sample loads through kOut (no branch around any load).
     constexpr int CH = PV_ENCODE_CH;
+    const int planeBytes = (int)(a.histPlane * 4);
+    auto planeRsrc = [&](int t) { return makeRsrc(a.hist + (long long)t * a.histPlane, planeBytes); };
+    const int vo = pc0.g * 4, voX = gX * 4, voY = gY * 4;
 
     // dry energy + flux, Analyzer.cpp:170-195: both sums run from sample 0 (samples before tFirst are zero) to the end of
     // their windows behind the onset; vx / vy by the stencil's own recurrence as long as the flux needs them
@@ -127,29 +135,41 @@ __device__ __forceinline__ void encodeWave(const AnalyzeArgs& a, const DynParams
         for (int k = 0; k < CH; ++k) {
             const int t = t0 + k, tt = min(t, T - 1);
             const bool mine = t >= tBegin && t < directEnd, mineV = mine && t < sourceDirEnd;
-            pc[k] = mine ? hc.at(tt) : 0.f;
-            pxc[k] = (needVChunk && mineV && tt >= tFx) ? hx.at(tt) : 0.f;
-            pyc[k] = (needVChunk && mineV && tt >= tFy) ? hy.at(tt) : 0.f;
+            const rsrc_t rs = planeRsrc(tt);
+            pc[k] = bufLoadF(rs, mine ? vo : kOut, 0);
+            if (needVChunk) {
+                pxc[k] = bufLoadF(rs, (mineV && hasX && tt >= tFx) ? voX : kOut, 0);
+                pyc[k] = bufLoadF(rs, (mineV && hasY && tt >= tFy) ? voY : kOut, 0);
+            } else {
+                pxc[k] = pyc[k] = 0.f;
+            }
+        }
+        if (a.histAbove != nullptr && needVChunk) {  // (slab groups only, wave-uniform)
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const int t = t0 + k, tt = min(t, T - 1);
+                const bool mineV = t >= tBegin && t < directEnd && t < sourceDirEnd;
+                const float pa = bufLoadF(makeRsrc(a.histAbove + (long long)tt * a.histPitch, a.histPitch * 4),
+                                          (above && mineV) ? (pcol - dyn.histCol0) * 4 : kOut, 0);
+                pxc[k] = above ? pa : pxc[k];
+            }
         }
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
             const int t = t0 + k;
-            if (t < tBegin || t >= directEnd) continue;
-            const float p = pc[k];
-            if (t < sourceDirEnd) {
-                const float pxn = pxc[k], pyn = pyc[k];
-                const float ax = vx - C * (p - pxn), wx = kx * (p + pxn);
-                const float ay = vy - C * (p - pyn), wy = ky * (p + pyn);
-                vx = airX ? ax : wx;
-                vy = airY ? ay : wy;
-            }
-            Edry += p * p;
-            if (t < sourceDirEnd) {
-                fluxX += p * vx;
-                fluxY += p * vy;
-            }
+            const bool mine = t >= tBegin && t < directEnd, mineV = mine && t < sourceDirEnd;
+            const float p = pc[k];  // (0 outside the lane's window: the sums below then stay as they are, bit for bit)
+            const float pxn = pxc[k], pyn = pyc[k];
+            const float ax = vx - C * (p - pxn), wx = kx * (p + pxn);
+            const float ay = vy - C * (p - pyn), wy = ky * (p + pyn);
+            vx = mineV ? (airX ? ax : wx) : vx;
+            vy = mineV ? (airY ? ay : wy) : vy;
+            Edry = mine ? Edry + p * p : Edry;
+            fluxX = mineV ? fluxX + p * vx : fluxX;
+            fluxY = mineV ? fluxY + p * vy : fluxY;
         }
     }
+    CellHistory hc{a.hist + pc0.g, a.histPlane};
 
     // wet gain, Analyzer.cpp:235-247: forwards over [onset + N_dry + 1, + N_wet) ^ [0, T)
     float wet = 0.f;
@@ -201,16 +221,29 @@ __device__ __forceinline__ float rowRor1Add(float acc, float addend) {  // acc[l
                                                                   false)) + addend;
 }
 
-template <int NCH>
-__device__ __forceinline__ void rowChains(float (&acc)[NCH], const float (&add)[NCH], const int sub) {
+// One chunk of a sequential sum along a row of 16 lanes: lane j ends up having added a_0 ... a_j, in that order, to the value
+// lane 15 carried in.  Every step is ONE instruction for the whole wave, acc = acc[lane - 1] + a (v_add_f32 row_ror:1), with no
+// lane frozen: at step j lane j reads lane j - 1, which became final at step j - 1, and what a lane holds after its own step is
+// never read again -- except lane 15's, the carry into the next chunk, and that one is final because its step is the last.
+// (Rounds 3-4 froze every lane after its step with a select ON the chain -- add, select, two wait states for the DPP read of a
+// just-written register -- 16 x ~16 cycles per chain and chunk for a lone wave; here the chain is the adds alone, and a lane that
+// needs its own partial sum -- the energy per sample -- captures it with a select BESIDE the chain.)
+template <bool CAPTURE>
+__device__ __forceinline__ float rowScan(float& acc, const float a, const int sub) {
+    float own = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const bool mine = sub == j;
+        acc = rowRor1Add(acc, a);
+        if (CAPTURE) own = sub == j ? acc : own;
+    }
+    return own;
+}
+// two independent sums at once: their instructions alternate, which covers the wait states between a write and its DPP read
+__device__ __forceinline__ void rowScan2(float& accA, const float aA, float& accB, const float aB) {
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const float t = rowRor1Add(acc[c], add[c]);
-            acc[c] = mine ? t : acc[c];
-        }
+    for (int j = 0; j < 16; ++j) {
+        accA = rowRor1Add(accA, aA);
+        accB = rowRor1Add(accB, aB);
     }
 }
 
@@ -226,12 +259,14 @@ __device__ __forceinline__ void rt60WaveBody(const AnalyzeArgs& a, const int sub
     int n = max(T - lowest, 0);
 #pragma unroll
     for (int off = 16; off < 64; off <<= 1) n = max(n, __shfl_xor(n, off));
-    float acc[3] = {0.f, 0.f, 0.f};  // edc, xysum, ysum: lane 15 of the row carries them from chunk to chunk
+    n = __builtin_amdgcn_readfirstlane(n);
+    float edc = 0.f, xysum = 0.f, ysum = 0.f;  // lane 15 of the row carries them from chunk to chunk
     float pNext = 0.f;
     {
         const int i = T - 1 - sub;
         pNext = (live && i >= lowest && i >= 0) ? hc.at(i) : 0.f;
     }
+#pragma unroll 1
     for (int n0 = 0; n0 < n; n0 += 16) {
         const int i = T - 1 - n0 - sub;
         const float p = pNext;
@@ -239,35 +274,29 @@ __device__ __forceinline__ void rt60WaveBody(const AnalyzeArgs& a, const int sub
             const int in = i - 16;
             pNext = (live && n0 + 16 < n && in >= lowest && in >= 0) ? hc.at(in) : 0.f;
         }
-        float e[1] = {acc[0]};
-        const float q[1] = {p * p};  // 0 outside [lowest, T): edc + 0 = edc
-        rowChains<1>(e, q, sub);
-        acc[0] = e[0];
+        const float e = rowScan<true>(edc, p * p, sub);  // (p = 0 outside [lowest, T): edc + 0 = edc)
         const bool regress = i >= startingPoint && i < endPoint;
-        const float y = 10.f * pvLog10fNonNeg(regress ? e[0] : 1.f);
-        const float add[2] = {regress ? y * (float)(i - startingPoint) : 0.f, regress ? y : 0.f};
-        float sums[2] = {acc[1], acc[2]};
-        rowChains<2>(sums, add, sub);
-        acc[1] = sums[0];
-        acc[2] = sums[1];
+        const float y = 10.f * pvLog10fNonNeg(regress ? e : 1.f);
+        rowScan2(xysum, regress ? y * (float)(i - startingPoint) : 0.f, ysum, regress ? y : 0.f);
     }
     // wet gain (Analyzer.cpp:235-247): the same chain, forwards over [startingPoint, startingPoint + N_wet) ^ [0, T)
     const int wetEnd = min(startingPoint + a.nWet, T);
     int nw = max(wetEnd - startingPoint, 0);
 #pragma unroll
     for (int off = 16; off < 64; off <<= 1) nw = max(nw, __shfl_xor(nw, off));
-    float wetAcc[1] = {0.f};
+    nw = __builtin_amdgcn_readfirstlane(nw);
+    float wet = 0.f;
     pNext = (live && startingPoint + sub < wetEnd) ? hc.at(startingPoint + sub) : 0.f;
+#pragma unroll 1
     for (int j0 = 0; j0 < nw; j0 += 16) {
         const float p = pNext;
         const int jn = startingPoint + j0 + 16 + sub;
         pNext = (live && j0 + 16 < nw && jn < wetEnd) ? hc.at(jn) : 0.f;
-        const float q[1] = {p * p};
-        rowChains<1>(wetAcc, q, sub);
+        (void)rowScan<false>(wet, p * p, sub);
     }
     if (live && sub == 15) {
-        a.out[a.resN + s] = sqrtf(wetAcc[0] / a.efree);
-        a.out[2 * a.resN + s] = rt60FromSums(a, startingPointIn, acc[1], acc[2]);
+        a.out[a.resN + s] = sqrtf(wet / a.efree);
+        a.out[2 * a.resN + s] = rt60FromSums(a, startingPointIn, xysum, ysum);
     }
 }
 
@@ -410,6 +439,101 @@ __device__ __forceinline__ void rt60BlockedBody(const AnalyzeArgs& a, const LogT
         a.out[a.resN + s] = sqrtf(wet / a.efree);
         a.out[2 * a.resN + s] = rt60FromSums(a, startingPointIn, xysum, ysum);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dry gain, source directivity, low-pass cutoff with L LANES PER CELL (16 or 4): the small windows' form of encodeWave
+// ---------------------------------------------------------------------------------------------------------------
+// One lane per cell walks a cell's dry window sample by sample: ~50 instructions per sample, and at 70^2 ... 254^2 the kernel
+// lasts as long as its longest walk (a cell behind a corner: 100-250 samples -> 27 us at 70^2, the longest pass of the analysis).
+// Here the L lanes of a group take L consecutive samples of a chunk, forwards in time, and the five sequential sums of the
+// reference's loop (Analyzer.cpp:170-195) are chains along the group like the decay-time forms' (rowScan): lane j adds its
+// term to the value of lane j - 1, fetched by the DPP rotation riding on the add; the last lane carries into the next chunk.
+//   vx, vy   on an air|air face the stencil's recurrence v_t = v_{t-1} - C (p_t[i] - p_t[n]) IS a running sum of the terms
+//            -(C (p_t[i] - p_t[n])) (a - b and a + (-b) are the same float); every lane keeps the value of ITS sample (the flux
+//            needs it).  On a wall face v_t = k (p_t[i] + p_t[n]) needs no chain.
+//   Edry, fluxX, fluxY   plain sums; only their totals are wanted: the chain is the adds alone.
+// Terms outside a cell's window are +0.0f, which leaves a float sum as it is (a sum that is -0.0f becomes +0.0f: the sign of a
+// zero, which no comparison in the test suite or the reference's consumers sees).  Same additions in the same order: same bits.
+template <int L, bool CAPTURE>
+__device__ __forceinline__ float groupScan(float& acc, const float a, const int sub) {
+    float own = 0.f;
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+        acc = prevInGroup<L>(acc) + a;
+        if (CAPTURE) own = sub == j ? acc : own;
+    }
+    return own;
+}
+
+// every lane of the wave must call; gcell = plane offset of the lane's cell (the same in the L lanes of a group), sub = the lane's
+// place in its group, live = the cell has an onset
+template <int L, bool SC1>
+__device__ __forceinline__ void encodeGroups(const AnalyzeArgs& a, const DynParams& dyn, const PlaneCell& pc0, const int sub,
+                                             const bool live, const int onsetIn) {
+    const int X = pc0.X, Y = pc0.Y;
+    const int s = X * a.gy + Y;
+    const int onset = live ? onsetIn : 0;
+    const int T = a.T;
+    const int prow = X + a.G, pcol = Y + a.G;
+    const int tileCells = a.rxi * a.wi;
+    const bool hasX = pc0.hti > 0 || pc0.row > 0, hasY = pc0.htj > 0 || pc0.col > 0;
+    const int gX = pc0.row > 0 ? pc0.g - a.wi : pc0.g - dyn.histTilesY * tileCells + (a.rxi - 1) * a.wi;
+    const int gY = pc0.col > 0 ? pc0.g - 1 : pc0.g - tileCells + (a.wi - 1);
+    const int tileX = pc0.row > 0 ? pc0.tile : pc0.tile - a.nty, tileY = pc0.col > 0 ? pc0.tile : pc0.tile - 1;
+    int tFirst = T, tFx = INT_MAX, tFy = INT_MAX;
+    FaceCoef fc{0.f, 0.f, 0.f};
+    if (live) {
+        tFirst = a.tileFirst[pc0.tile];
+        if (hasX) tFx = a.tileFirst[tileX];
+        if (hasY) tFy = a.tileFirst[tileY];
+        fc = a.coef[(size_t)prow * a.pitch + pcol];
+    }
+    const bool above = live && X == 0 && a.histAbove != nullptr;  // (first row of a slab: encodeWave)
+    if (above) tFx = 0;
+    const float kx = fc.kx, ky = fc.ky;
+    const bool airX = kx != kx, airY = ky != ky;
+    const float C = a.courant;
+    const int sourceDirEnd = live ? onset + a.nDir : 0, directEnd = live ? min(onset + a.nDry, T) : 0;
+    const int m = abs(X - (dyn.lrow - a.G)) + abs(Y - (dyn.lcol - a.G));
+    const int tBegin = max(tFirst, m - 1);  // (first sample that can be non-zero: encodeWave)
+    const int tLo = waveMin(live ? tBegin : INT_MAX), tHi = waveMax(directEnd);
+    const float* const hbase = a.hist;
+    float accVx = 0.f, accVy = 0.f, Edry = 0.f, fluxX = 0.f, fluxY = 0.f;  // the group's last lane carries them
+#pragma unroll 1
+    for (int t0 = tLo; t0 < tHi; t0 += L) {
+        const int t = t0 + sub, tt = min(t, T - 1);
+        const bool mine = t >= tBegin && t < directEnd, mineV = mine && t < sourceDirEnd;
+        // (the L lanes of a group read L planes: per-lane addresses)
+        const float* const hp = hbase + (long long)tt * a.histPlane;
+        const float p = mine ? hp[pc0.g] : 0.f;
+        float pxn = (mineV && hasX && tt >= tFx) ? hp[gX] : 0.f;
+        const float pyn = (mineV && hasY && tt >= tFy) ? hp[gY] : 0.f;
+        if (above && mineV) pxn = a.histAbove[(long long)tt * a.histPitch + (pcol - dyn.histCol0)];
+        // the velocities of this lane's sample: chain on air faces, closed form on wall faces
+        const float dX = (mineV && airX) ? -(C * (p - pxn)) : 0.f, dY = (mineV && airY) ? -(C * (p - pyn)) : 0.f;
+        float vx = groupScan<L, true>(accVx, dX, sub), vy = groupScan<L, true>(accVy, dY, sub);
+        vx = airX ? vx : kx * (p + pxn);
+        vy = airY ? vy : ky * (p + pyn);
+        (void)groupScan<L, false>(Edry, mine ? p * p : 0.f, sub);
+        (void)groupScan<L, false>(fluxX, mineV ? p * vx : 0.f, sub);
+        (void)groupScan<L, false>(fluxY, mineV ? p * vy : 0.f, sub);
+    }
+    if (!live || sub != L - 1) return;
+
+    // obstruction gain + source directivity, Analyzer.cpp:197-220
+    const float EfreePr = efreePerR(a.efree, a.dx, a.lcx, a.lcy, X + a.x0, Y);
+    const float occ = sqrtf(Edry / EfreePr);
+    float norm = sqrtf(fluxX * fluxX + fluxY * fluxY);
+    norm = -1.0f / (norm > 0.0f ? norm : 1.0f);
+    const float sdx = norm * fluxX, sdy = norm * fluxY;
+    // low-pass cutoff, Analyzer.cpp:227-230 (std::max(0.001f, g) == (0.001f < g) ? g : 0.001f)
+    const float rr = 1.0f / ((0.001f < occ) ? occ : 0.001f);
+    const float lowpass = -147.f + (18390.f) / (1.f + pvPowf(rr / 12.f, 0.8f));
+    xStoreF<SC1>(a.out + s, occ);  // (read by the listener-direction pass, of OTHER cells)
+    a.out[3 * a.resN + s] = lowpass;
+    a.out[6 * a.resN + s] = sdx;
+    a.out[7 * a.resN + s] = sdy;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

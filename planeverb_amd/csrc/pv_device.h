@@ -305,6 +305,8 @@ struct AnalyzeArgs {
     // is materialised when a whole-map reader asks (pv_far_dir_kernel) or computed in closed form by the output gathers.
     int lazyFar;
     int prevR0, prevC0, prevNR, prevNC;
+    int wholeWindow;     // the history window is the whole grid (the reference's presets): no far cells at all -- pv_onset_kernel writes
+                         // "no onset" itself and counts the active cells, the direction pass covers every cell: no far-frame launch
     // streaming analysis (sparse-emitter mode): the history is a ring of `ring` planes and the forward sums of
     // every cell are carried in per-cell state planes between passes
     int ring;            // 0 = full history (plane index = t), else plane index = t % ring

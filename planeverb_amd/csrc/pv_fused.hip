@@ -122,6 +122,10 @@ __device__ __forceinline__ void fusedCells(const FusedArgs& f, const DynParams& 
         }
     }
     __syncthreads();
+#ifdef PV_FUSED_DEBUG
+    unsigned long long* const dbg = reinterpret_cast<unsigned long long*>(f.ctl + kFusedCtlWords);
+    if (threadIdx.x == 0) atomicMax(dbg + 22, (unsigned long long)wall_clock64());
+#endif
     const int onset = sh.found[ci];
     const bool live = air && onset != INT_MAX;
     const int s = c.X * a.gy + c.Y;
@@ -149,6 +153,9 @@ __device__ __forceinline__ void fusedCells(const FusedArgs& f, const DynParams& 
 #ifndef PV_FUSED_NO_ENCODE
         if (mr != 0ull) encodeWave<true>(a, dyn, c, mine && live, onset, false);
 #endif
+#ifdef PV_FUSED_DEBUG
+        if (lane == 0) atomicMax(dbg + 24, (unsigned long long)wall_clock64());
+#endif
     } else {
         // ---- wet gain + decay time: wave w takes cells [w CI / 4, (w + 1) CI / 4) with L = 64 / (CI / 4) lanes each ----
         constexpr int L = 256 / CI;  // 16 (CI = 16) or 4 (CI = 64)
@@ -170,6 +177,9 @@ __device__ __forceinline__ void fusedCells(const FusedArgs& f, const DynParams& 
             else
                 rt60BlockedBody<4, 4>(a, LogTabLds{sh.tab}, sub, lv, sj, h0, on + a.nDry + 1);
         }
+#ifdef PV_FUSED_DEBUG
+        if (lane == 0) atomicMax(dbg + 26, (unsigned long long)wall_clock64());
+#endif
     }
 }
 
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(kFusedThreads) void pv_analysis_fused_kernel(const 
     if (blockIdx.x == 0 && threadIdx.x == 0) a.activeCount[0] = active;
 
 #ifdef PV_FUSED_DEBUG
-    if (threadIdx.x == 0) { atomicAdd(ctl + 12, 1u); ctl[13] = total; ctl[14] = (unsigned)nB; }
+    if (threadIdx.x == 0) atomicMin(reinterpret_cast<unsigned long long*>(ctl + kFusedCtlWords), (unsigned long long)wall_clock64());
 #endif
     // (One single-lane region per turn -- the previous item's phase counter and the next ticket together -- closed by a barrier
     // before anything else happens: with the counter raised at the END of a turn and the ticket drawn at the START of the next,
@@ -234,7 +244,10 @@ __global__ __launch_bounds__(kFusedThreads) void pv_analysis_fused_kernel(const 
             __syncthreads();
         }
 #ifdef PV_FUSED_DEBUG
-        if (threadIdx.x == 0) { atomicAdd(ctl + 9, 1u); atomicMax(ctl + 10, t); }
+        // development build: 100 MHz stamps -- dbg[0] = first worker in, dbg[1 + 2 p] / dbg[2 + 2 p] = first item of phase p begun /
+        // last one ended (its wait included in "begun" - previous "ended")
+        unsigned long long* const dbg = reinterpret_cast<unsigned long long*>(ctl + kFusedCtlWords);
+        if (threadIdx.x == 0) atomicMin(dbg + 1 + 2 * phase, (unsigned long long)wall_clock64());
 #endif
         if (phase == 0) {
             if (CI == 16)
@@ -258,7 +271,7 @@ __global__ __launch_bounds__(kFusedThreads) void pv_analysis_fused_kernel(const 
             }
         }
 #ifdef PV_FUSED_DEBUG
-        if (threadIdx.x == 0) atomicAdd(ctl + 11, 1u);
+        if (threadIdx.x == 0) atomicMax(dbg + 2 + 2 * phase, (unsigned long long)wall_clock64());
 #endif
         // the item's write-through stores have left this CU before its phase counter moves
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -320,10 +333,11 @@ __global__ __launch_bounds__(512) void pv_run_finish_kernel(const float* __restr
         status[2] = counts[1];
         status[3] = claims ? (int)*claims : -1;
         status[4] = counts[3];
-        // (the fused analysis adds to the two cell counters: they start every run at zero)
+        // (the analysis adds to the cell counters and the list of groups with work: they start every run at zero)
         counts[1] = 0;
         counts[2] = 0;
         counts[3] = 0;
+        counts[4] = 0;
     }
 }
 }  // namespace

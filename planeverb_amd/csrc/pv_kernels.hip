@@ -2324,6 +2324,21 @@ __global__ __launch_bounds__(64 * kOnsetWaves) void pv_onset_kernel(const Analyz
     }
     if (wave == 0) found[lane] = INT_MAX;
     __syncthreads();
+    if (a.wholeWindow) {
+        // no far-frame launch in front of this one: "no onset" for the cells that will not get one, and the count of active cells
+        // (what pv_far_frame_kernel's first block does; the run's last kernel has left the other counters at zero)
+        if (wave == 0 && c.inGrid && !live) a.delay[c.X * a.gy + c.Y] = FLT_MAX;
+        if (blockIdx.x == 0 && wave == 1) {
+            int n = 0;
+            for (int i = lane; i < dyn.histTilesX * dyn.histTilesY; i += 64) {
+                const int ti = dyn.histTileX0 + i / dyn.histTilesY, tj = dyn.histTileY0 + i % dyn.histTilesY;
+                if (a.tileFirst[ti * a.nty + tj] < T) n += a.rxi * a.wi;
+            }
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) n += __shfl_xor(n, off);
+            if (lane == 0) a.activeCount[0] = n;
+        }
+    }
     if (__ballot(live) == 0ull) return;  // (the same lanes in every wave of the block: block-uniform)
     // A run starts from zero fields and the stencil moves a value by one cell per step along one axis (FDTD.cpp:124-199): the
     // recorded pressure of a cell at Manhattan distance m from the listener is exactly zero up to and including step m,
@@ -2357,7 +2372,10 @@ __global__ __launch_bounds__(64 * kOnsetWaves) void pv_onset_kernel(const Analyz
     __syncthreads();
     if (wave != 0) return;
     const int onset = found[lane];
-    if (live && onset != INT_MAX) a.delay[c.X * a.gy + c.Y] = (float)onset;
+    if (live) {
+        if (onset != INT_MAX) a.delay[c.X * a.gy + c.Y] = (float)onset;
+        else if (a.wholeWindow) a.delay[c.X * a.gy + c.Y] = FLT_MAX;
+    }
     // reached cells of this run (bench / PvAmdTimings.reachedCells) and silent ones: one atomic each per block
     const unsigned long long mr = __ballot(live && onset != INT_MAX), ms = __ballot(live && onset == INT_MAX);
     if (lane == 0) {
@@ -2381,6 +2399,23 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
     const bool live = delay != FLT_MAX;  // no onset (Analyzer.cpp:160-165): the result record stays as it is
     if (__ballot(live) == 0ull) return;
     encodeWave<false>(a, dyn, pc0, live, live ? (int)delay : 0, rt60LanesPerCell(a, *a.activeCount) == 1);
+}
+
+// the same pass with L lanes per cell (encodeGroups, pv_analysis_dev.h): the small windows, where the longest walk is the kernel.
+// A 64-cell group of the list is L waves: L / 4 workgroups
+template <int L>
+__global__ __launch_bounds__(256) void pv_encode_groups_kernel(const AnalyzeArgs a) {
+    if (analysisAborted(a)) return;
+    const DynParams dyn = *a.dyn;
+    constexpr int BPU = L / 4;  // workgroups per group of 64 cells
+    const int unit = blockIdx.x / BPU;
+    if (unit >= a.activeCount[4]) return;
+    const int ww = (blockIdx.x % BPU) * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const PlaneCell pc0 = planeCell(a, dyn, (long long)a.unitList[unit] * 64 + ww * (64 / L) + lane / L);
+    const float delay = pc0.inGrid ? a.delay[pc0.X * a.gy + pc0.Y] : FLT_MAX;
+    const bool live = delay != FLT_MAX;
+    if (__ballot(live) == 0ull) return;
+    encodeGroups<L, false>(a, dyn, pc0, lane % L, live, live ? (int)delay : 0);
 }
 
 // wet gain + decay time, sixteen lanes per cell (rt60WaveBody, pv_analysis_dev.h): the few thousand cells of a closed room
@@ -2778,7 +2813,16 @@ void launchOnset(const AnalyzeArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(pv_onset_kernel, dim3((unsigned)((a.histPlane + 63) / 64)), dim3(64 * kOnsetWaves), 0, stream, a);
 }
 void launchEncode(const AnalyzeArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL(pv_encode_kernel, dim3((unsigned)((a.histPlane + 255) / 256)), dim3(256), 0, stream, a);
+    // lanes per cell by the window's size (an upper bound of the cells with work): sixteen where a cell's walk IS the kernel's
+    // duration, four up to the sizes the four-lane decay-time form serves, one (which then also takes the wet gain beside the
+    // lane-per-cell decay-time form) above
+    const unsigned units = (unsigned)((a.histPlane + 63) / 64);
+    if (a.rt60Lanes != 1 && a.histPlane <= 16384)
+        hipLaunchKernelGGL(pv_encode_groups_kernel<16>, dim3(units * 4), dim3(256), 0, stream, a);
+    else if (a.rt60Lanes != 1 && a.histPlane <= kRt60TileMinCells)
+        hipLaunchKernelGGL(pv_encode_groups_kernel<4>, dim3(units), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(pv_encode_kernel, dim3((unsigned)((a.histPlane + 255) / 256)), dim3(256), 0, stream, a);
 }
 // wet gain + decay time: sixteen lanes per cell or one by the number of reachable cells, decided on the device (the launch
 // of the other form leaves at once; a forced form, PVA_OPT_RT60_LANES, launches only itself)
@@ -2796,6 +2840,9 @@ void launchAnalysisCells(const AnalyzeArgs& a, hipStream_t stream) {
 
 void launchAnalysisDirection(const AnalyzeArgs& a, hipStream_t stream) {
     const dim3 grid = analysisWindowGrid(a);
+    // (the whole pass in ONE workgroup with the table in LDS -- no kernel boundaries between init, jumps and final -- was built and
+    // measured for the windows of up to 16 384 cells: 25-80 us slower, one CU's memory pipeline does the 17 loads per cell of
+    // init and final for everybody: docs/experiments/fused_analysis.md)
     if (a.dirJump)
         launchDirectionJump(a, a.dirScratch, stream);
     else
@@ -2807,6 +2854,7 @@ void launchFillDelay(float* delay, long long n, hipStream_t stream) {
 }
 
 void launchAnalysisFar(const AnalyzeArgs& a, hipStream_t stream) {
+    if (a.wholeWindow) return;  // (no far cells: pv_onset_kernel does what is left of this pass)
     const int n = a.gx * a.gy;
     if (a.lazyFar) {
         const int nr = max(a.prevNR, min(a.winRows, a.gx)), nc = max(a.prevNC, min(a.winCols, a.gy));
@@ -2820,13 +2868,9 @@ void launchAnalysisFar(const AnalyzeArgs& a, hipStream_t stream) {
 void launchAnalysis(const AnalyzeArgs& a, hipStream_t stream) {
     launchAnalysisFar(a, stream);
     launchAnalysisCells(a, stream);
-    const dim3 grid = analysisWindowGrid(a);
     // listener direction: the plain walk where walks are short (small windows: rooms, the sandbox's grids), pointer
     // jumping where a window is wide enough for hundreds of steps (a dozen tiny launches, path-length independent)
-    if (a.dirJump)
-        launchDirectionJump(a, a.dirScratch, stream);
-    else
-        hipLaunchKernelGGL(pv_direction_kernel, grid, dim3(256), 0, stream, a);
+    launchAnalysisDirection(a, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -27,11 +27,12 @@ __global__ void pv_run_status_kernel(const int* err, int* counts, const unsigned
         out[1] = counts[0];
         out[2] = counts[1];
         out[3] = claims ? (int)*claims : -1;
-        // hint for the next run's pv_encode_kernel: many silent cells (counts[3]) -> look for an audible sample first
-        // (the kernel lasts as long as its slowest thread: a silent cell's walk over all T samples of three planes -- a percent
-        // or two of such cells is enough)
-        counts[2] = (long long)counts[3] * 64 > (long long)counts[1] ? 1 : 0;
         out[4] = counts[3];
+        // the cell counters and the list of groups with work start the next run's analysis at zero (pv_onset_kernel adds to them)
+        counts[1] = 0;
+        counts[2] = 0;
+        counts[3] = 0;
+        counts[4] = 0;
     }
 }
 }  // namespace

@@ -16,13 +16,16 @@
 
 namespace pva {
 
+#ifndef PV_ANALYSIS_FORK_CELLS
+#define PV_ANALYSIS_FORK_CELLS 4096
+#endif
 namespace {
 // Row bands per sweep when the option is left at "auto": 1 = off.  Measured on MI355X (profiles/r02_bands.txt): the
 // banded sweeps are bit-exact but 6-35 % SLOWER than one launch per sweep at 4096^2 and 8192^2 for every band count --
 // two cross-stream event waits per band and sweep cost more than the chip-wide drain they remove.
 constexpr int kAutoRowBands = 1;
 constexpr int kDefaultPatch = 0;  // persistent patch kernel for the (12, 36) tile: off until measured faster (PVA_OPT_PATCH_KERNEL)
-constexpr long long kAnalysisForkCells = 32768;  // window cells from which the decay-time pass runs beside the encode pass (enqueueAnalysis)
+constexpr long long kAnalysisForkCells = PV_ANALYSIS_FORK_CELLS;  // window cells from which the decay-time pass runs beside the encode pass (enqueueAnalysis)
 constexpr int kMinGuard = 8;  // guard width = max(this, K): a tile's halo never leaves the allocation
 inline int roundUp(int v, int m) { return (v + m - 1) / m * m; }
 inline int ceilDiv(int a, int b) { return (a + b - 1) / b; }
@@ -421,11 +424,12 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     // Fused analysis (pv_fused.hip): the grids whose history window is the whole grid, up to the cell count the four-lane
     // decay-time form serves
     {
-        const bool wanted = opt_.fusedAnalysis != 0;
+        const bool wanted = opt_.fusedAnalysis > 0;  // (opt-in: measured slower than the separate kernels, docs/experiments/fused_analysis.md)
         useFused_ = wanted && !opt_.streaming && !isSlab() && !opt_.denseHistory && histTilesX_ == geo_.ntx &&
                     histTilesY_ == geo_.nty && histPlane_ <= 98304 && (opt_.rt60Lanes == 0 || opt_.rt60Lanes == 16 || opt_.rt60Lanes == 4) &&
                     fusedAnalysisOk(analyzeArgs(0.f, 0.f));
-        if (useFused_ && !dalloc(&fusedCtl_, (size_t)kFusedCtlWords, true)) return false;
+        // (+ 32 64-bit phase stamps behind the words: development builds, -DPV_FUSED_DEBUG + PLANEVERB_AMD_FUSED_DEBUG=2)
+        if (useFused_ && !dalloc(&fusedCtl_, (size_t)kFusedCtlWords + 64, true)) return false;
     }
 
     warnIfPulseDiffers();
@@ -1190,6 +1194,7 @@ AnalyzeArgs Solver::analyzeArgs(float lx, float lz) const {
     a.lz = lz;
     listenerCellRecip(g_, lx, lz, &a.lcx, &a.lcy);
     a.lazyFar = lazyFar_ ? 1 : 0;
+    a.wholeWindow = (!isSlab() && !opt_.streaming && histTilesX_ == geo_.ntx && histTilesY_ == geo_.nty) ? 1 : 0;
     a.prevR0 = farWin_.r0;
     a.prevC0 = farWin_.c0;
     a.prevNR = farWin_.nr;
@@ -1266,22 +1271,23 @@ void Solver::enqueueAnalysis(float lx, float lz) {
     }
     launchAnalysisFar(a, stream_);
     launchOnset(a, stream_);
-    // wet gain / decay time beside the encode pass: both only read the onsets and the history, and write different planes.
-    // Worth two cross-stream waits where the decay-time pass is long (windows of tens of thousands of cells)
-    const bool fork = histPlane_ >= kAnalysisForkCells && opt_.analysisFork != 0;
+    // Wet gain / decay time on the second stream, beside everything else behind the onsets: the encode pass AND the listener-
+    // direction passes (which need the onsets and the occlusion map, nothing of the decay-time pass).  Worth two cross-stream
+    // waits where the passes are long (windows of tens of thousands of cells) -- or always: PVA_OPT_ANALYSIS_FORK = 2
+    const bool fork = opt_.analysisFork == 2 || (opt_.analysisFork != 0 && histPlane_ >= kAnalysisForkCells);
     if (fork) {
         hipEventRecord(anaEv_[0], stream_);
         hipStreamWaitEvent(stream2_, anaEv_[0], 0);
         launchRt60(a, stream2_);
         hipEventRecord(anaEv_[1], stream2_);
         launchEncode(a, stream_);
-        hipStreamWaitEvent(stream_, anaEv_[1], 0);
     } else {
         launchEncode(a, stream_);
         launchRt60(a, stream_);
     }
     if (carry) launchCarryResults(a, carryFrom_->res_, stream_);
     launchAnalysisDirection(a, stream_);
+    if (fork) hipStreamWaitEvent(stream_, anaEv_[1], 0);
     if (lazyFar_) {
         farWin_ = curWindow();
         farDirValid_ = false;
@@ -1691,6 +1697,23 @@ bool Solver::sync() {
         }
     }
     if (!hipOk(hipStreamSynchronize(stream_), "stream sync")) return false;
+    if (useFused_) {
+        static const char* dbgEnv = std::getenv("PLANEVERB_AMD_FUSED_DEBUG");
+        if (dbgEnv && std::atoi(dbgEnv) == 2 && pendingTimings_) {
+            unsigned long long st[32];
+            hipMemcpy(st, fusedCtl_ + kFusedCtlWords, sizeof(st), hipMemcpyDeviceToHost);
+            std::fprintf(stderr, "[fused] us since the first worker: ");
+            for (int p = 0; p < 10; ++p) {
+                if (st[1 + 2 * p] == ~0ull) break;
+                std::fprintf(stderr, " p%d %.1f-%.1f", p, (double)(st[1 + 2 * p] - st[0]) * 0.01, (double)(st[2 + 2 * p] - st[0]) * 0.01);
+            }
+            std::fprintf(stderr, " | last onset %.1f encode %.1f decay %.1f\n", (double)(st[22] - st[0]) * 0.01, (double)(st[24] - st[0]) * 0.01,
+                         (double)(st[26] - st[0]) * 0.01);
+            hipMemset(fusedCtl_ + kFusedCtlWords + 2 * 22, 0, 8 * 6);
+            hipMemset(fusedCtl_ + kFusedCtlWords, 0xff, 8 * 21);
+            for (int p = 0; p < 10; ++p) hipMemset(fusedCtl_ + kFusedCtlWords + 2 * (2 + 2 * p), 0, 8);
+        }
+    }
     releaseResident();
     if (pendingTimings_) {
         pendingTimings_ = false;
