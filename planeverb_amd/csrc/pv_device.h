@@ -193,10 +193,13 @@ struct ResidentArgs {
     const FaceCoef* coef;
     const float* pulse;    // >= T floats
     float* hist;           // window base (the window is the whole grid), plane stride histPlane
-    int* tileFirst;        // per tile: first step block in which the tile was non-zero (reset to INT_MAX before the launch)
-    const DynParams* dyn;
+    int* tileFirst;        // per tile: first step block in which the tile was non-zero (every block resets its own tile's entry)
+    DynParams dynVal;      // the run's parameters, by value: no begin-run launch in front of this kernel (it read them from pinned
+                           // host memory, 7-8 us of a 0.3 ms run); block 0 leaves a copy at dynOut for the analysis kernels
+    DynParams* dynOut;
     int* errFlag;          // 3 = a block gave up waiting for a neighbour (every block then leaves: the run failed)
-    unsigned* flags;       // ntiles epoch counters + 1 abort word + 1 claim counter (one-XCD mode), zeroed before every launch
+    unsigned* flags;       // ntiles epoch counters + 1 abort word + 1 claim counter (one-XCD mode), zero before every launch (the
+                           // previous run's last kernel clears them: launchRunFinish)
     int xcdMode;           // 1: the blocks that run on XCD xcdTarget claim the tiles; hand-off through that XCD's L2
     int xcdTarget;
     long long histPlane;   // floats per recorded step

@@ -306,8 +306,8 @@ void launchAnalysisFused(const FusedArgs& f, hipStream_t stream) {
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 __global__ __launch_bounds__(512) void pv_run_finish_kernel(const float* __restrict__ res, long long n, const long long* cells, int nq,
-                                                            float* out, const FarInfo f, const int* err, int* counts,
-                                                            const unsigned* claims, int* status) {
+                                                            float* out, const FarInfo f, int* err, int* counts,
+                                                            const unsigned* claims, int* status, unsigned* zeroWords, int nZero) {
     const int q = threadIdx.x >> 3, k = threadIdx.x & 7;
     if (q < nq) {
         const long long c = cells[q];
@@ -327,11 +327,16 @@ __global__ __launch_bounds__(512) void pv_run_finish_kernel(const float* __restr
         }
         out[q * 8 + k] = v;
     }
+    const int claimed = claims ? (int)*claims : -1;  // (before the words are cleared below: every thread reads, thread 0 uses)
+    __syncthreads();
+    // the resident kernel's flag words and the error flag start the NEXT run at zero (no begin-run launch in front of that kernel)
+    for (int i = threadIdx.x; i < nZero; i += 512) zeroWords[i] = 0u;
     if (threadIdx.x == 0) {
         status[0] = *err;
+        if (nZero > 0) *err = 0;
         status[1] = counts[0];
         status[2] = counts[1];
-        status[3] = claims ? (int)*claims : -1;
+        status[3] = claimed;
         status[4] = counts[3];
         // (the analysis adds to the cell counters and the list of groups with work: they start every run at zero)
         counts[1] = 0;
@@ -343,9 +348,9 @@ __global__ __launch_bounds__(512) void pv_run_finish_kernel(const float* __restr
 }  // namespace
 
 void launchRunFinish(const float* res, long long n, const long long* cellsHost, int nq, float* outHost, const FarInfo& far,
-                     const int* err, int* counts, const unsigned* claims, int* statusHost, hipStream_t stream) {
+                     int* err, int* counts, const unsigned* claims, int* statusHost, unsigned* zeroWords, int nZero, hipStream_t stream) {
     hipLaunchKernelGGL(pv_run_finish_kernel, dim3(1), dim3(512), 0, stream, res, n, cellsHost, nq, outHost, far, err, counts, claims,
-                       statusHost);
+                       statusHost, zeroWords, nZero);
 }
 
 }  // namespace pva

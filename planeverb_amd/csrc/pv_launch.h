@@ -82,8 +82,9 @@ void launchAnalysisDirection(const AnalyzeArgs& a, hipStream_t stream);
 // counters fit; launchRunFinish: a run's output queries + status words in one launch (last kernel of a run)
 bool fusedAnalysisOk(const AnalyzeArgs& a);
 void launchAnalysisFused(const FusedArgs& f, hipStream_t stream);
+// (zeroWords / nZero: words to clear behind everything else -- the resident kernel's flags, for the next run; with them the error flag)
 void launchRunFinish(const float* res, long long n, const long long* cellsHost, int nq, float* outHost, const FarInfo& far,
-                     const int* err, int* counts, const unsigned* claims, int* statusHost, hipStream_t stream);
+                     int* err, int* counts, const unsigned* claims, int* statusHost, unsigned* zeroWords, int nZero, hipStream_t stream);
 // wet gain + decay time, blocked forms (pv_rt60.hip: four lanes / one lane per cell; each launch checks on the device whether it is the one)
 void launchRt60Blocked(const AnalyzeArgs& a, hipStream_t stream);
 // slab halos: src[i] -> dst[i] for up to six blocks of n floats (n % 4 == 0, 16-byte aligned); dst[i] = NULL skips a block

@@ -1423,7 +1423,8 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
         }
         lastLcx_ = lcx;
         lastLcy_ = lcy;
-        enqueueBeginRun(true);  // (also clears the flag words)
+        // (no begin-run launch: the run's parameters travel in the kernel's arguments, every block resets its own tile's entry, and
+        // the flag words and the error flag were cleared by the previous run's last kernel -- or by the allocation)
         ResidentArgs ra{};
         for (int i = 0; i < 2; ++i) {
             ra.pr[i] = pr_[i];
@@ -1434,7 +1435,8 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
         ra.pulse = pulseDev_;
         ra.hist = hist_;
         ra.tileFirst = tileFirst_;
-        ra.dyn = dynDev_;
+        ra.dynVal = dynCur_;
+        ra.dynOut = dynDev_;
         ra.errFlag = errFlag_;
         ra.flags = resFlags_;
         ra.xcdMode = xcd ? 1 : 0;
@@ -1507,7 +1509,8 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
     lastRunBatched_ = false;
     // last kernel of the run: the registered queries' outputs and the status words, both into pinned memory
     launchRunFinish(res_, (long long)g_.gx * g_.gy, qCellsHost_, opt_.skipAnalysis ? 0 : numQueries_, qOutHost_, farInfo(), errFlag_,
-                    activeCount_, lastRunXcd_ ? resFlags_ + geo_.ntx * geo_.nty + 1 : nullptr, statusHost_, stream_);
+                    activeCount_, lastRunXcd_ ? resFlags_ + geo_.ntx * geo_.nty + 1 : nullptr, statusHost_, resFlags_,
+                    resFlags_ ? geo_.ntx * geo_.nty + 2 : 0, stream_);
     statusQueued_ = true;
     pendingTimings_ = true;
     return hipOk(hipGetLastError(), "run launch");
