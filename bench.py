@@ -221,6 +221,83 @@ class GpuHooks:
         else:
             dist.barrier()
 
+    def power_watts(self):
+        """socket power of this GPU right now (amdgpu hwmon, microwatts), or None"""
+        import glob
+        for pat in ("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average", "/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"):
+            fs = sorted(glob.glob(pat))
+            if fs:
+                try:
+                    return float(open(fs[min(self.local_rank, len(fs) - 1)]).read().strip()) / 1e6
+                except Exception:
+                    return None
+        return None
+
+    def dense_leg(self, solvers_in_flight, K, T, cells, seconds=1.2):
+        """roofline.dense: the raw stencil (PvAmdRunSteps: the dominant kernel and nothing else) on SEEDED
+        RANDOM fields -- every cell non-zero -- at the bench's grid, tile and number of runs in flight, behind the timed region.
+        The headline scene keeps the field at zero outside a 70^2-cell room (the closed-room workload BASELINE names): same
+        instructions, but operands that toggle no bits.  Reports the wall rate, the launch durations (HIP events around each
+        call's back-to-back launches: p50 / p90 over the calls), the shader clock and the socket power beside it, and the same
+        for ZERO fields measured the same way right after, so that the two are comparable call for call."""
+        import threading
+        rng = np.random.default_rng(1)
+        launches = max(1, T // K)
+        out = {"fields": "uniform random in (-5e-4, 5e-4) for pr, vx, vy of every cell (numpy default_rng(1)), scene geometry in place",
+               "steps_per_call": launches * K, "runs_in_flight": len(solvers_in_flight)}
+
+        def leg(tag):
+            per_call, clocks, power = [], [], []
+            stop = [False]
+
+            def work(sv):
+                while not stop[0]:
+                    sv.run_steps(launches * K)
+                    per_call.append(sv.timings().fdtdMs / launches)
+
+            def watch():
+                while not stop[0]:
+                    clocks.append(self.clock_probe())
+                    pw = self.power_watts()
+                    if pw is not None:
+                        power.append(pw)
+                    time.sleep(0.05)
+            for sv in solvers_in_flight:  # warm (first launch from these fields)
+                sv.run_steps(K)
+            self.device_sync()
+            per_call.clear()
+            th = [threading.Thread(target=work, args=(sv,)) for sv in solvers_in_flight] + [threading.Thread(target=watch)]
+            t0 = time.perf_counter()
+            for t in th:
+                t.start()
+            time.sleep(seconds)
+            stop[0] = True
+            for t in th:
+                t.join()
+            self.device_sync()
+            dt = time.perf_counter() - t0
+            n = len(per_call)
+            pc = np.sort(np.asarray(per_call)) if n else np.zeros(1)
+            out[tag] = {"value": n * launches * K * cells / dt, "unit": "cell-updates/s (wall)", "calls": n,
+                        "launch_ms_p50": float(pc[len(pc) // 2]), "launch_ms_p90": float(pc[min(len(pc) - 1, int(0.9 * len(pc)))]),
+                        "clock_mhz_median": float(np.median(clocks)) if clocks else None,
+                        "clock_mhz_min": float(np.min(clocks)) if clocks else None,
+                        "power_w_median": float(np.median(power)) if power else None,
+                        "power_w_max": float(np.max(power)) if power else None}
+        try:
+            for sv in solvers_in_flight:
+                shp = (sv.gx + 1, sv.gy + 1)
+                sv.set_fields(*[(rng.random(shp, np.float32) - np.float32(0.5)) * np.float32(1e-3) for _ in range(3)])
+            leg("random")
+            for sv in solvers_in_flight:
+                z = np.zeros((sv.gx + 1, sv.gy + 1), np.float32)
+                sv.set_fields(z, z, z)
+            leg("zero")
+            out["random_over_zero"] = out["random"]["value"] / out["zero"]["value"]
+        except Exception as e:  # noqa: BLE001  (e.g. a tile configuration without stencil-only stepping)
+            out["skipped"] = str(e)
+        return out
+
 
 def main(argv=None, hooks=None):
     ap = argparse.ArgumentParser()
@@ -245,6 +322,7 @@ def main(argv=None, hooks=None):
     ap.add_argument("--alternate-sweeps", type=int, default=-1,
                     help="PVA_OPT_ALTERNATE_SWEEPS (development: odd launches walk the tiles backwards)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dense-leg", action="store_true", help="skip roofline.dense (the raw stencil on random fields, ~3 s)")
     ap.add_argument("--cpu-baseline-cells", type=int, default=1025,
                     help="side of the cell array of the bounded CPU-baseline sample (same scene, dx and T)")
     ap.add_argument("--stream-priority", type=int, default=0,
@@ -694,6 +772,12 @@ def main(argv=None, hooks=None):
                                  "flight"},
         }
         # rank 0 only, after the timed region (the other ranks wait at the final barrier)
+        if not args.no_dense_leg and hasattr(hooks, "dense_leg") and NB == 1:
+            dense = hooks.dense_leg(solvers[:G], K, T, cells)
+            if "random" in dense:
+                dense["random"]["frac"] = dense["random"]["value"] * ALG_BYTES_PER_CELL_STEP / 1e9 / HBM_PEAK_GBS
+                dense["random"]["vs_headline_fdtd_rate"] = dense["random"]["value"] / (world * B * cells * T / fd) * world
+            out["roofline"]["dense"] = dense
         out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(args.cpu_baseline_cells)
         line = json.dumps(out)
     for sv in solvers:

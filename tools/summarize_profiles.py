@@ -97,22 +97,30 @@ for tag, fd, wd in (("4096", "pmc_fetch", "pmc_write"), ("8192", "pmc_fetch8k", 
     lines.append("")
 # the analysis half of the metric: bytes of the analysis chain per RUN (sum over its kernels' launches / runs), for the bench's
 # grid (from the bench passes above) and for the all-cells-reached workload (tools/gpu_analysis_workload.py)
-ANALYSIS = ("pv_far_frame_kernel", "pv_far_cells_kernel", "pv_encode_kernel", "pv_rt60_wave_kernel", "pv_rt60_blocked_kernel",
-            "pv_direction_kernel", "pv_dir_init_kernel", "pv_dir_jump_kernel", "pv_dir_final_kernel", "pv_carry_results_kernel")
+ANALYSIS = ("pv_far_frame_kernel", "pv_far_cells_kernel", "pv_onset_kernel", "pv_encode_kernel", "pv_encode_groups_kernel",
+            "pv_rt60_wave_kernel", "pv_rt60_blocked_kernel", "pv_rt60_tile_kernel", "pv_direction_kernel", "pv_dir_init_kernel",
+            "pv_dir_jump_kernel", "pv_dir_final_kernel", "pv_carry_results_kernel", "pv_analysis_fused_kernel", "pv_run_finish_kernel")
+
+
+def short_name(k):
+    """kernel name without return type, namespaces and argument list ('(anonymous namespace)::' holds the first parenthesis of
+    the kernels of pv_rt60.hip: cut at it, round 4's tables had blank rows for them)"""
+    k = k.replace("(anonymous namespace)::", "").replace("void ", "").replace("pva::", "")
+    return k.split("(")[0]
 
 
 def analysis_bytes(fp, wp):
     if not (os.path.exists(fp) and os.path.exists(wp)):
         return None
     F, W = counters(fp), counters(wp)
-    runs = max([len(v) for k, v in F.items() if "pv_encode_kernel" in k] + [0])
+    runs = max([len(v) for k, v in F.items() if "pv_onset_kernel" in k or "pv_encode_kernel" in k] + [0])
     if not runs:
         return None
     per = {}
     for k in sorted(F):
         if not any(a in k for a in ANALYSIS):
             continue
-        short = k.split("(")[0].replace("void pva::", "").replace("pva::", "").replace("(anonymous namespace)::", "")
+        short = short_name(k)
         rb = sum(F[k]) * 1024 * fetch_corr / runs
         wb = sum(W.get(k, [0.0])) * 1024 * write_corr / runs
         per[short] = {"launches_per_run": len(F[k]) / runs, "read_bytes_per_run": rb, "write_bytes_per_run": wb}
