@@ -185,10 +185,6 @@ class GpuHooks:
         from planeverb_amd import dist as pvd
         return pvd.make_comm(dist, self.local_rank)
 
-    def dummy_stream(self):
-        """an idle stream, kept alive by the caller: shifts which hardware queue the streams created after it are dealt"""
-        return self.torch.cuda.Stream(device=self.torch.device("cuda", self.local_rank))
-
     def device_sync(self):
         self.torch.cuda.synchronize()
 
@@ -328,10 +324,8 @@ def main(argv=None, hooks=None):
     ap.add_argument("--stream-priority", type=int, default=0,
                     help="1: every other in-flight group's solvers get PVA_OPT_STREAM_PRIORITY (a hardware queue of another "
                          "priority; measured 6 %% SLOWER at 4096^2: the two runs then take turns instead of sharing the chip)")
-    ap.add_argument("--placement-tries", type=int, default=4,
-                    help="before the timed steps: if the in-flight groups do not run beside each other (their streams were dealt "
-                         "one hardware queue: two runs then take as long together as one after the other), re-create the groups "
-                         "after the first behind an idle stream, up to this many times; 0 = take the placement as it comes")
+    ap.add_argument("--placement-tries", type=int, default=0,
+                    help="(accepted and ignored: stream placement moved into the library in round 5, Solver::claimOwnQueue)")
     ap.add_argument("--aux-streams", type=int, default=-1,
                     help="PVA_OPT_AUX_STREAMS of every solver (idle streams that shift which hardware queue the next solver's "
                          "streams are dealt); -1: the library's / batch_solver_options' default")
@@ -459,53 +453,10 @@ def main(argv=None, hooks=None):
                 clock_loaded.append(hooks.clock_probe())  # (a stream of its own: beside the runs in flight)
             for sv in solvers:
                 sv.sync()
-    # Stream placement.  The runtime multiplexes a process's streams on a handful of hardware queues by creation order, and two
-    # groups whose step loops were dealt the same queue run their launches one after the other: the same command line then gives
-    # 1.47e12 or 1.70e12 at 4096^2 (profiles/r04_placement.txt).  So: how long do the groups take together, how long one after the
-    # other?  If being in flight together buys nothing, the groups after the first are re-created behind one more idle stream
-    # (same objects, same work; nothing of this is timed) -- what a host application that keeps several solvers busy would do once.
-    placement = {"tries": 0, "together_over_sequential": []}
-    if G > 1 and args.placement_tries > 0 and args.warmup > 0 and hasattr(hooks, "dummy_stream"):
-        def together_ms():
-            best = 1e30
-            for _ in range(3):
-                hooks.device_sync()
-                t0 = time.perf_counter()
-                for g in range(G):
-                    start_group(0, g)
-                for sv in solvers:
-                    sv.sync()
-                best = min(best, (time.perf_counter() - t0) * 1e3)
-            return best
-
-        def sequential_ms():
-            best = 1e30
-            for _ in range(2):
-                hooks.device_sync()
-                t0 = time.perf_counter()
-                for g in range(G):
-                    start_group(0, g)
-                    for sv in solvers[g * NB:(g + 1) * NB]:
-                        sv.sync()
-                best = min(best, (time.perf_counter() - t0) * 1e3)
-            return best
-
-        idle = []
-        while True:
-            ratio = together_ms() / sequential_ms()
-            placement["together_over_sequential"].append(round(ratio, 3))
-            # (side by side: 0.85 at 4096^2, 0.67 at 2048^2; on one queue: 0.95-1.0)
-            if ratio < 0.92 or placement["tries"] >= args.placement_tries:
-                break
-            placement["tries"] += 1
-            for b in range(NB, B):
-                solvers[b].close()
-            idle.append(hooks.dummy_stream())
-            for b in range(NB, B):
-                solvers[b] = new_solver(b)
-                solvers[b].run(listener(0, b))  # (graph capture, first-run work)
-        placement["idle_streams"] = len(idle)
-        hooks._idle_streams = idle  # (alive until the process ends)
+    # Stream placement is the LIBRARY's business since round 5: a solver's main stream is checked at creation against the other
+    # live solvers' (Solver::claimOwnQueue: do the two take turns on one dispatch pipe?) and re-dealt if so -- what rounds 3-4 did
+    # here, for this program only, by timing the groups together and one after the other and re-creating solvers.
+    placement = {"in": "libplaneverb_amd.so (Solver::claimOwnQueue, PLANEVERB_AMD_QUEUE_PROBE)"}
     # The one collective of the data path: the C++ side's own RCCL communicator (PvAmdComm: ncclCommInitRank /
     # ncclAllGather inside libplaneverb_amd.so; torch.distributed only carries the 128-byte id to the ranks).  Should
     # RCCL not bind there, torch.distributed's all_gather does the same job and the JSON line says so.

@@ -52,6 +52,8 @@ bool residentConfigOk(int K, int rxi);
 int residentExtraRows(int K, int rxi);   // rows its blocks load beyond rxi + 2K at the bottom
 int residentMaxBlocks(int K, int rxi, int device);
 void launchResident(int K, int rxi, const ResidentArgs& a, hipStream_t stream);
+// do the two (idle) streams share a hardware queue?  stamps = 4 words of pinned host memory (pv_probe.hip)
+bool streamsShareQueue(hipStream_t a, hipStream_t b, unsigned long long* stamps);
 // shader clock of the moment (pv_probe.hip): MHz by a timed s_sleep, or 0
 float clockProbeMHz(int device, float* byMemtime);
 // error flag, {cells of non-zero tiles, cells with an onset}, resident claim counter (or NULL) -> 4 ints of pinned host memory

@@ -4,6 +4,9 @@
 // stream of its own so that it can sit beside the solvers' launches.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "pv_launch.h"
 
 namespace pva {
@@ -39,6 +42,43 @@ __global__ void pv_run_status_kernel(const int* err, int* counts, const unsigned
 
 void launchRunStatus(const int* err, int* counts, const unsigned* claims, int* outHost, hipStream_t stream) {
     hipLaunchKernelGGL(pv_run_status_kernel, dim3(1), dim3(64), 0, stream, err, counts, claims, outHost);
+}
+
+// Do two idle streams take turns?  Streams are dealt hardware queues, and queues that sit on the same dispatch pipe are served
+// one packet at a time: a kernel with more workgroups than the chip holds occupies its pipe until its LAST workgroup has been
+// launched, and a kernel of another stream on that pipe starts only then -- two K-step stencil launches of 6 000 tiles each then
+// run one after the other although they are "in flight together".  (A one-wave kernel does not show it: it is launched at once.)
+// The probe: four rounds of workgroups that sleep 10 us each on `a`, one stamp on `b` right behind.  On separate pipes the
+// stamp is taken while `a` still has workgroups to launch; on one pipe after the last of them has started.
+// stamps: 4 words of pinned host memory.  (~0.1 ms; Solver::claimOwnQueue)
+namespace {
+__global__ __launch_bounds__(256) void pv_queue_sleep_kernel(unsigned long long* out) {
+    const unsigned long long t0 = wall_clock64();
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = t0;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[1] = t0;  // the last workgroup has been launched
+    while (wall_clock64() - t0 < 1000ull) __builtin_amdgcn_s_sleep(32);  // 10 us of the 100 MHz counter
+}
+__global__ void pv_queue_stamp_kernel(unsigned long long* out) { out[2] = wall_clock64(); }
+}  // namespace
+
+bool streamsShareQueue(hipStream_t a, hipStream_t b, unsigned long long* stamps) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    const unsigned blocks = 4u * 8u * (unsigned)prop.multiProcessorCount;  // four times what the chip holds at once
+    int votes = 0;
+    for (int i = 0; i < 3; ++i) {  // (two of three: a launch can be late for other reasons)
+        stamps[1] = stamps[2] = 0;
+        hipLaunchKernelGGL(pv_queue_sleep_kernel, dim3(blocks), dim3(256), 0, a, stamps);
+        hipLaunchKernelGGL(pv_queue_stamp_kernel, dim3(1), dim3(64), 0, b, stamps);
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
+        if (stamps[2] >= stamps[1]) ++votes;
+        if (const char* e = getenv("PLANEVERB_AMD_QUEUE_PROBE"))
+            if (atoi(e) == 3)
+                std::fprintf(stderr, "[planeverb_amd] queue probe: stamp at %.1f us of a dispatch window of %.1f us\n",
+                             ((double)stamps[2] - (double)stamps[0]) * 0.01, ((double)stamps[1] - (double)stamps[0]) * 0.01);
+    }
+    return votes >= 2;
 }
 
 // MHz by the s_sleep method (and by s_memtime in *byMemtime), or 0 on failure

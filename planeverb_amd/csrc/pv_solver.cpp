@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 
 #include "pv_launch.h"
 
@@ -71,6 +72,56 @@ bool Solver::dalloc(Tp** p, size_t count, bool zero) {
     return true;
 }
 
+// main streams of the live solvers, per device (claimOwnQueue)
+namespace {
+std::mutex g_streamRegistryMutex;
+std::vector<std::pair<int, hipStream_t>> g_mainStreams;
+}  // namespace
+
+bool Solver::claimOwnQueue() {
+    const char* e = getenv("PLANEVERB_AMD_QUEUE_PROBE");
+    if (e && atoi(e) == 0) return true;
+    std::lock_guard<std::mutex> lk(g_streamRegistryMutex);
+    unsigned long long* stamps = nullptr;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        bool shared = false;
+        for (const auto& other : g_mainStreams) {
+            if (other.first != device_ || hipStreamQuery(other.second) != hipSuccess) continue;  // (a busy stream is left alone)
+            if (!stamps && hipHostMalloc((void**)&stamps, 4 * sizeof(unsigned long long)) != hipSuccess) return true;
+            if (streamsShareQueue(other.second, stream_, stamps)) {
+                shared = true;
+                break;
+            }
+        }
+        if (!shared) break;
+        parkedStreams_.push_back(stream_);  // (alive until the solver goes: the pool then deals the next stream another queue)
+        stream_ = nullptr;
+        if (!hipOk(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate")) {
+            if (stamps) hipHostFree(stamps);
+            return false;
+        }
+        ++queueRedeals_;
+    }
+    if (stamps) hipHostFree(stamps);
+    if (e && atoi(e) >= 2)
+        std::fprintf(stderr, "[planeverb_amd] main stream of solver %p: %d re-deal(s), %zu other main stream(s) on device %d\n", (void*)this,
+                     queueRedeals_, g_mainStreams.size(), device_);
+    g_mainStreams.emplace_back(device_, stream_);
+    registered_ = true;
+    return true;
+}
+
+void Solver::releaseOwnQueue() {
+    if (!registered_) return;
+    std::lock_guard<std::mutex> lk(g_streamRegistryMutex);
+    for (size_t i = 0; i < g_mainStreams.size(); ++i)
+        if (g_mainStreams[i].second == stream_) {
+            g_mainStreams.erase(g_mainStreams.begin() + (long)i);
+            break;
+        }
+    registered_ = false;
+}
+
 Solver* Solver::create(const GridSpec& spec, int device, const SolverOptions& opt, std::string* err) {
     Solver* s = new Solver();
     if (!s->init(spec, device, opt)) {
@@ -102,6 +153,14 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         if (!hipOk(high ? hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, hi)
                         : hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate"))
             return false;
+        // A hardware queue apart from the other solvers' for the main stream: the runtime multiplexes a process's streams on a
+        // small pool of hardware queues (four per priority by default), dealt by the number of streams that already use each,
+        // and launches of two streams that share one run one after the other -- two runs "in flight" on two solvers then take as
+        // long as one after the other (1.47-1.59e12 instead of 1.70e12 at 4096^2, by how many streams the process had created
+        // before: profiles/r04_placement.txt; round 4 repaired that in bench.py, for itself).  Checked here, once, against every
+        // other live solver's main stream on the device; a stream that shares a queue is kept (parked, so that the pool deals
+        // the next one elsewhere) and replaced.  (A stream with a CU mask does not get a queue of its own either: measured.)
+        if (!high && !opt.skipAnalysis && !claimOwnQueue()) return false;  // (not the free-grid child: it runs alone, once)
     }
     {
         int lo = 0, hi = 0;  // numerically lowest = highest priority
@@ -534,6 +593,8 @@ Solver::~Solver() {
     for (hipEvent_t e : openEv_)
         if (e) hipEventDestroy(e);
     if (openStream_) hipStreamDestroy(openStream_);
+    releaseOwnQueue();
+    for (hipStream_t x : parkedStreams_) hipStreamDestroy(x);
     if (stream2_) hipStreamDestroy(stream2_);
     if (stream_) hipStreamDestroy(stream_);
 }

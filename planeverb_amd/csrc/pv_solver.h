@@ -223,6 +223,11 @@ private:
     bool lastRunBatched_ = false;          // the last run was a member of a batch of several
     std::vector<hipStream_t> auxStreams_;  // PVA_OPT_AUX_STREAMS
     std::vector<hipEvent_t> airDone_, genDone_;  // per-launch cross-stream dependencies (no timing)
+    std::vector<hipStream_t> parkedStreams_;  // claimOwnQueue: streams that shared a hardware queue with another solver's
+    int queueRedeals_ = 0;
+    bool registered_ = false;
+    bool claimOwnQueue();
+    void releaseOwnQueue();
     hipEvent_t forkEv_ = nullptr;
     hipEvent_t anaEv_[2] = {nullptr, nullptr};  // enqueueAnalysis: onsets known -> stream2_, decay times done -> stream_
     // captured launch schedule of one run (reset + all step launches on both streams), replayed per run

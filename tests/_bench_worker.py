@@ -107,12 +107,6 @@ class CpuHooks:
     def device_sync(self):
         pass
 
-    def dummy_stream(self):
-        """bench.py's stream-placement check: on the fake solvers "together" takes as long as "one after the other", so every
-        re-deal is tried (the groups after the first are closed and re-created behind one more idle stream)"""
-        self.idle = getattr(self, "idle", 0) + 1
-        return object()
-
     def barrier(self, dist, backend):
         self.barriers += 1
         dist.barrier()

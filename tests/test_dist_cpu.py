@@ -130,9 +130,8 @@ def test_bench_orchestration_gloo_world2(comm_mode, tmp_path):
         assert len(r["block_s"]) == 5 and all(b > 0 for b in r["block_s"])
         assert r["warmup_s"] >= 0 and r["comm_init_and_first_gather_s"] >= 0
         assert "torch.distributed.all_gather_into_tensor" in r["gather"]
-        # the stream-placement check ran on every rank (fake solvers gain nothing from being in flight together: all re-deals tried)
-        sp_r = r["stream_placement"]
-        assert sp_r["tries"] == len(sp_r["together_over_sequential"]) - 1 == sp_r["idle_streams"] <= 4
+        # stream placement is the library's business (round 5): bench.py only says so
+        assert "claimOwnQueue" in r["stream_placement"]["in"]
     assert j["roofline"]["analysis"]["cells_per_run"] == 4096 * 4096
     assert "torch.distributed.all_gather_into_tensor" in j["config"]["gather"]
     assert j["config"]["backend"] == "gloo"
