@@ -15,8 +15,9 @@ namespace pva {
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // The s_nop in front of the inline-asm DPP subtracts (subLanePrev2).  The product build's kernels never need it -- the pressure
-// rows a vy sweep shifts were written a whole vx sweep earlier -- and tools/check_dpp_hazard.py (run by tests/test_host_cpu.py on
-// the generated assembly of every kernel source) PROVES that for the build at hand; 273 s_nop fewer per air tile are worth ~3 % at
+// rows a vy sweep shifts were written a whole vx sweep earlier -- and tools/check_dpp_hazard.py checks that for the build at hand:
+// the Makefile runs it on the assembly of the very flags the objects are built with, along every path into every such
+// instruction, and a hazard fails the build (tests/test_host_cpu.py runs it too); 273 s_nop fewer per air tile are worth ~3 % at
 // 4096^2 (profiles/r04_load_order.txt).  The experimental build keeps it: three of its instantiations do read a register written
 // one wait state earlier.
 #ifndef PV_DPP_ASM_NOP

@@ -465,7 +465,8 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
                        histTilesY_ == geo_.nty && kGuard >= K_ + residentExtraRows(K_, rxi_) && T_ >= 1;
         if (useResident_) {
             const int cap = residentMaxBlocks(K_, rxi_, device_);
-            if (ntiles > std::min(cap * 3 / 4, kResidentMaxTiles)) useResident_ = false;  // (= the run-time budget of enqueueRun)
+            residentBudget_ = cap * 3 / 4;  // (an occupancy query and the device properties: once, not per 0.3 ms run)
+            if (ntiles > std::min(residentBudget_, kResidentMaxTiles)) useResident_ = false;  // (= the run-time budget of enqueueRun)
         }
         if (useResident_ && !dalloc(&resFlags_, (size_t)ntiles + 2, true)) return false;
         if (useResident_) {
@@ -508,6 +509,16 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
 
     if (opt.withFreeGrid) {
         if (!computeEfree()) return false;
+    }
+    // One-XCD hand-off (pv_resident.hip): whether the blocks of a launch are spread over the XCDs as that mode needs is a property of
+    // the device / partition mode, found out by a run that fails its claim check (errFlag 4) and is repeated in sync().  Find it out
+    // HERE, with a throw-away run of the stencil alone: the live module publishes a run's results before it calls sync(), and its
+    // first iteration on each solver would otherwise publish the aborted run's (silent) maps.
+    if (useResident_ && xcdOk_ && ntiles <= kResidentXcdMaxTiles && !opt_.skipAnalysis) {
+        opt_.skipAnalysis = true;
+        const bool ok = enqueueRun(g_.gx / 2, g_.gy / 2, 0.f, 0.f) && sync();
+        opt_.skipAnalysis = false;
+        if (!ok) return false;
     }
     return true;
 }
@@ -1460,8 +1471,9 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
     // takes its blocks out of the device's budget until sync(); when concurrent runs of other solvers have used the budget
     // up, this run goes out as the replayed graph instead (never a wait, never a deadlock)
     bool resident = useResident_ && !(small && opt_.resident != 1);
+    releaseResident();  // (a run enqueued without a sync() behind the previous one: its reservation goes back first)
     if (resident) {
-        const int budget = residentMaxBlocks(K_, rxi_, device_) * 3 / 4;
+        const int budget = residentBudget_;
         std::atomic<int>& inFlight = residentInFlight(device_);
         if (inFlight.fetch_add(ntiles) + ntiles > budget) {
             inFlight.fetch_sub(ntiles);
@@ -1830,6 +1842,15 @@ bool Solver::sync() {
             xcdOk_ = false;
             std::fprintf(stderr, "[planeverb_amd] resident kernel: one-XCD mode not available on this device (workgroups are "
                                  "not spread over the XCDs as expected); using the placement-independent hand-off\n");
+            return enqueueRun(lastLcx_, lastLcy_, lastLx_, lastLz_) && sync();
+        }
+        if (flag == 3 && useResident_) {
+            // A workgroup waited ~2 s for a neighbour: the blocks were not all on the chip (another process, or a long kernel
+            // of the host application, holds CUs -- the per-process budget cannot see those).  The replayed-graph path needs no
+            // co-residency and gives the same bits: this solver uses it from now on, and the run is repeated in it.
+            useResident_ = false;
+            std::fprintf(stderr, "[planeverb_amd] resident kernel: a workgroup gave up waiting for its neighbours (the device is "
+                                 "shared?); this solver runs its steps as a replayed graph from now on\n");
             return enqueueRun(lastLcx_, lastLcy_, lastLx_, lastLz_) && sync();
         }
         if (flag == 3 || flag == 4) return fail("resident kernel: a workgroup gave up waiting for its neighbours (run aborted)");

@@ -266,6 +266,7 @@ private:
     int* generalCount_ = nullptr;
     DynParams* dynDev_ = nullptr;
     int* errFlag_ = nullptr;
+    int residentBudget_ = 0;        // blocks of the resident kernel this device holds at once x 3/4 (init)
     unsigned* fusedCtl_ = nullptr;  // FusedArgs::ctl
     bool useFused_ = false;
     int* unitList_ = nullptr;     // AnalyzeArgs::unitList: histPlane / 64 + 1 ints

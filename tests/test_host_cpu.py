@@ -222,6 +222,25 @@ def test_inline_asm_dpp_has_no_pipeline_hazard(tmp_path, src, extra):
     assert r.returncode == 0, r.stdout[-3000:]
 
 
+def test_dpp_hazard_lint_follows_branches(tmp_path):
+    """the lint walks every path into a DPP read: a writer that reaches it through a branch is found, a fall-through path that has
+    its wait states is not flagged, and a kernel with no such instruction fails (nothing was checked)"""
+    import subprocess
+    import sys
+    lint = os.path.join(ROOT, "tools", "check_dpp_hazard.py")
+    bad = tmp_path / "bad.s"
+    bad.write_text("k:\n\tv_mov_b32_e32 v2, v1\n\ts_cbranch_scc1 .LBB0_2\n\ts_nop 4\n.LBB0_2:\n"
+                   "\tv_subrev_f32_dpp v5, v2, v2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_endpgm\n")
+    good = tmp_path / "good.s"
+    good.write_text("k:\n\tv_mov_b32_e32 v2, v1\n\ts_nop 0\n\ts_cbranch_scc1 .LBB0_2\n\ts_nop 4\n.LBB0_2:\n"
+                    "\tv_subrev_f32_dpp v5, v2, v2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_endpgm\n")
+    none = tmp_path / "none.s"
+    none.write_text("k:\n\tv_mov_b32_e32 v2, v1\n\ts_endpgm\n")
+    assert subprocess.run([sys.executable, lint, str(bad)], capture_output=True).returncode == 1
+    assert subprocess.run([sys.executable, lint, str(good)], capture_output=True).returncode == 0
+    assert subprocess.run([sys.executable, lint, str(none)], capture_output=True).returncode == 1
+
+
 def test_cpp_binding_links_against_reference_headers():
     """bindings/PlaneverbAmdBinding.cpp -- the forwarding unit INTEGRATION.md section 2 gives a maintainer: the
     reference's namespace API (Planeverb.h:12-47, all 12 functions) on top of this library's C-ABI.  Where the reference
