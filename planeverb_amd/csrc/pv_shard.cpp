@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 namespace pva {
 
@@ -36,7 +37,9 @@ struct Rccl {
     int (*commDestroy)(ncclComm_t) = nullptr;
     int (*allGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*errorString)(int) = nullptr;
+    int (*getVersion)(int*) = nullptr;
     std::string why;
+    std::string bound;  // which library was bound, and the version it reports: part of every error message
 };
 
 Rccl& rccl() {
@@ -69,6 +72,8 @@ Rccl& rccl() {
             if (!r.lib) {
                 const char* e = dlerror();
                 lastErr = e ? e : "?";
+            } else {
+                r.bound = name;
             }
         };
         if (!path.empty()) tryOpen(path.c_str());
@@ -84,7 +89,18 @@ Rccl& rccl() {
         r.commDestroy = reinterpret_cast<decltype(r.commDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
         r.allGather = reinterpret_cast<decltype(r.allGather)>(dlsym(r.lib, "ncclAllGather"));
         r.errorString = reinterpret_cast<decltype(r.errorString)>(dlsym(r.lib, "ncclGetErrorString"));
-        if (!r.getUniqueId || !r.commInitRank || !r.commDestroy || !r.allGather) r.why = "librccl lacks an nccl* entry point";
+        r.getVersion = reinterpret_cast<decltype(r.getVersion)>(dlsym(r.lib, "ncclGetVersion"));
+        // The four entry points above are declared HERE (no rccl.h at build time: the library is bound at run time), with the
+        // layout of ncclUniqueId (128 bytes, by value) and ncclFloat32 = 7 of the RCCL this was written against (2.26).  Should a
+        // later RCCL change either, a first multi-rank contact fails inside ncclCommInitRank / ncclAllGather: every error message
+        // therefore says which library was bound and which version it reports.
+        int v = 0;
+        if (r.getVersion && r.getVersion(&v) == 0)
+            r.bound += " (ncclGetVersion " + std::to_string(v) + " = " + std::to_string(v / 10000) + "." + std::to_string(v / 100 % 100) + "." +
+                       std::to_string(v % 100) + "; written against 2.26)";
+        else
+            r.bound += " (no ncclGetVersion)";
+        if (!r.getUniqueId || !r.commInitRank || !r.commDestroy || !r.allGather) r.why = "librccl lacks an nccl* entry point: " + r.bound;
     });
     return r;
 }
@@ -92,7 +108,8 @@ Rccl& rccl() {
 bool ncclOk(int rc, const char* what, std::string* err) {
     if (rc == 0) return true;
     Rccl& r = rccl();
-    if (err) *err = std::string(what) + ": " + (r.errorString ? r.errorString(rc) : "RCCL error " + std::to_string(rc));
+    if (err)
+        *err = std::string(what) + ": " + (r.errorString ? r.errorString(rc) : "RCCL error " + std::to_string(rc)) + " [bound " + r.bound + "]";
     return false;
 }
 
@@ -133,6 +150,19 @@ Comm* Comm::create(const char idBytes[128], int rank, int world, int device, std
     if (hipStreamCreateWithFlags(&c->stream_, hipStreamNonBlocking) != hipSuccess ||
         !ncclOk(r.commInitRank(&c->comm_, world, id, rank), "ncclCommInitRank", err)) {
         if (err && err->empty()) *err = "hipStreamCreate failed";
+        delete c;
+        return nullptr;
+    }
+    // first contact: one float per rank through the very collective of the data path.  ncclFloat32 and the by-value ncclUniqueId
+    // are declared by hand above; a librccl that disagrees with them shows here, at creation, with a message -- not as garbage
+    // records (or a hang) in the middle of a sharded job
+    std::vector<float> all((size_t)world, -1.f);
+    const float mine = (float)(rank + 1);
+    std::string e;
+    bool ok = c->allGather(&mine, 1, all.data(), &e);
+    for (int i = 0; ok && i < world; ++i) ok = all[(size_t)i] == (float)(i + 1);
+    if (!ok) {
+        if (err) *err = "RCCL self-test at communicator creation failed (" + (e.empty() ? std::string("wrong values gathered") : e) + ") [bound " + r.bound + "]";
         delete c;
         return nullptr;
     }

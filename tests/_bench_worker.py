@@ -15,6 +15,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import bench  # noqa: E402
 
@@ -93,6 +94,13 @@ class CpuHooks:
     def make_comm(self, dist):
         # "fail": the C++ RCCL communicator cannot be made on ANY rank (no GPU here): every rank must fall back together.
         # "fail-rank1": it fails on rank 1 only; rank 0's communicator must be closed and both use the torch gather.
+        if self.comm_mode == "gloo-comm":  # the native gather's code path with the real world size: a stand-in communicator
+            from _dist_worker import GlooComm
+
+            class _G(GlooComm):
+                def close(self_inner):
+                    pass
+            return _G(dist)
         if self.comm_mode == "fail" or dist.get_rank() == 1:
             raise RuntimeError("no RCCL on a CPU host")
 
@@ -115,7 +123,13 @@ class CpuHooks:
 def main():
     comm_mode, out_path = sys.argv[1], sys.argv[2]
     hooks = CpuHooks(comm_mode)
-    argv = ["--gpus", "2", "--steps", "3", "--warmup", "2", "--cpu-baseline-cells", "97"]
+    world = os.environ.get("WORLD_SIZE", "2")
+    shape = os.environ.get("PV_BENCH_WORKER_SHAPE", "")
+    argv = ["--gpus", world, "--steps", "3", "--warmup", "2", "--cpu-baseline-cells", "97"]
+    if shape == "config4":  # one run per GPU and step
+        argv += ["--inflight", "1"]
+    elif shape == "config5":  # two in flight, 4 steps x 2 x 8 ranks = 64 runs
+        argv[3] = "4"
     import io
     from contextlib import redirect_stdout
     buf = io.StringIO()

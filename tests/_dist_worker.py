@@ -40,6 +40,23 @@ class FakeSolver:
         pass
 
 
+class GlooComm:
+    """stands in for planeverb_amd.api.Comm (PvAmdComm: ncclAllGather inside libplaneverb_amd.so): the same interface over
+    torch.distributed, so that gather_outputs_native's packing and ordering run with the real world size on CPU"""
+
+    def __init__(self, dist):
+        self.dist, self.rank, self.world = dist, dist.get_rank(), dist.get_world_size()
+        self.calls = 0
+
+    def all_gather(self, mine):
+        import torch
+        mine = np.ascontiguousarray(mine, np.float32).ravel()
+        out = torch.empty(self.world * mine.size, dtype=torch.float32)
+        self.dist.all_gather_into_tensor(out, torch.from_numpy(mine))
+        self.calls += 1
+        return out.numpy().reshape(self.world, -1)
+
+
 def main():
     rank, world, port, n_runs, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), sys.argv[5]
     import torch.distributed as dist
@@ -48,8 +65,15 @@ def main():
     os.environ["MASTER_PORT"] = port
     dist.init_process_group("gloo", rank=rank, world_size=world)
     mine = pvd.shard_runs(n_runs, world, rank)
+    assert mine == [k for k in range(n_runs) if k % world == rank]  # run k -> rank k mod W
     local = {k: fake_result(k) for k in mine}
     res = pvd.gather_outputs(local, n_runs, dist)
+    # the native gather's packing (one all-gather of per_rank x n_em x 8 floats, also from ranks that own no run) against it
+    comm = GlooComm(dist)
+    res_native = pvd.gather_outputs_native(local, n_runs, comm, n_em=3)
+    assert np.array_equal(res, res_native), "gather_outputs_native differs from gather_outputs"
+    assert comm.calls == 1, "exactly one collective on the data path"
+    assert np.array_equal(pvd.gather_outputs_native(local, n_runs, comm), res)  # (n_em agreed on by one more 4-byte gather)
     # the same through run_sharded with two runs in flight per rank
     res2 = pvd.run_sharded(FakeSolver, [(k, 0, 0) for k in range(n_runs)], lambda k: [0, 1, 2], dist, inflight=2)
     assert np.array_equal(res, res2), "run_sharded differs from gather_outputs"

@@ -36,6 +36,27 @@ def test_gather_outputs_gloo_world2(n_runs, tmp_path):
     assert sorted(owned) == list(range(n_runs))  # every run simulated exactly once
 
 
+@pytest.mark.parametrize("n_runs", [8, 64, 3])
+def test_gather_outputs_gloo_world8(n_runs, tmp_path):
+    """the REAL multi-GPU shape on CPU: eight ranks under gloo -- BASELINE config 4 (8 runs, one per rank),
+    config 5 (64 runs, eight per rank, two in flight) and fewer runs than ranks; run -> rank mapping, gather order, the native
+    gather's packing against torch's (tests/_dist_worker.py)"""
+    import subprocess
+    from _dist_worker import fake_result
+    port = str(_free_port())
+    worker = os.path.join(ROOT, "tests", "_dist_worker.py")
+    W = 8
+    outs = [str(tmp_path / ("rank%d.npz" % r)) for r in range(W)]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(W), port, str(n_runs), outs[r]]) for r in range(W)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    want = np.stack([fake_result(k) for k in range(n_runs)])
+    for r in range(W):
+        d = np.load(outs[r])
+        assert np.array_equal(d["out"], want), r
+        assert list(d["mine"]) == list(range(r, n_runs, W))
+
+
 def test_shard_runs_partition():
     from planeverb_amd import dist as pvd
     for n in (0, 1, 7, 8, 64):
@@ -91,6 +112,50 @@ def test_slab_schedule_local_equals_undivided():
         final, hist = whole_domain(NX, cols, T, K, src)
         assert np.array_equal(np.concatenate([s.u[K:K + s.n] for s in slabs]), final)
         assert np.array_equal(root.maps, analysis(hist, np.zeros((T, cols)))) and root.finished
+
+
+@pytest.mark.parametrize("shape", ["config4", "config5"])
+def test_bench_orchestration_gloo_world8(shape, tmp_path):
+    """bench.py's orchestration with EIGHT ranks on CPU, in the two shapes the driver's 8-GPU node will see: config 4 (one run
+    per GPU and step: --inflight 1) and config 5 (two runs in flight per GPU; 4 steps = 64 runs, eight per rank), once through the
+    native gather's code path (a stand-in communicator over gloo) and once through torch's (PV_BENCH_GATHER=torch): both verify
+    every gathered record against the reference's, and must agree on every number that does not depend on time."""
+    import json
+    import subprocess
+    worker = os.path.join(ROOT, "tests", "_bench_worker.py")
+    W = 8
+    lines = {}
+    for how in ("native", "torch"):
+        port = str(_free_port())
+        outs = [str(tmp_path / ("%s_rank%d.txt" % (how, r))) for r in range(W)]
+        procs = []
+        for r in range(W):
+            env = dict(os.environ, WORLD_SIZE=str(W), RANK=str(r), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                       PV_BENCH_BACKEND="gloo", PV_BENCH_WORKER_SHAPE=shape)
+            env.pop("PV_BENCH_FORCE_DIST", None)
+            env.pop("PV_BENCH_GATHER", None)
+            if how == "torch":
+                env["PV_BENCH_GATHER"] = "torch"
+            procs.append(subprocess.Popen([sys.executable, worker, "gloo-comm", outs[r]], env=env))
+        for p in procs:
+            assert p.wait(timeout=600) == 0
+        for r in range(1, W):
+            assert open(outs[r]).read().strip() == "", "only rank 0 prints"
+        l0 = [l for l in open(outs[0]).read().splitlines() if l.strip()]
+        assert len(l0) == 1, l0
+        lines[how] = json.loads(l0[0])
+    inflight, steps = (1, 3) if shape == "config4" else (2, 4)
+    for how, j in lines.items():
+        assert j["n_gpus"] == W and j["steps"] == steps and j["scaling"] == "weak"
+        assert j["config"]["runs_in_flight_per_gpu"] == inflight
+        assert j["timed_runs"] == 5 * steps * inflight * W and j["verified_runs"] == j["timed_runs"], how
+        assert [r["rank"] for r in j["ranks"]] == list(range(W)) and [r["local_rank"] for r in j["ranks"]] == list(range(W))
+        for r in j["ranks"]:
+            assert len(r["block_s"]) == 5 and all(b > 0 for b in r["block_s"])
+            assert ("ncclAllGather" in r["gather"]) == (how == "native") and ("PV_BENCH_GATHER=torch" in r["gather"]) == (how == "torch")
+        assert j["value"] == pytest.approx(W * inflight * 4097 * 4097 * 435 * steps / (j["ms_per_step"] * steps * 1e-3), rel=1e-9)
+    assert lines["native"]["timed_runs"] == lines["torch"]["timed_runs"]
+    assert lines["native"]["roofline"]["algorithmic_bytes_per_launch"] == lines["torch"]["roofline"]["algorithmic_bytes_per_launch"]
 
 
 @pytest.mark.parametrize("comm_mode", ["fail", "fail-rank1"])
