@@ -78,12 +78,6 @@ struct StepArgs {
     float* vxOut;
     float* vyOut;
     const FaceCoef* coef;  // face coefficients + beta of every padded cell (general tiles only)
-    const void* layoutPad;  // never read.  The merged kernel's register allocation is balanced on a knife's edge: which of the
-                            // air arm's ~100 scalar row offsets get parked in VGPR lanes depends on everything else in the
-                            // kernel, down to the layout of these arguments.  Without this field the air tiles reload
-                            // parked offsets on EVERY step (237 v_readlane inside the arithmetic instead of 0: 3-4 %
-                            // slower at 4096^2); tools/check_kernel_isa.py (run by tests/test_host_cpu.py) holds the
-                            // compiled form to what was measured.
     const float* pulse;    // T floats
     float* hist;           // window base, plane stride histPlane
     int* tileFirst;        // per tile: first step block in which the tile was non-zero (INT_MAX = never)

@@ -613,6 +613,15 @@ __device__ __forceinline__ void leapfrogStepMirror(v2f (&pr)[NP], v2f (&vx)[NP],
 #ifndef PV_EDGE_TILES
 #define PV_EDGE_TILES 0
 #endif
+// Row offsets of the air arm (round 5): the history rows' offsets ride in the stores' immediate fields on two scalar bases, and the
+// output rows' offsets are formed behind the K steps from a base the compiler cannot identify with the loads' -- so no row offset
+// is alive during the steps.  Rounds 3-4 kept ~100 of them alive through the kernel; the register allocator parked some in VGPR
+// lanes, WHICH ones depended on everything else in the kernel, and a never-read pointer in the kernel's arguments
+// (StepArgs::layoutPad) steered it away from reloading them on every step (237 v_readlane inside the arithmetic, 3-4 % slower at
+// 4096^2).  0 = that form (without the pad: the bad allocation), for A/B builds.
+#ifndef PV_ROWOFF2
+#define PV_ROWOFF2 1
+#endif
 #ifndef PV_LOAD_FENCE
 #define PV_LOAD_FENCE 0
 #endif
@@ -701,9 +710,25 @@ struct MirrorSteps {
                 leapfrogStepMirror<NP, PV_MIRROR_G, S>(pr, vx, vy, vxS, C);
                 if (recLane) {  // pressure of this step, interior rows (air tiles never hold the listener)
                     const rsrc_t rH = makeRsrc(hplane, a.histPlane * 4);
+#if PV_ROWOFF2
+                    // the rows of a tile's history block are a compile-time pitch apart (tile-major planes): their offsets ride in
+                    // the store's 12-bit immediate field on TWO scalar bases, instead of one scalar register per row that must
+                    // stay alive through all K steps (36 of the ~100 row offsets the register allocator used to park in VGPR lanes)
+                    const int hb1 = hsoff0 + K * hpitchB, hb2 = hb1 + 4096;
+#pragma unroll
+                    for (int r = K; r < ROWS - K; ++r) {
+                        const int off = (r - K) * hpitchB;
+                        const float v = r < NP ? pr[r].x : pr[ROWS - 1 - r].y;
+                        if (off < 4096)
+                            bufStoreF(v, rH, hvoff + off, hb1);
+                        else
+                            bufStoreF(v, rH, hvoff + (off - 4096), hb2);
+                    }
+#else
 #pragma unroll
                     for (int r = K; r < ROWS - K; ++r)
                         bufStoreF(r < NP ? pr[r].x : pr[ROWS - 1 - r].y, rH, hvoff, hsoff0 + r * hpitchB);
+#endif
                 }
 #if PV_STEP_SCHEDBAR
                 __builtin_amdgcn_sched_barrier(0);  // keep the steps apart: interleaving them only costs registers
@@ -853,9 +878,17 @@ __device__ __forceinline__ void stepTileAirMirror(const StepArgs& a, const int t
 #else
     if (inCols) {
 #endif
+#if PV_ROWOFF2
+        // the output rows' offsets are formed HERE, from a base and a pitch the compiler cannot identify with the ones the loads
+        // used: nothing of them is alive during the K steps
+        int soffS = soff0, pitchS = pitchB;
+        asm volatile("" : "+s"(soffS), "+s"(pitchS));
+#else
+        const int soffS = soff0, pitchS = pitchB;
+#endif
 #pragma unroll
         for (int r = K; r < ROWS - K; ++r) {
-            const int so = soff0 + r * pitchB;
+            const int so = soffS + r * pitchS;
             const float p = r < NP ? pr[r].x : pr[ROWS - 1 - r].y;
             const float x = r < NP ? vx[r].x : (r == NP ? vxS : -vx[ROWS - r].y);
             const float y = r < NP ? vy[r].x : vy[ROWS - 1 - r].y;

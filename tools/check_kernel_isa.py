@@ -1,17 +1,20 @@
 #!/usr/bin/env python3
 """Guard of the dominant kernel's compiled form (CPU only: hipcc -S for gfx950, ~1.5 min).
 
-pv_step_merged_kernel holds the air arm (one wave per tile, 180 registers of fields) and the general arm in ONE function, and
-its register allocation is balanced on a knife's edge: the air arm needs ~100 scalar row offsets, more than the SGPR file holds,
-so some are parked in VGPR lanes (v_writelane / v_readlane) -- WHICH ones, and how the 180 tile loads are scheduled against their
-first consumers, changes with anything else in the kernel, down to the layout of its arguments.  Two compiled forms were
-measured on MI355X in round 3 (profiles/r03_palette_ab.txt):
+pv_step_merged_kernel holds the air arm (one wave per tile, 180 registers of fields) and the general arm in ONE function.  Until
+round 5 the air arm kept ~100 scalar row offsets alive through the kernel, more than the SGPR file holds, so some were parked in
+VGPR lanes (v_writelane / v_readlane) -- WHICH ones, and how the 180 tile loads are scheduled against their first consumers,
+changed with anything else in the kernel, down to the layout of its arguments (a never-read StepArgs::layoutPad steered it).
+Since round 5 no row offset is alive during the steps (PV_ROWOFF2 in pv_kernels.hip) and the pad is gone; the guard stays, for
+the two compiled forms that were measured slow on MI355X in round 3 (profiles/r03_palette_ab.txt):
   * parked offsets reloaded INSIDE the twelve steps (237 v_readlane within the packed arithmetic instead of 0-8): 3-4 % slower
     at 4096^2, 2-3 % at 2048^2;
   * the tile loads issued in groups with full waits (s_waitcnt vmcnt(0)) between them instead of all 180 before the first
     consumer: 18-23 % slower at 4096^2 / 8192^2.
 This script compiles pv_kernels.hip with the Makefile's flags and checks the large-grid instantiations for both.
-tests/test_host_cpu.py runs it, so that an unrelated edit cannot cost the headline silently.
+tests/test_host_cpu.py runs it, so that an unrelated edit cannot cost the headline silently.  The thresholds were taken on the
+compiler named in THRESHOLDS_TAKEN_ON; with another hipcc the numbers are printed and the verdict is "not judged" (exit code 0):
+a different register allocator needs its own measurement, not this one's bounds.
 
     python tools/check_kernel_isa.py [file.s]      (exit code 1 on a violation)"""
 import collections
@@ -23,6 +26,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "planeverb_amd", "csrc")
+THRESHOLDS_TAKEN_ON = "HIP version: 7.2.26015"  # hipcc --version, first line (prefix)
 FLAGS = ["--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-fvisibility=hidden"]
 # kernel -> (max v_readlane inside the packed-arithmetic span, as measured good: 0-8 / 13-86)
 KERNELS = {
@@ -61,7 +65,17 @@ def check(asm):
     return ok
 
 
+def compiler_version():
+    try:
+        return subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True).stdout.splitlines()[0].strip()
+    except Exception:  # noqa: BLE001
+        return "unknown"
+
+
 def main():
+    ver = compiler_version()
+    judged = ver.startswith(THRESHOLDS_TAKEN_ON)
+    print("compiler: %s (thresholds taken on '%s...': %s)" % (ver, THRESHOLDS_TAKEN_ON, "judged" if judged else "NOT JUDGED, numbers only"))
     if len(sys.argv) > 1:
         asm = open(sys.argv[1]).read()
     else:
@@ -70,7 +84,8 @@ def main():
             subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + ["-S", "--cuda-device-only", "-o", out, "pv_kernels.hip"],
                                   cwd=CSRC, stderr=subprocess.DEVNULL)
             asm = open(out).read()
-    return 0 if check(asm) else 1
+    ok = check(asm)
+    return 0 if (ok or not judged) else 1
 
 
 if __name__ == "__main__":
