@@ -302,6 +302,13 @@ struct AnalyzeArgs {
     // is materialised when a whole-map reader asks (pv_far_dir_kernel) or computed in closed form by the output gathers.
     int lazyFar;
     int prevR0, prevC0, prevNR, prevNC;
+    const int* labels;   // per array cell ((gx + 1) x (gy + 1), index x * labelNY + y): its 4-connected AIR component, -1 for a wall
+                         // cell -- or NULL (large grids, slabs).  Pressure never crosses a wall cell (beta = 0 keeps it at zero,
+                         // FDTD.cpp:139, and a wall|air face's velocity is a multiple of the AIR cell's pressure, :165-168): a cell of
+                         // another component than the listener's is exactly zero for the whole run.  pv_onset_kernel leaves such
+                         // cells without reading their history (the air outside a closed room, in the tiles its walls cross: every
+                         // one of them cost a scan of all T samples, 100 of the kernel's 140 us at 512^2 / T = 3179)
+    int labelNY;
     int wholeWindow;     // the history window is the whole grid (the reference's presets): no far cells at all -- pv_onset_kernel writes
                          // "no onset" itself and counts the active cells, the direction pass covers every cell: no far-frame launch
     // streaming analysis (sparse-emitter mode): the history is a ring of `ring` planes and the forward sums of

@@ -91,6 +91,13 @@ __device__ __forceinline__ void fusedCells(const FusedArgs& f, const DynParams& 
         // never reached by the pulse, or a wall (beta = 0: pr is identically zero, FDTD.cpp:139): no onset
         air = tF < T && a.coef[(size_t)(c.X + a.G) * a.pitch + (c.Y + a.G)].beta != 0.f;
     }
+    const bool airCell = air;  // (counts as silent without an onset)
+    if (a.labels) {  // ... nor a cell that no chain of air cells joins to the listener's (AnalyzeArgs::labels): not scanned
+        const int lX = dyn.lrow - a.G, lY = dyn.lcol - a.G;
+        const int mineL = air ? a.labels[(size_t)c.X * a.labelNY + c.Y] : -1;
+        const int theirs = (lX >= 0 && lX <= a.gx && lY >= 0 && lY < a.labelNY) ? a.labels[(size_t)lX * a.labelNY + lY] : -2;
+        air = air && mineL == theirs;
+    }
     if (threadIdx.x < 64) sh.found[threadIdx.x] = INT_MAX;
     __syncthreads();
 
@@ -145,7 +152,7 @@ __device__ __forceinline__ void fusedCells(const FusedArgs& f, const DynParams& 
                 a.out[7 * a.resN + s] = src[7 * a.resN + s];
             }
         }
-        const unsigned long long mr = __ballot(mine && live), ms = __ballot(mine && air && !live);
+        const unsigned long long mr = __ballot(mine && live), ms = __ballot(mine && airCell && !live);
         if (lane == 0) {
             if (mr) atomicAdd(a.activeCount + 1, __popcll(mr));
             if (ms) atomicAdd(a.activeCount + 3, __popcll(ms));

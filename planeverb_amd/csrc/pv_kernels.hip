@@ -2355,6 +2355,14 @@ __global__ __launch_bounds__(64 * kOnsetWaves) void pv_onset_kernel(const Analyz
         // never reached by the pulse, or a wall (beta = 0: pr is identically zero, FDTD.cpp:139): no onset
         live = tF < T && a.coef[(size_t)(c.X + a.G) * a.pitch + (c.Y + a.G)].beta != 0.f;
     }
+    const bool air = live;  // (an air cell of a reached tile: without an onset it counts as silent)
+    if (a.labels) {
+        // ... nor has a cell that no chain of air cells joins to the listener's (AnalyzeArgs::labels): not scanned
+        const int lX = dyn.lrow - a.G, lY = dyn.lcol - a.G;
+        const int mine = live ? a.labels[(size_t)c.X * a.labelNY + c.Y] : -1;
+        const int theirs = (lX >= 0 && lX <= a.gx && lY >= 0 && lY < a.labelNY) ? a.labels[(size_t)lX * a.labelNY + lY] : -2;
+        live = live && mine == theirs;
+    }
     if (wave == 0) found[lane] = INT_MAX;
     __syncthreads();
     if (a.wholeWindow) {
@@ -2372,7 +2380,11 @@ __global__ __launch_bounds__(64 * kOnsetWaves) void pv_onset_kernel(const Analyz
             if (lane == 0) a.activeCount[0] = n;
         }
     }
-    if (__ballot(live) == 0ull) return;  // (the same lanes in every wave of the block: block-uniform)
+    if (__ballot(live) == 0ull) {  // (the same lanes in every wave of the block: block-uniform)
+        const unsigned long long ms = __ballot(air);
+        if (wave == 0 && lane == 0 && ms) atomicAdd(a.activeCount + 3, __popcll(ms));
+        return;
+    }
     // A run starts from zero fields and the stencil moves a value by one cell per step along one axis (FDTD.cpp:124-199): the
     // recorded pressure of a cell at Manhattan distance m from the listener is exactly zero up to and including step m,
     // whatever the geometry.  The search starts there (cells far from the listener: half the samples between the tile's first
@@ -2410,7 +2422,7 @@ __global__ __launch_bounds__(64 * kOnsetWaves) void pv_onset_kernel(const Analyz
         else if (a.wholeWindow) a.delay[c.X * a.gy + c.Y] = FLT_MAX;
     }
     // reached cells of this run (bench / PvAmdTimings.reachedCells) and silent ones: one atomic each per block
-    const unsigned long long mr = __ballot(live && onset != INT_MAX), ms = __ballot(live && onset == INT_MAX);
+    const unsigned long long mr = __ballot(live && onset != INT_MAX), ms = __ballot(air && !(live && onset != INT_MAX));
     if (lane == 0) {
         if (mr) {
             atomicAdd(a.activeCount + 1, __popcll(mr));

@@ -17,6 +17,9 @@
 
 namespace pva {
 
+#ifndef PV_LABEL_MAX_CELLS
+#define PV_LABEL_MAX_CELLS (1100 * 1100)  // array cells up to which the air components are labelled on the host (~15 ns per cell)
+#endif
 #ifndef PV_ANALYSIS_FORK_CELLS
 #define PV_ANALYSIS_FORK_CELLS 4096
 #endif
@@ -566,7 +569,7 @@ Solver::~Solver() {
     if (emCells_) hipFree(emCells_);
     if (emTrace_) hipFree(emTrace_);
     void* ptrs[] = {coef_,      matDev_, pulseDev_, hist_,  tileFirst_, tileClass_, generalList_,
-                    generalCount_, dynDev_, errFlag_, res8_,     delay_, scratch_, res_, activeCount_, win8_, unitList_, fusedCtl_,
+                    generalCount_, dynDev_, errFlag_, res8_,     delay_, scratch_, res_, activeCount_, win8_, unitList_, fusedCtl_, labelDev_,
                     histAbove_, histEdge_, tileDead_, deadCount_};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -722,6 +725,7 @@ bool Solver::applyGeometry() {
         !hipOk(hipStreamSynchronize(stream_), "geometry sync"))
         return false;
     std::sort(wallTiles_.begin(), wallTiles_.end());
+    if (!makeLabels()) return false;
     mat_.clearDirty();
     geometryDirty_ = false;
     planesDirty_ = true;  // a tile that is dead now may hold an earlier scene's fields
@@ -730,6 +734,37 @@ bool Solver::applyGeometry() {
     tim_.geometryMs =
         std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return true;
+}
+
+// 4-connected components of the air cells (AnalyzeArgs::labels), on the host from the rasteriser's own beta plane: a flood fill
+// per component.  Small grids only (the reference's presets, the 512^2 configurations): O(cells) per geometry change.
+bool Solver::makeLabels() {
+    const size_t n = (size_t)g_.NX * g_.NY;
+    if (isSlab() || opt_.streaming || opt_.skipAnalysis || n > (size_t)PV_LABEL_MAX_CELLS) return true;
+    if (!labelDev_ && !dalloc(&labelDev_, n, false)) return false;
+    labelHost_.assign(n, -1);
+    std::vector<int> stack;
+    int next = 0;
+    const int NX = g_.NX, NY = g_.NY;
+    for (size_t seed = 0; seed < n; ++seed) {
+        if (!betaHost_[seed] || labelHost_[seed] >= 0) continue;
+        labelHost_[seed] = next;
+        stack.push_back((int)seed);
+        while (!stack.empty()) {
+            const int i = stack.back();
+            stack.pop_back();
+            const int x = i / NY, y = i - x * NY;
+            const int nb[4] = {x > 0 ? i - NY : -1, x + 1 < NX ? i + NY : -1, y > 0 ? i - 1 : -1, y + 1 < NY ? i + 1 : -1};
+            for (int j : nb)
+                if (j >= 0 && betaHost_[(size_t)j] && labelHost_[(size_t)j] < 0) {
+                    labelHost_[(size_t)j] = next;
+                    stack.push_back(j);
+                }
+        }
+        ++next;
+    }
+    return hipOk(hipMemcpyAsync(labelDev_, labelHost_.data(), n * sizeof(int), hipMemcpyHostToDevice, stream_), "label upload") &&
+           hipOk(hipStreamSynchronize(stream_), "label sync");
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -1266,6 +1301,8 @@ AnalyzeArgs Solver::analyzeArgs(float lx, float lz) const {
     a.lz = lz;
     listenerCellRecip(g_, lx, lz, &a.lcx, &a.lcy);
     a.lazyFar = lazyFar_ ? 1 : 0;
+    a.labels = labelDev_;
+    a.labelNY = g_.NY;
     a.wholeWindow = (!isSlab() && !opt_.streaming && histTilesX_ == geo_.ntx && histTilesY_ == geo_.nty) ? 1 : 0;
     a.prevR0 = farWin_.r0;
     a.prevC0 = farWin_.c0;

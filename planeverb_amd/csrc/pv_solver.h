@@ -267,6 +267,9 @@ private:
     DynParams* dynDev_ = nullptr;
     int* errFlag_ = nullptr;
     int residentBudget_ = 0;        // blocks of the resident kernel this device holds at once x 3/4 (init)
+    int* labelDev_ = nullptr;       // AnalyzeArgs::labels (grids of up to kLabelMaxCells array cells), re-made by applyGeometry
+    std::vector<int> labelHost_;
+    bool makeLabels();
     unsigned* fusedCtl_ = nullptr;  // FusedArgs::ctl
     bool useFused_ = false;
     int* unitList_ = nullptr;     // AnalyzeArgs::unitList: histPlane / 64 + 1 ints
