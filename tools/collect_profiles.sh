@@ -8,13 +8,13 @@ O=gpurun_out/$R
 rm -rf $O && mkdir -p $O
 # (--steps 20: the kernel average below then is dominated by the timed, overlapped launches -- 2 of the 42 runs of the
 # command are warm-up runs made one at a time)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python bench.py --no-cpu-baseline --steps 20 --warmup 1 > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python bench.py --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2> $O/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python bench.py --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2> $O/pmc_write.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch8k -o f -- python bench.py --no-cpu-baseline --grid 8192 --steps 2 --warmup 1 > /dev/null 2> $O/pmc_fetch8k.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write8k -o w -- python bench.py --no-cpu-baseline --grid 8192 --steps 2 --warmup 1 > /dev/null 2> $O/pmc_write8k.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch2k -o f -- python bench.py --no-cpu-baseline --grid 2048 --scene BigRoom.pv --steps 3 --warmup 1 > /dev/null 2> $O/pmc_fetch2k.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write2k -o w -- python bench.py --no-cpu-baseline --grid 2048 --scene BigRoom.pv --steps 3 --warmup 1 > /dev/null 2> $O/pmc_write2k.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python bench.py --no-cpu-baseline --no-dense-leg --steps 20 --warmup 1 > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python bench.py --no-cpu-baseline --no-dense-leg --steps 3 --warmup 1 > /dev/null 2> $O/pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python bench.py --no-cpu-baseline --no-dense-leg --steps 3 --warmup 1 > /dev/null 2> $O/pmc_write.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch8k -o f -- python bench.py --no-cpu-baseline --no-dense-leg --grid 8192 --steps 2 --warmup 1 > /dev/null 2> $O/pmc_fetch8k.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write8k -o w -- python bench.py --no-cpu-baseline --no-dense-leg --grid 8192 --steps 2 --warmup 1 > /dev/null 2> $O/pmc_write8k.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch2k -o f -- python bench.py --no-cpu-baseline --no-dense-leg --grid 2048 --scene BigRoom.pv --steps 3 --warmup 1 > /dev/null 2> $O/pmc_fetch2k.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write2k -o w -- python bench.py --no-cpu-baseline --no-dense-leg --grid 2048 --scene BigRoom.pv --steps 3 --warmup 1 > /dev/null 2> $O/pmc_write2k.err
 hipcc --offload-arch=gfx950 -O3 tools/hbm_calib.hip -o /tmp/hbm_calib 2>/dev/null
 /tmp/hbm_calib > $O/hbm_calib.txt
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/calib_fetch -o c -- /tmp/hbm_calib > /dev/null 2>&1
@@ -55,7 +55,13 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_an
 python tools/gpu_resident.py 275 375 500 750 1000 1250 1500 stress=10 > $O/presets.txt 2>&1
 for r in 275 750; do rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_presets_$r -o p -- python tools/gpu_presets.py $r use_graph=0 > /dev/null 2>&1; done
 (for p in 1 2; do echo "== PLANEVERB_AMD_LIVE_PIPELINE=$p"; PLANEVERB_AMD_LIVE_PIPELINE=$p python tools/gpu_presets.py 275 375 500 750 1000 2>&1 | grep -v "^#"; done) > $O/live_pipeline.txt 2>&1
-python tools/gpu_rt60.py 275 500 750 1000 1500 2009 > $O/rt60.txt 2>&1
 python tools/gpu_run_times.py > $O/run_times.txt 2>&1
+# round 5 additions: raw stencil on random vs zero fields (bench.py's roofline.dense leg) across tiles, per-kernel traces of two presets
+python tools/gpu_dense.py 4096 2 12,36 10,36 8,40 > $O/dense.txt 2>&1
+python tools/gpu_dense.py 4096 1 12,36 2>&1 | tail -1 >> $O/dense.txt
+python tools/gpu_dense.py 8192 2 12,36 2>&1 | tail -1 >> $O/dense.txt
+LANES=16,4,1,0 python tools/gpu_rt60.py 275 375 500 750 1000 1250 1500 2009 > $O/rt60.txt 2>&1
+for r in 275 750 1000 1500; do tools/gpu_preset_trace.sh $O/preset_trace_$r $r "" > $O/preset_trace_$r.txt 2>/dev/null; done
+tools/gpu_analysis_trace.sh $O/analysis_trace "" > $O/analysis_trace.txt 2>/dev/null
 # phase stamps of the resident kernel (needs the trace build, made HERE before the call: see tools/gpu_resident_trace.py)
 if [ -f planeverb_amd/libplaneverb_amd_trace.so ]; then PLANEVERB_AMD_LIB=$PWD/planeverb_amd/libplaneverb_amd_trace.so python tools/gpu_resident_trace.py 275 750 > $O/resident_trace.txt 2>&1; fi
