@@ -10,6 +10,14 @@ import os
 import shutil
 import sys
 
+
+def short_name(k):
+    """kernel name without return type, namespaces and argument list ('(anonymous namespace)::' holds the first parenthesis of
+    the kernels of pv_rt60.hip: cut at it, round 4's tables had blank rows for them)"""
+    k = k.replace("(anonymous namespace)::", "").replace("void ", "").replace("pva::", "")
+    return k.split("(")[0]
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 R = sys.argv[1] if len(sys.argv) > 1 else "r01"
 SRC = os.path.join(ROOT, "gpurun_out", R)
@@ -84,7 +92,7 @@ for tag, fd, wd in (("4096", "pmc_fetch", "pmc_write"), ("8192", "pmc_fetch8k", 
             continue
         f, w = steady(F[k]), steady(W.get(k, [0.0]))
         rb, wb = f * 1024 * fetch_corr, w * 1024 * write_corr
-        short = k.split("(")[0].replace("void pva::", "").replace("pva::", "")
+        short = short_name(k)
         g[short] = {"launches_profiled": len(F[k]), "fetch_kib": f, "write_kib": w, "read_bytes": rb,
                     "write_bytes": wb, "bytes_per_launch": rb + wb}
         lines.append("| %s | %d | %.0f | %.1f | %.0f | %.1f | %.1f |" % (short, len(F[k]), f, rb / 1e6, w, wb / 1e6,
@@ -102,11 +110,6 @@ ANALYSIS = ("pv_far_frame_kernel", "pv_far_cells_kernel", "pv_onset_kernel", "pv
             "pv_dir_jump_kernel", "pv_dir_final_kernel", "pv_carry_results_kernel", "pv_analysis_fused_kernel", "pv_run_finish_kernel")
 
 
-def short_name(k):
-    """kernel name without return type, namespaces and argument list ('(anonymous namespace)::' holds the first parenthesis of
-    the kernels of pv_rt60.hip: cut at it, round 4's tables had blank rows for them)"""
-    k = k.replace("(anonymous namespace)::", "").replace("void ", "").replace("pva::", "")
-    return k.split("(")[0]
 
 
 def analysis_bytes(fp, wp):
