@@ -77,7 +77,18 @@ bool SlabGroup::init(const GridSpec& spec, const std::vector<int>& devices, cons
         }
     rootDevice_ = devices_[0];
     if (!hipOk(hipSetDevice(rootDevice_), "hipSetDevice")) return false;
-    if (!hipOk(hipStreamCreateWithFlags(&rootStream_, hipStreamNonBlocking), "hipStreamCreate")) return false;
+    {
+        // The root stream WAITS for the slabs' events: on a hardware queue of one of theirs it would park that slab's launches.
+        // Even slabs run on normal-priority streams, odd ones on high-priority streams (Solver::init); the root is claimed apart
+        // from the even ones.  (PLANEVERB_AMD_SLAB_ROOT_PRIORITY=1 puts it on a low-priority stream, a third pool of queues:
+        // measured 15 % slower at 4096^2, S = 2, whenever another solver had lived in the process -- profiles/r05_slabs.txt.)
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const char* er = getenv("PLANEVERB_AMD_SLAB_ROOT_PRIORITY");
+        if (!(er && atoi(er) == 1)) lo = 0;
+        if (!hipOk(hipStreamCreateWithPriority(&rootStream_, hipStreamNonBlocking, lo), "hipStreamCreate")) return false;
+        if (!rootQueue_.claim(rootDevice_, &rootStream_, lo != 0 ? QueueClaim::kLow : QueueClaim::kNormal, this)) return fail("hipStreamCreate");
+    }
     for (auto& e : rootEv_)
         if (!hipOk(hipEventCreate(&e), "hipEventCreate")) return false;
     stepEv_.resize((size_t)2 * S);
@@ -99,19 +110,30 @@ bool SlabGroup::init(const GridSpec& spec, const std::vector<int>& devices, cons
         // A push kernel WAITS for its neighbours' pushes: every slab's stream needs a hardware queue to itself -- the runtime
         // multiplexes a process's streams on GPU_MAX_HW_QUEUES (default 4) of them by creation order, and a waiting kernel
         // parks whatever sits behind it in its queue (the neighbour's launches, if they share it: the wait then ends in its
-        // time-out).  So: only with S slab streams + the root stream <= that number, and only after a dry run of the hand-off
-        // on this group's own streams has come through (probeHandoff).
+        // time-out).  So: only if the streams of each priority (even slabs and the root: normal, odd slabs: high) are no more than
+        // that number, after QueueClaim has dealt them apart, and after a dry run of the hand-off on this group's own streams has
+        // come through (probeHandoff).
         const char* e = getenv("PLANEVERB_AMD_SLAB_HANDOFF");
         const char* q = getenv("GPU_MAX_HW_QUEUES");
         const int queues = q && atoi(q) > 0 ? atoi(q) : 4;
+        int prLo = 0, prHi = 0;
+        hipDeviceGetStreamPriorityRange(&prLo, &prHi);
+        const char* er = getenv("PLANEVERB_AMD_SLAB_ROOT_PRIORITY");
+        const bool lowIsNormal = prLo == 0 || !(er && atoi(er) == 1);  // (no low priority on this device: the root shares the even slabs' pool)
+        const char* ep = getenv("PLANEVERB_AMD_SLAB_PRIORITY");
+        const int normalStreams = ((ep && atoi(ep) == 0) ? S : (S + 1) / 2) + (lowIsNormal ? 1 : 0);
         const bool forced = e && atoi(e) == 2;  // (2: whatever the queue count says -- the stress tests of the fallback)
-        if (any && oneDev && pushHalos_ && !(e && atoi(e) == 0) && (S + 1 <= queues || forced)) {
+        if (any && oneDev && pushHalos_ && !(e && atoi(e) == 0) && (normalStreams <= queues || forced)) {
             if (!hipOk(hipMalloc((void**)&handoff_, sizeof(unsigned) * (3 * (size_t)S + 1)), "hipMalloc")) return false;
             if (!forced && !probeHandoff()) {
                 hipFree(handoff_);
                 handoff_ = nullptr;
             }
         }
+        const char* dbg = getenv("PLANEVERB_AMD_QUEUE_PROBE");
+        if (dbg && atoi(dbg) >= 2)
+            std::fprintf(stderr, "[planeverb_amd] slab group %p: %d slabs, hand-off words %s\n", (void*)this, S,
+                         handoff_ ? "on" : (any && oneDev ? "OFF (stream events)" : "not applicable"));
     }
     const size_t n = (size_t)g_.gx * g_.gy;
     winRows_ = a.histTilesXG_ * rxi_;
@@ -195,6 +217,7 @@ SlabGroup::~SlabGroup() {
     if (outHost_) hipHostFree(outHost_);
     for (auto& e : rootEv_)
         if (e) hipEventDestroy(e);
+    rootQueue_.release();
     if (rootStream_) hipStreamDestroy(rootStream_);
 }
 

@@ -81,6 +81,7 @@ private:
     // whole-grid maps on devices_[0]
     int rootDevice_ = 0;
     hipStream_t rootStream_ = nullptr;
+    QueueClaim rootQueue_;
     hipEvent_t rootEv_[3] = {nullptr, nullptr, nullptr};
     float* res_ = nullptr;    // 8 planes x gx*gy
     float* res8_ = nullptr;   // AoS, on demand

@@ -75,54 +75,74 @@ bool Solver::dalloc(Tp** p, size_t count, bool zero) {
     return true;
 }
 
-// main streams of the live solvers, per device (claimOwnQueue)
+// claimed streams (the live solvers' main streams, slab groups' root streams), per device (QueueClaim)
 namespace {
+struct ClaimedStream {
+    int device, priority;
+    hipStream_t stream;
+};
 std::mutex g_streamRegistryMutex;
-std::vector<std::pair<int, hipStream_t>> g_mainStreams;
+std::vector<ClaimedStream> g_claimedStreams;
+
+hipError_t createStream(hipStream_t* s, int priority) {  // priority: QueueClaim's classes
+    int lo = 0, hi = 0;  // numerically lowest = highest priority
+    hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (priority == QueueClaim::kNormal) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, priority == QueueClaim::kHigh ? hi : lo);
+}
 }  // namespace
 
-bool Solver::claimOwnQueue() {
+bool QueueClaim::claim(int device, hipStream_t* stream, int priority, const void* owner) {
     const char* e = getenv("PLANEVERB_AMD_QUEUE_PROBE");
     if (e && atoi(e) == 0) return true;
     std::lock_guard<std::mutex> lk(g_streamRegistryMutex);
     unsigned long long* stamps = nullptr;
+    size_t peers = 0;
     for (int attempt = 0; attempt < 6; ++attempt) {
         bool shared = false;
-        for (const auto& other : g_mainStreams) {
-            if (other.first != device_ || hipStreamQuery(other.second) != hipSuccess) continue;  // (a busy stream is left alone)
+        peers = 0;
+        for (const auto& other : g_claimedStreams) {
+            // Streams of different priorities never share a queue (a pool per priority) -- and the probe cannot tell: a
+            // high-priority sleeper keeps a normal stream's stamp kernel waiting from ANOTHER queue just as well.
+            if (other.device != device || other.priority != priority) continue;
+            ++peers;
+            if (hipStreamQuery(other.stream) != hipSuccess) continue;  // (a busy stream is left alone)
             if (!stamps && hipHostMalloc((void**)&stamps, 4 * sizeof(unsigned long long)) != hipSuccess) return true;
-            if (streamsShareQueue(other.second, stream_, stamps)) {
+            if (streamsShareQueue(other.stream, *stream, stamps)) {
                 shared = true;
                 break;
             }
         }
         if (!shared) break;
-        parkedStreams_.push_back(stream_);  // (alive until the solver goes: the pool then deals the next stream another queue)
-        stream_ = nullptr;
-        if (!hipOk(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate")) {
+        parked.push_back(*stream);  // (alive until the owner goes: the pool then deals the next stream another queue)
+        *stream = nullptr;
+        if (createStream(stream, priority) != hipSuccess) {
             if (stamps) hipHostFree(stamps);
             return false;
         }
-        ++queueRedeals_;
+        ++redeals;
     }
     if (stamps) hipHostFree(stamps);
     if (e && atoi(e) >= 2)
-        std::fprintf(stderr, "[planeverb_amd] main stream of solver %p: %d re-deal(s), %zu other main stream(s) on device %d\n", (void*)this,
-                     queueRedeals_, g_mainStreams.size(), device_);
-    g_mainStreams.emplace_back(device_, stream_);
-    registered_ = true;
+        std::fprintf(stderr, "[planeverb_amd] stream of %p (priority class %d): %d re-deal(s), %zu claimed stream(s) of its class, device %d\n",
+                     owner, priority, redeals, peers, device);
+    g_claimedStreams.push_back(ClaimedStream{device, priority, *stream});
+    claimed = *stream;
     return true;
 }
 
-void Solver::releaseOwnQueue() {
-    if (!registered_) return;
-    std::lock_guard<std::mutex> lk(g_streamRegistryMutex);
-    for (size_t i = 0; i < g_mainStreams.size(); ++i)
-        if (g_mainStreams[i].second == stream_) {
-            g_mainStreams.erase(g_mainStreams.begin() + (long)i);
-            break;
-        }
-    registered_ = false;
+void QueueClaim::release() {
+    if (claimed) {
+        std::lock_guard<std::mutex> lk(g_streamRegistryMutex);
+        for (size_t i = 0; i < g_claimedStreams.size(); ++i)
+            if (g_claimedStreams[i].stream == claimed) {
+                g_claimedStreams.erase(g_claimedStreams.begin() + (long)i);
+                break;
+            }
+        claimed = nullptr;
+    }
+    for (hipStream_t x : parked) hipStreamDestroy(x);
+    parked.clear();
 }
 
 Solver* Solver::create(const GridSpec& spec, int device, const SolverOptions& opt, std::string* err) {
@@ -163,7 +183,9 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         // before: profiles/r04_placement.txt; round 4 repaired that in bench.py, for itself).  Checked here, once, against every
         // other live solver's main stream on the device; a stream that shares a queue is kept (parked, so that the pool deals
         // the next one elsewhere) and replaced.  (A stream with a CU mask does not get a queue of its own either: measured.)
-        if (!high && !opt.skipAnalysis && !claimOwnQueue()) return false;  // (not the free-grid child: it runs alone, once)
+        // Slab groups: every slab's stream, whatever its priority (a push kernel of the hand-off WAITS for the neighbour's).
+        if (!opt.skipAnalysis && (!high || opt.slabCount > 1) && !queue_.claim(device_, &stream_, high ? QueueClaim::kHigh : QueueClaim::kNormal, this))
+            return fail("hipStreamCreate");  // (not the free-grid child: it runs alone, once)
     }
     {
         int lo = 0, hi = 0;  // numerically lowest = highest priority
@@ -607,8 +629,7 @@ Solver::~Solver() {
     for (hipEvent_t e : openEv_)
         if (e) hipEventDestroy(e);
     if (openStream_) hipStreamDestroy(openStream_);
-    releaseOwnQueue();
-    for (hipStream_t x : parkedStreams_) hipStreamDestroy(x);
+    queue_.release();
     if (stream2_) hipStreamDestroy(stream2_);
     if (stream_) hipStreamDestroy(stream_);
 }

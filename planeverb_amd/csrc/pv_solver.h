@@ -82,6 +82,20 @@ class SlabGroup;
 class SlabRoot;
 struct SlabRankOps;
 
+// A stream with a hardware queue apart from every other claimed stream of its device.  The runtime multiplexes a process's streams
+// on a small pool of hardware queues (four per priority by default), dealt by the number of streams that already use each; packets
+// of two streams on one queue run one after the other, and a waiting packet parks what sits behind it.  claim() probes the stream
+// against every claimed, idle stream of the device (streamsShareQueue, pv_probe.hip) and replaces it while it shares -- the
+// replaced ones stay alive ("parked") until release(), so that the pool deals the next one elsewhere.
+struct QueueClaim {
+    std::vector<hipStream_t> parked;
+    hipStream_t claimed = nullptr;
+    int redeals = 0;
+    enum { kNormal = 0, kHigh = 1, kLow = 2 };  // the runtime keeps a pool of hardware queues per priority
+    bool claim(int device, hipStream_t* stream, int priority, const void* owner);
+    void release();  // before the stream itself is destroyed
+};
+
 class Solver {
     friend class SlabGroup;
     friend class SlabRoot;
@@ -223,11 +237,7 @@ private:
     bool lastRunBatched_ = false;          // the last run was a member of a batch of several
     std::vector<hipStream_t> auxStreams_;  // PVA_OPT_AUX_STREAMS
     std::vector<hipEvent_t> airDone_, genDone_;  // per-launch cross-stream dependencies (no timing)
-    std::vector<hipStream_t> parkedStreams_;  // claimOwnQueue: streams that shared a hardware queue with another solver's
-    int queueRedeals_ = 0;
-    bool registered_ = false;
-    bool claimOwnQueue();
-    void releaseOwnQueue();
+    QueueClaim queue_;                     // stream_'s hardware queue, apart from the other solvers' (Solver::init)
     hipEvent_t forkEv_ = nullptr;
     hipEvent_t anaEv_[2] = {nullptr, nullptr};  // enqueueAnalysis: onsets known -> stream2_, decay times done -> stream_
     // captured launch schedule of one run (reset + all step launches on both streams), replayed per run

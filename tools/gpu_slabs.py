@@ -16,7 +16,7 @@ scene = os.path.join(ROOT, "tests", "scenes", "HugeRoom.pv")
 for n in [int(a) for a in sys.argv[1:]] or [4096]:
     size = float((n + 0.5) * dx)
     want = None
-    for S in (1, 2, 4, 8):
+    for S in [int(x) for x in os.environ.get("SLABS", "1,2,4,8").split(",")]:
         s = pv.Solver(size, size, 275, slabs=None if S == 1 else [0] * S)
         s.load_scene(scene)
         for _ in range(2):
