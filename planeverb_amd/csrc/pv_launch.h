@@ -20,6 +20,8 @@ int stepConfigExtraRows(int K, int rxi);
 // 4 = both in ONE merged launch (one block per general tile first, then the air tiles)
 // The general kernel goes to stream2 when given (the caller orders the two streams with events).
 void launchStep(int K, int rxi, const StepArgs& a, hipStream_t stream, int which = 3, hipStream_t stream2 = nullptr);
+// which = 4 | kStepGeneralPacked: the merged launch whose general-tile arm is the packed one also at K = 12 (scenes with many wall tiles)
+constexpr int kStepGeneralPacked = 32;
 // persistent patch kernel (pv_patch.h): the AIR tiles of one sweep by `blocks` resident workgroups (one per CU, multiple
 // of 8); the general tiles of the sweep are launched with launchStep(..., which = 16)
 bool patchConfigOk(int K, int rxi);

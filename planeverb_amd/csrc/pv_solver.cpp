@@ -746,6 +746,14 @@ bool Solver::applyGeometry() {
         !hipOk(hipStreamSynchronize(stream_), "geometry sync"))
         return false;
     std::sort(wallTiles_.begin(), wallTiles_.end());
+    {
+        // Scenes with many wall tiles (>= 8 % general: the 25 m rooms at 4096^2 / 8192^2 have 13-16 %) take the merged kernel
+        // whose general arm is the packed one also at K = 12 (launchStep, kStepGeneralPacked); decided per geometry, so a
+        // captured run graph never mixes the two.  PLANEVERB_AMD_GENERAL_PACKED = 0 / 1: never / always.
+        const char* e = getenv("PLANEVERB_AMD_GENERAL_PACKED");
+        const long long nt = (long long)geo_.ntx * geo_.nty;
+        stepWhich_ = 4 | (((e ? atoi(e) != 0 : (long long)count * 100 >= 8 * nt)) ? kStepGeneralPacked : 0);
+    }
     if (!makeLabels()) return false;
     mat_.clearDirty();
     geometryDirty_ = false;
@@ -903,6 +911,8 @@ bool Solver::prepareDyn(int lcx, int lcy, bool withPulse, bool banded) {
     numGeneral_ = n;
     dynCur_.numGeneral = n;
     dynHost_->numGeneral = n;
+    if (const char* v = getenv("PLANEVERB_AMD_VERBOSE"); v && atoi(v) > 0)
+        std::fprintf(stderr, "[planeverb_amd] %d x %d tiles (K %d, %d rows): %d general, %d dead\n", geo_.ntx, geo_.nty, K_, rxi_, n, numDead_);
     segActive_ = useSeg_ && !bandedRun_;
     numSeg_ = 0;
     if (segActive_) buildSegments(n);
@@ -1134,7 +1144,7 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
                     if (b > 0) hipStreamWaitEvent(sb, bandEv_[(size_t)2 * (b - 1) + ((li - 1) & 1)], 0);
                     if (b + 1 < nb_) hipStreamWaitEvent(sb, bandEv_[(size_t)2 * (b + 1) + ((li - 1) & 1)], 0);
                 }
-                launchStep(K_, rxi_, bandStepArgs(a, b), sb, 4);
+                launchStep(K_, rxi_, bandStepArgs(a, b), sb, stepWhich_);
                 hipEventRecord(bandEv_[(size_t)2 * b + (li & 1)], sb);
             }
             cur_ ^= 1;
@@ -1179,7 +1189,7 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
                 StepArgs a2 = a;
                 a2.tileClass = classStream_;
                 a2.tileOpen = ringOpen_;
-                launchStep(K_, rxi_, a2, stream_, 4);
+                launchStep(K_, rxi_, a2, stream_, stepWhich_);
                 OpenArgs o{};
                 o.sOnset = sOnset_;
                 o.sEdry = sState_[0];
@@ -1204,7 +1214,7 @@ bool Solver::enqueueSteps(int firstStep, int nsteps, bool withPulse, bool record
                 launchStep(K_, rxi_, a, stream_, 16);
                 launchStepPatch(K_, rxi_, a, patchBlocks_, stream_);
             } else {
-                launchStep(K_, rxi_, a, stream_, 4);
+                launchStep(K_, rxi_, a, stream_, stepWhich_);
             }
             if (te) {
                 hipEventRecord(te[1], stream_);

@@ -237,6 +237,7 @@ private:
     bool lastRunBatched_ = false;          // the last run was a member of a batch of several
     std::vector<hipStream_t> auxStreams_;  // PVA_OPT_AUX_STREAMS
     std::vector<hipEvent_t> airDone_, genDone_;  // per-launch cross-stream dependencies (no timing)
+    int stepWhich_ = 4;                    // launchStep's `which` of the merged launch (applyGeometry: | kStepGeneralPacked)
     QueueClaim queue_;                     // stream_'s hardware queue, apart from the other solvers' (Solver::init)
     hipEvent_t forkEv_ = nullptr;
     hipEvent_t anaEv_[2] = {nullptr, nullptr};  // enqueueAnalysis: onsets known -> stream2_, decay times done -> stream_

@@ -30,8 +30,10 @@ THRESHOLDS_TAKEN_ON = "HIP version: 7.2.26015"  # hipcc --version, first line (p
 FLAGS = ["--offload-arch=gfx950", "-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", "-fvisibility=hidden"]
 # kernel -> (max v_readlane inside the packed-arithmetic span, as measured good: 0-8 / 13-86)
 KERNELS = {
-    "pv_step_merged_kernel<12, 36, 2, 9> (4096^2, 8192^2)": ("_ZN3pva21pv_step_merged_kernelILi12ELi36ELi2ELi9EEEvNS_8StepArgsE", 16),
-    "pv_step_merged_kernel<10, 36, 2, 9> (2048^2)": ("_ZN3pva21pv_step_merged_kernelILi10ELi36ELi2ELi9EEEvNS_8StepArgsE", 100),
+    "pv_step_merged_kernel<12, 36, 2, 9> (4096^2, 8192^2)": ("_ZN3pva21pv_step_merged_kernelILi12ELi36ELi2ELi9ELb0EEEvNS_8StepArgsE", 16),
+    "pv_step_merged_kernel<12, 36, 2, 9, packed general arm> (scenes with >= 8 % wall tiles)": (
+        "_ZN3pva21pv_step_merged_kernelILi12ELi36ELi2ELi9ELb1EEEvNS_8StepArgsE", 16),
+    "pv_step_merged_kernel<10, 36, 2, 9> (2048^2)": ("_ZN3pva21pv_step_merged_kernelILi10ELi36ELi2ELi9ELb0EEEvNS_8StepArgsE", 100),
 }
 
 

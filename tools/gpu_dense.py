@@ -16,11 +16,16 @@ inflight = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 cfgs = [tuple(int(v) for v in a.split(",")) for a in sys.argv[3:]] or [(0, 0)]
 hooks = bench.GpuHooks(0)
 size = bench.mode_a_size(grid)
+res = 275
+if os.environ.get("MODEB"):  # the 25 m scene at the resolution that gives this grid (Mode B's geometry: thick walls, 4 % general tiles)
+    size, res = 25.0, {512: 2009, 1024: 4017, 2048: 8034, 4096: 16067, 8192: 32134}[grid]
 print("# %d^2, HugeRoom.pv, %d run(s) in flight; raw stencil (PvAmdRunSteps), ~1.2 s per leg" % (grid, inflight))
 print("# K rows | random: upd/s  launch p50/p90 ms  clock MHz (median/min)  W | zero: upd/s  p50/p90  clock  W | random/zero")
 for K, rows in cfgs:
     opts = dict(steps_per_launch=K, tile_rows=rows) if K else {}
-    solvers = [hooks.make_solver(size, 275, **opts) for _ in range(inflight)]
+    if os.environ.get("MODEB"):
+        opts["streaming_analysis"] = 1  # (no T x cells history at these T; the leg itself is raw stepping)
+    solvers = [hooks.make_solver(size, res, **opts) for _ in range(inflight)]
     for s in solvers:
         s.load_scene(os.path.join(ROOT, "tests", "scenes", "HugeRoom.pv"))
     s = solvers[0]
