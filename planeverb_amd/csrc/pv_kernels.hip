@@ -1285,13 +1285,15 @@ __device__ __forceinline__ void stepTileGeneral4Packed(const StepArgs& a, const 
     }
 }
 
-template <int K, int RXI>
+template <int K, int RXI, bool GP = false>
 __device__ __forceinline__ void stepTileGeneral4(const StepArgs& a, const int tile, const int wave, const int lane, GenShared& sh) {
     // Measured (profiles/r02_ab_general_packed.txt): +9-10 % at 512^2 (4 runs in flight, K = 8 tiles: a quarter of all
     // tiles are general), +1.5 % at 2048^2 (K = 10) -- and 3 % SLOWER at 4096^2 / 8192^2, where 4 % of the tiles are
     // general and the changed arm disturbs the register allocation of the air arm that shares its kernel (DESIGN.md 8.4
-    // has two more cases of that).  So the large-grid tile (K = 12) keeps the scalar form.
-    if constexpr (PV_GENERAL_PACKED == 1 ? K < 12 : PV_GENERAL_PACKED != 0)
+    // has two more cases of that).  So the large-grid tile (K = 12) keeps the scalar form -- unless a scene has MANY general
+    // tiles (GP: a second instantiation of the merged kernel, chosen per geometry by Solver::applyGeometry when >= 8 % of the
+    // tiles are general -- the 25 m rooms at 4096^2 / 8192^2, Mode B: 13-16 %, profiles/r05_modeB_general.txt).
+    if constexpr (GP || (PV_GENERAL_PACKED == 1 ? K < 12 : PV_GENERAL_PACKED != 0))
         stepTileGeneral4Packed<K, RXI>(a, tile, wave, lane, sh);
     else
         stepTileGeneral4Scalar<K, RXI>(a, tile, wave, lane, sh);
@@ -1593,7 +1595,7 @@ __global__ __launch_bounds__(256, 2) void pv_step_general_kernel(const StepArgs 
 // its rows, stepTileGeneral4), every other block four air tiles (one wave each).  Versus the two-kernel / two-stream
 // form this removes the cross-stream event hand-shake between every pair of launches; the general arm (~110 VGPRs)
 // fits inside the air arm's register budget.  SUB is the slice height of the two-kernel form and unused here.
-template <int K, int RXI, int WPS, int SUB>
+template <int K, int RXI, int WPS, int SUB, bool GP = false>
 __global__ __launch_bounds__(256, WPS) void pv_step_merged_kernel(const StepArgs a) {
     __shared__ GenShared gsh;
     const int lane = threadIdx.x & 63;
@@ -1606,7 +1608,7 @@ __global__ __launch_bounds__(256, WPS) void pv_step_merged_kernel(const StepArgs
         if ((int)blockIdx.x >= a.dyn->numGeneral) return;
         const int tile = __builtin_amdgcn_readfirstlane(a.generalList[blockIdx.x]);
         if (deadTileSkippable<K, RXI>(a, tile)) return;  // (block-uniform)
-        stepTileGeneral4<K, RXI>(a, tile, wave, lane, gsh);
+        stepTileGeneral4<K, RXI, GP>(a, tile, wave, lane, gsh);
         return;
     }
     const int b = blockIdx.x - gblocks;
@@ -1753,7 +1755,7 @@ __global__ __launch_bounds__(256) void pv_tileclass_kernel(const FaceCoef* coef,
 }
 
 // Dead tiles: every interior cell is a wall cell whose x and y face coefficients are +0 (wall|wall, or a wall of admittance 0
-// against air: the same update).  Then pr = beta * (...)
+// against air: the same update) or whose neighbour across the face is a wall cell as well.  Then pr = beta * (...)
 // = 0 (FDTD.cpp:139) and both velocities are 0 (FDTD.cpp:165-168 with beta = beta_n = 0) whatever the halo holds, so a
 // run that starts from zero fields never has to touch the tile: both buffer sets keep their zeros there.  One wave per tile.
 __global__ __launch_bounds__(256) void pv_tiledead_kernel(const FaceCoef* coef, uint8_t* dead, int* count, Geometry g,
@@ -1764,11 +1766,17 @@ __global__ __launch_bounds__(256) void pv_tiledead_kernel(const FaceCoef* coef, 
     const int WI = 64 - 2 * K;
     const int ti = tile / g.nty, tj = tile - ti * g.nty;
     const size_t base = (size_t)(g.G + ti * g.rxi) * g.pitch + (g.G + tj * WI - K + lane);
+    // Round 5: a face with a non-zero wall coefficient is as good as a +0 one when the cell across it is a wall cell too
+    // (v = k * (0 + 0)): the ghost row / column of the grid (k = 1, FDTD.cpp:201-223) inside a thick outer wall.
     bool ok = true;
     if (lane >= K && lane < 64 - K)
         for (int r = 0; r < g.rxi; ++r) {
-            const FaceCoef c = coef[base + (size_t)r * g.pitch];
-            ok = ok && (__float_as_uint(c.kx) | __float_as_uint(c.ky)) == 0u;
+            const size_t at = base + (size_t)r * g.pitch;
+            const FaceCoef c = coef[at];
+            const bool solid = c.beta == 0.f;
+            const bool fx = __float_as_uint(c.kx) == 0u || (c.kx == c.kx && coef[at - g.pitch].beta == 0.f);
+            const bool fy = __float_as_uint(c.ky) == 0u || (c.ky == c.ky && coef[at - 1].beta == 0.f);
+            ok = ok && solid && fx && fy;
         }
     const bool d = __ballot(!ok) == 0ull;
     if (lane == 0) {
@@ -1956,10 +1964,18 @@ static void launchStepT(const StepArgs& a, hipStream_t stream, int which, hipStr
             hipLaunchKernelGGL((pv_step_merged_kernel<K, RXI, WPS, SUB>), dim3(a.numGeneral), dim3(256), 0, stream, a);
         return;
     }
-    if (which == 4) {  // merged single launch: one block per general tile, then 4 air tiles per block
+    if ((which & ~kStepGeneralPacked) == 4) {  // merged single launch: one block per general tile, then 4 air tiles per block
+        // (All general blocks FIRST.  Spreading them over the launch in groups of eight, so that no round of the launch holds
+        // general blocks only, was measured in round 5: 8-10 % slower at 4096^2 / 8192^2 in Mode B's geometry, 3-5 % in Mode A's.)
         const int blocks = a.numGeneral + 8 * ((bandPositions(a) + 3) / 4);
         // (PV_PROBE_LDS = bytes of dynamic LDS per block: measurement aid, limits the blocks resident per CU)
         static const int probeLds = getenv("PV_PROBE_LDS") ? atoi(getenv("PV_PROBE_LDS")) : 0;
+        if constexpr (K >= 12 && PV_GENERAL_PACKED == 1) {  // (smaller K: the packed general arm is the only one)
+            if (which & kStepGeneralPacked) {
+                hipLaunchKernelGGL((pv_step_merged_kernel<K, RXI, WPS, SUB, true>), dim3(blocks), dim3(256), probeLds, stream, a);
+                return;
+            }
+        }
         hipLaunchKernelGGL((pv_step_merged_kernel<K, RXI, WPS, SUB>), dim3(blocks), dim3(256), probeLds, stream, a);
         return;
     }
