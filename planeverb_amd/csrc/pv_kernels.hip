@@ -1608,6 +1608,7 @@ __global__ __launch_bounds__(256, WPS) void pv_step_merged_kernel(const StepArgs
         if ((int)blockIdx.x >= a.dyn->numGeneral) return;
         const int tile = __builtin_amdgcn_readfirstlane(a.generalList[blockIdx.x]);
         if (deadTileSkippable<K, RXI>(a, tile)) return;  // (block-uniform)
+        // (s_setprio(3) for these few, long, barrier-bound waves: +2 % with one run in flight, -3 % with two -- round 5, not kept)
         stepTileGeneral4<K, RXI, GP>(a, tile, wave, lane, gsh);
         return;
     }
@@ -1967,7 +1968,9 @@ static void launchStepT(const StepArgs& a, hipStream_t stream, int which, hipStr
     if ((which & ~kStepGeneralPacked) == 4) {  // merged single launch: one block per general tile, then 4 air tiles per block
         // (All general blocks FIRST.  Spreading them over the launch in groups of eight, so that no round of the launch holds
         // general blocks only, was measured in round 5: 8-10 % slower at 4096^2 / 8192^2 in Mode B's geometry, 3-5 % in Mode A's.)
-        const int blocks = a.numGeneral + 8 * ((bandPositions(a) + 3) / 4);
+        // (PV_PROBE_GENERAL_ONLY: measurement aid -- the launch ends behind its general blocks, the air tiles are not advanced)
+        static const bool genOnly = getenv("PV_PROBE_GENERAL_ONLY") != nullptr;
+        const int blocks = a.numGeneral + (genOnly ? 0 : 8 * ((bandPositions(a) + 3) / 4));
         // (PV_PROBE_LDS = bytes of dynamic LDS per block: measurement aid, limits the blocks resident per CU)
         static const int probeLds = getenv("PV_PROBE_LDS") ? atoi(getenv("PV_PROBE_LDS")) : 0;
         if constexpr (K >= 12 && PV_GENERAL_PACKED == 1) {  // (smaller K: the packed general arm is the only one)
