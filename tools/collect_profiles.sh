@@ -65,3 +65,8 @@ for r in 275 750 1000 1500; do tools/gpu_preset_trace.sh $O/preset_trace_$r $r "
 tools/gpu_analysis_trace.sh $O/analysis_trace "" > $O/analysis_trace.txt 2>/dev/null
 # phase stamps of the resident kernel (needs the trace build, made HERE before the call: see tools/gpu_resident_trace.py)
 if [ -f planeverb_amd/libplaneverb_amd_trace.so ]; then PLANEVERB_AMD_LIB=$PWD/planeverb_amd/libplaneverb_amd_trace.so python tools/gpu_resident_trace.py 275 750 > $O/resident_trace.txt 2>&1; fi
+# (round 5, later additions) slab groups in several process orders, the general arm of Mode B's geometry, the persistent-form probe
+(for i in 1 2; do echo "== process $i: 4096 then 2048, S = 1, 2, 4, 8"; python tools/gpu_slabs.py 4096 2048 2>&1 | cut -c1-100; echo "== process: S = 2 only, 2048 4096 2048 4096"; SLABS=2 python tools/gpu_slabs.py 2048 4096 2048 4096 2>&1 | cut -c1-100; done) > $O/slabs_orders.txt 2>&1
+(for m in "" 1; do MODEB=$m python tools/gpu_dense.py 4096 1 12,36 2>&1 | tail -1; MODEB=$m PV_PROBE_GENERAL_ONLY=1 python tools/gpu_dense.py 4096 1 12,36 2>&1 | tail -1; done) > $O/general_arm.txt 2>&1
+tools/gpu_modeb_trace.sh $O/modeb_trace 16067 > $O/modeb_trace_4096.txt 2>/dev/null
+hipcc --offload-arch=gfx950 -O3 tools/persist_probe.hip -o /tmp/persist_probe 2>/dev/null && timeout 120 /tmp/persist_probe > $O/persist_probe.txt 2>&1
