@@ -517,6 +517,50 @@ def test_dead_tiles_thick_walls_vs_oracle(pvlib, oracle):
         assert check(s, [bar, late], (30.0, 0.0, 70.0)) > 5000        # and a run after that starts clean again
 
 
+@pytest.mark.parametrize("opts,packed", [(dict(steps_per_launch=8, tile_rows=24), None), (dict(steps_per_launch=12, tile_rows=12), "0"),
+                                         (dict(steps_per_launch=12, tile_rows=12), "1")])
+def test_solid_border_walls_dead_to_the_ghost_row_vs_oracle(pvlib, oracle, opts, packed):
+    """A room whose four walls are thick boxes along the grid's borders: the tiles inside the right / bottom wall hold the grid's
+    ghost row / column, whose face coefficient is 1, not 0 -- dead all the same since round 5 (the cell across the face is a wall cell
+    too).  Whole maps, recorded planes and final fields against the oracle; at K = 12 with the scalar and with the packed general arm
+    (PLANEVERB_AMD_GENERAL_PACKED: the second instantiation of the merged kernel that scenes with many wall tiles take)."""
+    dx = np.float32(343.21) / np.float32(275) / np.float32(3.5)
+    size = float((256 + 0.5) * dx)
+    w = 12.0
+    walls = [[w / 2, size / 2, w, size, 0.8], [size - w / 2, size / 2, w, size, 0.6], [size / 2, w / 2, size, w, 0.7],
+             [size / 2, size - w / 2, size, w, 0.9], [40.0, 50.0, 9.0, 14.0, 0.5]]
+    ef = oracle.free_energy(size, size, 275)
+    old = os.environ.get("PLANEVERB_AMD_GENERAL_PACKED")
+    if packed is not None:
+        os.environ["PLANEVERB_AMD_GENERAL_PACKED"] = packed
+    try:
+        with pvlib.Solver(size, size, 275, **opts) as s:
+            for b in walls:
+                s.add_geometry(b)
+            for L in ((30.0, 0.0, 30.0), (size - w - 1.0, 0.0, size - w - 1.0), (size - 2.0, 0.0, 40.0)):  # mid-room, the far corner, INSIDE the wall
+                s.run(L)
+                o = oracle.OracleGrid(size, size, 275, np.array(walls, np.float32))
+                f = o.fdtd(L, want_fields=True)
+                hp, _, _ = o.history()
+                for t in (0, 60, 300, 434):
+                    assert same_bits(s.history_plane(t), hp[t]).all(), "recorded pr, step %d" % t
+                for mine, ref in zip(s.fields(), f):
+                    assert same_bits(mine, ref).all(), "final fields"
+                rres, rdelay, _ = o.analyze(ef, L)
+                res, delay = s.results()
+                o.close()
+                assert same_bits(delay, rdelay).all(), "delay map"
+                valid, onset = valid_mask(rdelay, 435, 1443), rdelay < 1e30
+                for k, nm in enumerate(NAMES):
+                    m = onset if k in (4, 5) else valid
+                    assert same_bits(res[..., k][m], rres[..., k][m]).all(), "%s %s" % (L, nm)
+    finally:
+        if old is None:
+            os.environ.pop("PLANEVERB_AMD_GENERAL_PACKED", None)
+        else:
+            os.environ["PLANEVERB_AMD_GENERAL_PACKED"] = old
+
+
 def test_step_composition_and_zero_fixed_point(pvlib, pvlib_exp):
     """raw stencil properties: 2n steps == n steps twice (any K), and an all-zero field stays all-zero"""
     rng = np.random.default_rng(11)
