@@ -139,6 +139,10 @@ def cpu_baseline(grid_cells=1025, scene="HugeRoom.pv"):
             out["cpu_model"] = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
     except Exception:
         out["cpu_model"] = None
+    # (the bounded sample is a 1025^2 grid so that the default run stays short; the same reference at the headline's full size, measured
+    # once on a GPU box's host: 63.6 s of FDTD for one 4097^2 run)
+    out["full_size"] = {"value": 1.148e8, "unit": "cell-updates/s", "cores": 1, "workload": "HugeRoom.pv, 4097x4097 cells, T=435",
+                        "source": "profiles/r03_cpu_reference_4097.txt (EPYC 9575F, round 3)"}
     return out
 
 
