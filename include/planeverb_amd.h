@@ -164,7 +164,7 @@ enum {
     PVA_OPT_STREAMING_ANALYSIS = 12, /* 1 = sparse-emitter mode: ring history + incremental analysis (see PvAmdSetEmitters) */
     PVA_OPT_STREAM_ROWS = 13,  /* N > 0: the air part of the grid is advanced by about N row-streaming segments per sweep (a wave streams down a 256-column strip, K time levels in flight) instead of one wave per air tile; tile configurations (8, 40) and (12, 36) only, ignored elsewhere and with slabs / row bands / graphs / streaming analysis.  Bit-identical; experimental: slower than the tile kernels at 4096^2.  Default 0 = off */
     PVA_OPT_MERGED_LAUNCH = 14, /* 1 (default) = general + air tiles in one launch per K steps; 0 = two kernels, two streams */
-    PVA_OPT_ROW_BANDS = 16,    /* B > 1: every K-step sweep is launched as B bands of tile rows on B HIP streams; band b of sweep n+1 waits only for bands b-1, b, b+1 of sweep n, so consecutive sweeps of ONE run overlap (no chip-wide drain between launches) -- what gives a single run most of the two-runs-in-flight rate.  0 = auto by grid size, 1 = one launch per sweep.  Large grids with the merged kernel only; ignored elsewhere (streaming analysis, graphs, batched runs) */
+    PVA_OPT_ROW_BANDS = 16,    /* B > 1: every K-step sweep is launched as B bands of tile rows on B HIP streams; band b of sweep n+1 waits only for bands b-1, b, b+1 of sweep n, so consecutive sweeps of ONE run overlap (no chip-wide drain between launches).  Bit-identical; on the current runtime the cross-queue event waits cost more than the overlap gains (4096^2, one run in flight: 1.52e12 with one launch per sweep, 1.34e12 with two bands, 1.13e12 with three -- round 5), so 0 = auto means 1 = one launch per sweep.  Large grids with the merged kernel only; ignored elsewhere (streaming analysis, graphs, batched runs) */
     PVA_OPT_PATCH_KERNEL = 17, /* air tiles by the persistent per-CU kernel with LDS-DMA run-ahead (csrc/pv_patch.h: one 512-thread workgroup per CU, the next 4-tile patch lands in LDS while the current one computes) instead of one wave per tile; general tiles in a launch of their own.  Only the large-grid tile (steps per launch 12, tile rows 36) has the kernel; ignored elsewhere and with streaming analysis, slabs, edge tiles, kernel timing.  -1 = default for the configuration, 0 = off, 1 = on */
     PVA_OPT_LAZY_FAR_CELLS = 19, /* 1 (default): a run resets "no onset" / the default listener direction only in the previous and the current history-window block of the result map; the listener direction of the other far cells (unit vector listener -> cell, Analyzer.cpp:365-391,415-428) is materialised when a whole-map read-back asks for it and computed in closed form by PvAmdGetOutput / the output queries.  0: rewrite every far cell on every run (201 MB at 4096^2), the form of rounds 1-2 (validation) */
     PVA_OPT_STREAM_FUSE = 20,  /* streaming analysis only: the forward sums of the analysis (onset, dry energy, source-direction flux) of AIR tiles advance inside the step kernel (csrc/pv_stream.h: open half tiles with the sums in registers); the ring of pressure planes and the accumulate pass then serve only tiles with walls, grid edges, the listener or a registered emitter.  -1 (default): by grid size (on from 6000 tiles, where the ring traffic binds); 0: ring + accumulate pass for every tile (round 2's form); 1: on */
