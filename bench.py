@@ -139,10 +139,12 @@ def cpu_baseline(grid_cells=1025, scene="HugeRoom.pv"):
             out["cpu_model"] = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
     except Exception:
         out["cpu_model"] = None
-    # (the bounded sample is a 1025^2 grid so that the default run stays short; the same reference at the headline's full size, measured
-    # once on a GPU box's host: 63.6 s of FDTD for one 4097^2 run)
-    out["full_size"] = {"value": 1.148e8, "unit": "cell-updates/s", "cores": 1, "workload": "HugeRoom.pv, 4097x4097 cells, T=435",
-                        "source": "profiles/r03_cpu_reference_4097.txt (EPYC 9575F, round 3)"}
+    # (the bounded sample is a 1025^2 grid so that the default run stays short.  --cpu-baseline-cells 4097 times the same
+    # reference at the headline's full size in this very run: two impulse-response cubes of 117 GB each in host memory and
+    # ~65 s of FDTD on one core; measured that way once, on a GPU box's host: profiles/r03_cpu_reference_4097.txt.)
+    out["sample_cells"] = grid_cells
+    out["full_size_how"] = ("--cpu-baseline-cells 4097 (needs ~240 GB of host memory for the reference's two T-step cubes, ~65 s of FDTD); "
+                            "a record of such a run: profiles/r03_cpu_reference_4097.txt")
     return out
 
 
@@ -195,6 +197,11 @@ class GpuHooks:
     def clock_probe(self):
         from planeverb_amd import api
         return api.clock_probe(self.local_rank)[0]
+
+    def bandwidth_probe(self):
+        """the box's own streaming bandwidth (PvAmdBandwidthProbe: device-to-device copy, read, write; ~60 ms, idle device)"""
+        from planeverb_amd import api
+        return api.bandwidth_probe(self.local_rank)
 
     def device_record(self):
         p = self.torch.cuda.get_device_properties(self.local_rank)
@@ -711,8 +718,9 @@ def main(argv=None, hooks=None):
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "basis": "achieved / peak / frac are on SURVEY.md 8d's basis: ALGORITHMIC bytes (24 B per "
                                   "cell-step) against the 8 TB/s HBM peak.  K-step temporal blocking in registers moves "
-                                  "9-10x fewer bytes than that, so frac > 1 and HBM is NOT what binds: the kernel is bound "
-                                  "by VALU issue (see valu, hbm, useful_lane_fraction)",
+                                  "9-10x fewer bytes than that, so frac > 1: what binds is named in `bound` from the two measured "
+                                  "fractions, VALU issue (valu.frac) and the counter-HBM bytes against the box's own copy rate "
+                                  "(hbm.frac_of_measured_copy); useful_lane_fraction says how much of the issued arithmetic is halo",
                          "valu": valu, "hbm": hbm, "useful_lane_fraction": useful_lane_fraction,
                          "kernel": "pv_step_merged_kernel<K=%d,rows=%d> (air tiles + general tiles, one launch per K "
                                    "steps)" % (K, info.tileRows),
@@ -727,6 +735,37 @@ def main(argv=None, hooks=None):
                                  "flight"},
         }
         # rank 0 only, after the timed region (the other ranks wait at the final barrier)
+        # "confirm on the box with a device-to-device copy micro-benchmark and report against both" -- the box's own
+        # copy / read / write rates, measured now (idle device), and the kernel's fractions of them beside the fractions of the spec
+        rl = out["roofline"]
+        if hasattr(hooks, "bandwidth_probe"):
+            try:
+                bw = hooks.bandwidth_probe()
+                copy = max(bw["copy_x4"], bw["copy_dword"])
+                rl["measured_bandwidth"] = dict(bw, unit="GB/s", copy=copy,
+                                                how="PvAmdBandwidthProbe behind the timed region: 1 GiB buffers, best of 5 launches per leg "
+                                                    "(copy = bytes read + written per second; read / write = 4 B per lane in 256-byte rows per "
+                                                    "wave, the stencil kernels' pattern)")
+                rl["frac_of_measured_copy"] = achieved / copy  # (algorithmic bytes, like frac)
+                if hbm:
+                    hbm["frac_of_measured_copy"] = hbm["achieved"] / copy
+                    # reads against the read-only rate and writes against the write-only rate, summed: the time the kernel's own
+                    # mix of bytes would take at the box's one-directional rates, over the time it took
+                    if prof.get("read_bytes") and prof.get("write_bytes") and bw["read_dword"] > 0 and bw["write_dword"] > 0:
+                        t_mix = (prof["read_bytes"] / bw["read_dword"] + prof["write_bytes"] / bw["write_dword"]) / 1e9
+                        hbm["frac_of_measured_read_write_mix"] = G * t_mix / (air * 1e-3)
+            except Exception as e:  # noqa: BLE001
+                rl["measured_bandwidth"] = {"skipped": str(e)}
+        if valu:
+            valu["frac"] = valu["issue_utilisation"]
+        fr_valu = (valu or {}).get("frac")
+        fr_hbm = (hbm or {}).get("frac_of_measured_copy")
+        if fr_valu is not None and fr_hbm is not None:
+            rl["bound"] = "valu+hbm-path" if min(fr_valu, fr_hbm) >= 0.75 else ("valu" if fr_valu >= fr_hbm else "hbm-path")
+            rl["bound_how"] = ("VALU issue %.2f of the SIMDs' rate, counter-HBM bytes at %.2f of the box's measured copy rate: named "
+                               "together when both are >= 0.75" % (fr_valu, fr_hbm))
+        else:
+            rl["bound_how"] = "counter profile not quoted (see traffic_note): the bound named is round 5's finding"
         if not args.no_dense_leg and hasattr(hooks, "dense_leg") and NB == 1:
             dense = hooks.dense_leg(solvers[:G], K, T, cells)
             if "random" in dense:

@@ -171,8 +171,8 @@ enum {
     PVA_OPT_AUX_STREAMS = 21,  /* HIP streams the solver creates beside its own two and never launches on (default 0).  The streams of a process share a handful of hardware queues, handed out by creation order, and two step loops that land on one queue run their launches strictly one after the other.  Measured on MI355X / ROCm 7.0 at 512^2: with 1, the two batch groups' step loops overlap (batched launches 33 instead of 63 us: 3.5e11 instead of 2.1e11 cell-updates/s); with 0, four pipelined single runs keep 2.8e11 instead of 2.5e11.  api.batch_solver_options sets 1 */
     PVA_OPT_RESIDENT_KERNEL = 22, /* the resident kernel (csrc/pv_resident.hip): ONE launch per run, every tile a workgroup that stays on its CU for all T steps and hands its interior to its neighbours every K steps through write-through stores + one flag word per tile (no kernel boundary, no grid barrier) -- for the grids the reference ships (its 275 ... 750 Hz presets on a 25 m scene: 70^2 ... 191^2) and everything else whose history window is the whole grid and whose tiles fit the chip at once.  0 (default) = auto: where the solver runs its default tile for launch-bound grids; 1 = also with an explicitly chosen (steps per launch, tile rows) = (12, 12); 2 = never (the replayed graph of tile-kernel launches) */
     PVA_OPT_RT60_LANES = 23,   /* wet gain + decay time (Analyzer.cpp:235-247,282-327): lanes that share a cell -- 16 (DPP row: few cells, parallel logarithms), 1 (lane per cell over the tile-major history, csrc/pv_rt60.hip: fewest instructions and bytes per sample) or 4 (round 4's blocked form, kept for validation); same bits in every form.  0 (default) = 16 or 1, chosen on the device from the number of reachable cells */
-    PVA_OPT_FUSED_ANALYSIS = 29, /* grids whose pressure history covers the whole grid, up to 98 304 cells (the reference's presets): -1 / 1 (default) = the whole analysis of a run is ONE launch (csrc/pv_fused.hip: onsets, dry / wet gain, decay time, listener direction as phases of workers that draw items from a ticket counter); 0 = the separate kernels.  Results do not depend on it */
-    PVA_OPT_ANALYSIS_FORK = 28, /* 1 (default) = on windows of 32 768 cells and more the wet gain / decay-time pass runs on the solver's second stream beside the dry-gain pass (both only read the onsets); 0 = behind it.  Results do not depend on it */
+    PVA_OPT_FUSED_ANALYSIS = 29, /* grids whose pressure history covers the whole grid, up to 98 304 cells (the reference's presets): 1 = the whole analysis of a run is ONE launch (csrc/pv_fused.hip: onsets, dry / wet gain, decay time, listener direction as phases of workers that draw items from a ticket counter) -- an arm of the EXPERIMENTAL build of the library (bit-identical, measured slower); the product build refuses it.  -1 / 0 (default) = the separate kernels.  Results do not depend on it */
+    PVA_OPT_ANALYSIS_FORK = 28, /* 1 (default) = on windows of 4 096 cells and more (PV_ANALYSIS_FORK_CELLS, csrc/pv_solver.cpp) the wet gain / decay-time pass runs on the solver's second stream beside the dry-gain pass (both only read the onsets); 0 = behind it; 2 = beside it on every window.  Results do not depend on it */
     PVA_OPT_STREAM_PRIORITY = 25, /* 1 = the solver's main stream is created with the device's highest priority.  Streams of different priorities never share a hardware queue (the runtime multiplexes the streams of a process on a handful of them, and launches of streams that share one run one after the other): give every other solver of a group that is meant to run side by side -- two runs in flight on one GPU -- this option.  Results do not depend on it.  Default 0 */
     PVA_OPT_ALTERNATE_SWEEPS = 26, /* tile order 3 only: 1 = odd launches of a run walk every XCD's strip of tiles from its last tile row to its first, so that a launch reads first what the previous launch wrote last (still in the 256 MiB Infinity Cache) instead of streaming through the cache in the order that evicts everything before it is read again.  Results do not depend on it.  -1 = default, 0 = off */
     PVA_OPT_XCD_REGIONS = 27, /* tile order 3 only: 1 = every XCD owns one of 2 x 4 regions of the grid (walked row-major) instead of one of 8 strips of tile columns: a region is twice as wide, so half as many cache lines on its sides are fetched by two XCDs, and a tile's vertical neighbours are still close enough for the XCD's L2.  Results do not depend on it.  -1 = default (on), 0 = strips */
@@ -279,6 +279,12 @@ PVA_EXPORT int PvAmdRunBatch(PvAmdSolver* const* solvers, int n, const float* li
  * them against the constant 100 MHz counter, on a stream of its own (so it can run beside solvers at work).  *byMemtimeMHz
  * (optional) = the same span by s_memtime.  0 on failure.  bench.py's device record. */
 PVA_EXPORT float PvAmdClockProbe(int device, float* byMemtimeMHz);
+/* The device's own streaming bandwidth, GB/s ("confirm on the box with a device-to-device copy micro-benchmark
+ * and report against both"): gbPerS4[0] = device-to-device copy, 16 B per lane (bytes read + written per second), [1] = the
+ * same with 4 B per lane, [2] = read only and [3] = write only, 4 B per lane in 256-byte rows per wave (the stencil kernels'
+ * pattern).  1 GiB per buffer (2 GiB of device memory while it runs), best of five launches each, ~60 ms, on a stream of its
+ * own; call it on an idle device.  0, or -1 on failure.  bench.py's roofline record. */
+PVA_EXPORT int PvAmdBandwidthProbe(int device, float* gbPerS4);
 PVA_EXPORT int PvAmdGetTimings(PvAmdSolver* s, PvAmdTimings* out);
 
 /* Streaming-analysis (sparse-emitter) mode only -- SURVEY.md 8f N3.  Registers the emitter positions (n x {x,y,z})

@@ -159,6 +159,7 @@ SYMBOLS = {
     "PvAmdRunBatch": (C.c_int, [C.POINTER(_vp), C.c_int, _fp, C.c_int]),
     "PvAmdGetTimings": (C.c_int, [_vp, C.POINTER(PvAmdTimings)]),
     "PvAmdClockProbe": (C.c_float, [C.c_int, _fp]),
+    "PvAmdBandwidthProbe": (C.c_int, [C.c_int, _fp]),
     "PvAmdSetEmitters": (C.c_int, [_vp, _fp, C.c_int]),
     "PvAmdGetOutput": (C.c_int, [_vp] + [C.c_float] * 3 + [C.POINTER(PlaneverbOutput)]),
     "PvAmdSetOutputQueries": (C.c_int, [_vp, _fp, C.c_int]),
@@ -397,6 +398,14 @@ def clock_probe(device=0):
     m = C.c_float(0.0)
     v = lib().PvAmdClockProbe(int(device), C.byref(m))
     return float(v), float(m.value)
+
+
+def bandwidth_probe(device=0):
+    """the device's own streaming bandwidth in GB/s (PvAmdBandwidthProbe): copy with 16 B and with 4 B per lane (bytes read +
+    written per second), read only, write only"""
+    v = (C.c_float * 4)()
+    _check(lib().PvAmdBandwidthProbe(int(device), v))
+    return {"copy_x4": float(v[0]), "copy_dword": float(v[1]), "read_dword": float(v[2]), "write_dword": float(v[3])}
 
 
 def device_count():

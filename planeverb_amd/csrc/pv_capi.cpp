@@ -2,6 +2,8 @@
 // No C++ exception leaves this file; the reference's sentinels are kept (-1 ids, occlusion = -1).
 #include <cstdio>
 #include <cstring>
+#include <memory>
+#include <new>
 #include <string>
 
 #include "../../include/planeverb_amd.h"
@@ -18,6 +20,39 @@ using namespace pva;
 
 static thread_local std::string g_lastError;
 
+// ---------------------------------------------------------------------------------------------------------------
+// The exception barrier (the reference throws from Init, PvContext.cpp:106,123, Grid.cpp:69; a C-ABI must
+// not).  EVERY extern "C" body below is a function-try-block closed by one of these macros: whatever is thrown underneath
+// (std::bad_alloc from a table growing, std::system_error from a thread or a mutex, anything from the HIP runtime's C++
+// side) ends here, the call returns its failure sentinel and PvAmdLastError() names the function and the exception.
+// tests/host/alloc_fault.cpp drives every allocation of the Part 1 calls into failure, one at a time.
+// ---------------------------------------------------------------------------------------------------------------
+static void noteException(const char* fn) noexcept {
+    try {
+        std::string what = "unknown exception";
+        try {
+            throw;
+        } catch (const std::bad_alloc&) {
+            what = "out of memory (std::bad_alloc)";
+        } catch (const std::exception& e) {
+            what = e.what();
+        } catch (...) {
+        }
+        g_lastError = std::string("exception in ") + fn + ": " + what;
+    } catch (...) {  // (not even the message could be built)
+        g_lastError.clear();
+    }
+}
+static PlaneverbOutput invalidOutput() noexcept {
+    PlaneverbOutput o;
+    std::memset(&o, 0, sizeof(o));
+    o.occlusion = kInvalidDryGain;  // FDTD.cpp:22-26
+    return o;
+}
+#define PV_API_CATCH(sentinel) catch (...) { noteException(__func__); return sentinel; }
+#define PV_API_CATCH_VOID      catch (...) { noteException(__func__); }
+#define PV_API_CATCH_OUTPUT    catch (...) { noteException(__func__); return invalidOutput(); }
+
 #ifndef PVA_HOST_TEST
 struct PvAmdSolver {
     Solver* s = nullptr;
@@ -26,6 +61,10 @@ struct PvAmdSolver {
     SolverOptions opt;
     GridSpec spec;
     int device = 0;
+    ~PvAmdSolver() {
+        delete s;
+        delete g;
+    }
 };
 
 // creates the solver / slab group on first use (options come first); `slabsOk` = the call is implemented for groups
@@ -71,53 +110,46 @@ extern "C" {
 // Part 1: reference C-ABI
 // ---------------------------------------------------------------------------------------------------------------
 
-void UnityPluginLoad(void*) {}
-void UnityPluginUnload(void) {}
+void UnityPluginLoad(void*) try {} PV_API_CATCH_VOID
+void UnityPluginUnload(void) try {} PV_API_CATCH_VOID
 
 void PlaneverbInit(float gridSizeX, float gridSizeY, int gridResolution, int gridBoundaryType, char* tempFileDir,
-                   int maxThreadUsage, int threadExecutionType) {
-    try {
-        LiveConfig c;
-        c.sizeX = gridSizeX;
-        c.sizeY = gridSizeY;
-        c.res = gridResolution;
-        c.boundaryType = gridBoundaryType;
-        c.tempDir = tempFileDir;
-        c.maxThreads = maxThreadUsage;
-        c.executionType = threadExecutionType;  // 0 (pv_CPU) and 1 (pv_GPU) both run on the HIP device here
-        std::string err;
-        if (!Context::init(c, &err)) {
-            g_lastError = err;
-            std::fprintf(stderr, "[planeverb_amd] PlaneverbInit failed: %s\n", err.c_str());
-        }
-    } catch (...) {
-        g_lastError = "exception in PlaneverbInit";
+                   int maxThreadUsage, int threadExecutionType) try {
+    LiveConfig c;
+    c.sizeX = gridSizeX;
+    c.sizeY = gridSizeY;
+    c.res = gridResolution;
+    c.boundaryType = gridBoundaryType;
+    c.tempDir = tempFileDir;
+    c.maxThreads = maxThreadUsage;
+    c.executionType = threadExecutionType;  // 0 (pv_CPU) and 1 (pv_GPU) both run on the HIP device here
+    std::string err;
+    if (!Context::init(c, &err)) {
+        g_lastError = err;
+        std::fprintf(stderr, "[planeverb_amd] PlaneverbInit failed: %s\n", err.c_str());
     }
-}
+} PV_API_CATCH_VOID
 
-void PlaneverbExit(void) {
-    try {
-        Context::exit();
-    } catch (...) {
-    }
-}
+void PlaneverbExit(void) try {
+    Context::exit();
+} PV_API_CATCH_VOID
 
-int PlaneverbEmit(float x, float y, float z) {
+int PlaneverbEmit(float x, float y, float z) try {
     Context::Ref c;
     return c ? c->emit(x, y, z) : -1;
-}
+} PV_API_CATCH(-1)
 
-void PlaneverbUpdateEmission(int id, float x, float y, float z) {
+void PlaneverbUpdateEmission(int id, float x, float y, float z) try {
     Context::Ref c;
     if (c) c->updateEmission(id, x, y, z);
-}
+} PV_API_CATCH_VOID
 
-void PlaneverbEndEmission(int id) {
+void PlaneverbEndEmission(int id) try {
     Context::Ref c;
     if (c) c->endEmission(id);
-}
+} PV_API_CATCH_VOID
 
-PlaneverbOutput PlaneverbGetOutput(int emissionID) {
+PlaneverbOutput PlaneverbGetOutput(int emissionID) try {
     PlaneverbOutput o;
     std::memset(&o, 0, sizeof(o));
     Context::Ref c;
@@ -128,71 +160,71 @@ PlaneverbOutput PlaneverbGetOutput(int emissionID) {
     const Out8 r = c->getOutput(emissionID);
     std::memcpy(&o, r.v, sizeof(o));
     return o;
-}
+} PV_API_CATCH_OUTPUT
 
-int PlaneverbAddGeometry(float posX, float posY, float width, float height, float absorption) {
+int PlaneverbAddGeometry(float posX, float posY, float width, float height, float absorption) try {
     Context::Ref c;
     return c ? c->addGeometry(Box{posX, posY, width, height, absorption}) : -1;
-}
+} PV_API_CATCH(-1)
 
-void PlaneverbUpdateGeometry(int id, float posX, float posY, float width, float height, float absorption) {
+void PlaneverbUpdateGeometry(int id, float posX, float posY, float width, float height, float absorption) try {
     Context::Ref c;
     if (c) c->updateGeometry(id, Box{posX, posY, width, height, absorption});
-}
+} PV_API_CATCH_VOID
 
-void PlaneverbRemoveGeometry(int id) {
+void PlaneverbRemoveGeometry(int id) try {
     Context::Ref c;
     if (c) c->removeGeometry(id);
-}
+} PV_API_CATCH_VOID
 
-void PlaneverbSetListenerPosition(float x, float y, float z) {
+void PlaneverbSetListenerPosition(float x, float y, float z) try {
     Context::Ref c;
     if (c) c->setListener(x, y, z);
-}
+} PV_API_CATCH_VOID
 
-int PlaneverbLoadScene(const char* pvPath) {
+int PlaneverbLoadScene(const char* pvPath) try {
     Context::Ref c;
     if (!c || !pvPath) return -1;
     std::vector<Box> boxes;
     if (!loadPv(pvPath, &boxes, &g_lastError)) return -1;
     for (const Box& b : boxes) c->addGeometry(b);
     return (int)boxes.size();
-}
+} PV_API_CATCH(-1)
 
-long long PlaneverbIterationCount(void) {
+long long PlaneverbIterationCount(void) try {
     Context::Ref c;
     return c ? c->iterations() : 0;
-}
+} PV_API_CATCH(0)
 
-long long PlaneverbWaitIterations(long long count, int timeoutMs) {
+long long PlaneverbWaitIterations(long long count, int timeoutMs) try {
     Context::Ref c;
     return c ? c->waitIterations(count, timeoutMs) : 0;
-}
+} PV_API_CATCH(0)
 
 // 0 also when the simulation worker has stopped on an error (PvAmdLastError then says why)
-int PlaneverbIsRunning(void) {
+int PlaneverbIsRunning(void) try {
     Context::Ref c;
     return (c && !c->failed()) ? 1 : 0;
-}
+} PV_API_CATCH(0)
 
-int PlaneverbIsStreaming(void) {
+int PlaneverbIsStreaming(void) try {
     Context::Ref c;
     return (c && c->streaming()) ? 1 : 0;
-}
+} PV_API_CATCH(0)
 
-int PlaneverbGetImpulseResponse(float x, float y, float z, PlaneverbCell* out, int capacity) {
+int PlaneverbGetImpulseResponse(float x, float y, float z, PlaneverbCell* out, int capacity) try {
     Context::Ref c;
     if (!c || capacity < 0) return -1;
     const int n = c->impulseResponse(x, y, z, out, capacity);
     if (n < 0) g_lastError = "impulse response not available (no completed iteration yet, or solver error)";
     return n;
-}
+} PV_API_CATCH(-1)
 
 // ---------------------------------------------------------------------------------------------------------------
 // Part 2: batch solver handle
 // ---------------------------------------------------------------------------------------------------------------
 
-const char* PvAmdLastError(void) {
+const char* PvAmdLastError(void) try {
     // A live module whose worker died reports that -- ONCE per failed context and thread, so that the errors of later,
     // unrelated calls on this thread (batch solver, slabs, communicator) stay readable.  PlaneverbWorkerError() always
     // has the worker's reason.
@@ -205,23 +237,23 @@ const char* PvAmdLastError(void) {
         }
     }
     return g_lastError.c_str();
-}
-const char* PlaneverbWorkerError(void) {
+} PV_API_CATCH("")
+const char* PlaneverbWorkerError(void) try {
     static thread_local std::string w;
     Context::Ref c;
     w = (c && c->failed()) ? c->workerError() : std::string();
     return w.c_str();
-}
-const char* PvAmdVersion(void) { return "planeverb_amd 0.2 (gfx950)"; }
+} PV_API_CATCH("")
+const char* PvAmdVersion(void) try { return "planeverb_amd 0.2 (gfx950)"; } PV_API_CATCH("")
 
 #ifndef PVA_HOST_TEST
-int PvAmdDeviceCount(void) {
+int PvAmdDeviceCount(void) try {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
-}
+} PV_API_CATCH(0)
 
-PvAmdSolver* PvAmdCreate(float gridSizeX, float gridSizeY, int gridResolution, int device) {
+PvAmdSolver* PvAmdCreate(float gridSizeX, float gridSizeY, int gridResolution, int device) try {
     if (gridResolution < kLowResolution || gridSizeX == 0.f || gridSizeY == 0.f) {
         g_lastError = "invalid config (pv_InvalidConfig)";  // PvContext.cpp:101-107
         return nullptr;
@@ -235,7 +267,7 @@ PvAmdSolver* PvAmdCreate(float gridSizeX, float gridSizeY, int gridResolution, i
         g_lastError = "HIP device index out of range";
         return nullptr;
     }
-    PvAmdSolver* h = new PvAmdSolver();
+    std::unique_ptr<PvAmdSolver> h(new PvAmdSolver());
     h->spec = makeGridSpec(gridSizeX, gridSizeY, gridResolution);
     h->device = device;
     if (h->spec.gx != h->spec.gy) {
@@ -246,33 +278,32 @@ PvAmdSolver* PvAmdCreate(float gridSizeX, float gridSizeY, int gridResolution, i
                                  "gy+1 throughout), not by the reference\n", h->spec.gx, h->spec.gy);
         warned = true;
     }
-    return h;
-}
+    return h.release();
+} PV_API_CATCH(nullptr)
 
-PvAmdSolver* PlaneverbCreateGrid(float gridSizeX, float gridSizeY, int gridResolution, int device) {
+PvAmdSolver* PlaneverbCreateGrid(float gridSizeX, float gridSizeY, int gridResolution, int device) try {
     return PvAmdCreate(gridSizeX, gridSizeY, gridResolution, device);
-}
+} PV_API_CATCH(nullptr)
 
-PvAmdSolver* PvAmdCreateSlabs(float gridSizeX, float gridSizeY, int gridResolution, const int* devices, int nslabs) {
+PvAmdSolver* PvAmdCreateSlabs(float gridSizeX, float gridSizeY, int gridResolution, const int* devices, int nslabs) try {
     if (!devices || nslabs < 2 || nslabs > 16) {
         g_lastError = "PvAmdCreateSlabs: 2..16 slabs and their devices";
         return nullptr;
     }
-    PvAmdSolver* h = PvAmdCreate(gridSizeX, gridSizeY, gridResolution, devices[0]);
+    std::unique_ptr<PvAmdSolver> h(PvAmdCreate(gridSizeX, gridSizeY, gridResolution, devices[0]));
     if (!h) return nullptr;
     const int n = PvAmdDeviceCount();
     for (int i = 0; i < nslabs; ++i) {
         if (devices[i] < 0 || devices[i] >= n) {
             g_lastError = "HIP device index out of range";
-            delete h;
             return nullptr;
         }
         h->slabDevices.push_back(devices[i]);
     }
-    return h;
-}
+    return h.release();
+} PV_API_CATCH(nullptr)
 
-int PvAmdGetSlabInfo(PvAmdSolver* h, PvAmdSlabInfo* out) {
+int PvAmdGetSlabInfo(PvAmdSolver* h, PvAmdSlabInfo* out) try {
     if (!out || !ensure(h, true) || !h->g) return -1;
     std::memset(out, 0, sizeof(*out));
     out->nslabs = h->g->numSlabs();
@@ -285,33 +316,31 @@ int PvAmdGetSlabInfo(PvAmdSolver* h, PvAmdSlabInfo* out) {
     out->haloBytesPerLaunch = h->g->haloBytesPerLaunch();
     out->exchangeBytesPerRun = h->g->exchangeBytesPerRun();
     return 0;
-}
+} PV_API_CATCH(-1)
 
 PvAmdSolver* PvAmdCreateSlabRank(float gridSizeX, float gridSizeY, int gridResolution, int device, int slabIndex,
-                                 int slabCount) {
-    PvAmdSolver* h = PvAmdCreate(gridSizeX, gridSizeY, gridResolution, device);
-    if (!h) return nullptr;
+                                 int slabCount) try {
     if (slabCount < 2 || slabIndex < 0 || slabIndex >= slabCount) {
         g_lastError = "PvAmdCreateSlabRank: 0 <= slabIndex < slabCount, slabCount >= 2";
-        delete h;
         return nullptr;
     }
+    PvAmdSolver* h = PvAmdCreate(gridSizeX, gridSizeY, gridResolution, device);
+    if (!h) return nullptr;
     h->opt.slabIndex = slabIndex;
     h->opt.slabCount = slabCount;
     return h;
-}
+} PV_API_CATCH(nullptr)
 
-int PvAmdComputeEfree(float gridSizeX, float gridSizeY, int gridResolution, int device, float* efree) {
+int PvAmdComputeEfree(float gridSizeX, float gridSizeY, int gridResolution, int device, float* efree) try {
     if (!efree) return -1;
-    PvAmdSolver* h = PvAmdCreate(gridSizeX, gridSizeY, gridResolution, device);
+    std::unique_ptr<PvAmdSolver> h(PvAmdCreate(gridSizeX, gridSizeY, gridResolution, device));
     if (!h) return -1;
     // a throw-away solver of a tiny grid would have another centre cell: the free-field run depends on the grid size
     // (FreeGrid.cpp:78-84), so the real config is used; its planes are what the windowed FreeGrid run needs anyway
-    const bool ok = ensure(h);
+    const bool ok = ensure(h.get());
     if (ok) *efree = h->s->efree();
-    PvAmdDestroy(h);
     return ok ? 0 : -1;
-}
+} PV_API_CATCH(-1)
 
 static Solver* slabOf(PvAmdSolver* h) {
     if (!ensure(h)) return nullptr;
@@ -322,91 +351,88 @@ static Solver* slabOf(PvAmdSolver* h) {
     return h->s;
 }
 
-int PvAmdSlabSetEfree(PvAmdSolver* h, float efree) {
+int PvAmdSlabSetEfree(PvAmdSolver* h, float efree) try {
     Solver* s = slabOf(h);
     if (!s) return -1;
     s->setEfree(efree);
     return 0;
-}
-int PvAmdSlabBegin(PvAmdSolver* h, float lx, float ly, float lz) {
+} PV_API_CATCH(-1)
+int PvAmdSlabBegin(PvAmdSolver* h, float lx, float ly, float lz) try {
     Solver* s = slabOf(h);
     return s ? ret(h, SlabRankOps::begin(*s, lx, ly, lz)) : -1;
-}
-int PvAmdSlabNumLaunches(PvAmdSolver* h) {
+} PV_API_CATCH(-1)
+int PvAmdSlabNumLaunches(PvAmdSolver* h) try {
     Solver* s = slabOf(h);
     return s ? SlabRankOps::numLaunches(*s) : -1;
-}
-int PvAmdSlabLaunch(PvAmdSolver* h, int li) {
+} PV_API_CATCH(-1)
+int PvAmdSlabLaunch(PvAmdSolver* h, int li) try {
     Solver* s = slabOf(h);
     return s ? ret(h, SlabRankOps::launch(*s, li)) : -1;
-}
-int PvAmdSlabHaloFloats(PvAmdSolver* h) {
+} PV_API_CATCH(-1)
+int PvAmdSlabHaloFloats(PvAmdSolver* h) try {
     Solver* s = slabOf(h);
     return s ? SlabRankOps::haloFloats(*s) : -1;
-}
-int PvAmdSlabExportHalo(PvAmdSolver* h, int side, float* host) {
+} PV_API_CATCH(-1)
+int PvAmdSlabExportHalo(PvAmdSolver* h, int side, float* host) try {
     Solver* s = slabOf(h);
     return (s && host) ? ret(h, SlabRankOps::exportHalo(*s, side, host)) : -1;
-}
-int PvAmdSlabImportHalo(PvAmdSolver* h, int side, const float* host) {
+} PV_API_CATCH(-1)
+int PvAmdSlabImportHalo(PvAmdSolver* h, int side, const float* host) try {
     Solver* s = slabOf(h);
     return (s && host) ? ret(h, SlabRankOps::importHalo(*s, side, host)) : -1;
-}
-int PvAmdSlabHistoryFloats(PvAmdSolver* h) {
+} PV_API_CATCH(-1)
+int PvAmdSlabHistoryFloats(PvAmdSolver* h) try {
     Solver* s = slabOf(h);
     return s ? SlabRankOps::historyFloats(*s) : -1;
-}
-int PvAmdSlabExportEdgeHistory(PvAmdSolver* h, float* host) {
+} PV_API_CATCH(-1)
+int PvAmdSlabExportEdgeHistory(PvAmdSolver* h, float* host) try {
     Solver* s = slabOf(h);
     return (s && host) ? ret(h, SlabRankOps::exportEdgeHistory(*s, host)) : -1;
-}
-int PvAmdSlabImportAboveHistory(PvAmdSolver* h, const float* host) {
+} PV_API_CATCH(-1)
+int PvAmdSlabImportAboveHistory(PvAmdSolver* h, const float* host) try {
     Solver* s = slabOf(h);
     return (s && host) ? ret(h, SlabRankOps::importAboveHistory(*s, host)) : -1;
-}
-int PvAmdSlabAnalyze(PvAmdSolver* h) {
+} PV_API_CATCH(-1)
+int PvAmdSlabAnalyze(PvAmdSolver* h) try {
     Solver* s = slabOf(h);
     return s ? ret(h, SlabRankOps::analyze(*s)) : -1;
-}
-long long PvAmdSlabWindowBlock(PvAmdSolver* h, int* info4, float* host, long long cap) {
+} PV_API_CATCH(-1)
+long long PvAmdSlabWindowBlock(PvAmdSolver* h, int* info4, float* host, long long cap) try {
     Solver* s = slabOf(h);
     if (!s || !info4) return -1;
     const long long n = SlabRankOps::windowBlock(*s, &info4[0], &info4[1], &info4[2], &info4[3], host, cap);
     if (n < 0) ret(h, false);
     return n;
-}
+} PV_API_CATCH(-1)
 
 struct PvAmdSlabRoot {
     SlabRoot* r = nullptr;
+    ~PvAmdSlabRoot() { delete r; }
 };
-PvAmdSlabRoot* PvAmdSlabRootCreate(PvAmdSolver* anySlab, int device) {
+PvAmdSlabRoot* PvAmdSlabRootCreate(PvAmdSolver* anySlab, int device) try {
     Solver* s = slabOf(anySlab);
     if (!s) return nullptr;
-    SlabRoot* r = SlabRoot::create(*s, device, &g_lastError);
-    if (!r) return nullptr;
-    PvAmdSlabRoot* h = new PvAmdSlabRoot();
-    h->r = r;
-    return h;
-}
-void PvAmdSlabRootDestroy(PvAmdSlabRoot* h) {
-    if (!h) return;
-    delete h->r;
+    std::unique_ptr<PvAmdSlabRoot> h(new PvAmdSlabRoot());
+    h->r = SlabRoot::create(*s, device, &g_lastError);
+    return h->r ? h.release() : nullptr;
+} PV_API_CATCH(nullptr)
+void PvAmdSlabRootDestroy(PvAmdSlabRoot* h) try {
     delete h;
-}
+} PV_API_CATCH_VOID
 static int rootRet(PvAmdSlabRoot* h, bool ok) {
     if (!ok && h && h->r) g_lastError = h->r->lastError();
     return ok ? 0 : -1;
 }
-int PvAmdSlabRootBegin(PvAmdSlabRoot* h, float lx, float ly, float lz) {
+int PvAmdSlabRootBegin(PvAmdSlabRoot* h, float lx, float ly, float lz) try {
     return (h && h->r) ? rootRet(h, h->r->begin(lx, ly, lz)) : -1;
-}
-int PvAmdSlabRootImportBlock(PvAmdSlabRoot* h, const int* info4, const float* host) {
+} PV_API_CATCH(-1)
+int PvAmdSlabRootImportBlock(PvAmdSlabRoot* h, const int* info4, const float* host) try {
     return (h && h->r && info4 && (host || info4[2] * info4[3] == 0))
                ? rootRet(h, h->r->importBlock(info4[0], info4[1], info4[2], info4[3], host))
                : -1;
-}
-int PvAmdSlabRootFinish(PvAmdSlabRoot* h) { return (h && h->r) ? rootRet(h, h->r->finish()) : -1; }
-int PvAmdSlabRootGetOutput(PvAmdSlabRoot* h, float ex, float ey, float ez, PlaneverbOutput* out) {
+} PV_API_CATCH(-1)
+int PvAmdSlabRootFinish(PvAmdSlabRoot* h) try { return (h && h->r) ? rootRet(h, h->r->finish()) : -1; } PV_API_CATCH(-1)
+int PvAmdSlabRootGetOutput(PvAmdSlabRoot* h, float ex, float ey, float ez, PlaneverbOutput* out) try {
     if (!h || !h->r || !out) return -1;
     float v[8];
     bool valid = false;
@@ -417,19 +443,16 @@ int PvAmdSlabRootGetOutput(PvAmdSlabRoot* h, float ex, float ey, float ez, Plane
     else
         out->occlusion = kInvalidDryGain;
     return 0;
-}
-int PvAmdSlabRootCopyResults(PvAmdSlabRoot* h, float* res8, float* delay) {
+} PV_API_CATCH(-1)
+int PvAmdSlabRootCopyResults(PvAmdSlabRoot* h, float* res8, float* delay) try {
     return (h && h->r) ? rootRet(h, h->r->copyResults(res8, delay)) : -1;
-}
+} PV_API_CATCH(-1)
 
-void PvAmdDestroy(PvAmdSolver* h) {
-    if (!h) return;
-    delete h->s;
-    delete h->g;
+void PvAmdDestroy(PvAmdSolver* h) try {
     delete h;
-}
+} PV_API_CATCH_VOID
 
-int PvAmdSetOption(PvAmdSolver* h, int key, long long value) {
+int PvAmdSetOption(PvAmdSolver* h, int key, long long value) try {
     if (!h) return -1;
     if (h->s || h->g) {
         g_lastError = "options must be set before the solver is first used";
@@ -468,9 +491,9 @@ int PvAmdSetOption(PvAmdSolver* h, int key, long long value) {
         default: g_lastError = "unknown option"; return -1;
     }
     return 0;
-}
+} PV_API_CATCH(-1)
 
-int PvAmdGetInfo(PvAmdSolver* h, PvAmdInfo* out) {
+int PvAmdGetInfo(PvAmdSolver* h, PvAmdInfo* out) try {
     if (!out || !ensure(h, true)) return -1;
     if (h->g) {
         const GridSpec& g = h->g->spec();
@@ -520,28 +543,28 @@ int PvAmdGetInfo(PvAmdSolver* h, PvAmdInfo* out) {
     out->streamFuse = h->s->streamFuse() ? 1 : 0;
     out->residentKernel = h->s->residentKernel() ? 1 : 0;
     return 0;
-}
+} PV_API_CATCH(-1)
 
-int PvAmdAddGeometry(PvAmdSolver* h, float posX, float posY, float width, float height, float absorption) {
+int PvAmdAddGeometry(PvAmdSolver* h, float posX, float posY, float width, float height, float absorption) try {
     if (!ensure(h, true)) return -1;
     if (h->g) return h->g->addBox(Box{posX, posY, width, height, absorption});
     return h->s->addBox(Box{posX, posY, width, height, absorption});
-}
+} PV_API_CATCH(-1)
 
 int PvAmdUpdateGeometry(PvAmdSolver* h, int id, float posX, float posY, float width, float height,
-                        float absorption) {
+                        float absorption) try {
     if (!ensure(h, true)) return -1;
     if (h->g) return ret(h, h->g->updateBox(id, Box{posX, posY, width, height, absorption}));
     return ret(h, h->s->updateBox(id, Box{posX, posY, width, height, absorption}));
-}
+} PV_API_CATCH(-1)
 
-int PvAmdRemoveGeometry(PvAmdSolver* h, int id) {
+int PvAmdRemoveGeometry(PvAmdSolver* h, int id) try {
     if (!ensure(h, true)) return -1;
     if (h->g) return ret(h, h->g->removeBox(id));
     return ret(h, h->s->removeBox(id));
-}
+} PV_API_CATCH(-1)
 
-int PvAmdLoadScene(PvAmdSolver* h, const char* pvPath) {
+int PvAmdLoadScene(PvAmdSolver* h, const char* pvPath) try {
     if (!ensure(h, true) || !pvPath) return -1;
     std::vector<Box> boxes;
     if (!loadPv(pvPath, &boxes, &g_lastError)) return -1;
@@ -552,34 +575,34 @@ int PvAmdLoadScene(PvAmdSolver* h, const char* pvPath) {
             h->s->addBox(b);
     }
     return (int)boxes.size();
-}
+} PV_API_CATCH(-1)
 
-int PvAmdSaveScene(PvAmdSolver* h, const char* pvPath) {
+int PvAmdSaveScene(PvAmdSolver* h, const char* pvPath) try {
     if (!ensure(h) || !pvPath) return -1;
     return savePv(pvPath, h->s->boxes(), &g_lastError) ? 0 : -1;
-}
+} PV_API_CATCH(-1)
 
-int PvAmdRun(PvAmdSolver* h, float lx, float ly, float lz) {
+int PvAmdRun(PvAmdSolver* h, float lx, float ly, float lz) try {
     if (!wholeGrid(h) || !ensure(h, true)) return -1;
     if (h->g) return ret(h, h->g->run(lx, ly, lz));
     return ret(h, h->s->run(lx, ly, lz, true));
-}
+} PV_API_CATCH(-1)
 
-int PvAmdRunAsync(PvAmdSolver* h, float lx, float ly, float lz) {
+int PvAmdRunAsync(PvAmdSolver* h, float lx, float ly, float lz) try {
     if (!wholeGrid(h) || !ensure(h)) return -1;
     return ret(h, h->s->run(lx, ly, lz, false));
-}
+} PV_API_CATCH(-1)
 
-int PvAmdRunAsyncAfter(PvAmdSolver* h, PvAmdSolver* prev, float lx, float ly, float lz) {
+int PvAmdRunAsyncAfter(PvAmdSolver* h, PvAmdSolver* prev, float lx, float ly, float lz) try {
     if (!wholeGrid(h) || !ensure(h) || !prev || !wholeGrid(prev) || !ensure(prev)) return -1;
     if (prev->s->spec().gx != h->s->spec().gx || prev->s->spec().gy != h->s->spec().gy || prev->s->device() != h->s->device()) {
         g_lastError = "PvAmdRunAsyncAfter: the two solvers must have the same grid and device";
         return -1;
     }
     return ret(h, h->s->run(lx, ly, lz, false, prev->s));
-}
+} PV_API_CATCH(-1)
 
-int PvAmdRunBatch(PvAmdSolver* const* hs, int n, const float* listenersXYZ, int wait) {
+int PvAmdRunBatch(PvAmdSolver* const* hs, int n, const float* listenersXYZ, int wait) try {
     if (!hs || !listenersXYZ || n < 1 || n > kBatchMax) {
         g_lastError = "PvAmdRunBatch: 1..8 solvers and their listener positions";
         return -1;
@@ -593,22 +616,25 @@ int PvAmdRunBatch(PvAmdSolver* const* hs, int n, const float* listenersXYZ, int 
     if (Solver::runBatch(s, n, listenersXYZ, wait != 0, &err)) return 0;
     g_lastError = err.empty() ? "batched run failed" : err;
     return -1;
-}
+} PV_API_CATCH(-1)
 
-int PvAmdSync(PvAmdSolver* h) {
+int PvAmdSync(PvAmdSolver* h) try {
     if (!wholeGrid(h) || !ensure(h)) return -1;
     return ret(h, h->s->sync());
-}
+} PV_API_CATCH(-1)
 
-float PvAmdClockProbe(int device, float* byMemtimeMHz) {
-    try {
-        return clockProbeMHz(device, byMemtimeMHz);
-    } catch (...) {
-        return 0.f;
-    }
-}
+float PvAmdClockProbe(int device, float* byMemtimeMHz) try {
+    return clockProbeMHz(device, byMemtimeMHz);
+} PV_API_CATCH(0.f)
 
-int PvAmdGetTimings(PvAmdSolver* h, PvAmdTimings* out) {
+int PvAmdBandwidthProbe(int device, float* gbPerS4) try {
+    if (!gbPerS4) return -1;
+    if (bandwidthProbeGBs(device, gbPerS4)) return 0;
+    g_lastError = "PvAmdBandwidthProbe: allocation or launch failed (2 GiB of device memory are needed)";
+    return -1;
+} PV_API_CATCH(-1)
+
+int PvAmdGetTimings(PvAmdSolver* h, PvAmdTimings* out) try {
     if (!out || !ensure(h, true)) return -1;
     const SolverTimings& t = h->g ? h->g->timings() : h->s->timings();
     out->fdtdMs = t.fdtdMs;
@@ -625,14 +651,14 @@ int PvAmdGetTimings(PvAmdSolver* h, PvAmdTimings* out) {
     out->activeCells = t.activeCells;
     out->silentCells = t.silentCells;
     return 0;
-}
+} PV_API_CATCH(-1)
 
-int PvAmdSetEmitters(PvAmdSolver* h, const float* xyz, int n) {
+int PvAmdSetEmitters(PvAmdSolver* h, const float* xyz, int n) try {
     if (!wholeGrid(h) || !ensure(h) || (n > 0 && !xyz)) return -1;
     return ret(h, h->s->setEmitters(xyz, n));
-}
+} PV_API_CATCH(-1)
 
-int PvAmdGetOutput(PvAmdSolver* h, float ex, float ey, float ez, PlaneverbOutput* out) {
+int PvAmdGetOutput(PvAmdSolver* h, float ex, float ey, float ez, PlaneverbOutput* out) try {
     if (!wholeGrid(h) || !out || !ensure(h, true)) return -1;
     float v[8];
     bool valid = false;
@@ -644,14 +670,14 @@ int PvAmdGetOutput(PvAmdSolver* h, float ex, float ey, float ez, PlaneverbOutput
     }
     std::memcpy(out, v, sizeof(*out));
     return 0;
-}
+} PV_API_CATCH(-1)
 
-int PvAmdSetOutputQueries(PvAmdSolver* h, const float* xyz, int n) {
+int PvAmdSetOutputQueries(PvAmdSolver* h, const float* xyz, int n) try {
     if (!wholeGrid(h) || (n > 0 && !xyz) || !ensure(h)) return -1;
     return ret(h, h->s->setOutputQueries(xyz, n));
-}
+} PV_API_CATCH(-1)
 
-int PvAmdGetQueriedOutputs(PvAmdSolver* h, PlaneverbOutput* out, int n) {
+int PvAmdGetQueriedOutputs(PvAmdSolver* h, PlaneverbOutput* out, int n) try {
     if (n < 0 || n > Solver::kMaxQueries || (n > 0 && !out) || !wholeGrid(h) || !ensure(h)) return -1;
     float v[Solver::kMaxQueries * 8];
     unsigned char valid[Solver::kMaxQueries];
@@ -665,58 +691,58 @@ int PvAmdGetQueriedOutputs(PvAmdSolver* h, PlaneverbOutput* out, int n) {
         }
     }
     return 0;
-}
+} PV_API_CATCH(-1)
 
-int PvAmdCopyResults(PvAmdSolver* h, float* res8, float* delay) {
+int PvAmdCopyResults(PvAmdSolver* h, float* res8, float* delay) try {
     if (!wholeGrid(h) || !ensure(h, true)) return -1;
     return ret(h, h->g ? h->g->copyResults(res8, delay) : h->s->copyResults(res8, delay));
-}
+} PV_API_CATCH(-1)
 
-int PvAmdCopyResultsBlock(PvAmdSolver* h, int r0, int c0, int nr, int nc, float* res8, float* delay) {
+int PvAmdCopyResultsBlock(PvAmdSolver* h, int r0, int c0, int nr, int nc, float* res8, float* delay) try {
     if (!wholeGrid(h) || !ensure(h)) return -1;
     return ret(h, h->s->copyResultsBlock(r0, c0, nr, nc, res8, delay));
-}
+} PV_API_CATCH(-1)
 
-int PvAmdGetImpulseResponse(PvAmdSolver* h, int cx, int cy, float* out3T) {
+int PvAmdGetImpulseResponse(PvAmdSolver* h, int cx, int cy, float* out3T) try {
     if (!out3T || !ensure(h, true)) return -1;
     return ret(h, h->g ? h->g->impulseResponse(cx, cy, out3T) : h->s->impulseResponse(cx, cy, out3T));
-}
+} PV_API_CATCH(-1)
 
-int PvAmdGetImpulseResponseCells(PvAmdSolver* h, int cx, int cy, PlaneverbCell* outT) {
+int PvAmdGetImpulseResponseCells(PvAmdSolver* h, int cx, int cy, PlaneverbCell* outT) try {
     if (!outT || !ensure(h)) return -1;
     static_assert(sizeof(PlaneverbCell) == 16, "PvTypes.h:106-121");
     return ret(h, h->s->impulseResponseCells(cx, cy, outT));
-}
+} PV_API_CATCH(-1)
 
-int PvAmdCopyFields(PvAmdSolver* h, float* pr, float* vx, float* vy) {
+int PvAmdCopyFields(PvAmdSolver* h, float* pr, float* vx, float* vy) try {
     if (!ensure(h, true)) return -1;
     return ret(h, h->g ? h->g->copyFields(pr, vx, vy) : h->s->copyFields(pr, vx, vy));
-}
+} PV_API_CATCH(-1)
 
-int PvAmdCopyHistoryPlane(PvAmdSolver* h, int t, float* pr) {
+int PvAmdCopyHistoryPlane(PvAmdSolver* h, int t, float* pr) try {
     if (!pr || !ensure(h, true)) return -1;
     return ret(h, h->g ? h->g->copyHistoryPlane(t, pr) : h->s->copyHistoryPlane(t, pr));
-}
+} PV_API_CATCH(-1)
 
-int PvAmdCopyPulse(PvAmdSolver* h, float* out) {
+int PvAmdCopyPulse(PvAmdSolver* h, float* out) try {
     if (!out || !ensure(h, true)) return -1;
     return ret(h, h->g ? h->g->copyPulse(out) : h->s->copyPulse(out));
-}
+} PV_API_CATCH(-1)
 
-int PvAmdCopyMaterial(PvAmdSolver* h, uint8_t* beta, float* R) {
+int PvAmdCopyMaterial(PvAmdSolver* h, uint8_t* beta, float* R) try {
     if (!ensure(h, true)) return -1;
     return ret(h, h->g ? h->g->copyMaterial(beta, R) : h->s->copyMaterial(beta, R));
-}
+} PV_API_CATCH(-1)
 
-int PvAmdSetFields(PvAmdSolver* h, const float* pr, const float* vx, const float* vy) {
+int PvAmdSetFields(PvAmdSolver* h, const float* pr, const float* vx, const float* vy) try {
     if (!ensure(h)) return -1;
     return ret(h, h->s->setFields(pr, vx, vy));
-}
+} PV_API_CATCH(-1)
 
-int PvAmdRunSteps(PvAmdSolver* h, int nsteps, int withPulse, float lx, float lz) {
+int PvAmdRunSteps(PvAmdSolver* h, int nsteps, int withPulse, float lx, float lz) try {
     if (!wholeGrid(h) || !ensure(h)) return -1;
     return ret(h, h->s->runSteps(nsteps, withPulse != 0, lx, lz));
-}
+} PV_API_CATCH(-1)
 
 // ---------------------------------------------------------------------------------------------------------------
 // Part 3: sharded runs + RCCL gather
@@ -724,19 +750,20 @@ int PvAmdRunSteps(PvAmdSolver* h, int nsteps, int withPulse, float lx, float lz)
 
 struct PvAmdComm {
     Comm* c = nullptr;
+    ~PvAmdComm() { delete c; }
 };
 
-int PvAmdShardPlan(int nRuns, int world, int rank, int nLocalSolvers, int* runIdx, int* solverIdx, int cap) {
+int PvAmdShardPlan(int nRuns, int world, int rank, int nLocalSolvers, int* runIdx, int* solverIdx, int cap) try {
     const std::vector<ShardItem> plan = shardPlan(nRuns, world, rank, nLocalSolvers);
     for (int i = 0; i < (int)plan.size() && i < cap; ++i) {
         if (runIdx) runIdx[i] = plan[(size_t)i].run;
         if (solverIdx) solverIdx[i] = plan[(size_t)i].solver;
     }
     return (int)plan.size();
-}
+} PV_API_CATCH(-1)
 
 int PvAmdPlanSegments(const unsigned char* air, int ntx, int nty, int tileRows, int maxTileColumns, int target, int* seg4,
-                      int cap) {
+                      int cap) try {
     if (!air || ntx < 1 || nty < 1) return 0;
     const std::vector<SegRect> segs = planSegments(air, ntx, nty, tileRows, maxTileColumns, target);
     for (int i = 0; i < (int)segs.size() && i < cap && seg4; ++i) {
@@ -746,35 +773,31 @@ int PvAmdPlanSegments(const unsigned char* air, int ntx, int nty, int tileRows, 
         seg4[4 * i + 3] = segs[(size_t)i].w;
     }
     return (int)segs.size();
-}
+} PV_API_CATCH(0)
 
-int PvAmdCommUniqueId(char id128[128]) {
+int PvAmdCommUniqueId(char id128[128]) try {
     if (!id128) return -1;
     return Comm::uniqueId(id128, &g_lastError) ? 0 : -1;
-}
+} PV_API_CATCH(-1)
 
-PvAmdComm* PvAmdCommCreate(const char id128[128], int rank, int world, int device) {
+PvAmdComm* PvAmdCommCreate(const char id128[128], int rank, int world, int device) try {
     if (!id128) return nullptr;
-    Comm* c = Comm::create(id128, rank, world, device, &g_lastError);
-    if (!c) return nullptr;
-    PvAmdComm* h = new PvAmdComm();
-    h->c = c;
-    return h;
-}
+    std::unique_ptr<PvAmdComm> h(new PvAmdComm());
+    h->c = Comm::create(id128, rank, world, device, &g_lastError);
+    return h->c ? h.release() : nullptr;
+} PV_API_CATCH(nullptr)
 
-void PvAmdCommDestroy(PvAmdComm* h) {
-    if (!h) return;
-    delete h->c;
+void PvAmdCommDestroy(PvAmdComm* h) try {
     delete h;
-}
+} PV_API_CATCH_VOID
 
-int PvAmdCommAllGather(PvAmdComm* h, const float* mine, int countPerRank, float* all) {
+int PvAmdCommAllGather(PvAmdComm* h, const float* mine, int countPerRank, float* all) try {
     if (!h || !h->c || !mine || !all) return -1;
     return h->c->allGather(mine, countPerRank, all, &g_lastError) ? 0 : -1;
-}
+} PV_API_CATCH(-1)
 
 int PvAmdRunSharded(PvAmdSolver* const* hs, int nSolvers, const float* listenersXYZ, int nRuns, const float* emittersXYZ,
-                    int E, int rank, int world, PvAmdComm* comm, PlaneverbOutput* out) {
+                    int E, int rank, int world, PvAmdComm* comm, PlaneverbOutput* out) try {
     if (!hs || nSolvers < 1 || !listenersXYZ || nRuns < 0 || (E > 0 && !emittersXYZ) || E < 0 || E > Solver::kMaxQueries ||
         !out || world < 1 || rank < 0 || rank >= world) {
         g_lastError = "PvAmdRunSharded: invalid arguments";
@@ -831,11 +854,11 @@ int PvAmdRunSharded(PvAmdSolver* const* hs, int nSolvers, const float* listeners
     for (int k = 0; k < nRuns; ++k)  // run k = the (k / world)-th run of rank k mod world
         std::memcpy(o + (size_t)k * rec, all.data() + ((size_t)(k % world) * perRank + (size_t)(k / world)) * rec, rec * 4);
     return 0;
-}
+} PV_API_CATCH(-1)
 
 #endif  // !PVA_HOST_TEST
 
-int PvAmdHostGridInfo(float sx, float sy, int res, PvAmdInfo* out) {
+int PvAmdHostGridInfo(float sx, float sy, int res, PvAmdInfo* out) try {
     if (!out || res < kLowResolution) return -1;
     const GridSpec g = makeGridSpec(sx, sy, res);
     std::memset(out, 0, sizeof(*out));
@@ -847,20 +870,20 @@ int PvAmdHostGridInfo(float sx, float sy, int res, PvAmdInfo* out) {
     out->dx = g.dx;
     out->dt = g.dt;
     return 0;
-}
+} PV_API_CATCH(-1)
 
-int PvAmdHostPulseSelfCheck(void) { return pulseMatchesReferenceLibm() ? 1 : 0; }
+int PvAmdHostPulseSelfCheck(void) try { return pulseMatchesReferenceLibm() ? 1 : 0; } PV_API_CATCH(0)
 
-int PvAmdHostPulse(float sx, float sy, int res, float* out) {
+int PvAmdHostPulse(float sx, float sy, int res, float* out) try {
     if (!out || res < kLowResolution) return -1;
     const GridSpec g = makeGridSpec(sx, sy, res);
     const std::vector<float> p = gaussianPulse(g);
     std::memcpy(out, p.data(), p.size() * sizeof(float));
     return 0;
-}
+} PV_API_CATCH(-1)
 
 int PvAmdHostRasterize(float sx, float sy, int res, const float* b5, const int* ops, int n, uint8_t* beta,
-                       float* R) {
+                       float* R) try {
     if (res < kLowResolution) return -1;
     const GridSpec g = makeGridSpec(sx, sy, res);
     MaterialPlane m;
@@ -876,9 +899,9 @@ int PvAmdHostRasterize(float sx, float sy, int res, const float* b5, const int* 
     if (beta) std::memcpy(beta, m.beta().data(), cells);
     if (R) std::memcpy(R, m.R().data(), cells * sizeof(float));
     return 0;
-}
+} PV_API_CATCH(-1)
 
-int PvAmdHostLoadPv(const char* path, float* b5, int maxBoxes) {
+int PvAmdHostLoadPv(const char* path, float* b5, int maxBoxes) try {
     if (!path) return -1;
     std::vector<Box> boxes;
     if (!loadPv(path, &boxes, &g_lastError)) return -1;
@@ -890,18 +913,18 @@ int PvAmdHostLoadPv(const char* path, float* b5, int maxBoxes) {
         b5[5 * i + 4] = boxes[(size_t)i].R;
     }
     return (int)boxes.size();
-}
+} PV_API_CATCH(-1)
 
-int PvAmdHostSavePv(const char* path, const float* b5, const int* ids, int n) {
+int PvAmdHostSavePv(const char* path, const float* b5, const int* ids, int n) try {
     if (!path || (n > 0 && !b5)) return -1;
     std::vector<std::pair<int, Box>> boxes;
     for (int i = 0; i < n; ++i)
         boxes.emplace_back(ids ? ids[i] : i, Box{b5[5 * i], b5[5 * i + 1], b5[5 * i + 2], b5[5 * i + 3], b5[5 * i + 4]});
     return savePv(path, boxes, &g_lastError) ? 0 : -1;
-}
+} PV_API_CATCH(-1)
 
 int PvAmdHostCells(float sx, float sy, int res, float x, float z, int* lcx, int* lcy, int* rcx, int* rcy,
-                   int* rvalid) {
+                   int* rvalid) try {
     if (res < kLowResolution) return -1;
     const GridSpec g = makeGridSpec(sx, sy, res);
     listenerCell(g, x, z, lcx, lcy);
@@ -910,10 +933,10 @@ int PvAmdHostCells(float sx, float sy, int res, float x, float z, int* lcx, int*
     *rcx = cx;
     *rcy = cy;
     return 0;
-}
+} PV_API_CATCH(-1)
 
-void PvAmdReverbBusGains(float rt60, float wetGain, float* a, float* b, float* c) {
+void PvAmdReverbBusGains(float rt60, float wetGain, float* a, float* b, float* c) try {
     reverbBusGains(rt60, wetGain, a, b, c);
-}
+} PV_API_CATCH_VOID
 
 }  // extern "C"

@@ -92,14 +92,17 @@ bool Context::init(const LiveConfig& cfg, std::string* err) {
     SolverOptions opt;
     opt.autoStreaming = true;
     if (const char* e = std::getenv("PLANEVERB_AMD_LIVE_STREAMING")) opt.streaming = std::atoi(e) != 0;
-    Context* c = new Context();
+    // (owned until it is published: an exception from underneath -- a table or the worker thread that cannot be created --
+    // unwinds through ~Context, which stops the worker and releases the solvers, and ends at the C-ABI's barrier, pv_capi.cpp)
+    struct Owner {
+        Context* c;
+        ~Owner() { delete c; }
+    } own{new Context()};
+    Context* const c = own.c;
     static std::atomic<unsigned long long> generations{0};
     c->generation_ = generations.fetch_add(1) + 1;
     c->solver_ = Solver::create(spec, device, opt, err);
-    if (!c->solver_) {
-        delete c;
-        return false;
-    }
+    if (!c->solver_) return false;
     c->streaming_ = c->solver_->options().streaming;
     c->lastSolver_ = c->solver_;
     // Two iterations in flight where an iteration leaves most of the chip idle: the grids the resident kernel serves (the
@@ -108,10 +111,7 @@ bool Context::init(const LiveConfig& cfg, std::string* err) {
     if (const char* e = std::getenv("PLANEVERB_AMD_LIVE_PIPELINE")) pipeline = std::atoi(e) >= 2 && !c->streaming_ ? 2 : 1;
     if (pipeline == 2) {
         c->solver2_ = Solver::create(spec, device, opt, err);
-        if (!c->solver2_) {
-            delete c;
-            return false;
-        }
+        if (!c->solver2_) return false;
     }
     if (c->streaming_)
         std::fprintf(stderr, "[planeverb_amd] %d x %d grid, T = %d: sparse-emitter mode (wet gain / RT60 for the cells of the "
@@ -121,12 +121,12 @@ bool Context::init(const LiveConfig& cfg, std::string* err) {
         s.data = static_cast<float*>(Solver::hostAlloc(bytes));
         if (!s.data) {
             if (err) *err = "pinned host allocation failed for the published result block";
-            delete c;
             return false;
         }
     }
     c->running_.store(true);
-    c->worker_ = std::thread(c->solver2_ ? &Context::workerLoopPipelined : &Context::workerLoop, c);  // PvContext.cpp:160
+    c->worker_ = std::thread(&Context::workerMain, c);  // PvContext.cpp:160
+    own.c = nullptr;
     g_context.store(c, std::memory_order_seq_cst);
     return true;
 }
@@ -173,6 +173,35 @@ bool Context::registerEmitters() {
         }
     }
     return solver_->setEmitters(xyz.data(), (int)(xyz.size() / 3));
+}
+
+// The thread's entry: no exception leaves the worker (std::terminate would take the host process -- the game -- with it).
+// One that reaches this point stops the worker like a solver error does: IsRunning reports 0, PvAmdLastError /
+// PlaneverbWorkerError carry the reason, GetOutput keeps serving the last published iteration.
+void Context::workerMain() {
+    try {
+        if (solver2_)
+            workerLoopPipelined();
+        else
+            workerLoop();
+        return;
+    } catch (const std::exception& e) {
+        try {
+            std::lock_guard<std::mutex> lock(errMutex_);
+            workerErr_ = std::string("exception in the simulation worker: ") + e.what();
+        } catch (...) {
+        }
+    } catch (...) {
+        try {
+            std::lock_guard<std::mutex> lock(errMutex_);
+            workerErr_ = "unknown exception in the simulation worker";
+        } catch (...) {
+        }
+    }
+    std::fprintf(stderr, "[planeverb_amd] simulation worker stopped on an exception\n");
+    failed_.store(true, std::memory_order_release);
+    running_.store(false);
+    iterCv_.notify_all();
 }
 
 void Context::workerLoop() {
@@ -534,11 +563,21 @@ int Context::impulseResponse(float x, float y, float z, void* cells16, int cap) 
 // geometry
 // ----------------------------------------------------------------------------------------------------------------
 
+namespace {
+// Room for k more elements BEFORE a table operation commits anything: the only step that can throw (std::bad_alloc) then
+// happens while the tables are still what they were, and the push_backs behind it cannot fail (geometric growth kept).
+template <class V>
+void ensureRoom(V& v, size_t k) {
+    if (v.capacity() - v.size() < k) v.reserve(std::max(v.capacity() * 2, v.size() + k));
+}
+}  // namespace
+
 int Context::addGeometry(const Box& b) {
     // (a non-finite absorption is refused: NaN marks air in the material and coefficient planes, pv_solver.cpp addBox)
     if (!std::isfinite(b.R)) return -1;
     std::lock_guard<std::mutex> lock(geomMutex_);
     int id;
+    ensureRoom(changes_, 1);
     if (geometryFree_.empty()) {  // GeometryManager.cpp:70-79
         id = (int)geometry_.size();
         geometry_.push_back(b);
@@ -554,6 +593,8 @@ int Context::addGeometry(const Box& b) {
 void Context::removeGeometry(int id) {
     std::lock_guard<std::mutex> lock(geomMutex_);
     if (id < 0 || id >= (int)geometry_.size()) return;
+    ensureRoom(changes_, 1);
+    ensureRoom(geometryFree_, 1);
     changes_.push_back({false, geometry_[(size_t)id]});  // GeometryManager.cpp:101-110
     geometry_[(size_t)id] = Box{0, 0, 0, 0, 0};
     geometryFree_.push_back(id);
@@ -563,6 +604,7 @@ void Context::updateGeometry(int id, const Box& b) {
     if (!std::isfinite(b.R)) return;
     std::lock_guard<std::mutex> lock(geomMutex_);
     if (id < 0 || id >= (int)geometry_.size()) return;
+    ensureRoom(changes_, 2);
     changes_.push_back({false, geometry_[(size_t)id]});  // GeometryManager.cpp:112-121
     geometry_[(size_t)id] = b;
     changes_.push_back({true, b});

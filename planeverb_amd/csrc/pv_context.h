@@ -108,6 +108,7 @@ public:
 private:
     Context() = default;
     ~Context();
+    void workerMain();
     void workerLoop();
     // Pipelined iterations (small grids): TWO solvers, two iterations in flight.  Iteration i + 1 starts -- with the listener
     // latched and the geometry pushed at that moment, as in the reference's loop (PvContext.cpp:86-89) -- while iteration i is

@@ -1,4 +1,8 @@
-// pv_fused.hip -- the WHOLE impulse-response analysis of a small grid as one launch (round 5).
+// pv_fused.hip -- the WHOLE impulse-response analysis of a small grid as one launch (round 5): an arm of the EXPERIMENTAL build
+// (-DPV_EXPERIMENTAL, libplaneverb_amd_exp.so) -- built, bit-identical to the separate kernels, measured slower than them
+// (docs/experiments/fused_analysis.md) and therefore not in the product library, which refuses PVA_OPT_FUSED_ANALYSIS = 1;
+// its equivalence tests (tests/test_gpu_resident.py::test_fused_analysis_*) load the experimental build.  The run's LAST kernel
+// (pv_run_finish_kernel, at the end of this file) is product code.
 //
 // The grids the reference ships (its resolution presets on a 25 m scene: 70^2 ... 254^2 cells, include/PvTypes.h:21-30) run
 // their T stencil steps as ONE launch (pv_resident.hip), but the analysis behind it (Analyzer::AnalyzeResponses,
@@ -29,6 +33,7 @@
 #include <cfloat>
 #include <climits>
 #include <cstdint>
+#include <cstdlib>
 
 #include "pv_analysis.h"
 #include "pv_analysis_dev.h"
@@ -39,6 +44,7 @@
 
 namespace pva {
 
+#ifdef PV_EXPERIMENTAL
 namespace {
 
 constexpr int kFusedThreads = 320;      // waves 0-3: a quarter of the item's cells each (decay time), wave 4: their dry windows
@@ -196,6 +202,9 @@ __global__ __launch_bounds__(kFusedThreads) void pv_analysis_fused_kernel(const 
     __shared__ FusedShared sh;
     const AnalyzeArgs& a = f.a;
     unsigned* const ctl = f.ctl;
+    // (a run whose stencil was given up -- resident kernel, errFlag 3 / 4 -- has a half-written history: nothing to analyse, as in
+    // every separate kernel.  Grid-uniform, and no ticket has been drawn: the control words stay at zero.)
+    if (analysisAborted(a)) return;
     const DynParams dyn = *a.dyn;
     fillLogTab(sh.tab, threadIdx.x, kFusedThreads);
     const int active = fusedActiveCells(a, dyn, sh);  // (synchronises: the table is in place)
@@ -294,6 +303,8 @@ __global__ __launch_bounds__(kFusedThreads) void pv_analysis_fused_kernel(const 
     }
 }
 
+bool fusedAnalysisBuilt() { return true; }
+
 bool fusedAnalysisOk(const AnalyzeArgs& a) {
     // phase counters: 1 ticket + (2 + passes + 1) phases + 1 exit word
     return 1 + 2 + dirJumpPasses(a.T) + 1 + 1 <= kFusedCtlWords;
@@ -301,11 +312,19 @@ bool fusedAnalysisOk(const AnalyzeArgs& a) {
 
 void launchAnalysisFused(const FusedArgs& f, hipStream_t stream) {
     // enough workers to hold every item of the widest phase at once where the chip has room for them (tickets make any number
-    // correct); a worker is five waves
+    // correct); a worker is five waves.  PLANEVERB_AMD_FUSED_WORKERS caps the number (the equivalence tests run the launch with
+    // 1, 2 and 3 workers: "no deadlock whatever the number of resident workgroups").
     const long long items = (f.a.histPlane + 15) / 16;
-    const unsigned grid = (unsigned)std::min<long long>(std::max<long long>(items, 64), 1024);
+    unsigned grid = (unsigned)std::min<long long>(std::max<long long>(items, 64), 1024);
+    if (const char* e = std::getenv("PLANEVERB_AMD_FUSED_WORKERS"))
+        if (std::atoi(e) > 0) grid = std::min(grid, (unsigned)std::atoi(e));
     hipLaunchKernelGGL(pv_analysis_fused_kernel, dim3(grid), dim3(kFusedThreads), 0, stream, f);
 }
+#else   // product build: the arm is not compiled in (Solver::init refuses the option)
+bool fusedAnalysisBuilt() { return false; }
+bool fusedAnalysisOk(const AnalyzeArgs&) { return false; }
+void launchAnalysisFused(const FusedArgs&, hipStream_t) {}
+#endif  // PV_EXPERIMENTAL
 
 // ---------------------------------------------------------------------------------------------------------------
 // last kernel of a run: the registered output queries (pv_gather_queries_kernel) and the status words (pv_run_status_kernel)

@@ -58,6 +58,8 @@ void launchResident(int K, int rxi, const ResidentArgs& a, hipStream_t stream);
 bool streamsShareQueue(hipStream_t a, hipStream_t b, unsigned long long* stamps);
 // shader clock of the moment (pv_probe.hip): MHz by a timed s_sleep, or 0
 float clockProbeMHz(int device, float* byMemtime);
+// the device's own streaming bandwidth in GB/s: {copy 16 B per lane, copy 4 B per lane, read only, write only} (pv_probe.hip)
+bool bandwidthProbeGBs(int device, float out[4]);
 // error flag, {cells of non-zero tiles, cells with an onset}, resident claim counter (or NULL) -> 4 ints of pinned host memory
 void launchRunStatus(const int* err, int* counts, const unsigned* claims, int* outHost, hipStream_t stream);
 #ifdef PV_RESIDENT_TRACE
@@ -84,6 +86,7 @@ void launchRt60(const AnalyzeArgs& a, hipStream_t stream);    // wet gain, decay
 void launchAnalysisDirection(const AnalyzeArgs& a, hipStream_t stream);
 // the whole analysis of a grid whose history window is the grid, in one launch (pv_fused.hip); fusedAnalysisOk: its phase
 // counters fit; launchRunFinish: a run's output queries + status words in one launch (last kernel of a run)
+bool fusedAnalysisBuilt();  // false in the product build: the arm lives in the experimental build only
 bool fusedAnalysisOk(const AnalyzeArgs& a);
 void launchAnalysisFused(const FusedArgs& f, hipStream_t stream);
 // (zeroWords / nZero: words to clear behind everything else -- the resident kernel's flags, for the next run; with them the error flag)

@@ -95,4 +95,75 @@ float clockProbeMHz(int device, float* byMemtime) {
     return (float)(100.0 * 127.0 * 64.0 / (double)host[0] * 100.0);
 }
 
+// The box's own streaming bandwidth (SURVEY.md 8d "confirm on the box with a device-to-device copy micro-benchmark and report
+// against both"): tools/hbm_calib.hip's legs made callable, for bench.py's roofline record.  1 GiB per buffer (four times the
+// 256 MiB Infinity Cache), best of five launches each, HIP events on a stream of its own:
+//   out[0] copy, 16 B per lane (bytes read + written per second)     out[1] copy, 4 B per lane
+//   out[2] read only, 4 B per lane in 256-byte rows per wave (the stencil kernels' load pattern)     out[3] write only, likewise
+namespace {
+__global__ __launch_bounds__(256) void pv_bw_copy16_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long long n4) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void pv_bw_copy4_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void pv_bw_read_kernel(const float* __restrict__ src, float* sink, long long nfloat) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), rows = nfloat / 64;
+    float acc = 0.f;
+    for (long long r = wave * 40; r < rows; r += (long long)gridDim.x * 4 * 40) {
+#pragma unroll
+        for (int k = 0; k < 40; ++k)
+            if (r + k < rows) acc += src[(r + k) * 64 + lane];
+    }
+    if (acc == 123.456f) sink[0] = acc;
+}
+__global__ __launch_bounds__(256) void pv_bw_write_kernel(float* dst, long long nfloat) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), rows = nfloat / 64;
+    for (long long r = wave * 40; r < rows; r += (long long)gridDim.x * 4 * 40) {
+#pragma unroll
+        for (int k = 0; k < 40; ++k)
+            if (r + k < rows) dst[(r + k) * 64 + lane] = 1.0f;
+    }
+}
+}  // namespace
+
+bool bandwidthProbeGBs(int device, float out[4]) {
+    if (hipSetDevice(device) != hipSuccess) return false;
+    const long long bytes = 1ll << 30, nfloat = bytes / 4;
+    float *a = nullptr, *b = nullptr, *sink = nullptr;
+    hipStream_t st = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool ok = hipMalloc((void**)&a, bytes) == hipSuccess && hipMalloc((void**)&b, bytes) == hipSuccess &&
+              hipMalloc((void**)&sink, 4) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess &&
+              hipMemsetAsync(a, 0, bytes, st) == hipSuccess && hipMemsetAsync(b, 0, bytes, st) == hipSuccess;
+    auto best = [&](double moved, auto&& launch) -> float {
+        float bestMs = 1e30f;
+        for (int i = 0; ok && i < 6; ++i) {  // (the first one warms)
+            hipEventRecord(e0, st);
+            launch();
+            hipEventRecord(e1, st);
+            float ms = 0.f;
+            ok = hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+            if (ok && i > 0 && ms < bestMs) bestMs = ms;
+        }
+        return ok ? (float)(moved / bestMs / 1e6) : 0.f;
+    };
+    if (ok) {
+        out[0] = best(2.0 * bytes, [&] { hipLaunchKernelGGL(pv_bw_copy16_kernel, dim3(2048), dim3(256), 0, st, (const float4*)a, (float4*)b, nfloat / 4); });
+        out[1] = best(2.0 * bytes, [&] { hipLaunchKernelGGL(pv_bw_copy4_kernel, dim3(2048), dim3(256), 0, st, a, b, nfloat); });
+        out[2] = best((double)bytes, [&] { hipLaunchKernelGGL(pv_bw_read_kernel, dim3(2048), dim3(256), 0, st, a, sink, nfloat); });
+        out[3] = best((double)bytes, [&] { hipLaunchKernelGGL(pv_bw_write_kernel, dim3(2048), dim3(256), 0, st, b, nfloat); });
+    }
+    if (st) hipStreamSynchronize(st);
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    if (st) hipStreamDestroy(st);
+    for (float* p : {a, b, sink})
+        if (p) hipFree(p);
+    return ok;
+}
+
 }  // namespace pva

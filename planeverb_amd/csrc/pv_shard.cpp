@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -141,7 +142,7 @@ Comm* Comm::create(const char idBytes[128], int rank, int world, int device, std
         if (err) *err = "hipSetDevice failed";
         return nullptr;
     }
-    Comm* c = new Comm();
+    std::unique_ptr<Comm> c(new Comm());
     c->rank_ = rank;
     c->world_ = world;
     c->device_ = device;
@@ -150,7 +151,6 @@ Comm* Comm::create(const char idBytes[128], int rank, int world, int device, std
     if (hipStreamCreateWithFlags(&c->stream_, hipStreamNonBlocking) != hipSuccess ||
         !ncclOk(r.commInitRank(&c->comm_, world, id, rank), "ncclCommInitRank", err)) {
         if (err && err->empty()) *err = "hipStreamCreate failed";
-        delete c;
         return nullptr;
     }
     // first contact: one float per rank through the very collective of the data path.  ncclFloat32 and the by-value ncclUniqueId
@@ -163,10 +163,9 @@ Comm* Comm::create(const char idBytes[128], int rank, int world, int device, std
     for (int i = 0; ok && i < world; ++i) ok = all[(size_t)i] == (float)(i + 1);
     if (!ok) {
         if (err) *err = "RCCL self-test at communicator creation failed (" + (e.empty() ? std::string("wrong values gathered") : e) + ") [bound " + r.bound + "]";
-        delete c;
         return nullptr;
     }
-    return c;
+    return c.release();
 }
 
 Comm::~Comm() {

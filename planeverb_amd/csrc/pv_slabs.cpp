@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <climits>
 #include <cstring>
+#include <memory>
 
 #include "pv_launch.h"
 
@@ -33,13 +34,12 @@ bool SlabGroup::slabFailed(int s) {
 
 SlabGroup* SlabGroup::create(const GridSpec& spec, const std::vector<int>& devices, const SolverOptions& opt,
                              std::string* err) {
-    SlabGroup* g = new SlabGroup();
+    std::unique_ptr<SlabGroup> g(new SlabGroup());  // (owned across init: see Solver::create)
     if (!g->init(spec, devices, opt)) {
         if (err) *err = g->err_;
-        delete g;
         return nullptr;
     }
-    return g;
+    return g.release();
 }
 
 bool SlabGroup::init(const GridSpec& spec, const std::vector<int>& devices, const SolverOptions& opt) {
@@ -698,7 +698,7 @@ long long SlabRankOps::windowBlock(Solver& v, int* r0g, int* c0, int* nr, int* n
 }
 
 SlabRoot* SlabRoot::create(const Solver& a, int device, std::string* err) {
-    SlabRoot* r = new SlabRoot();
+    std::unique_ptr<SlabRoot> r(new SlabRoot());
     r->g_ = a.g_;
     r->device_ = device;
     r->G_ = a.geo_.G;
@@ -727,10 +727,9 @@ SlabRoot* SlabRoot::create(const Solver& a, int device, std::string* err) {
               hipStreamSynchronize(r->stream_) == hipSuccess;  // (never the legacy stream: see Solver::applyGeometry)
     if (!ok) {
         if (err) *err = "slab root: allocation failed";
-        delete r;
         return nullptr;
     }
-    return r;
+    return r.release();
 }
 
 SlabRoot::~SlabRoot() {

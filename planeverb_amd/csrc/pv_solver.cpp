@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <mutex>
 
 #include "pv_launch.h"
@@ -146,13 +147,14 @@ void QueueClaim::release() {
 }
 
 Solver* Solver::create(const GridSpec& spec, int device, const SolverOptions& opt, std::string* err) {
-    Solver* s = new Solver();
+    // (owned across init: an exception from underneath -- a table that cannot grow -- unwinds through ~Solver, which releases
+    // whatever init had created, and leaves through the C-ABI's barrier in pv_capi.cpp)
+    std::unique_ptr<Solver> s(new Solver());
     if (!s->init(spec, device, opt)) {
         if (err) *err = s->err_;
-        delete s;
         return nullptr;
     }
-    return s;
+    return s.release();
 }
 
 bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
@@ -506,10 +508,12 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         }
     }
 
-    // Fused analysis (pv_fused.hip): the grids whose history window is the whole grid, up to the cell count the four-lane
-    // decay-time form serves
+    // Fused analysis (pv_fused.hip; experimental build only): the grids whose history window is the whole grid, up to the cell
+    // count the four-lane decay-time form serves
     {
         const bool wanted = opt_.fusedAnalysis > 0;  // (opt-in: measured slower than the separate kernels, docs/experiments/fused_analysis.md)
+        if (wanted && !fusedAnalysisBuilt())
+            return fail("PVA_OPT_FUSED_ANALYSIS = 1 (the one-launch analysis) is an arm of the experimental build of the library");
         useFused_ = wanted && !opt_.streaming && !isSlab() && !opt_.denseHistory && histTilesX_ == geo_.ntx &&
                     histTilesY_ == geo_.nty && histPlane_ <= 98304 && (opt_.rt60Lanes == 0 || opt_.rt60Lanes == 16 || opt_.rt60Lanes == 4) &&
                     fusedAnalysisOk(analyzeArgs(0.f, 0.f));
@@ -1924,15 +1928,16 @@ bool Solver::sync() {
         if (flag == 3 || flag == 4) return fail("resident kernel: a workgroup gave up waiting for its neighbours (run aborted)");
         if (flag == 5) return fail("slab decomposition: a neighbour's halo rows never arrived (run aborted)");
         if (flag == 6) {
+            // (on the solver's own stream, never the legacy stream: see applyGeometry)
             unsigned w[kFusedCtlWords] = {};
             if (fusedCtl_) {
-                hipMemcpy(w, fusedCtl_, sizeof(w), hipMemcpyDeviceToHost);
-                hipMemset(fusedCtl_, 0, sizeof(w));
+                hipMemcpyAsync(w, fusedCtl_, sizeof(w), hipMemcpyDeviceToHost, stream_);
+                hipMemsetAsync(fusedCtl_, 0, sizeof(w), stream_);
             }
+            hipMemsetAsync(errFlag_, 0, sizeof(int), stream_);
+            hipStreamSynchronize(stream_);
             std::string m = "fused analysis: a worker waited for a phase in vain (run aborted); ticket and phase counters:";
             for (unsigned v : w) m += " " + std::to_string(v);
-            int zero = 0;
-            hipMemcpy(errFlag_, &zero, sizeof(int), hipMemcpyHostToDevice);
             return fail(m);
         }
         if (flag) return fail("pressure history window overflow (a tile outside the window became non-zero)");

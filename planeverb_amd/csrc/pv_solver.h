@@ -53,7 +53,7 @@ struct SolverOptions {
     int patchStrip = 3;   // patch columns per strip of its walk
     int streamPriority = 0;  // PVA_OPT_STREAM_PRIORITY: 1 = main stream on the highest priority (a hardware queue apart from the default-priority streams)
     bool debugLoseFirstCapture = false;  // PVA_OPT_DEBUG_LOSE_FIRST_CAPTURE: the solver's first graph capture counts as lost
-    int fusedAnalysis = -1; // grids whose history window is the whole grid (up to 98 304 cells): the analysis as ONE launch (pv_fused.hip); -1 = auto (on), 0 = the separate kernels
+    int fusedAnalysis = -1; // 1 = grids whose history window is the whole grid (up to 98 304 cells) run their analysis as ONE launch (pv_fused.hip: EXPERIMENTAL build only, refused by the product build); -1 / 0 (default) = the separate kernels
     int analysisFork = 1; // 0: wet gain / decay time behind the encode pass instead of beside it (measurements)
     int rt60Lanes = 0;    // decay-time pass: lanes per cell (pv_rt60.hip): 0 = by the number of reachable cells, 16 / 4 / 1 = forced
     int resident = 0;     // resident kernel (pv_resident.hip: one launch per run, every tile a workgroup that stays on its CU for

@@ -12,6 +12,8 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -41,6 +43,10 @@ public:
         static std::atomic<int> v{-1};
         return v;
     }
+    static std::atomic<bool>& throwInRun() {  // the next run() throws (the worker's exception barrier, alloc_fault.cpp)
+        static std::atomic<bool> v{false};
+        return v;
+    }
     static std::atomic<long long>& liveInstances() {
         static std::atomic<long long> v{0};
         return v;
@@ -51,12 +57,11 @@ public:
             if (err) *err = "grid has no cells";
             return nullptr;
         }
-        Solver* s = new Solver();
+        std::unique_ptr<Solver> s(new Solver());  // (owned across init, as the real Solver::create: alloc_fault.cpp)
         s->opt_ = o;
         s->g_ = spec;
         s->mat_.init(spec);
-        liveInstances().fetch_add(1);
-        return s;
+        return s.release();
     }
     ~Solver() { liveInstances().fetch_sub(1); }
 
@@ -75,6 +80,7 @@ public:
     bool residentKernel() const { return false; }
     bool run(float lx, float, float lz, bool, Solver* carryFrom = nullptr) {
         (void)carryFrom;
+        if (throwInRun().exchange(false)) throw std::runtime_error("fake solver: injected exception");
         const int fa = failAfterRuns().load();
         if (fa >= 0 && runs_ >= fa) {
             err_ = "fake solver: injected failure";
@@ -154,7 +160,7 @@ public:
     static void hostFree(void* p) { std::free(p); }
 
 private:
-    Solver() = default;
+    Solver() { liveInstances().fetch_add(1); }
     GridSpec g_;
     SolverOptions opt_;
     int emitters_ = 0;

@@ -104,9 +104,9 @@ def test_resident_kernel_hand_off_modes(pvlib, monkeypatch, env):
                 assert same_bits(s.history_plane(int(t)), g["snaps"][i][0]).all(), "recorded pr, step %d" % t
 
 
-def test_resident_kernel_random_scenes_vs_oracle(pvlib, oracle):
-    """seeded random box scenes at 70^2 ... 140^2, resident kernel against the pinned oracle"""
+def _random_scenes_vs_oracle(lib, oracle, **opts):
     rng = np.random.default_rng(2024)
+    ran = 0
     for case in range(6):
         res = int(rng.choice([275, 300, 375, 420, 550]))
         size = float(rng.choice([25.0, 18.0, 31.0]))
@@ -124,7 +124,7 @@ def test_resident_kernel_random_scenes_vs_oracle(pvlib, oracle):
         ef = oracle.free_energy(size, size, res)
         rres, rdelay, _ = o.analyze(ef, L)
         hp, _, _ = o.history()
-        with pvlib.Solver(size, size, res) as s:
+        with lib.Solver(size, size, res, **opts) as s:
             if not s.info.residentKernel:
                 o.close()
                 continue
@@ -137,7 +137,14 @@ def test_resident_kernel_random_scenes_vs_oracle(pvlib, oracle):
                 assert same_bits(s.history_plane(t), hp[t]).all(), "case %d recorded pr, step %d" % (case, t)
             res8, delay = s.results()
             compare_maps(res8, delay, rres, rdelay, o.T, o.fs, "case %d" % case)
+            ran += 1
         o.close()
+    assert ran >= 3, ran
+
+
+def test_resident_kernel_random_scenes_vs_oracle(pvlib, oracle):
+    """seeded random box scenes at 70^2 ... 140^2, resident kernel against the pinned oracle"""
+    _random_scenes_vs_oracle(pvlib, oracle)
 
 
 def test_resident_kernel_concurrent_solvers_and_budget(pvlib):
@@ -216,6 +223,10 @@ def test_two_solvers_taking_turns_equal_one_solver(pvlib):
     """PvAmdRunAsyncAfter: iterations alternate between two solvers, each run enqueued while the previous one is still in
     flight; what an iteration leaves untouched (cells without an onset: the reference's persistent m_results) is
     carried over on the device.  Every map after every iteration equals one solver running the whole sequence."""
+    _taking_turns(pvlib)
+
+
+def _taking_turns(pvlib, **pair_opts):
     size, res = 25.0, 375
     scene = os.path.join(SCENES, "FloorPlanScene.pv")
     # listeners that see different parts of the plan (so that cells lose their onset from one iteration to the next), and
@@ -223,7 +234,8 @@ def test_two_solvers_taking_turns_equal_one_solver(pvlib):
     seq = [((3.0, 0.0, 3.0), None), ((22.0, 0.0, 22.0), None), ((3.0, 0.0, 22.0), ("add", [12.5, 12.5, 20.0, 1.0, 0.99])),
            ((22.0, 0.0, 3.0), None), ((12.5, 0.0, 5.0), ("add", [12.5, 8.0, 1.0, 12.0, 0.99])), ((12.5, 0.0, 20.0), None),
            ((3.0, 0.0, 3.0), ("remove", 0)), ((20.0, 0.0, 12.0), None)]
-    with pvlib.Solver(size, size, res) as one, pvlib.Solver(size, size, res) as a, pvlib.Solver(size, size, res) as b:
+    with pvlib.Solver(size, size, res) as one, pvlib.Solver(size, size, res, **pair_opts) as a, \
+            pvlib.Solver(size, size, res, **pair_opts) as b:
         for s in (one, a, b):
             s.load_scene(scene)
         added = {one: [], a: [], b: []}
@@ -268,3 +280,68 @@ def test_reached_cells_and_clock_probe(pvlib):
         assert s.timings().reachedCells == int((g["delay"] < 1e30).sum())
     mhz, by_memtime = pvlib.clock_probe(0)
     assert 500.0 < mhz < 4000.0 and by_memtime > 0.0
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The one-launch analysis (csrc/pv_fused.hip, PVA_OPT_FUSED_ANALYSIS = 1): an arm of the EXPERIMENTAL build -- workers that draw
+# items from a ticket counter, phases ordered by counters, agent-scope hand-offs inside the launch.  It re-schedules
+# Analyzer::AnalyzeResponses (Analyzer.cpp:48-104: the cell loop, then the direction loop that needs every cell's delay and
+# occlusion); its per-cell bodies are the separate kernels' own functions, so every map must equal theirs -- and the reference's
+# vectors -- bit for bit.
+# ----------------------------------------------------------------------------------------------------------------------
+def test_fused_analysis_refused_by_the_product_build(pvlib):
+    with pytest.raises(pvlib.PlaneverbError, match="experimental build"):
+        with pvlib.Solver(25.0, 25.0, 275, fused_analysis=1) as s:
+            s.run((5.0, 0.0, 4.0))
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_fused_analysis_golden_small(pvlib_exp, name):
+    """the reference's vectors on the 71^2 / 96^2 grids: whole result and delay maps and the emitters' records, two runs back
+    to back (the second finds the control words the first left)"""
+    g = golden(name)
+    gx, gy, T, fs = (int(v) for v in g["dims"])
+    with pvlib_exp.Solver(float(g["size"]), float(g["size"]), int(g["res"]), fused_analysis=1) as s:
+        for b in g["boxes"]:
+            s.add_geometry(b)
+        for rep in range(2):
+            s.run(g["listener"])
+            res, delay = s.results()
+            compare_maps(res, delay, g["results"], g["delay"], T, fs, "%s run %d" % (name, rep))
+            for e, ref8 in zip(g["emitters"], g["emitter_out"]):
+                compare_output(s.get_output(e), ref8, name)
+        assert s.timings().reachedCells == int((g["delay"] < 1e30).sum())
+
+
+def test_fused_analysis_random_scenes_vs_oracle(pvlib_exp, oracle):
+    """test_resident_kernel_random_scenes_vs_oracle's scenes (walls, closed pockets, several absorptions) with the analysis as one
+    launch, against the pinned oracle"""
+    _random_scenes_vs_oracle(pvlib_exp, oracle, fused_analysis=1)
+
+
+def test_fused_analysis_two_iterations_in_flight(pvlib_exp):
+    """two solvers taking turns, each run's carry pass inside the fused launch (FusedArgs::carrySrc: cells without an onset take
+    the other solver's record), against ONE solver with the separate kernels running the whole sequence"""
+    _taking_turns(pvlib_exp, fused_analysis=1)
+
+
+@pytest.mark.parametrize("workers", ["1", "2", "3"])
+@pytest.mark.parametrize("res,scene", [(275, "SmallRoomScene.pv"), (750, "FloorPlanScene.pv")])
+def test_fused_analysis_any_number_of_workers(pvlib_exp, monkeypatch, workers, res, scene):
+    """"no deadlock whatever the number of resident workgroups": the launch capped at 1, 2 and 3 workers (tickets are handed out
+    in phase order, so whoever waits, waits for items that running workers hold) -- same maps as the separate kernels; 750 Hz
+    takes the four-lane decay-time form (64 cells per item), 275 Hz the sixteen-lane one"""
+    L = (5.0, 0.0, 4.0)
+    with pvlib_exp.Solver(25.0, 25.0, res, fused_analysis=0) as ref:
+        ref.load_scene(os.path.join(SCENES, scene))
+        ref.run(L)
+        want = ref.results()
+    monkeypatch.setenv("PLANEVERB_AMD_FUSED_WORKERS", workers)
+    with pvlib_exp.Solver(25.0, 25.0, res, fused_analysis=1) as s:
+        s.load_scene(os.path.join(SCENES, scene))
+        for rep in range(2):
+            s.run(L)
+            got = s.results()
+            assert same_bits(got[1], want[1]).all(), "delay, run %d" % rep
+            for k, nm in enumerate(NAMES):
+                assert same_bits(got[0][..., k], want[0][..., k]).all(), "%s, run %d" % (nm, rep)

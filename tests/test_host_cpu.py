@@ -345,6 +345,39 @@ def test_live_module_host_side_under_sanitizers(san, pipeline, tmp_path):
     assert " 0 bad, phase3 flags 0" in r.stdout, r.stdout
 
 
+@pytest.mark.parametrize("pipeline", ["1", "2"])
+def test_no_exception_crosses_the_c_abi(pipeline, tmp_path):
+    """SURVEY.md 5 / 8b ("a C-ABI must not leak C++ exceptions -- catch at the boundary"; the reference throws from Init,
+    PvContext.cpp:106,123, Grid.cpp:69).  (i) EVERY extern "C" definition of pv_capi.cpp is a function-try-block closed by one
+    of the PV_API_CATCH macros; (ii) tests/host/alloc_fault.cpp replaces operator new in the HIP-less build of the live module
+    and fails every allocation of every Part 1 call, one at a time (and one on the worker thread, and an exception thrown by
+    the solver inside an iteration): each call returns its sentinel, PvAmdLastError names the function, the id tables are
+    unchanged, the per-frame calls allocate nothing, the worker stops instead of terminating the host.  Under ASan + UBSan."""
+    import re
+    src = open(os.path.join(ROOT, "planeverb_amd", "csrc", "pv_capi.cpp")).read()
+    body = src[src.index('extern "C" {'):src.index('}  // extern "C"')]
+    defs = re.findall(r"^(?!static|struct|//|#|\}|typedef)[A-Za-z][^;{}()]*?\b(\w+)\s*\([^;{}]*?\)\s*(try)?\s*\{", body, re.M)
+    names = [n for n, _ in defs]
+    assert len(names) >= 90, len(names)
+    unguarded = [n for n, t in defs if not t]
+    assert not unguarded, unguarded
+    assert body.count("PV_API_CATCH") == len(names), (body.count("PV_API_CATCH"), len(names))
+    # every symbol the header declares is one of them
+    hdr = open(os.path.join(ROOT, "include", "planeverb_amd.h")).read()
+    declared = set(re.findall(r"\b((?:Planeverb|PvAmd|UnityPlugin)\w+)\s*\(", hdr))
+    assert declared <= set(names), sorted(declared - set(names))
+    out = str(tmp_path / "build")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "host"), "OUT=" + out, out + "/alloc_fault_asan"],
+                          stdout=subprocess.DEVNULL)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1 exitcode=67", PLANEVERB_AMD_LIVE_PIPELINE=pipeline,
+               PV_TEST_SCENE=os.path.join(ROOT, "tests", "scenes", "SmallRoomScene.pv"))
+    r = subprocess.run([out + "/alloc_fault_asan"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    assert "Sanitizer" not in r.stderr, r.stderr[-4000:]
+    assert "alloc_fault: 0 failure(s)" in r.stdout, r.stdout
+    assert "injected exception" not in r.stdout  # (only ever in PlaneverbWorkerError, checked inside)
+
+
 def test_header_is_plain_c(tmp_path):
     """include/planeverb_amd.h is a C header (the drop-in boundary: extern "C", plain pointers and sizes): it must compile
     as C99 on its own, and PlaneverbOutput / PlaneverbCell must have the reference's sizes (8 floats; 16 bytes)"""
