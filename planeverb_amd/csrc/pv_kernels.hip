@@ -697,6 +697,53 @@ __device__ __forceinline__ void edgeStepMirror(v2f (&pr)[NP], v2f (&vx)[NP], v2f
     }
 }
 
+// The y-trapezoid's dead LANES switched off (round 6).  A tile's 64 lanes are 64 - 2K interior columns + K halo columns on each
+// side; for the interior [K, 63 - K] to be right after step K - 1, step s needs its pressure on lanes [s, 62 - s] and its
+// velocities on [s + 1, 62 - s] (the pressure sweep reads vy of lane + 1, the vy sweep pr of lane - 1: one lane lost per side and
+// step).  The x-trapezoid skips its dead ROWS outright; the dead lanes kept executing all 13 packed operations per row pair and
+// step on garbage -- at full toggle power on non-zero fields (roofline.dense: 2.03 instead of 2.40 GHz).
+// PV_EXEC_TRAPEZOID = N > 0 narrows EXEC in front of the steps s = N, 2N, ... to lanes [s - PV_EXEC_MARGIN, 63 - s] and restores
+// it behind the last step.  (63 - s, not 62 - s: a DPP read of a switched-off lane returns zero, bound_ctrl, and the pressure
+// sweep of lane 62 - s reads vy of lane 63 - s, which is still valid data.  A lane that reads a switched-off neighbour on the
+// other side is itself outside the next step's range, so no valid cell sees it; the bit-exact suite is the proof.)  Same
+// instruction count per lane that stays on: what changes is the lanes that toggle.  Measured: profiles/r06_exec_mask.txt.
+#ifndef PV_EXEC_TRAPEZOID
+#ifdef PV_EXPERIMENTAL
+#define PV_EXEC_TRAPEZOID 1  // (the experimental build carries it: tests/test_gpu_parity.py::test_exec_trapezoid_equals_product)
+#else
+#define PV_EXEC_TRAPEZOID 0  // off: measured, profiles/r06_exec_mask.txt (any partial mask costs ~1.6 % of the launch; the clock it buys back is worth +2 %)
+#endif
+#endif
+#ifndef PV_EXEC_MARGIN
+#define PV_EXEC_MARGIN 0
+#endif
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"  // ("exec" on the clobber list is the point: the compiler must know)
+template <unsigned long long MASK>
+__device__ __forceinline__ void setExecMask() {
+    asm volatile("s_mov_b32 exec_lo, %0\n\ts_mov_b32 exec_hi, %1" ::"i"((int)(unsigned)(MASK & 0xffffffffull)), "i"((int)(unsigned)(MASK >> 32))
+                 : "exec");
+}
+#pragma clang diagnostic pop
+template <int S>
+__device__ __forceinline__ void narrowExecToStep() {
+#if PV_EXEC_TRAPEZOID == 63  // (measurement build: lane 63 alone goes off at step 1 -- does ANY partial mask cost time?)
+    if constexpr (S == 1) setExecMask<(~0ull >> 1)>();
+#elif PV_EXEC_TRAPEZOID
+    if constexpr (S > 0 && S % PV_EXEC_TRAPEZOID == 0) {
+        constexpr int lo = S - PV_EXEC_MARGIN < 0 ? 0 : S - PV_EXEC_MARGIN;
+        constexpr int hi = 63 - S;
+        constexpr unsigned long long upTo = hi == 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull);
+        setExecMask<(upTo & ~((1ull << lo) - 1ull))>();
+    }
+#endif
+}
+__device__ __forceinline__ void restoreExec() {
+#if PV_EXEC_TRAPEZOID
+    setExecMask<~0ull>();
+#endif
+}
+
 template <int K, int RXI, int S>
 struct MirrorSteps {
     static constexpr int ROWS = RXI + 2 * K;
@@ -707,6 +754,7 @@ struct MirrorSteps {
                                                const int hpitchB) {
         if constexpr (S < K) {
             if (S < a.nsteps) {
+                narrowExecToStep<S>();
                 leapfrogStepMirror<NP, PV_MIRROR_G, S>(pr, vx, vy, vxS, C);
                 if (recLane) {  // pressure of this step, interior rows (air tiles never hold the listener)
                     const rsrc_t rH = makeRsrc(hplane, a.histPlane * 4);
@@ -860,6 +908,7 @@ __device__ __forceinline__ void stepTileAirMirror(const StepArgs& a, const int t
         }
     } else {
         MirrorSteps<K, RXI, 0>::run(pr, vx, vy, vxS, C, a, rec && inCols, hplane, hvoff, hsoff0, hpitchB);
+        restoreExec();
     }
 
 #if PV_LATE_ARGS

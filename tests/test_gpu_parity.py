@@ -661,6 +661,28 @@ def test_free_grid_energy(pvlib, size, res, want):
         assert np.float32(s.efree) == np.float32(want)
 
 
+@pytest.mark.parametrize("n", [2048, 4096])
+def test_exec_trapezoid_equals_product(pvlib, pvlib_exp, n):
+    """The air arm with the y-trapezoid's dead lanes switched off (PV_EXEC_TRAPEZOID: EXEC narrowed to lanes [s, 63 - s] before step
+    s; compiled into the EXPERIMENTAL build, measured and left out of the product: profiles/r06_exec_mask.txt) against the product
+    kernel on seeded random fields -- every cell of every tile non-zero, so a lane switched off one step too early shows in the
+    next tile column (the first mask, [s, 62 - s], passed every closed-room test) -- K-step launches plus a remainder launch"""
+    dx = np.float32(343.21) / np.float32(275) / np.float32(3.5)
+    size = float((n + 0.5) * dx)
+    rng = np.random.default_rng(7)
+    f0 = [(rng.random((n + 1, n + 1), np.float32) - np.float32(0.5)) * np.float32(1e-3) for _ in range(3)]
+    got = []
+    for lib in (pvlib, pvlib_exp):
+        with lib.Solver(size, size, 275) as s:
+            s.load_scene(os.path.join(SCENES, "HugeRoom.pv"))
+            s.set_fields(*f0)
+            s.run_steps(2 * s.info.stepsPerLaunch + 5)
+            got.append(s.fields())
+    for a, b, nm in zip(got[0], got[1], ("pr", "vx", "vy")):
+        assert np.isfinite(a).all()
+        assert same_bits(a, b).all(), "%s: %d cells differ" % (nm, int((~same_bits(a, b)).sum()))
+
+
 def test_open_field_8192_vs_oracle_window(pvlib, oracle):
     """BASELINE config 5 at full size (8192^2 open grid, Mode A): in the open field the pressure history and the onset
     map around the listener do not depend on where the listener sits, and -- inside the region the grid edges cannot

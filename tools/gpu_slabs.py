@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Single-grid decomposition (PvAmdCreateSlabs) on ONE device: time per run for S = 1 (plain solver), 2, 4, 8 slabs, with
 the bytes exchanged -- what the decomposition costs before any second GPU helps (profiles/r02_slabs.txt).
-    python tools/gpu_slabs.py [grid ...]"""
+    python tools/gpu_slabs.py [grid ...]
+SLAB_DEVICES="0,1" (default "0") deals the slabs over several devices in turn -- slab i on device i mod n: the peer / xGMI path
+of pv_slabs.cpp that no 1-GPU box of the pool can exercise (tools/first_contact.sh)."""
 import os
 import sys
 import time
@@ -17,7 +19,8 @@ for n in [int(a) for a in sys.argv[1:]] or [4096]:
     size = float((n + 0.5) * dx)
     want = None
     for S in [int(x) for x in os.environ.get("SLABS", "1,2,4,8").split(",")]:
-        s = pv.Solver(size, size, 275, slabs=None if S == 1 else [0] * S)
+        devs = [int(d) for d in os.environ.get("SLAB_DEVICES", "0").split(",")]
+        s = pv.Solver(size, size, 275, slabs=None if S == 1 else [devs[i % len(devs)] for i in range(S)])
         s.load_scene(scene)
         for _ in range(2):
             s.run((5, 0, 4))
