@@ -13,6 +13,46 @@ namespace pva {
 // (slab groups: see AnalyzeArgs::abortWord)
 __device__ __forceinline__ bool analysisAborted(const AnalyzeArgs& a) { return a.abortWord && *a.abortWord != 0u; }
 
+// The near box (AnalyzeArgs::box / FarInfo::box): the reached cells' bounding box grown by one cell, inside the window block
+// [wr0, wr0 + wnr) x [wc0, wc0 + wnc).  Inclusive bounds; empty when r1 < r0 or c1 < c0.
+struct NearBox {
+    int r0, c0, r1, c1;
+    __device__ __forceinline__ bool holds(int r, int c) const { return r >= r0 && r <= r1 && c >= c0 && c <= c1; }
+};
+__device__ __forceinline__ NearBox nearBoxOf(const int* box, int wr0, int wc0, int wnr, int wnc) {
+    NearBox b;
+    b.r0 = max(box[0] - 1, wr0);  // (an empty box holds INT_MAX / -1: no overflow either way)
+    b.c0 = max(box[1] - 1, wc0);
+    b.r1 = min(box[2] + 1, wr0 + wnr - 1);
+    b.c1 = min(box[3] + 1, wc0 + wnc - 1);
+    return b;
+}
+__device__ __forceinline__ NearBox nearBoxOf(const AnalyzeArgs& a, const DynParams& dyn) {
+    const int wr0 = dyn.histRow0 - a.G, wc0 = dyn.histCol0 - a.G;
+    return nearBoxOf(a.box, wr0, wc0, min(a.winRows, a.gx - wr0), min(a.winCols, a.gy - wc0));
+}
+
+// closed-form listener direction of a far cell: what storeDirection(a, index, index) writes (a walk that stays put)
+__device__ __forceinline__ void farDirectionOf(const FarInfo& f, long long cell, float* ox, float* oy) {
+    const int r = (int)(cell / f.gy), c = (int)(cell - (long long)r * f.gy);
+    float x = (float)r * f.dx - f.lx, y = (float)c * f.dx - f.lz;
+    float len = (x * x) + (y * y);
+    if (len != 0.f) {
+        len = sqrtf(len);
+        x /= len;
+        y /= len;
+    }
+    *ox = x;
+    *oy = y;
+}
+// is the direction of this cell NOT in the result planes?
+__device__ __forceinline__ bool isFarCell(const FarInfo& f, long long cell) {
+    if (!f.on) return false;
+    const int r = (int)(cell / f.gy), c = (int)(cell - (long long)r * f.gy);
+    if (f.box) return !nearBoxOf(f.box, f.r0, f.c0, f.nr, f.nc).holds(r, c);
+    return r < f.r0 || r >= f.r0 + f.nr || c < f.c0 || c >= f.c0 + f.nc;
+}
+
 struct CellHistory {
     const float* h;     // this cell, step 0
     long long plane;
@@ -66,15 +106,16 @@ __device__ __forceinline__ float efreePerR(float efree, float dx, int lX, int lY
 // differ in how many LANES share a cell (pv_rt60.hip).  Which one runs is decided on the device from the number of cells
 // of the window's ever-non-zero tiles (an upper bound of the reached cells, counted by block 0 of the far-cells pass):
 // few cells -> sixteen lanes per cell (parallelism), more -> four (fewer instructions per sample).
-constexpr int kRt60TileMinCells = 98304;
 __device__ __forceinline__ int rt60LanesPerCell(const AnalyzeArgs& a, int activeCells) {
     if (a.rt60Lanes) return a.rt60Lanes;  // (PVA_OPT_RT60_LANES: validation / measurement)
     // (measured on MI355X, profiles/r04_rt60.txt: 70^2 0.093 / 0.098 ms, 127^2 0.156 / 0.148 ms for sixteen / four lanes; round 5:
     // one lane per cell over the tile-major history replaces the four-lane form, profiles/r05_rt60.txt)
     // sixteen lanes per cell for a few thousand cells (parallelism), one lane per cell over the tile-major plane from ~100 000 (fewest
     // instructions and bytes per sample; it needs two waves per SIMD worth of cells), four in between: profiles/r05_rt60.txt
+    // (round 6: counted on the cells WITH AN ONSET -- pv_onset_kernel runs in front of every pass that asks -- instead of the cells
+    // of the window's ever-non-zero tiles: a closed room of 4 400 reached cells sat in 13 000 cells of tiles and took the four-lane form)
     if (activeCells <= 8192) return 16;
-    if (activeCells <= kRt60TileMinCells) return 4;
+    if (activeCells <= kRt60TileMinCells || !a.rt60Tile) return 4;  // (no launch of the lane-per-cell form: AnalyzeArgs::rt60Tile)
     return a.histPlane * 4 * 16 < (1ll << 31) ? 1 : 4;  // (the lane-per-cell form reaches a chunk's planes through one descriptor and scalar offsets)
 }
 

@@ -247,9 +247,17 @@ __device__ __forceinline__ void rowScan2(float& accA, const float aA, float& acc
     }
 }
 
+#ifndef PV_RT60_AHEAD
+#define PV_RT60_AHEAD 4
+#endif
+constexpr int kRt60Ahead = PV_RT60_AHEAD;  // chunks of history loads in flight per wave in the sixteen- and four-lane decay-time forms
+
 // every lane of the wave must call; live / s / hc / startingPointIn are the values of the lane's cell (the same in the 16
 // lanes of a row), sub = the lane's place in its row
-__device__ __forceinline__ void rt60WaveBody(const AnalyzeArgs& a, const int sub, const bool live, const int s,
+// tab: the logarithm's table functor (LogTabLds: a per-lane index into a constant array is a global load at the head of every
+// evaluation -- the one dependent memory round trip per chunk this form had left, round 6)
+template <class TabF>
+__device__ __forceinline__ void rt60WaveBody(const AnalyzeArgs& a, const TabF& tab, const int sub, const bool live, const int s,
                                              const CellHistory hc, const int startingPointIn) {
     const int T = a.T;
     const int endPoint = T - a.nCut;
@@ -261,23 +269,34 @@ __device__ __forceinline__ void rt60WaveBody(const AnalyzeArgs& a, const int sub
     for (int off = 16; off < 64; off <<= 1) n = max(n, __shfl_xor(n, off));
     n = __builtin_amdgcn_readfirstlane(n);
     float edc = 0.f, xysum = 0.f, ysum = 0.f;  // lane 15 of the row carries them from chunk to chunk
-    float pNext = 0.f;
-    {
-        const int i = T - 1 - sub;
-        pNext = (live && i >= lowest && i >= 0) ? hc.at(i) : 0.f;
+    // kRt60Ahead chunks of loads in flight (round 6; one until then): a chunk's chains and logarithm take ~0.3 us of a wave's
+    // time, a load from a plane 150 KB - 3 MB further down ~1 us -- the pass waited a memory round trip per chunk (30 us for the
+    // 27 chunks of T = 435: profiles/r06_analysis_chain.txt).  A ring of fixed registers, the loop unrolled over it, every load
+    // issued in consumption order (the wait counts then retire one chunk at a time).  Same additions in the same order.
+    float ring[kRt60Ahead];
+#pragma unroll
+    for (int b = 0; b < kRt60Ahead; ++b) {
+        const int i = T - 1 - 16 * b - sub;
+        ring[b] = (live && 16 * b < n && i >= lowest && i >= 0) ? hc.at(i) : 0.f;
     }
 #pragma unroll 1
-    for (int n0 = 0; n0 < n; n0 += 16) {
-        const int i = T - 1 - n0 - sub;
-        const float p = pNext;
-        {  // the next chunk's load is in flight while this chunk's chains run
-            const int in = i - 16;
-            pNext = (live && n0 + 16 < n && in >= lowest && in >= 0) ? hc.at(in) : 0.f;
+    for (int n0 = 0; n0 < n; n0 += 16 * kRt60Ahead) {
+#pragma unroll
+        for (int b = 0; b < kRt60Ahead; ++b) {
+            const int c0 = n0 + 16 * b;
+            if (c0 < n) {  // (scalar)
+                const int i = T - 1 - c0 - sub;
+                const float p = ring[b];
+                {  // the slot's next occupant
+                    const int in = i - 16 * kRt60Ahead;
+                    ring[b] = (live && c0 + 16 * kRt60Ahead < n && in >= lowest && in >= 0) ? hc.at(in) : 0.f;
+                }
+                const float e = rowScan<true>(edc, p * p, sub);  // (p = 0 outside [lowest, T): edc + 0 = edc)
+                const bool regress = i >= startingPoint && i < endPoint;
+                const float y = 10.f * pvLog10fNonNegT(regress ? e : 1.f, tab);
+                rowScan2(xysum, regress ? y * (float)(i - startingPoint) : 0.f, ysum, regress ? y : 0.f);
+            }
         }
-        const float e = rowScan<true>(edc, p * p, sub);  // (p = 0 outside [lowest, T): edc + 0 = edc)
-        const bool regress = i >= startingPoint && i < endPoint;
-        const float y = 10.f * pvLog10fNonNeg(regress ? e : 1.f);
-        rowScan2(xysum, regress ? y * (float)(i - startingPoint) : 0.f, ysum, regress ? y : 0.f);
     }
     // wet gain (Analyzer.cpp:235-247): the same chain, forwards over [startingPoint, startingPoint + N_wet) ^ [0, T)
     const int wetEnd = min(startingPoint + a.nWet, T);
@@ -286,7 +305,7 @@ __device__ __forceinline__ void rt60WaveBody(const AnalyzeArgs& a, const int sub
     for (int off = 16; off < 64; off <<= 1) nw = max(nw, __shfl_xor(nw, off));
     nw = __builtin_amdgcn_readfirstlane(nw);
     float wet = 0.f;
-    pNext = (live && startingPoint + sub < wetEnd) ? hc.at(startingPoint + sub) : 0.f;
+    float pNext = (live && startingPoint + sub < wetEnd) ? hc.at(startingPoint + sub) : 0.f;
 #pragma unroll 1
     for (int j0 = 0; j0 < nw; j0 += 16) {
         const float p = pNext;
@@ -371,42 +390,54 @@ __device__ __forceinline__ void rt60BlockedBody(const AnalyzeArgs& a, const LogT
     int n = T - lowest;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) n = max(n, __shfl_xor(n, off));
+    n = __builtin_amdgcn_readfirstlane(n);  // (wave-uniform by value: scalar loop counters and branches)
     float edc = 0.f, xysum = 0.f, ysum = 0.f;
-    float pNext[S];
+    // kRt60Ahead chunks of loads in flight, as in rt60WaveBody (round 6; one until then: 124 us for 36 000 cells at T = 1187, two
+    // waves per SIMD waiting a memory round trip per chunk of 16 samples)
+    float ring[kRt60Ahead][S];
 #pragma unroll
-    for (int k = 0; k < S; ++k) {
-        const int i = T - 1 - sub * S - k;
-        pNext[k] = (live && i >= lowest && i >= 0) ? h0[(long long)i * plane] : 0.f;
-    }
-#pragma unroll 1
-    for (int n0 = 0; n0 < n; n0 += L * S) {
-        const int iTop = T - 1 - n0 - sub * S;  // this lane's samples: iTop - k
-        float q[S];
-#pragma unroll
-        for (int k = 0; k < S; ++k) q[k] = pNext[k] * pNext[k];  // 0 outside [lowest, T): edc + 0 = edc
-        if (n0 + L * S < n) {  // the next chunk's loads are in flight while this chunk's chains and logarithms run
-#pragma unroll
-            for (int k = 0; k < S; ++k) {
-                const int i = iTop - L * S - k;
-                pNext[k] = (live && i >= lowest && i >= 0) ? h0[(long long)i * plane] : 0.f;
-            }
-        }
-        float e[S];
-#pragma unroll
-        for (int k = 0; k < S; ++k) e[k] = 0.f;
-        groupChain<L, S, true>(edc, q, sub, e);
-        float ax[S], ay[S];
+    for (int b = 0; b < kRt60Ahead; ++b) {
 #pragma unroll
         for (int k = 0; k < S; ++k) {
-            const int i = iTop - k;
-            const bool regress = i >= startingPoint && i < endPoint;
-            const float y = 10.f * pvLog10fNonNegT(regress ? e[k] : 1.f, ltab);
-            ax[k] = regress ? y * (float)(i - startingPoint) : 0.f;
-            ay[k] = regress ? y : 0.f;
+            const int i = T - 1 - b * L * S - sub * S - k;
+            ring[b][k] = (live && b * L * S < n && i >= lowest && i >= 0) ? h0[(long long)i * plane] : 0.f;
         }
-        float unused[S];
-        groupChain<L, S, false>(xysum, ax, sub, unused);
-        groupChain<L, S, false>(ysum, ay, sub, unused);
+    }
+#pragma unroll 1
+    for (int n0 = 0; n0 < n; n0 += kRt60Ahead * L * S) {
+#pragma unroll
+        for (int b = 0; b < kRt60Ahead; ++b) {
+            const int c0 = n0 + b * L * S;
+            if (c0 < n) {  // (scalar)
+                const int iTop = T - 1 - c0 - sub * S;  // this lane's samples: iTop - k
+                float q[S];
+#pragma unroll
+                for (int k = 0; k < S; ++k) q[k] = ring[b][k] * ring[b][k];  // 0 outside [lowest, T): edc + 0 = edc
+                if (c0 + kRt60Ahead * L * S < n) {  // the slot's next occupant
+#pragma unroll
+                    for (int k = 0; k < S; ++k) {
+                        const int i = iTop - kRt60Ahead * L * S - k;
+                        ring[b][k] = (live && i >= lowest && i >= 0) ? h0[(long long)i * plane] : 0.f;
+                    }
+                }
+                float e[S];
+#pragma unroll
+                for (int k = 0; k < S; ++k) e[k] = 0.f;
+                groupChain<L, S, true>(edc, q, sub, e);
+                float ax[S], ay[S];
+#pragma unroll
+                for (int k = 0; k < S; ++k) {
+                    const int i = iTop - k;
+                    const bool regress = i >= startingPoint && i < endPoint;
+                    const float y = 10.f * pvLog10fNonNegT(regress ? e[k] : 1.f, ltab);
+                    ax[k] = regress ? y * (float)(i - startingPoint) : 0.f;
+                    ay[k] = regress ? y : 0.f;
+                }
+                float unused[S];
+                groupChain<L, S, false>(xysum, ax, sub, unused);
+                groupChain<L, S, false>(ysum, ay, sub, unused);
+            }
+        }
     }
 
     // ---- wet gain (Analyzer.cpp:235-247): the same chain, forwards over [startingPoint, startingPoint + N_wet) ^ [0, T) ----
@@ -415,6 +446,7 @@ __device__ __forceinline__ void rt60BlockedBody(const AnalyzeArgs& a, const LogT
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) nw = max(nw, __shfl_xor(nw, off));
     float wet = 0.f;
+    float pNext[S];
 #pragma unroll
     for (int k = 0; k < S; ++k) {
         const int j = startingPoint + sub * S + k;

@@ -244,12 +244,16 @@ struct ClassifyArgs {
     int withPulse;
 };
 
+constexpr int kRt60TileMinCells = 98304;  // cells with an onset from which the decay-time pass runs one lane per cell (pv_rt60.hip)
+
 // where the far cells of the last run begin, and what their listener direction is (output gathers, pv_far_dir_kernel)
 struct FarInfo {
     int on;              // 0: every cell's direction is in the result planes
     int r0, c0, nr, nc;  // the last run's window block of the result map: directions inside it are in the planes
     int gy;
     float lx, lz, dx;
+    const int* box;      // device words {r0, c0, r1, c1}: bounding box of the last run's REACHED cells (AnalyzeArgs::box), or NULL.
+                         // With it, only the box grown by one cell (inside the window block) has its directions in the planes
 };
 
 struct AnalyzeArgs {
@@ -281,7 +285,8 @@ struct AnalyzeArgs {
                            // lie in the plane (launched over the plane, a third of the SIMDs got three waves of it, most one)
     int* dirScratch;       // winRows x winCols ints for the listener-direction pointer jumping
     int dirJump;           // listener direction by pointer jumping (wide windows) instead of the plain walk
-    int rt60Lanes;         // 0 = by the number of reachable cells (rt60LanesPerCell); 16 / 4 / 1 = that form of the decay-time pass
+    int rt60Lanes;         // 0 = by the number of reached cells (rt60LanesPerCell); 16 / 4 / 1 = that form of the decay-time pass
+    int rt60Tile;          // the lane-per-cell form of the decay-time pass is launched (launchRt60Forms): it may be chosen
     int T;
     int nDir, nDry, nWet, nCut;
     unsigned fs;
@@ -302,6 +307,17 @@ struct AnalyzeArgs {
     // is materialised when a whole-map reader asks (pv_far_dir_kernel) or computed in closed form by the output gathers.
     int lazyFar;
     int prevR0, prevC0, prevNR, prevNC;
+    // Round 6: the window block is an upper bound of what a run can reach ((2T + 3)^2 cells around the listener: 760 000 at
+    // T = 435), a closed room reaches a few thousand of them -- and the far frame and the listener-direction passes moved 62 MB
+    // per run for them (profiles/r05_analysis_pmc.md).  box = four device words {r0, c0, r1, c1}, the inclusive bounding box of
+    // the cells pv_onset_kernel finds an onset in (atomics; empty = {INT_MAX, INT_MAX, -1, -1}); prevBox = the same of the
+    // previous analysed run of this solver.  With them the first launch resets only prevBox's cells to "no onset"
+    // (pv_near_reset_kernel), the direction passes cover the box grown by one cell (a cell further away has no neighbour with
+    // an onset: its walk stays put, Analyzer.cpp:365-391 -- the closed form), and every other cell of the window is a far cell
+    // like the ones outside it (FarInfo::box).  pv_onset_kernel empties prevBox for the run after the next.  NULL: the
+    // window-wide passes (slabs, whole-grid windows, the experimental one-launch analysis).
+    int* box;
+    int* prevBox;
     const int* labels;   // per array cell ((gx + 1) x (gy + 1), index x * labelNY + y): its 4-connected AIR component, -1 for a wall
                          // cell -- or NULL (large grids, slabs).  Pressure never crosses a wall cell (beta = 0 keeps it at zero,
                          // FDTD.cpp:139, and a wall|air face's velocity is a multiple of the AIR cell's pressure, :165-168): a cell of

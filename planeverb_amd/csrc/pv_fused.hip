@@ -186,7 +186,7 @@ __device__ __forceinline__ void fusedCells(const FusedArgs& f, const DynParams& 
             const int sj = cc.X * a.gy + cc.Y;
             const float* h0 = a.hist + gj;
             if constexpr (L == 16)
-                rt60WaveBody(a, sub, lv, sj, CellHistory{h0, a.histPlane}, on + a.nDry + 1);
+                rt60WaveBody(a, LogTabLds{sh.tab}, sub, lv, sj, CellHistory{h0, a.histPlane}, on + a.nDry + 1);
             else
                 rt60BlockedBody<4, 4>(a, LogTabLds{sh.tab}, sub, lv, sj, h0, on + a.nDry + 1);
         }
@@ -338,18 +338,10 @@ __global__ __launch_bounds__(512) void pv_run_finish_kernel(const float* __restr
     if (q < nq) {
         const long long c = cells[q];
         float v = c >= 0 ? res[k * n + c] : 0.f;
-        if (c >= 0 && (k == 4 || k == 5) && f.on) {
-            const int r = (int)(c / f.gy), cc = (int)(c - (long long)r * f.gy);
-            if (r < f.r0 || r >= f.r0 + f.nr || cc < f.c0 || cc >= f.c0 + f.nc) {  // a far cell: its direction in closed form
-                float x = (float)r * f.dx - f.lx, y = (float)cc * f.dx - f.lz;
-                float len = (x * x) + (y * y);
-                if (len != 0.f) {
-                    len = sqrtf(len);
-                    x /= len;
-                    y /= len;
-                }
-                v = k == 4 ? x : y;
-            }
+        if (c >= 0 && (k == 4 || k == 5) && isFarCell(f, c)) {  // a far cell: its direction in closed form
+            float x, y;
+            farDirectionOf(f, c, &x, &y);
+            v = k == 4 ? x : y;
         }
         out[q * 8 + k] = v;
     }

@@ -2433,10 +2433,26 @@ __global__ __launch_bounds__(64 * kOnsetWaves) void pv_onset_kernel(const Analyz
     }
     if (wave == 0) found[lane] = INT_MAX;
     __syncthreads();
-    if (a.wholeWindow) {
+    // near box (AnalyzeArgs::box): the cells the PREVIOUS run reached get "no onset" back unless this run reaches them again --
+    // every other cell of the map holds it already.  A cell of this window is its own lane's business (below, and where the
+    // search ends); the previous box's cells OUTSIDE this window (the listener moved far) are dealt over the workgroups here.
+    bool inPrev = false;
+    if (a.box) {
+        const int p0 = a.prevBox[0], p1 = a.prevBox[1], p2 = min(a.prevBox[2], a.gx - 1), p3 = min(a.prevBox[3], a.gy - 1);
+        inPrev = c.inGrid && c.X >= p0 && c.X <= p2 && c.Y >= p1 && c.Y <= p3;
+        if (p2 >= p0 && p3 >= p1) {  // (empty: INT_MAX / -1 -- no arithmetic on those)
+            const int wr0 = dyn.histRow0 - a.G, wc0 = dyn.histCol0 - a.G;
+            const int wr1 = wr0 + min(a.winRows, a.gx - wr0) - 1, wc1 = wc0 + min(a.winCols, a.gy - wc0) - 1;
+            if (p0 < wr0 || p2 > wr1 || p1 < wc0 || p3 > wc1)  // (block-uniform)
+                for (int r = p0 + (int)blockIdx.x; r <= p2; r += (int)gridDim.x)
+                    for (int cc = p1 + (int)threadIdx.x; cc <= p3; cc += (int)blockDim.x)
+                        if (r < wr0 || r > wr1 || cc < wc0 || cc > wc1) a.delay[r * a.gy + cc] = FLT_MAX;
+        }
+    }
+    if (a.wholeWindow || a.box) {
         // no far-frame launch in front of this one: "no onset" for the cells that will not get one, and the count of active cells
         // (what pv_far_frame_kernel's first block does; the run's last kernel has left the other counters at zero)
-        if (wave == 0 && c.inGrid && !live) a.delay[c.X * a.gy + c.Y] = FLT_MAX;
+        if (wave == 0 && c.inGrid && !live && (a.wholeWindow || inPrev)) a.delay[c.X * a.gy + c.Y] = FLT_MAX;
         if (blockIdx.x == 0 && wave == 1) {
             int n = 0;
             for (int i = lane; i < dyn.histTilesX * dyn.histTilesY; i += 64) {
@@ -2487,10 +2503,27 @@ __global__ __launch_bounds__(64 * kOnsetWaves) void pv_onset_kernel(const Analyz
     const int onset = found[lane];
     if (live) {
         if (onset != INT_MAX) a.delay[c.X * a.gy + c.Y] = (float)onset;
-        else if (a.wholeWindow) a.delay[c.X * a.gy + c.Y] = FLT_MAX;
+        else if (a.wholeWindow || inPrev) a.delay[c.X * a.gy + c.Y] = FLT_MAX;
     }
     // reached cells of this run (bench / PvAmdTimings.reachedCells) and silent ones: one atomic each per block
-    const unsigned long long mr = __ballot(live && onset != INT_MAX), ms = __ballot(air && !(live && onset != INT_MAX));
+    const bool reached = live && onset != INT_MAX;
+    const unsigned long long mr = __ballot(reached), ms = __ballot(air && !reached);
+    if (a.box && mr) {  // the reached cells' bounding box (AnalyzeArgs::box): four atomics per group with work
+        int r0 = reached ? c.X : INT_MAX, c0 = reached ? c.Y : INT_MAX, r1 = reached ? c.X : -1, c1 = reached ? c.Y : -1;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            r0 = min(r0, __shfl_xor(r0, off));
+            c0 = min(c0, __shfl_xor(c0, off));
+            r1 = max(r1, __shfl_xor(r1, off));
+            c1 = max(c1, __shfl_xor(c1, off));
+        }
+        if (lane == 0) {
+            atomicMin(a.box + 0, r0);
+            atomicMin(a.box + 1, c0);
+            atomicMax(a.box + 2, r1);
+            atomicMax(a.box + 3, c1);
+        }
+    }
     if (lane == 0) {
         if (mr) {
             atomicAdd(a.activeCount + 1, __popcll(mr));
@@ -2511,7 +2544,7 @@ __global__ __launch_bounds__(256) void pv_encode_kernel(const AnalyzeArgs a) {
     const float delay = pc0.inGrid ? a.delay[pc0.X * a.gy + pc0.Y] : FLT_MAX;
     const bool live = delay != FLT_MAX;  // no onset (Analyzer.cpp:160-165): the result record stays as it is
     if (__ballot(live) == 0ull) return;
-    encodeWave<false>(a, dyn, pc0, live, live ? (int)delay : 0, rt60LanesPerCell(a, *a.activeCount) == 1);
+    encodeWave<false>(a, dyn, pc0, live, live ? (int)delay : 0, rt60LanesPerCell(a, a.activeCount[1]) == 1);
 }
 
 // the same pass with L lanes per cell (encodeGroups, pv_analysis_dev.h): the small windows, where the longest walk is the kernel.
@@ -2529,22 +2562,6 @@ __global__ __launch_bounds__(256) void pv_encode_groups_kernel(const AnalyzeArgs
     const bool live = delay != FLT_MAX;
     if (__ballot(live) == 0ull) return;
     encodeGroups<L, false>(a, dyn, pc0, lane % L, live, live ? (int)delay : 0);
-}
-
-// wet gain + decay time, sixteen lanes per cell (rt60WaveBody, pv_analysis_dev.h): the few thousand cells of a closed room
-__global__ __launch_bounds__(256) void pv_rt60_wave_kernel(const AnalyzeArgs a) {
-    if (analysisAborted(a)) return;
-    if (rt60LanesPerCell(a, *a.activeCount) != 16) return;  // (more cells: the forms of pv_rt60.hip)
-    const DynParams dyn = *a.dyn;
-    // 16 cells per 256-thread block along the window's columns, one window row per blockIdx.y
-    const int sub = threadIdx.x & 15;
-    const int wc = blockIdx.x * 16 + (threadIdx.x >> 4), wr = blockIdx.y;
-    Rt60Cell c{-1, {nullptr, 0}, 0};
-    if (wc < a.winCols) c = rt60Cell(a, dyn, dyn.histRow0 - a.G + wr, dyn.histCol0 - a.G + wc);
-    // a wave leaves only when none of its four cells has work: the DPP chains need whole rows, not whole waves, but
-    // keeping the wave together costs nothing
-    if (__ballot(c.s >= 0) == 0ull) return;
-    rt60WaveBody(a, sub, c.s >= 0, c.s, c.hc, c.startingPoint);
 }
 
 // every cell of the map: no onset (Analyzer.cpp:64-68), listener direction = towards the cell itself (a walk that
@@ -2606,24 +2623,22 @@ __global__ __launch_bounds__(256) void pv_far_frame_kernel(const AnalyzeArgs a) 
     storeDirection(a, index, index);
 }
 
-// closed-form listener direction of a far cell (what storeDirection(a, index, index) writes)
-__device__ __forceinline__ void farDirectionOf(const FarInfo& f, long long cell, float* ox, float* oy) {
-    const int r = (int)(cell / f.gy), c = (int)(cell - (long long)r * f.gy);
-    float x = (float)r * f.dx - f.lx, y = (float)c * f.dx - f.lz;
-    float len = (x * x) + (y * y);
-    if (len != 0.f) {
-        len = sqrtf(len);
-        x /= len;
-        y /= len;
+// the cells a listener-direction pass covers: the near box (rows over blockIdx.y, columns over blockIdx.x and the threads), or --
+// without one -- the window block, one thread per cell
+template <class F>
+__device__ __forceinline__ void forDirectionCells(const AnalyzeArgs& a, const DynParams& dyn, F&& f) {
+    if (a.box) {
+        const NearBox b = nearBoxOf(a, dyn);
+        if (b.r1 < b.r0 || b.c1 < b.c0) return;  // (nothing reached)
+        for (int r = b.r0 + (int)blockIdx.y; r <= b.r1; r += (int)gridDim.y)
+            for (int c = b.c0 + (int)(blockIdx.x * blockDim.x + threadIdx.x); c <= b.c1; c += (int)(gridDim.x * blockDim.x)) f(r * a.gy + c);
+    } else {
+        int X, Y;
+        if (analysisWindowCell(a, dyn, &X, &Y)) f(X * a.gy + Y);
     }
-    *ox = x;
-    *oy = y;
 }
-__device__ __forceinline__ bool isFarCell(const FarInfo& f, long long cell) {
-    if (!f.on) return false;
-    const int r = (int)(cell / f.gy), c = (int)(cell - (long long)r * f.gy);
-    return r < f.r0 || r >= f.r0 + f.nr || c < f.c0 || c >= f.c0 + f.nc;
-}
+
+// (farDirectionOf / isFarCell: pv_analysis.h)
 
 // materialise the direction planes of the far cells (whole-map read-backs)
 __global__ __launch_bounds__(256) void pv_far_dir_kernel(float* __restrict__ dirX, float* __restrict__ dirY, long long n,
@@ -2642,12 +2657,7 @@ void launchFarDirections(float* res, long long n, const FarInfo& f, hipStream_t 
 
 void launchFillDelay(float* delay, long long n, hipStream_t stream);
 
-__global__ __launch_bounds__(256) void pv_direction_kernel(const AnalyzeArgs a) {
-    if (analysisAborted(a)) return;
-    const DynParams dyn = *a.dyn;
-    int X, Y;
-    if (!analysisWindowCell(a, dyn, &X, &Y)) return;
-    const int index = X * a.gy + Y;
+__device__ __forceinline__ void directionWalkCell(const AnalyzeArgs& a, const int index) {
     float loudness = a.out[index];
     int cur = index;
     float delay = FLT_MAX;
@@ -2683,33 +2693,36 @@ __global__ __launch_bounds__(256) void pv_direction_kernel(const AnalyzeArgs a) 
     }
     storeDirection(a, index, cur);
 }
+__global__ __launch_bounds__(256) void pv_direction_kernel(const AnalyzeArgs a) {
+    if (analysisAborted(a)) return;
+    const DynParams dyn = *a.dyn;
+    forDirectionCells(a, dyn, [&](const int index) { directionWalkCell(a, index); });
+}
 
 // listener direction by pointer jumping: the per-cell steps are dirInitCell / dirJumpCell / dirFinalCell (pv_analysis_dev.h)
 __global__ __launch_bounds__(256) void pv_dir_init_kernel(const AnalyzeArgs a, int* J) {
     if (analysisAborted(a)) return;
     const DynParams dyn = *a.dyn;
-    int X, Y;
-    if (!analysisWindowCell(a, dyn, &X, &Y)) return;
-    dirInitCell<false>(a, dyn, J, X * a.gy + Y);
+    forDirectionCells(a, dyn, [&](const int p) { dirInitCell<false>(a, dyn, J, p); });
 }
 
 __global__ __launch_bounds__(256) void pv_dir_jump_kernel(const AnalyzeArgs a, int* J) {
     if (analysisAborted(a)) return;
     const DynParams dyn = *a.dyn;
-    int X, Y;
-    if (!analysisWindowCell(a, dyn, &X, &Y)) return;
-    dirJumpCell<false>(a, dyn, J, X * a.gy + Y);
+    forDirectionCells(a, dyn, [&](const int p) { dirJumpCell<false>(a, dyn, J, p); });
 }
 
 __global__ __launch_bounds__(256) void pv_dir_final_kernel(const AnalyzeArgs a, const int* J) {
     if (analysisAborted(a)) return;
     const DynParams dyn = *a.dyn;
-    int X, Y;
-    if (!analysisWindowCell(a, dyn, &X, &Y)) return;
-    dirFinalCell<false>(a, dyn, J, X * a.gy + Y);
+    forDirectionCells(a, dyn, [&](const int p) { dirFinalCell<false>(a, dyn, J, p); });
 }
 
-static dim3 analysisWindowGrid(const AnalyzeArgs& a) { return dim3((a.winCols + 255) / 256, a.winRows); }
+// (with a near box: a bounded grid whose blocks stride over the box -- the blocks beyond it leave at once)
+static dim3 analysisWindowGrid(const AnalyzeArgs& a) {
+    if (a.box) return dim3((unsigned)std::min((a.winCols + 255) / 256, 4), (unsigned)std::min(a.winRows, 256));
+    return dim3((a.winCols + 255) / 256, a.winRows);
+}
 
 static void launchDirectionJump(const AnalyzeArgs& a, int* J, hipStream_t stream) {
     const dim3 grid = analysisWindowGrid(a), block(256);
@@ -2736,22 +2749,23 @@ __global__ void pv_pack_results_kernel(const float* __restrict__ res, long long 
 // the nr x nc block of the result map whose first cell is (r0, c0) as AoS records (the live module publishes only
 // the history window's block of every iteration: everything outside it is stale values + a closed-form direction)
 __global__ void pv_pack_window_kernel(const float* __restrict__ res, long long n, int gy, int r0, int c0, int nr, int nc,
-                                      float* __restrict__ out8) {
+                                      float* __restrict__ out8, const FarInfo f) {
     const int wc = blockIdx.x * blockDim.x + threadIdx.x, wr = blockIdx.y;
     if (wc >= nc || wr >= nr) return;
     const long long i = (long long)(r0 + wr) * gy + (c0 + wc);
     const long long o = (long long)wr * nc + wc;
     float4 lo = make_float4(res[i], res[n + i], res[2 * n + i], res[3 * n + i]);
     float4 hi = make_float4(res[4 * n + i], res[5 * n + i], res[6 * n + i], res[7 * n + i]);
+    if (isFarCell(f, i)) farDirectionOf(f, i, &hi.x, &hi.y);  // (a far cell: its direction is not in the planes)
     reinterpret_cast<float4*>(out8)[2 * o] = lo;
     reinterpret_cast<float4*>(out8)[2 * o + 1] = hi;
 }
 
-void launchPackWindow(const float* res, long long n, int gy, int r0, int c0, int nr, int nc, float* out8,
+void launchPackWindow(const float* res, long long n, int gy, int r0, int c0, int nr, int nc, float* out8, const FarInfo& far,
                       hipStream_t stream) {
     if (nr <= 0 || nc <= 0) return;
     hipLaunchKernelGGL(pv_pack_window_kernel, dim3((unsigned)((nc + 255) / 256), (unsigned)nr), dim3(256), 0, stream, res,
-                       n, gy, r0, c0, nr, nc, out8);
+                       n, gy, r0, c0, nr, nc, out8, far);
 }
 
 // one cell of the result map -> 8 floats in pinned host memory (Analyzer::GetResponseResult, Analyzer.cpp:106-116)
@@ -2937,13 +2951,8 @@ void launchEncode(const AnalyzeArgs& a, hipStream_t stream) {
     else
         hipLaunchKernelGGL(pv_encode_kernel, dim3((unsigned)((a.histPlane + 255) / 256)), dim3(256), 0, stream, a);
 }
-// wet gain + decay time: sixteen lanes per cell or one by the number of reachable cells, decided on the device (the launch
-// of the other form leaves at once; a forced form, PVA_OPT_RT60_LANES, launches only itself)
-void launchRt60(const AnalyzeArgs& a, hipStream_t stream) {
-    if (a.rt60Lanes == 0 || a.rt60Lanes == 16)
-        hipLaunchKernelGGL(pv_rt60_wave_kernel, dim3((a.winCols + 15) / 16, a.winRows), dim3(256), 0, stream, a);
-    launchRt60Blocked(a, stream);
-}
+// wet gain + decay time (pv_rt60.hip): the form is decided on the device from the number of cells with an onset
+void launchRt60(const AnalyzeArgs& a, hipStream_t stream) { launchRt60Forms(a, stream); }
 
 void launchAnalysisCells(const AnalyzeArgs& a, hipStream_t stream) {
     launchOnset(a, stream);
@@ -2967,7 +2976,7 @@ void launchFillDelay(float* delay, long long n, hipStream_t stream) {
 }
 
 void launchAnalysisFar(const AnalyzeArgs& a, hipStream_t stream) {
-    if (a.wholeWindow) return;  // (no far cells: pv_onset_kernel does what is left of this pass)
+    if (a.wholeWindow || a.box) return;  // (no far-cell pass: pv_onset_kernel does what is left of it)
     const int n = a.gx * a.gy;
     if (a.lazyFar) {
         const int nr = max(a.prevNR, min(a.winRows, a.gx)), nc = max(a.prevNC, min(a.winCols, a.gy));

@@ -92,8 +92,9 @@ void launchAnalysisFused(const FusedArgs& f, hipStream_t stream);
 // (zeroWords / nZero: words to clear behind everything else -- the resident kernel's flags, for the next run; with them the error flag)
 void launchRunFinish(const float* res, long long n, const long long* cellsHost, int nq, float* outHost, const FarInfo& far,
                      int* err, int* counts, const unsigned* claims, int* statusHost, unsigned* zeroWords, int nZero, hipStream_t stream);
-// wet gain + decay time, blocked forms (pv_rt60.hip: four lanes / one lane per cell; each launch checks on the device whether it is the one)
-void launchRt60Blocked(const AnalyzeArgs& a, hipStream_t stream);
+// wet gain + decay time (pv_rt60.hip): sixteen / four lanes per cell in one launch, the lane-per-cell form in a second one where
+// AnalyzeArgs::rt60Tile announces it; the form is chosen on the device
+void launchRt60Forms(const AnalyzeArgs& a, hipStream_t stream);
 // slab halos: src[i] -> dst[i] for up to six blocks of n floats (n % 4 == 0, 16-byte aligned); dst[i] = NULL skips a block
 void launchHaloPush(const float* const src[6], float* const dst[6], long long n, const HaloHandoff& hand, hipStream_t stream);
 void launchHistRow(const AnalyzeArgs& a, int X, float* outTxPitch, hipStream_t stream);
@@ -108,7 +109,7 @@ void launchGatherOutput(const float* res, long long n, long long cell, float* ou
 void launchFarDirections(float* res, long long n, const FarInfo& far, hipStream_t stream);
 void launchFillDelay(float* delay, long long n, hipStream_t stream);
 void launchPackResults(const float* res, long long n, float* res8, hipStream_t stream);
-void launchPackWindow(const float* res, long long n, int gy, int r0, int c0, int nr, int nc, float* out8,
+void launchPackWindow(const float* res, long long n, int gy, int r0, int c0, int nr, int nc, float* out8, const FarInfo& far,
                       hipStream_t stream);
 void launchStreamAccum(const AnalyzeArgs& a, const uint8_t* hasEmitter, uint8_t* tileOpen, int ntiles,
                        hipStream_t stream);

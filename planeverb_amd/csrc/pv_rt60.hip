@@ -19,7 +19,9 @@
 // cells need sixteen lanes each for parallelism, everything above runs four.  Same bits in every form.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
+#include <climits>
 #include <cstdint>
 
 #include "pv_analysis.h"
@@ -43,22 +45,55 @@ namespace pva {
 
 namespace {
 
-template <int L, int S>
-__global__ __launch_bounds__(256) void pv_rt60_blocked_kernel(const AnalyzeArgs a) {
+// The sixteen- and the four-lane form in ONE launch (round 6; they were two launches beside the lane-per-cell form's, two of the
+// three leaving at once: 5-22 us each behind a run's stencil).  Which one runs is decided here, from the number of cells
+// pv_onset_kernel found an onset in; both work through the list of 64-cell groups with work (AnalyzeArgs::unitList, like the
+// encode pass beside them) instead of the window's rows and columns -- a closed room in a 4096^2 grid is ~100 groups of a
+// 873 x 873-cell window, whose 12 000-48 000 workgroups took 57 us to find the 70 that had work.  The workgroups stride over the
+// list: 16 cells x 16 lanes (a quarter of a group) or 64 cells x 4 lanes per turn.
+__global__ __launch_bounds__(256) void pv_rt60_groups_kernel(const AnalyzeArgs a) {
     __shared__ double tab[96];
     if (analysisAborted(a)) return;
-    if (rt60LanesPerCell(a, *a.activeCount) != L) return;  // (grid-uniform: the other forms' launches do the work)
+    // (the previous run's near box was read by pv_onset_kernel, a launch in front of this one: emptied here, it is the box of the
+    // run after this one)
+    if (a.prevBox && blockIdx.x == 0 && threadIdx.x == 0) {
+        a.prevBox[0] = INT_MAX;
+        a.prevBox[1] = INT_MAX;
+        a.prevBox[2] = -1;
+        a.prevBox[3] = -1;
+    }
+    const int lanes = rt60LanesPerCell(a, a.activeCount[1]);  // (grid-uniform)
+    if (lanes == 1) return;  // (the lane-per-cell form's launch does the work)
+    const DynParams dyn = *a.dyn;
+    const int groups = a.activeCount[4];
     fillLogTab(tab, threadIdx.x, 256);
     __syncthreads();
     const LogTabLds ltab{tab};
-    const DynParams dyn = *a.dyn;
-    constexpr int CPB = 256 / L;  // cells per block, along the window's columns; one window row per blockIdx.y
-    const int sub = threadIdx.x % L;
-    const int wc = blockIdx.x * CPB + threadIdx.x / L, wr = blockIdx.y;
-    Rt60Cell c{-1, {nullptr, 0}, 0};
-    if (wc < a.winCols) c = rt60Cell(a, dyn, dyn.histRow0 - a.G + wr, dyn.histCol0 - a.G + wc);
-    if (__ballot(c.s >= 0) == 0ull) return;  // a wave leaves only when none of its cells has work
-    rt60BlockedBody<L, S>(a, ltab, sub, c.s >= 0, c.s, c.hc.h, c.startingPoint);
+    if (lanes == 16) {
+        const int sub = threadIdx.x & 15;
+        for (int q = blockIdx.x; q < 4 * groups; q += gridDim.x) {
+            const long long g = (long long)a.unitList[q >> 2] * 64 + (q & 3) * 16 + (threadIdx.x >> 4);
+            const PlaneCell pc = planeCell(a, dyn, g);
+            const int s = pc.X * a.gy + pc.Y;
+            const float d = pc.inGrid ? a.delay[s] : FLT_MAX;
+            const bool live = d != FLT_MAX;
+            // a wave skips only when none of its four cells has work: the DPP chains need whole rows, not whole waves, but
+            // keeping the wave together costs nothing
+            if (__ballot(live) == 0ull) continue;
+            rt60WaveBody(a, ltab, sub, live, s, CellHistory{a.hist + g, a.histPlane}, (int)(live ? d : 0.f) + a.nDry + 1);
+        }
+        return;
+    }
+    const int sub = threadIdx.x & 3;
+    for (int q = blockIdx.x; q < groups; q += gridDim.x) {
+        const long long g = (long long)a.unitList[q] * 64 + (threadIdx.x >> 2);
+        const PlaneCell pc = planeCell(a, dyn, g);
+        const int s = pc.X * a.gy + pc.Y;
+        const float d = pc.inGrid ? a.delay[s] : FLT_MAX;
+        const bool live = d != FLT_MAX;
+        if (__ballot(live) == 0ull) continue;
+        rt60BlockedBody<4, 4>(a, ltab, sub, live, s, a.hist + g, (int)(live ? d : 0.f) + a.nDry + 1);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -84,7 +119,7 @@ template <int S, int NB>
 __global__ __launch_bounds__(PV_RT60_TILE_BLOCK) void pv_rt60_tile_kernel(const AnalyzeArgs a) {
     __shared__ double tab[96];
     if (analysisAborted(a)) return;
-    if (rt60LanesPerCell(a, *a.activeCount) != 1) return;  // (grid-uniform)
+    if (rt60LanesPerCell(a, a.activeCount[1]) != 1) return;  // (grid-uniform)
     fillLogTab(tab, threadIdx.x, PV_RT60_TILE_BLOCK);
     __syncthreads();
     const LogTabLds ltab{tab};
@@ -260,20 +295,17 @@ void launchCarryResults(const AnalyzeArgs& a, const float* srcOut, hipStream_t s
     hipLaunchKernelGGL(pv_carry_results_kernel, dim3((a.winCols + 255) / 256, a.winRows), dim3(256), 0, stream, a, srcOut);
 }
 
-// the forms above; the sixteen-lane form (pv_rt60_wave_kernel, pv_kernels.hip) is launched beside them by launchAnalysis.  Which
-// one does the work is decided on the device (rt60LanesPerCell); a forced form (PVA_OPT_RT60_LANES) launches only itself.
-void launchRt60Blocked(const AnalyzeArgs& a, hipStream_t stream) {
-    // (the number of cells with work is known on the device only; the window's size bounds it: no launch for a form it rules out)
-    if (a.rt60Lanes == 4 || (a.rt60Lanes == 0 && a.histPlane > 8192)) {
-        hipLaunchKernelGGL((pv_rt60_blocked_kernel<4, 4>), dim3((a.winCols + 63) / 64, a.winRows), dim3(256), 0, stream, a);
-        // (one lane per cell ALONG WINDOW COLUMNS -- <1, 4>, <1, 8> -- was measured in round 4: slower than four lanes at every
-        // size, 0.27 vs 0.15 ms at 127^2, 1.93 vs 1.70 ms at 512^2 / T = 3179; <4, 8> and <4, 2> within 3 % of <4, 4>:
-        // profiles/r04_rt60.txt)
-    }
-    if (a.rt60Lanes == 1 || (a.rt60Lanes == 0 && a.histPlane > kRt60TileMinCells)) {
+// One launch for the sixteen- and four-lane forms, one more for the lane-per-cell form where the caller expects it to be the one
+// that runs (AnalyzeArgs::rt60Tile: the window can hold that many cells AND the previous run reached that many -- Solver::
+// analyzeArgs): without it the four-lane form takes whatever number of cells there is.  A forced form (PVA_OPT_RT60_LANES)
+// launches only itself.
+void launchRt60Forms(const AnalyzeArgs& a, hipStream_t stream) {
+    const long long groups = (a.histPlane + 63) / 64;
+    // (by choice the sixteen-lane form serves up to 8 192 cells = 512 quarters, the four-lane form 98 304 = 1 536 groups)
+    hipLaunchKernelGGL(pv_rt60_groups_kernel, dim3((unsigned)std::min<long long>(4 * groups, a.rt60Lanes ? 8192 : 2048)), dim3(256), 0, stream, a);
+    if (a.rt60Tile)
         hipLaunchKernelGGL((pv_rt60_tile_kernel<PV_RT60_TILE_S, PV_RT60_TILE_NB>),
                            dim3((unsigned)((a.histPlane + PV_RT60_TILE_BLOCK - 1) / PV_RT60_TILE_BLOCK)), dim3(PV_RT60_TILE_BLOCK), 0, stream, a);
-    }
 }
 
 }  // namespace pva

@@ -349,6 +349,16 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     // far cells lazily: whole grids with a windowed history (a slab group / the streaming mode run their own passes)
     lazyFar_ = opt_.lazyFar && !isSlab() && !opt_.streaming;
     if (lazyFar_) launchFillDelay(delay_, (long long)std::max(lgx_, 1) * g_.gy, stream_);  // "no onset", Analyzer.cpp:64-68
+    {
+        const char* e = getenv("PLANEVERB_AMD_NEAR_BOX");
+        useNearBox_ = lazyFar_ && !(e && atoi(e) == 0);
+        if (useNearBox_) {
+            if (!dalloc(&nearBox_, 8, false)) return false;
+            const int empty[8] = {INT_MAX, INT_MAX, -1, -1, INT_MAX, INT_MAX, -1, -1};
+            // (pageable source: the copy is staged before the call returns)
+            if (!hipOk(hipMemcpyAsync(nearBox_, empty, sizeof(empty), hipMemcpyHostToDevice, stream_), "near box")) return false;
+        }
+    }
     scratchCount_ = std::max<size_t>({(size_t)3 * std::max(T_, g_.T), (size_t)lNX_ * g_.NY * 3,
                                      (size_t)geo_.ntx * rxi_ * geo_.nty * wi_});  // the last: direction scratch
     if (!dalloc(&scratch_, scratchCount_, true)) return false;
@@ -595,7 +605,7 @@ Solver::~Solver() {
     if (emCells_) hipFree(emCells_);
     if (emTrace_) hipFree(emTrace_);
     void* ptrs[] = {coef_,      matDev_, pulseDev_, hist_,  tileFirst_, tileClass_, generalList_,
-                    generalCount_, dynDev_, errFlag_, res8_,     delay_, scratch_, res_, activeCount_, win8_, unitList_, fusedCtl_, labelDev_,
+                    generalCount_, dynDev_, errFlag_, res8_,     delay_, scratch_, res_, activeCount_, win8_, unitList_, fusedCtl_, labelDev_, nearBox_,
                     histAbove_, histEdge_, tileDead_, deadCount_};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -1322,6 +1332,11 @@ AnalyzeArgs Solver::analyzeArgs(float lx, float lz) const {
     const bool smallWindow = a.winRows <= 256 && a.winCols <= 256;
     a.dirJump = (!opt_.denseHistory && !(smallWindow && geo_.ntx * geo_.nty > 4096)) ? 1 : 0;
     a.rt60Lanes = (opt_.rt60Lanes == 16 || opt_.rt60Lanes == 4 || opt_.rt60Lanes == 1) ? opt_.rt60Lanes : 0;
+    // the lane-per-cell form of the decay-time pass gets its launch where it can be the one that runs: a window that holds that
+    // many cells, and -- once a run of this solver has been read back -- a run that reached half as many (a closed room in a large
+    // grid never does: one launch less behind every run; without the launch the four-lane form takes any number of cells)
+    a.rt60Tile = (a.rt60Lanes == 1 || (a.rt60Lanes == 0 && histPlane_ > kRt60TileMinCells &&
+                                       (lastReached_ < 0 || lastReached_ > kRt60TileMinCells / 2))) ? 1 : 0;
     a.T = T_;
     a.nDir = g_.nDir;
     a.nDry = g_.nDry;
@@ -1343,6 +1358,10 @@ AnalyzeArgs Solver::analyzeArgs(float lx, float lz) const {
     a.prevC0 = farWin_.c0;
     a.prevNR = farWin_.nr;
     a.prevNC = farWin_.nc;
+    if (useNearBox_ && !a.wholeWindow && !useFused_) {  // (nearPar_ names the box of the run analysed LAST: this run takes the other)
+        a.box = nearBox_ + 4 * (nearPar_ ^ 1);
+        a.prevBox = nearBox_ + 4 * nearPar_;
+    }
     a.ring = opt_.streaming ? ring_ : 0;
     a.sOnset = sOnset_;
     a.sEdry = sState_[0];
@@ -1378,6 +1397,7 @@ FarInfo Solver::farInfo() const {
     f.c0 = farWin_.c0;
     f.nr = farWin_.nr;
     f.nc = farWin_.nc;
+    f.box = (f.on && nearBoxValid_) ? nearBox_ + 4 * nearPar_ : nullptr;
     f.gy = g_.gy;
     f.lx = lastLx_;
     f.lz = lastLz_;
@@ -1411,6 +1431,7 @@ void Solver::enqueueAnalysis(float lx, float lz) {
             farWin_ = curWindow();
             farDirValid_ = false;
         }
+        nearBoxValid_ = false;
         return;
     }
     launchAnalysisFar(a, stream_);
@@ -1436,6 +1457,8 @@ void Solver::enqueueAnalysis(float lx, float lz) {
         farWin_ = curWindow();
         farDirValid_ = false;
     }
+    if (a.box) nearPar_ ^= 1;  // this run's box is now "the box of the run analysed last"
+    nearBoxValid_ = a.box != nullptr;
 }
 
 bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
@@ -1906,6 +1929,7 @@ bool Solver::sync() {
                 return false;
         }
         tim_.reachedCells = counts[1];
+        lastReached_ = counts[1];
         tim_.activeCells = counts[0];
         if (flag == 4 && xcdOk_) {
             // one-XCD mode: fewer workgroups than tiles turned up on this solver's XCD (another dispatch pattern / partition
@@ -2046,14 +2070,11 @@ bool Solver::copyResultsBlock(int r0, int c0, int nr, int nc, float* res8, float
     if (isSlab()) return fail("copyResultsBlock is not available on a slab");
     if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
     const size_t cells = (size_t)nr * nc;
-    // (a block inside the last run's window needs no far cell)
-    if (res8 && (r0 < farWin_.r0 || c0 < farWin_.c0 || r0 + nr > farWin_.r0 + farWin_.nr || c0 + nc > farWin_.c0 + farWin_.nc) &&
-        !ensureFarDirections())
-        return false;
+    // (far cells -- outside the last run's window, or outside its near box -- get their direction in closed form inside the pack)
     if (res8) {
         float* tmp = nullptr;
         if (!hipOk(hipMalloc((void**)&tmp, cells * 32), "hipMalloc result block")) return false;
-        launchPackWindow(res_, (long long)g_.gx * g_.gy, g_.gy, r0, c0, nr, nc, tmp, stream_);
+        launchPackWindow(res_, (long long)g_.gx * g_.gy, g_.gy, r0, c0, nr, nc, tmp, farInfo(), stream_);
         const bool ok = hipOk(hipMemcpyAsync(res8, tmp, cells * 32, hipMemcpyDeviceToHost, stream_), "block copy") &&
                         hipOk(hipStreamSynchronize(stream_), "block sync");
         hipFree(tmp);
@@ -2091,7 +2112,7 @@ bool Solver::publishWindowAsync(float* hostDst, WindowBlock* info, bool overlap)
             if (!hipOk(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate")) return false;
     }
     if (pubCopyPending_) hipStreamWaitEvent(stream_, pubEv_[1], 0);  // the staging block is free again
-    launchPackWindow(res_, (long long)g_.gx * g_.gy, g_.gy, w.r0, w.c0, w.nr, w.nc, win8_, stream_);
+    launchPackWindow(res_, (long long)g_.gx * g_.gy, g_.gy, w.r0, w.c0, w.nr, w.nc, win8_, farInfo(), stream_);
     if (!hipOk(hipGetLastError(), "pack window")) return false;
     *info = w;
     pubCopyPending_ = false;

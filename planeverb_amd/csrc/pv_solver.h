@@ -207,6 +207,13 @@ private:
     Block curWindow() const;        // the history-window block of the result map of the run prepared last
     Block farWin_;                  // window block of the last ANALYSED run (the far cells lie outside it)
     bool farDirValid_ = true;       // the direction planes hold the far cells' directions of that run
+    // Near box (AnalyzeArgs::box): two sets of four device words, the reached cells' bounding box of the run analysed last
+    // (nearBox_ + 4 nearPar_) and of the one before it; PLANEVERB_AMD_NEAR_BOX=0 keeps the window-wide passes
+    int* nearBox_ = nullptr;
+    int nearPar_ = 0;
+    bool useNearBox_ = false;
+    bool nearBoxValid_ = false;     // the last analysed run went through the near-box passes
+    int lastReached_ = -1;          // cells with an onset in the last run read back (-1: none yet): AnalyzeArgs::rt60Tile
     FarInfo farInfo() const;
     bool ensureFarDirections();
     void enqueueAnalysis(float lx, float lz);
