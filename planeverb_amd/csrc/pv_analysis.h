@@ -114,7 +114,7 @@ __device__ __forceinline__ int rt60LanesPerCell(const AnalyzeArgs& a, int active
     // instructions and bytes per sample; it needs two waves per SIMD worth of cells), four in between: profiles/r05_rt60.txt
     // (round 6: counted on the cells WITH AN ONSET -- pv_onset_kernel runs in front of every pass that asks -- instead of the cells
     // of the window's ever-non-zero tiles: a closed room of 4 400 reached cells sat in 13 000 cells of tiles and took the four-lane form)
-    if (activeCells <= 8192) return 16;
+    if (activeCells <= kRt60WaveMaxCells) return 16;
     if (activeCells <= kRt60TileMinCells || !a.rt60Tile) return 4;  // (no launch of the lane-per-cell form: AnalyzeArgs::rt60Tile)
     return a.histPlane * 4 * 16 < (1ll << 31) ? 1 : 4;  // (the lane-per-cell form reaches a chunk's planes through one descriptor and scalar offsets)
 }

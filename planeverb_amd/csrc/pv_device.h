@@ -244,7 +244,11 @@ struct ClassifyArgs {
     int withPulse;
 };
 
-constexpr int kRt60TileMinCells = 98304;  // cells with an onset from which the decay-time pass runs one lane per cell (pv_rt60.hip)
+// cells with an onset up to which the decay-time pass runs sixteen lanes per cell / from which it runs one lane per cell (four in
+// between): profiles/r06_rt60.txt -- 95^2 (8 617 cells) 0.066 / 0.074 ms with sixteen / four lanes, 127^2 (15 310) 0.107 / 0.101;
+// 254^2 (61 231) 0.317 / 0.298 with four / one, 318^2 (96 059) 0.481 / 0.366.  (Rounds 4-5: 8 192 and 98 304.)
+constexpr int kRt60WaveMaxCells = 12288;
+constexpr int kRt60TileMinCells = 49152;
 
 // where the far cells of the last run begin, and what their listener direction is (output gathers, pv_far_dir_kernel)
 struct FarInfo {

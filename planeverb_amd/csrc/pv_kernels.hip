@@ -1145,6 +1145,9 @@ __device__ __forceinline__ void stepTileGeneral4Scalar(const StepArgs& a, const 
 // a mask made once per launch from the face coefficient (NaN = air|air) instead of a compare + v_cndmask per face and
 // step: 12.5 instead of 21 VALU instructions per row and step.  Same operations per cell in the same order (packed ops
 // are IEEE per half; the wall value of an air face is computed and discarded, as before): same bits.
+#ifndef PV_GEN_LOAD_PIN
+#define PV_GEN_LOAD_PIN 0  // 1: the packed general arm's loads issued row by row (measurement: profiles/r06_general_arm.txt)
+#endif
 #ifndef PV_GENERAL_PACKED
 #define PV_GENERAL_PACKED 1  // 1 = where it pays (K < 12), 2 = everywhere, 0 = nowhere
 #endif
@@ -1176,6 +1179,24 @@ __device__ __forceinline__ void stepTileGeneral4Packed(const StepArgs& a, const 
         if (r & 1) v.y = val; else v.x = val;
     };
     float kxr[R], kyr[R], btr[R];
+#if PV_GEN_LOAD_PIN
+    {  // rows top to bottom, the row's coefficients with its fields, a scheduling barrier every two rows (the air arm's order: PV_LOAD_PIN)
+        typedef unsigned int u3v __attribute__((ext_vector_type(3)));
+        const rsrc_t rCoef = makeRsrc(a.coef, a.planeBytes * 3);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int so = soff0 + r * pitchB;
+            setc(pr[r / 2], r, bufLoadF(rPrIn, voff, so));
+            setc(vy[r / 2], r, bufLoadF(rVyIn, voff, so));
+            setc(vx[r / 2], r, bufLoadF(rVxIn, voff, so));
+            const u3v c = __builtin_amdgcn_raw_buffer_load_b96(rCoef, lane * 12, 3 * so, 0);
+            kxr[r] = __uint_as_float(c.x);
+            kyr[r] = __uint_as_float(c.y);
+            btr[r] = __uint_as_float(c.z);
+            if (r % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#else
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int so = soff0 + r * pitchB;
@@ -1184,6 +1205,7 @@ __device__ __forceinline__ void stepTileGeneral4Packed(const StepArgs& a, const 
         setc(vy[r / 2], r, bufLoadF(rVyIn, voff, so));
     }
     loadFaceCoefs<R>(a, lane, soff0, pitchB, kxr, kyr, btr);
+#endif
 #pragma unroll
     for (int r = 0; r < 2 * NP; ++r) {
         if (r < R) {

@@ -301,7 +301,7 @@ void launchCarryResults(const AnalyzeArgs& a, const float* srcOut, hipStream_t s
 // launches only itself.
 void launchRt60Forms(const AnalyzeArgs& a, hipStream_t stream) {
     const long long groups = (a.histPlane + 63) / 64;
-    // (by choice the sixteen-lane form serves up to 8 192 cells = 512 quarters, the four-lane form 98 304 = 1 536 groups)
+    // (the workgroups stride over the list: enough of them for either form's own range, kRt60WaveMaxCells / kRt60TileMinCells)
     hipLaunchKernelGGL(pv_rt60_groups_kernel, dim3((unsigned)std::min<long long>(4 * groups, a.rt60Lanes ? 8192 : 2048)), dim3(256), 0, stream, a);
     if (a.rt60Tile)
         hipLaunchKernelGGL((pv_rt60_tile_kernel<PV_RT60_TILE_S, PV_RT60_TILE_NB>),
