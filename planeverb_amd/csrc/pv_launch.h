@@ -61,7 +61,7 @@ float clockProbeMHz(int device, float* byMemtime);
 // the device's own streaming bandwidth in GB/s: {copy 16 B per lane, copy 4 B per lane, read only, write only} (pv_probe.hip)
 bool bandwidthProbeGBs(int device, float out[4]);
 // error flag, {cells of non-zero tiles, cells with an onset}, resident claim counter (or NULL) -> 4 ints of pinned host memory
-void launchRunStatus(const int* err, int* counts, const unsigned* claims, int* outHost, hipStream_t stream);
+void launchRunStatus(int* err, int* counts, const unsigned* claims, int* outHost, hipStream_t stream);
 #ifdef PV_RESIDENT_TRACE
 void residentDumpTrace();  // development builds: the phase stamps of the last launch to stderr
 #endif

@@ -24,9 +24,10 @@ __global__ void pv_clock_probe_kernel(unsigned long long* out) {
 // pinned host memory by the LAST kernel of the run, so that Solver::sync() reads them after its one stream synchronisation
 // instead of copying them back and synchronising a second time (~25-40 us of host latency per run: a tenth of a 70^2 run).
 namespace {
-__global__ void pv_run_status_kernel(const int* err, int* counts, const unsigned* claims, int* out) {
+__global__ void pv_run_status_kernel(int* err, int* counts, const unsigned* claims, int* out) {
     if (threadIdx.x == 0) {
         out[0] = *err;
+        *err = 0;  // reported: the next run -- a resident run has no launch in front of its kernel that would -- starts clean
         out[1] = counts[0];
         out[2] = counts[1];
         out[3] = claims ? (int)*claims : -1;
@@ -40,7 +41,7 @@ __global__ void pv_run_status_kernel(const int* err, int* counts, const unsigned
 }
 }  // namespace
 
-void launchRunStatus(const int* err, int* counts, const unsigned* claims, int* outHost, hipStream_t stream) {
+void launchRunStatus(int* err, int* counts, const unsigned* claims, int* outHost, hipStream_t stream) {
     hipLaunchKernelGGL(pv_run_status_kernel, dim3(1), dim3(64), 0, stream, err, counts, claims, outHost);
 }
 

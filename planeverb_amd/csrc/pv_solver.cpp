@@ -81,6 +81,7 @@ namespace {
 struct ClaimedStream {
     int device, priority;
     hipStream_t stream;
+    std::shared_ptr<std::recursive_mutex> use;  // QueueClaim::use of the owner
 };
 std::mutex g_streamRegistryMutex;
 std::vector<ClaimedStream> g_claimedStreams;
@@ -107,7 +108,12 @@ bool QueueClaim::claim(int device, hipStream_t* stream, int priority, const void
             // high-priority sleeper keeps a normal stream's stamp kernel waiting from ANOTHER queue just as well.
             if (other.device != device || other.priority != priority) continue;
             ++peers;
-            if (hipStreamQuery(other.stream) != hipSuccess) continue;  // (a busy stream is left alone)
+            // (the owner is enqueueing or capturing right now, or its stream is busy: left alone)
+            std::unique_lock<std::recursive_mutex> owner(*other.use, std::try_to_lock);
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (!owner.owns_lock() || hipStreamIsCapturing(other.stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone ||
+                hipStreamQuery(other.stream) != hipSuccess)
+                continue;
             if (!stamps && hipHostMalloc((void**)&stamps, 4 * sizeof(unsigned long long)) != hipSuccess) return true;
             if (streamsShareQueue(other.stream, *stream, stamps)) {
                 shared = true;
@@ -127,7 +133,8 @@ bool QueueClaim::claim(int device, hipStream_t* stream, int priority, const void
     if (e && atoi(e) >= 2)
         std::fprintf(stderr, "[planeverb_amd] stream of %p (priority class %d): %d re-deal(s), %zu claimed stream(s) of its class, device %d\n",
                      owner, priority, redeals, peers, device);
-    g_claimedStreams.push_back(ClaimedStream{device, priority, *stream});
+    use = std::make_shared<std::recursive_mutex>();
+    g_claimedStreams.push_back(ClaimedStream{device, priority, *stream, use});
     claimed = *stream;
     return true;
 }
@@ -558,6 +565,11 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
         const bool ok = enqueueRun(g_.gx / 2, g_.gy / 2, 0.f, 0.f) && sync();
         opt_.skipAnalysis = false;
         if (!ok) return false;
+        // (it was not a run: a fresh solver answers "no simulation has run yet" to whoever asks for a window, an impulse response
+        // or a history plane, and its timings are empty)
+        dynValid_ = false;
+        tim_ = SolverTimings{};
+        lastReached_ = -1;
     }
     return true;
 }
@@ -715,6 +727,7 @@ bool Solver::applyGeometry() {
     if (!geometryDirty_ && mat_.dirtyLo() >= mat_.dirtyHi()) return true;
     const auto t0 = std::chrono::steady_clock::now();
     int lo = mat_.dirtyLo(), hi = mat_.dirtyHi();
+    bool airChanged = geometryDirty_;  // did any cell change between air and wall?  (else the air components stand: makeLabels)
     if (lo < hi) {
         const auto& beta = mat_.beta();
         const auto& R = mat_.R();
@@ -726,6 +739,7 @@ bool Solver::applyGeometry() {
                 const size_t i = (size_t)x * g_.NY + y;
                 const float Rv = R[i];
                 matHost_[i] = beta[i] ? std::numeric_limits<float>::quiet_NaN() : (1.f - Rv) / (1.f + Rv);
+                airChanged = airChanged || betaHost_[i] != (beta[i] ? 1 : 0);
                 betaHost_[i] = beta[i] ? 1 : 0;
                 byHost_[i] = mat_.by()[i];
             }
@@ -768,7 +782,9 @@ bool Solver::applyGeometry() {
         const long long nt = (long long)geo_.ntx * geo_.nty;
         stepWhich_ = 4 | (((e ? atoi(e) != 0 : (long long)count * 100 >= 8 * nt)) ? kStepGeneralPacked : 0);
     }
-    if (!makeLabels()) return false;
+    // (an update that only changes absorption values -- or re-adds a box where it was -- leaves the air components as they are: no
+    // flood fill over the grid, no upload: 15-20 ms of a 1024^2 live iteration with moving absorbers)
+    if ((airChanged || !labelsValid_) && !makeLabels()) return false;
     mat_.clearDirty();
     geometryDirty_ = false;
     planesDirty_ = true;  // a tile that is dead now may hold an earlier scene's fields
@@ -783,7 +799,7 @@ bool Solver::applyGeometry() {
 // per component.  Small grids only (the reference's presets, the 512^2 configurations): O(cells) per geometry change.
 bool Solver::makeLabels() {
     const size_t n = (size_t)g_.NX * g_.NY;
-    if (isSlab() || opt_.streaming || opt_.skipAnalysis || n > (size_t)PV_LABEL_MAX_CELLS) return true;
+    if (isSlab() || opt_.streaming || opt_.skipAnalysis || n > (size_t)PV_LABEL_MAX_CELLS) return labelsValid_ = true;
     if (!labelDev_ && !dalloc(&labelDev_, n, false)) return false;
     labelHost_.assign(n, -1);
     std::vector<int> stack;
@@ -806,8 +822,9 @@ bool Solver::makeLabels() {
         }
         ++next;
     }
-    return hipOk(hipMemcpyAsync(labelDev_, labelHost_.data(), n * sizeof(int), hipMemcpyHostToDevice, stream_), "label upload") &&
-           hipOk(hipStreamSynchronize(stream_), "label sync");
+    labelsValid_ = hipOk(hipMemcpyAsync(labelDev_, labelHost_.data(), n * sizeof(int), hipMemcpyHostToDevice, stream_), "label upload") &&
+                   hipOk(hipStreamSynchronize(stream_), "label sync");
+    return labelsValid_;
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -1462,6 +1479,7 @@ void Solver::enqueueAnalysis(float lx, float lz) {
 }
 
 bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
+    const auto inUse = queue_.lockUse();  // (against another solver's creation probing this stream: QueueClaim::use)
     if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
     // one run in flight at a time: the pinned staging of the per-run parameters is reused
     if (pendingTimings_ && !sync()) return false;
@@ -1748,6 +1766,8 @@ bool Solver::runBatch(Solver* const* s, int n, const float* lxyz, bool wait, std
         return false;
     };
     if (n < 1 || n > kBatchMax) return bad("batch size must be 1..8");
+    std::unique_lock<std::recursive_mutex> inUse[kBatchMax];  // (every member's stream, in the batch's order)
+    for (int i = 0; i < n; ++i) inUse[i] = s[i]->queue_.lockUse();
     Solver& lead = *s[0];
     for (int i = 0; i < n; ++i) {
         Solver& v = *s[i];
@@ -1927,6 +1947,7 @@ bool Solver::sync() {
                 !hipOk(hipMemcpyAsync(counts, activeCount_, sizeof(counts), hipMemcpyDeviceToHost, fs), "count copy") ||
                 !hipOk(hipStreamSynchronize(fs), "errFlag sync"))
                 return false;
+            if (flag) hipMemsetAsync(errFlag_, 0, sizeof(int), fs);  // (reported: the next run starts clean)
         }
         tim_.reachedCells = counts[1];
         lastReached_ = counts[1];
@@ -1971,6 +1992,7 @@ bool Solver::sync() {
 
 bool Solver::runSteps(int nsteps, bool withPulse, float lx, float lz) {
     if (opt_.edgeTiles) return fail("stencil-only stepping is not available with edge tiles (batched kernel only)");
+    const auto inUse = queue_.lockUse();
     if (!hipOk(hipSetDevice(device_), "hipSetDevice")) return false;
     if (!applyGeometry()) return false;
     int lcx, lcy;

@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -91,6 +93,12 @@ struct QueueClaim {
     std::vector<hipStream_t> parked;
     hipStream_t claimed = nullptr;
     int redeals = 0;
+    // The probe of a NEW solver launches on the claimed streams of the live ones, from the creating thread.  `use` serialises it
+    // with the stream's owner: the owner holds it while it enqueues on (or captures) its stream, the prober only tries it and
+    // leaves a stream whose owner is at work alone (round 5's hipStreamQuery alone left a window in which the owner could begin
+    // a graph capture under the sleepers: ADVICE r05).
+    std::shared_ptr<std::recursive_mutex> use;
+    std::unique_lock<std::recursive_mutex> lockUse() const { return use ? std::unique_lock<std::recursive_mutex>(*use) : std::unique_lock<std::recursive_mutex>(); }  // (recursive: a run that falls back to the replayed graph re-enters enqueueRun from sync)
     enum { kNormal = 0, kHigh = 1, kLow = 2 };  // the runtime keeps a pool of hardware queues per priority
     bool claim(int device, hipStream_t* stream, int priority, const void* owner);
     void release();  // before the stream itself is destroyed
@@ -213,6 +221,7 @@ private:
     int nearPar_ = 0;
     bool useNearBox_ = false;
     bool nearBoxValid_ = false;     // the last analysed run went through the near-box passes
+    bool labelsValid_ = false;      // labelDev_ holds the air components of the current material plane
     int lastReached_ = -1;          // cells with an onset in the last run read back (-1: none yet): AnalyzeArgs::rt60Tile
     FarInfo farInfo() const;
     bool ensureFarDirections();
