@@ -202,6 +202,8 @@ struct ResidentArgs {
     int ntx, nty, ntiles;
     int T;
     float courant;
+    unsigned long long* stamp;  // pinned host words, or NULL: stamp[0] = the 100 MHz counter when the block that holds tile 0 starts
+                                // (Solver::stampTimed_: a run's timings without event packets between its kernels)
 };
 
 // slab decomposition, neighbours on one device: words in device memory instead of cross-queue events (pv_halo_push_kernel)
@@ -322,6 +324,7 @@ struct AnalyzeArgs {
     // window-wide passes (slabs, whole-grid windows, the experimental one-launch analysis).
     int* box;
     int* prevBox;
+    unsigned long long* stamp;  // pinned host words, or NULL: stamp[1] = the 100 MHz counter when the analysis' first kernel starts
     const int* labels;   // per array cell ((gx + 1) x (gy + 1), index x * labelNY + y): its 4-connected AIR component, -1 for a wall
                          // cell -- or NULL (large grids, slabs).  Pressure never crosses a wall cell (beta = 0 keeps it at zero,
                          // FDTD.cpp:139, and a wall|air face's velocity is a multiple of the AIR cell's pressure, :165-168): a cell of

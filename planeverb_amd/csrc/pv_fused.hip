@@ -205,6 +205,7 @@ __global__ __launch_bounds__(kFusedThreads) void pv_analysis_fused_kernel(const 
     // (a run whose stencil was given up -- resident kernel, errFlag 3 / 4 -- has a half-written history: nothing to analyse, as in
     // every separate kernel.  Grid-uniform, and no ticket has been drawn: the control words stay at zero.)
     if (analysisAborted(a)) return;
+    if (a.stamp && blockIdx.x == 0 && threadIdx.x == 0) a.stamp[1] = wall_clock64();
     const DynParams dyn = *a.dyn;
     fillLogTab(sh.tab, threadIdx.x, kFusedThreads);
     const int active = fusedActiveCells(a, dyn, sh);  // (synchronises: the table is in place)
@@ -333,7 +334,9 @@ void launchAnalysisFused(const FusedArgs&, hipStream_t) {}
 namespace {
 __global__ __launch_bounds__(512) void pv_run_finish_kernel(const float* __restrict__ res, long long n, const long long* cells, int nq,
                                                             float* out, const FarInfo f, int* err, int* counts,
-                                                            const unsigned* claims, int* status, unsigned* zeroWords, int nZero) {
+                                                            const unsigned* claims, int* status, unsigned* zeroWords, int nZero,
+                                                            unsigned long long* stamp) {
+    if (stamp && threadIdx.x == 0) stamp[2] = wall_clock64();  // (the run's device work ends here: Solver::stampTimed_)
     const int q = threadIdx.x >> 3, k = threadIdx.x & 7;
     if (q < nq) {
         const long long c = cells[q];
@@ -366,9 +369,10 @@ __global__ __launch_bounds__(512) void pv_run_finish_kernel(const float* __restr
 }  // namespace
 
 void launchRunFinish(const float* res, long long n, const long long* cellsHost, int nq, float* outHost, const FarInfo& far,
-                     int* err, int* counts, const unsigned* claims, int* statusHost, unsigned* zeroWords, int nZero, hipStream_t stream) {
+                     int* err, int* counts, const unsigned* claims, int* statusHost, unsigned* zeroWords, int nZero,
+                     unsigned long long* stamp, hipStream_t stream) {
     hipLaunchKernelGGL(pv_run_finish_kernel, dim3(1), dim3(512), 0, stream, res, n, cellsHost, nq, outHost, far, err, counts, claims,
-                       statusHost, zeroWords, nZero);
+                       statusHost, zeroWords, nZero, stamp);
 }
 
 }  // namespace pva

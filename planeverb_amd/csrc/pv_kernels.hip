@@ -2454,6 +2454,7 @@ __global__ __launch_bounds__(64 * kOnsetWaves) void pv_onset_kernel(const Analyz
         live = live && mine == theirs;
     }
     if (wave == 0) found[lane] = INT_MAX;
+    if (a.stamp && blockIdx.x == 0 && threadIdx.x == 0) a.stamp[1] = wall_clock64();
     __syncthreads();
     // near box (AnalyzeArgs::box): the cells the PREVIOUS run reached get "no onset" back unless this run reaches them again --
     // every other cell of the map holds it already.  A cell of this window is its own lane's business (below, and where the

@@ -91,7 +91,8 @@ bool fusedAnalysisOk(const AnalyzeArgs& a);
 void launchAnalysisFused(const FusedArgs& f, hipStream_t stream);
 // (zeroWords / nZero: words to clear behind everything else -- the resident kernel's flags, for the next run; with them the error flag)
 void launchRunFinish(const float* res, long long n, const long long* cellsHost, int nq, float* outHost, const FarInfo& far,
-                     int* err, int* counts, const unsigned* claims, int* statusHost, unsigned* zeroWords, int nZero, hipStream_t stream);
+                     int* err, int* counts, const unsigned* claims, int* statusHost, unsigned* zeroWords, int nZero,
+                     unsigned long long* stamp, hipStream_t stream);
 // wet gain + decay time (pv_rt60.hip): sixteen / four lanes per cell in one launch, the lane-per-cell form in a second one where
 // AnalyzeArgs::rt60Tile announces it; the form is chosen on the device
 void launchRt60Forms(const AnalyzeArgs& a, hipStream_t stream);

@@ -322,7 +322,10 @@ __global__ __launch_bounds__(64 * W) void pv_resident_kernel(const ResidentArgs 
     for (int i = 0; i < NP; ++i) pr[i] = vx[i] = vy[i] = v2f{0.f, 0.f};  // a run starts from zero fields, FDTD.cpp:109-119
 
     const DynParams dyn = a.dynVal;
-    if (tile == 0 && threadIdx.x == 0) *a.dynOut = a.dynVal;  // (the block that HOLDS tile 0: in the one-XCD mode block 0 may have left)
+    if (tile == 0 && threadIdx.x == 0) {  // (the block that HOLDS tile 0: in the one-XCD mode block 0 may have left)
+        *a.dynOut = a.dynVal;
+        if (a.stamp) a.stamp[0] = wall_clock64();
+    }
     if (threadIdx.x == 0) a.tileFirst[tile] = INT_MAX;  // (only this block ever touches the entry during the run)
     // listener row inside this wave's window: rows 0..R-2 hold a live pressure (row 0 = the copy of the previous wave's
     // last row), row R-1 does not

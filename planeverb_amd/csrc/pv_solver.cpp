@@ -439,6 +439,10 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
     if (!hipOk(hipHostMalloc((void**)&dynHost_, sizeof(DynParams)), "hipHostMalloc")) return false;
     if (!hipOk(hipHostMalloc((void**)&outHost_, 8 * sizeof(float)), "hipHostMalloc")) return false;
     if (!hipOk(hipHostMalloc((void**)&statusHost_, 8 * sizeof(int)), "hipHostMalloc")) return false;
+    {
+        const char* e = getenv("PLANEVERB_AMD_STAMP_TIMINGS");  // 0: HIP events around the stencil and the analysis of every run
+        if (!(e && atoi(e) == 0) && !hipOk(hipHostMalloc((void**)&stampsHost_, 4 * sizeof(unsigned long long)), "hipHostMalloc")) return false;
+    }
     if (!hipOk(hipHostMalloc((void**)&qCellsHost_, kMaxQueries * sizeof(long long)), "hipHostMalloc")) return false;
     if (!hipOk(hipHostMalloc((void**)&qOutHost_, kMaxQueries * 8 * sizeof(float)), "hipHostMalloc")) return false;
     if (!hipOk(hipHostMalloc((void**)&listHost_, sizeof(int) * (size_t)listCap_), "hipHostMalloc")) return false;
@@ -520,7 +524,7 @@ bool Solver::init(const GridSpec& spec, int device, const SolverOptions& opt) {
             if (const char* e = std::getenv("PLANEVERB_AMD_RESIDENT_XCD_TARGET")) xcdTarget_ = std::atoi(e);
             if (const char* e = std::getenv("PLANEVERB_AMD_RESIDENT_XCD")) {  // 0: never the one-XCD mode
                 xcdOk_ = std::atoi(e) != 0;
-                if (std::atoi(e) > 1) kResidentXcdMaxTiles = std::min(std::atoi(e), 64);
+                if (std::atoi(e) > 1) kResidentXcdMaxTiles = std::min(std::atoi(e), 128);  // (measurements: profiles/r06_resident_two_tiles.txt)
             }
         }
     }
@@ -635,6 +639,7 @@ Solver::~Solver() {
     if (dynHost_) hipHostFree(dynHost_);
     if (outHost_) hipHostFree(outHost_);
     if (statusHost_) hipHostFree(statusHost_);
+    if (stampsHost_) hipHostFree(stampsHost_);
     if (qCellsHost_) hipHostFree(qCellsHost_);
     if (qOutHost_) hipHostFree(qOutHost_);
     if (listHost_) hipHostFree(listHost_);
@@ -1369,6 +1374,7 @@ AnalyzeArgs Solver::analyzeArgs(float lx, float lz) const {
     listenerCellRecip(g_, lx, lz, &a.lcx, &a.lcy);
     a.lazyFar = lazyFar_ ? 1 : 0;
     a.labels = labelDev_;
+    a.stamp = stampTimed_ ? stampsHost_ : nullptr;
     a.labelNY = g_.NY;
     a.wholeWindow = (!isSlab() && !opt_.streaming && histTilesX_ == geo_.ntx && histTilesY_ == geo_.nty) ? 1 : 0;
     a.prevR0 = farWin_.r0;
@@ -1495,7 +1501,8 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
     kevUsed_ = 0;
     loopTimed_ = false;
     cur_ = 0;  // the reset clears set 0; a run never depends on the previous run's fields
-    hipEventRecord(ev_[0], stream_);
+    stampTimed_ = false;
+    if (opt_.streaming) hipEventRecord(ev_[0], stream_);  // (the other paths: below, once it is known whether the run is a resident one)
     // (an explicit tile configuration means "use the tile kernels")
     // The whole-grid-resident kernel wins where a run is a chain of tiny launches even as a replayed graph: measured on
     // MI355X (profiles/r03_presets.txt) 0.47 vs 0.62 ms at 28^2 and 0.67 vs 0.82 ms at 38^2 -- but 0.81 vs 0.69 ms at 39^2,
@@ -1595,6 +1602,8 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
             residentHeld_ = ntiles;
         }
     }
+    stampTimed_ = resident && stampsHost_ != nullptr;
+    if (!stampTimed_) hipEventRecord(ev_[0], stream_);
     if (resident) {
         // one-XCD mode where the grid fits one XCD's CUs and that XCD is not taken by another solver's run
         bool xcd = xcdOk_ && ntiles <= kResidentXcdMaxTiles;
@@ -1637,6 +1646,8 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
         ra.ntiles = ntiles;
         ra.T = T_;
         ra.courant = g_.courant;
+        ra.stamp = stampTimed_ ? stampsHost_ : nullptr;
+        if (stampTimed_) stampsHost_[0] = stampsHost_[1] = stampsHost_[2] = 0ull;  // (the previous run has been synced: enqueueRun's head)
         launchResident(K_, rxi_, ra, stream_);
         tim_.stepLaunches = ceilDiv(T_, K_);
         cur_ = tim_.stepLaunches & 1;
@@ -1689,14 +1700,17 @@ bool Solver::enqueueRun(int lcx, int lcy, float lx, float lz) {
         launchCap_ = numGeneral_;
         if (!enqueueResetAndSteps()) return false;
     }
-    hipEventRecord(ev_[1], stream_);
+    if (!stampTimed_) hipEventRecord(ev_[1], stream_);
     if (!opt_.skipAnalysis) enqueueAnalysis(lx, lz);
-    hipEventRecord(ev_[2], stream_);
+    if (!stampTimed_) hipEventRecord(ev_[2], stream_);
     lastRunBatched_ = false;
     // last kernel of the run: the registered queries' outputs and the status words, both into pinned memory
     launchRunFinish(res_, (long long)g_.gx * g_.gy, qCellsHost_, opt_.skipAnalysis ? 0 : numQueries_, qOutHost_, farInfo(), errFlag_,
                     activeCount_, lastRunXcd_ ? resFlags_ + geo_.ntx * geo_.nty + 1 : nullptr, statusHost_, resFlags_,
-                    resFlags_ ? geo_.ntx * geo_.nty + 2 : 0, stream_);
+                    resFlags_ ? geo_.ntx * geo_.nty + 2 : 0, stampTimed_ ? stampsHost_ : nullptr, stream_);
+    // (ev_[2] is also what the OTHER solver of a pipelined pair waits for before its carry pass reads this solver's maps: behind
+    // the last kernel here, where it delays nothing of this run)
+    if (stampTimed_) hipEventRecord(ev_[2], stream_);
     statusQueued_ = true;
     pendingTimings_ = true;
     return hipOk(hipGetLastError(), "run launch");
@@ -1803,6 +1817,7 @@ bool Solver::runBatch(Solver* const* s, int n, const float* lxyz, bool wait, std
         v.cur_ = 0;
         v.launchCap_ = v.numGeneral_;
         gcap = std::max(gcap, v.numGeneral_);
+        v.stampTimed_ = false;
         hipEventRecord(v.ev_[0], v.stream_);
         v.enqueueBeginRun(true);
         if (i > 0) {  // the shared step loop starts when every run's parameters are on the device
@@ -1908,8 +1923,14 @@ bool Solver::sync() {
     releaseResident();
     if (pendingTimings_) {
         pendingTimings_ = false;
-        hipEventElapsedTime(&tim_.fdtdMs, ev_[0], ev_[1]);
-        hipEventElapsedTime(&tim_.analysisMs, ev_[1], ev_[2]);
+        if (stampTimed_) {  // 100 MHz ticks: the run's first kernel, the analysis' first kernel (0: none ran), the run's last kernel
+            const unsigned long long s0 = stampsHost_[0], s2 = stampsHost_[2], s1 = stampsHost_[1] ? stampsHost_[1] : s2;
+            tim_.fdtdMs = (s0 && s1 > s0) ? (float)((double)(s1 - s0) * 1e-5) : 0.f;
+            tim_.analysisMs = (s2 > s1) ? (float)((double)(s2 - s1) * 1e-5) : 0.f;
+        } else {
+            hipEventElapsedTime(&tim_.fdtdMs, ev_[0], ev_[1]);
+            hipEventElapsedTime(&tim_.analysisMs, ev_[1], ev_[2]);
+        }
         tim_.stepLoopMs = 0.f;
         if (loopTimed_) hipEventElapsedTime(&tim_.stepLoopMs, ev_[3], ev_[1]);
         if (opt_.timeKernels && kevUsed_ > 0) {
@@ -2004,6 +2025,7 @@ bool Solver::runSteps(int nsteps, bool withPulse, float lx, float lz) {
     launchCap_ = numGeneral_;
     planesDirty_ = true;
     enqueueBeginRun(false);
+    stampTimed_ = false;
     hipEventRecord(ev_[0], stream_);
     if (!enqueueSteps(0, nsteps, withPulse, false)) return false;
     hipEventRecord(ev_[1], stream_);

@@ -221,6 +221,11 @@ private:
     int nearPar_ = 0;
     bool useNearBox_ = false;
     bool nearBoxValid_ = false;     // the last analysed run went through the near-box passes
+    // Timings of a resident-kernel run without event packets between its kernels (an event record on the stream is a barrier
+    // packet: ~7 us of bubble in front of the next kernel, three of them per 0.3 ms run): the run's first kernel, the analysis'
+    // first kernel and the run's last kernel write the 100 MHz counter into three pinned words, sync() takes the differences
+    unsigned long long* stampsHost_ = nullptr;
+    bool stampTimed_ = false;       // the run in flight is timed that way
     bool labelsValid_ = false;      // labelDev_ holds the air components of the current material plane
     int lastReached_ = -1;          // cells with an onset in the last run read back (-1: none yet): AnalyzeArgs::rt60Tile
     FarInfo farInfo() const;
