@@ -70,3 +70,7 @@ if [ -f planeverb_amd/libplaneverb_amd_trace.so ]; then PLANEVERB_AMD_LIB=$PWD/p
 (for m in "" 1; do MODEB=$m python tools/gpu_dense.py 4096 1 12,36 2>&1 | tail -1; MODEB=$m PV_PROBE_GENERAL_ONLY=1 python tools/gpu_dense.py 4096 1 12,36 2>&1 | tail -1; done) > $O/general_arm.txt 2>&1
 tools/gpu_modeb_trace.sh $O/modeb_trace 16067 > $O/modeb_trace_4096.txt 2>/dev/null
 hipcc --offload-arch=gfx950 -O3 tools/persist_probe.hip -o /tmp/persist_probe 2>/dev/null && timeout 120 /tmp/persist_probe > $O/persist_probe.txt 2>&1
+# round 6 additions: the timeline of the analysis chain behind a lone run (bench grid, three presets), the decay-time forms' table
+# with the re-measured thresholds, the presets' run times with event-timed runs beside (PLANEVERB_AMD_STAMP_TIMINGS=0)
+(for w in 4096 res:275 res:750 res:1000; do echo "== $w"; tools/gpu_chain_trace.sh $O/chain_$w $w 2>/dev/null | grep -v simple_timer; done) > $O/analysis_chain.txt 2>&1
+(echo "# stamps (default):"; python tools/gpu_run_times.py; echo "# PLANEVERB_AMD_STAMP_TIMINGS=0 (HIP events between the kernels of a resident run):"; PLANEVERB_AMD_STAMP_TIMINGS=0 python tools/gpu_run_times.py; echo "# analysis ms (tools/gpu_analysis_times.py):"; python tools/gpu_analysis_times.py; echo "# PLANEVERB_AMD_NEAR_BOX=0:"; PLANEVERB_AMD_NEAR_BOX=0 python tools/gpu_analysis_times.py) > $O/run_times_r06.txt 2>&1

@@ -43,6 +43,39 @@ def steady(v):
 
 
 shutil.copy(os.path.join(SRC, "trace", "bench_kernel_stats.csv"), os.path.join(DST, R + "_kernel_stats.csv"))
+# the dominant kernel's launches split by what ran beside them (the stats file above averages the warm-up's lone launches with
+# the timed, paired ones: 217 us in round 5, which matched neither quoted figure): a launch counts as PAIRED when launches of the
+# same kernel on another queue overlap more than half of it
+try:
+    tr = [r for r in csv.DictReader(open(os.path.join(SRC, "trace", "bench_kernel_trace.csv"))) if "pv_step_merged_kernel" in r["Kernel_Name"]]
+    ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"]) for r in tr)
+    full = sorted(e[1] - e[0] for e in ev)
+    cut = 0.6 * full[len(full) // 2]  # (the short remainder launch of every run: 3 of 435 steps)
+    groups = {"lone": [], "paired": []}
+    for i, (b0, e0, q0) in enumerate(ev):
+        if e0 - b0 < cut:
+            continue
+        ov = 0
+        j = i - 1
+        while j >= 0 and ev[j][0] > b0 - 2 * (e0 - b0):
+            if ev[j][2] != q0:
+                ov += max(0, min(e0, ev[j][1]) - max(b0, ev[j][0]))
+            j -= 1
+        j = i + 1
+        while j < len(ev) and ev[j][0] < e0:
+            if ev[j][2] != q0:
+                ov += max(0, min(e0, ev[j][1]) - max(b0, ev[j][0]))
+            j += 1
+        groups["paired" if ov > 0.5 * (e0 - b0) else "lone"].append((e0 - b0) / 1e3)
+    with open(os.path.join(DST, R + "_kernel_stats_split.txt"), "w") as fh:
+        fh.write("# pv_step_merged_kernel, full K-step launches of %s_kernel_stats.csv's trace split by what ran beside them (us)\n" % R)
+        fh.write("# class   launches   average   median   p10   p90\n")
+        for k in ("lone", "paired"):
+            v = sorted(groups[k])
+            if v:
+                fh.write("%-7s %9d %9.1f %8.1f %6.1f %6.1f\n" % (k, len(v), sum(v) / len(v), v[len(v) // 2], v[len(v) // 10], v[9 * len(v) // 10]))
+except Exception as e:  # noqa: BLE001
+    print("kernel_stats_split skipped:", e)
 if os.path.exists(os.path.join(ROOT, "gpurun_out", "r02_sq", "summary.md")):
     shutil.copy(os.path.join(ROOT, "gpurun_out", "r02_sq", "summary.md"), os.path.join(DST, R + "_sq_pmc.md"))
 for f in ("bench.json", "bench_8192.json", "bench_8192_open.json", "bench_2048.json", "bench_512.json", "bench_dense.json",
@@ -106,7 +139,7 @@ for tag, fd, wd in (("4096", "pmc_fetch", "pmc_write"), ("8192", "pmc_fetch8k", 
 # the analysis half of the metric: bytes of the analysis chain per RUN (sum over its kernels' launches / runs), for the bench's
 # grid (from the bench passes above) and for the all-cells-reached workload (tools/gpu_analysis_workload.py)
 ANALYSIS = ("pv_far_frame_kernel", "pv_far_cells_kernel", "pv_onset_kernel", "pv_encode_kernel", "pv_encode_groups_kernel",
-            "pv_rt60_wave_kernel", "pv_rt60_blocked_kernel", "pv_rt60_tile_kernel", "pv_direction_kernel", "pv_dir_init_kernel",
+            "pv_rt60_wave_kernel", "pv_rt60_blocked_kernel", "pv_rt60_groups_kernel", "pv_rt60_tile_kernel", "pv_direction_kernel", "pv_dir_init_kernel",
             "pv_dir_jump_kernel", "pv_dir_final_kernel", "pv_carry_results_kernel", "pv_analysis_fused_kernel", "pv_run_finish_kernel")
 
 
