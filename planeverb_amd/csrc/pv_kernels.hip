@@ -2540,11 +2540,18 @@ __global__ __launch_bounds__(64 * kOnsetWaves) void pv_onset_kernel(const Analyz
             r1 = max(r1, __shfl_xor(r1, off));
             c1 = max(c1, __shfl_xor(c1, off));
         }
+        // (an atomic only where the group can still move a bound: in an open field 4 300 groups have work, and four atomics each on
+        // the same four words took 330 us of the kernel -- same-address atomics are served one after the other; the plain reads
+        // may be stale, which only means an atomic that changes nothing)
         if (lane == 0) {
-            atomicMin(a.box + 0, r0);
-            atomicMin(a.box + 1, c0);
-            atomicMax(a.box + 2, r1);
-            atomicMax(a.box + 3, c1);
+            const int b0 = __hip_atomic_load(a.box + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int b1 = __hip_atomic_load(a.box + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int b2 = __hip_atomic_load(a.box + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int b3 = __hip_atomic_load(a.box + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (r0 < b0) atomicMin(a.box + 0, r0);
+            if (c0 < b1) atomicMin(a.box + 1, c0);
+            if (r1 > b2) atomicMax(a.box + 2, r1);
+            if (c1 > b3) atomicMax(a.box + 3, c1);
         }
     }
     if (lane == 0) {
@@ -2646,19 +2653,17 @@ __global__ __launch_bounds__(256) void pv_far_frame_kernel(const AnalyzeArgs a) 
     storeDirection(a, index, index);
 }
 
-// the cells a listener-direction pass covers: the near box (rows over blockIdx.y, columns over blockIdx.x and the threads), or --
-// without one -- the window block, one thread per cell
+// the cells a listener-direction pass covers: one thread per cell of the window block -- with a near box only the cells inside
+// it (the workgroups of the other rows and column blocks leave at once: a closed room's box is ~90 of the window's 3 500
+// workgroups.  A bounded grid whose workgroups stride over the box was measured first: fine for that room, but an open field's
+// box IS the window, and three cells per thread one after the other tripled these latency-bound passes -- 8192^2 open field
+// analysis 0.41 -> 0.75 ms)
 template <class F>
 __device__ __forceinline__ void forDirectionCells(const AnalyzeArgs& a, const DynParams& dyn, F&& f) {
-    if (a.box) {
-        const NearBox b = nearBoxOf(a, dyn);
-        if (b.r1 < b.r0 || b.c1 < b.c0) return;  // (nothing reached)
-        for (int r = b.r0 + (int)blockIdx.y; r <= b.r1; r += (int)gridDim.y)
-            for (int c = b.c0 + (int)(blockIdx.x * blockDim.x + threadIdx.x); c <= b.c1; c += (int)(gridDim.x * blockDim.x)) f(r * a.gy + c);
-    } else {
-        int X, Y;
-        if (analysisWindowCell(a, dyn, &X, &Y)) f(X * a.gy + Y);
-    }
+    int X, Y;
+    if (!analysisWindowCell(a, dyn, &X, &Y)) return;
+    if (a.box && !nearBoxOf(a, dyn).holds(X, Y)) return;
+    f(X * a.gy + Y);
 }
 
 // (farDirectionOf / isFarCell: pv_analysis.h)
@@ -2741,11 +2746,7 @@ __global__ __launch_bounds__(256) void pv_dir_final_kernel(const AnalyzeArgs a, 
     forDirectionCells(a, dyn, [&](const int p) { dirFinalCell<false>(a, dyn, J, p); });
 }
 
-// (with a near box: a bounded grid whose blocks stride over the box -- the blocks beyond it leave at once)
-static dim3 analysisWindowGrid(const AnalyzeArgs& a) {
-    if (a.box) return dim3((unsigned)std::min((a.winCols + 255) / 256, 4), (unsigned)std::min(a.winRows, 256));
-    return dim3((a.winCols + 255) / 256, a.winRows);
-}
+static dim3 analysisWindowGrid(const AnalyzeArgs& a) { return dim3((a.winCols + 255) / 256, a.winRows); }
 
 static void launchDirectionJump(const AnalyzeArgs& a, int* J, hipStream_t stream) {
     const dim3 grid = analysisWindowGrid(a), block(256);
