@@ -4,6 +4,7 @@
 #include <cstdio>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cstring>
 #include <memory>
@@ -125,15 +126,36 @@ bool SlabGroup::init(const GridSpec& spec, const std::vector<int>& devices, cons
         const bool forced = e && atoi(e) == 2;  // (2: whatever the queue count says -- the stress tests of the fallback)
         if (any && oneDev && pushHalos_ && !(e && atoi(e) == 0) && (normalStreams <= queues || forced)) {
             if (!hipOk(hipMalloc((void**)&handoff_, sizeof(unsigned) * (3 * (size_t)S + 1)), "hipMalloc")) return false;
-            if (!forced && !probeHandoff()) {
+            // (round 6: a dry run that times out is answered by other streams for every slab, up to three times, before the group falls
+            // back to stream events -- one creation in ten came up that way at 5.6 instead of 2.2 ms per run at 2048^2, always behind
+            // other groups of the same process: profiles/r05_slabs.txt)
+            // ... and so is a dry run that comes through SLOWLY: sixteen sweeps of push kernels that move no rows take ~4 us per slab and
+            // sweep where the slabs' streams run beside each other, and 2-4 x that where they only take turns -- the group then runs at
+            // 5.0-7.3 instead of 2.6-6.2 ms (profiles/r06_slabs.txt; the pairwise sleeper / stamp probe of QueueClaim sees nothing there)
+            bool ok = forced || probeHandoff();
+            const float slowUs = 6.5f * (float)S;
+            for (int attempt = 0; !forced && (!ok || probeUsPerSweep_ > slowUs) && attempt < 3; ++attempt) {
+                bool dealt = true;
+                for (Solver* sv : slabs_) {
+                    hipSetDevice(sv->device_);
+                    dealt = sv->redealMainStream() && dealt;
+                }
+                hipSetDevice(rootDevice_);
+                if (!dealt) break;
+                ok = probeHandoff();
+                const char* dbg = getenv("PLANEVERB_AMD_QUEUE_PROBE");
+                if (dbg && atoi(dbg) >= 2)
+                    std::fprintf(stderr, "[planeverb_amd] slab group %p: hand-off dry run after re-deal %d: %s, %.1f us per sweep\n", (void*)this, attempt + 1, ok ? "ok" : "timed out", probeUsPerSweep_);
+            }
+            if (!ok) {
                 hipFree(handoff_);
                 handoff_ = nullptr;
             }
         }
         const char* dbg = getenv("PLANEVERB_AMD_QUEUE_PROBE");
         if (dbg && atoi(dbg) >= 2)
-            std::fprintf(stderr, "[planeverb_amd] slab group %p: %d slabs, hand-off words %s\n", (void*)this, S,
-                         handoff_ ? "on" : (any && oneDev ? "OFF (stream events)" : "not applicable"));
+            std::fprintf(stderr, "[planeverb_amd] slab group %p: %d slabs, hand-off words %s (dry run: %.1f us per sweep)\n", (void*)this, S,
+                         handoff_ ? "on" : (any && oneDev ? "OFF (stream events)" : "not applicable"), probeUsPerSweep_);
     }
     const size_t n = (size_t)g_.gx * g_.gy;
     winRows_ = a.histTilesXG_ * rxi_;
@@ -177,7 +199,8 @@ bool SlabGroup::probeHandoff() {
         return false;
     const float* src[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     float* dst[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    for (int li = 0; li < 3; ++li)
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int li = 0; li < kProbeSweeps; ++li)
         for (int s = 0; s < S; ++s) {
             Solver& v = *slabs_[(size_t)s];
             HaloHandoff hand{};
@@ -197,6 +220,7 @@ bool SlabGroup::probeHandoff() {
         }
     bool ok = hipGetLastError() == hipSuccess;
     for (int s = 0; s < S; ++s) ok = (hipStreamSynchronize(slabs_[(size_t)s]->stream_) == hipSuccess) && ok;
+    probeUsPerSweep_ = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count() / (float)kProbeSweeps;
     unsigned word = 1;  // (never the legacy stream: see Solver::applyGeometry)
     ok = ok && hipMemcpyAsync(&word, handoff_ + 3 * S, sizeof(word), hipMemcpyDeviceToHost, rootStream_) == hipSuccess &&
          hipStreamSynchronize(rootStream_) == hipSuccess && word == 0u;

@@ -28,6 +28,8 @@ public:
     static SlabGroup* create(const GridSpec& spec, const std::vector<int>& devices, const SolverOptions& opt,
                              std::string* err);
     ~SlabGroup();
+    static constexpr int kProbeSweeps = 16;  // sweeps of the hand-off's dry run (probeHandoff)
+    float probeUsPerSweep_ = 0.f;            // how long one of them took, launches and sync included
 
     const GridSpec& spec() const { return g_; }
     int numSlabs() const { return (int)slabs_.size(); }

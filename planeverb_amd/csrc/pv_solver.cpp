@@ -136,6 +136,21 @@ bool QueueClaim::claim(int device, hipStream_t* stream, int priority, const void
     use = std::make_shared<std::recursive_mutex>();
     g_claimedStreams.push_back(ClaimedStream{device, priority, *stream, use});
     claimed = *stream;
+    priorityClass = priority;
+    return true;
+}
+
+bool QueueClaim::replace(hipStream_t* stream) {
+    if (!claimed || *stream != claimed) return false;  // (not a claimed stream: PLANEVERB_AMD_QUEUE_PROBE=0)
+    std::lock_guard<std::mutex> lk(g_streamRegistryMutex);
+    hipStream_t fresh = nullptr;
+    if (createStream(&fresh, priorityClass) != hipSuccess) return false;
+    for (auto& c : g_claimedStreams)
+        if (c.stream == claimed) c.stream = fresh;
+    parked.push_back(claimed);
+    claimed = fresh;
+    *stream = fresh;
+    ++redeals;
     return true;
 }
 

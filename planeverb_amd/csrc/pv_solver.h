@@ -101,6 +101,10 @@ struct QueueClaim {
     std::unique_lock<std::recursive_mutex> lockUse() const { return use ? std::unique_lock<std::recursive_mutex>(*use) : std::unique_lock<std::recursive_mutex>(); }  // (recursive: a run that falls back to the replayed graph re-enters enqueueRun from sync)
     enum { kNormal = 0, kHigh = 1, kLow = 2 };  // the runtime keeps a pool of hardware queues per priority
     bool claim(int device, hipStream_t* stream, int priority, const void* owner);
+    // another stream of the same priority in place of the claimed one (which stays parked, so that the pool deals elsewhere): a
+    // slab group whose hand-off's dry run did not come through on the streams it was dealt (SlabGroup::init)
+    bool replace(hipStream_t* stream);
+    int priorityClass = kNormal;
     void release();  // before the stream itself is destroyed
 };
 
@@ -260,6 +264,7 @@ private:
     std::vector<hipEvent_t> airDone_, genDone_;  // per-launch cross-stream dependencies (no timing)
     int stepWhich_ = 4;                    // launchStep's `which` of the merged launch (applyGeometry: | kStepGeneralPacked)
     QueueClaim queue_;                     // stream_'s hardware queue, apart from the other solvers' (Solver::init)
+    bool redealMainStream() { return queue_.replace(&stream_); }  // (before any run: nothing of the old stream is in flight)
     hipEvent_t forkEv_ = nullptr;
     hipEvent_t anaEv_[2] = {nullptr, nullptr};  // enqueueAnalysis: onsets known -> stream2_, decay times done -> stream_
     // captured launch schedule of one run (reset + all step launches on both streams), replayed per run
