@@ -876,6 +876,50 @@ def test_lazy_far_cells_equal_the_full_rewrite_1024(pvlib):
                 assert np.array_equal(rl.view(np.uint32), rf.view(np.uint32)), "result map, run %d" % k
 
 
+def test_near_box_closed_room_2048(pvlib, monkeypatch):
+    """Round 6: the analysis' window-wide far frame and direction passes are replaced by passes over the bounding box of the cells a
+    run REACHED (a device-side box left by the onset kernel; every other cell of the window is a far cell whose direction its readers
+    compute).  A closed room in a 2048^2 grid -- a box of ~75^2 cells in a 873^2-cell window -- with the listener moving inside the room,
+    then out into the open grid (a box that is the whole window, far from the previous one), then back: after every run the maps,
+    blocks across the room's wall and the window's edge, single outputs and output queries must equal the window-wide passes'
+    (PLANEVERB_AMD_NEAR_BOX=0), bit for bit."""
+    dx = np.float32(343.21) / np.float32(275) / np.float32(3.5)
+    n = 2048
+    size = float((n + 0.5) * dx)
+    scene = os.path.join(SCENES, "HugeRoom.pv")
+    cell = lambda cx, cy: ((cx + 0.5) * float(dx), 0.0, (cy + 0.5) * float(dx))
+    Ls = [(5.0, 0.0, 4.0), (20.0, 0.0, 20.0), cell(1500, 1200), (12.0, 0.0, 6.0), cell(900, 40), (5.0, 0.0, 20.0)]
+    probes = [(5.0, 0.0, 6.0), (24.0, 0.0, 24.0), (26.5, 0.0, 3.0), cell(1500, 1210), cell(1000, 1000), cell(2047, 2047), cell(80, 80)]
+    with pvlib.Solver(size, size, 275) as box:
+        monkeypatch.setenv("PLANEVERB_AMD_NEAR_BOX", "0")
+        with pvlib.Solver(size, size, 275) as wide:
+            monkeypatch.delenv("PLANEVERB_AMD_NEAR_BOX")
+            for s in (box, wide):
+                s.load_scene(scene)
+            for k, L in enumerate(Ls):
+                for s in (box, wide):
+                    s.set_output_queries(probes)
+                    s.run(L)
+                qa, qb = box.queried_outputs(), wide.queried_outputs()
+                assert np.array_equal(qa.view(np.uint32), qb.view(np.uint32)), "queries, run %d" % k
+                for p_ in probes[:4]:
+                    a, b = box.get_output(p_).as_array(), wide.get_output(p_).as_array()
+                    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "get_output, run %d" % k
+                # a block across the room's wall (the room is the grid's first ~71 x 71 cells) and one across the window's edge,
+                # BEFORE any whole-map read-back of this run
+                lcx, lcy = pvlib.host_cells(size, size, 275, L[0], L[2])[0]
+                for r0, c0 in ((40, 30), (max(0, min(lcx - 500, n - 301)), max(0, min(lcy + 300, n - 401)))):
+                    ba, bb = box.results_block(r0, c0, 300, 400), wide.results_block(r0, c0, 300, 400)
+                    assert np.array_equal(ba[0].view(np.uint32), bb[0].view(np.uint32)), "block at %d,%d, run %d" % (r0, c0, k)
+                    assert np.array_equal(ba[1].view(np.uint32), bb[1].view(np.uint32)), "delay block, run %d" % k
+                assert box.timings().reachedCells == wide.timings().reachedCells
+                if k != 1:  # (run 1 is followed by run 2 without a whole-map read-back in between)
+                    ra, da = box.results()
+                    rb, db = wide.results()
+                    assert np.array_equal(da.view(np.uint32), db.view(np.uint32)), "delay map, run %d" % k
+                    assert np.array_equal(ra.view(np.uint32), rb.view(np.uint32)), "result map, run %d" % k
+
+
 @pytest.mark.parametrize("fuse", [1, 0])
 def test_streaming_equals_full_history_2048_long(pvlib, fuse):
     """The regime the sparse-emitter mode lives in (parity-breadth note): fields non-zero everywhere and a response
