@@ -13,8 +13,11 @@ the two compiled forms that were measured slow on MI355X in round 3 (profiles/r0
     consumer: 18-23 % slower at 4096^2 / 8192^2.
 This script compiles pv_kernels.hip with the Makefile's flags and checks the large-grid instantiations for both.
 tests/test_host_cpu.py runs it, so that an unrelated edit cannot cost the headline silently.  The thresholds were taken on the
-compiler named in THRESHOLDS_TAKEN_ON; with another hipcc the numbers are printed and the verdict is "not judged" (exit code 0):
-a different register allocator needs its own measurement, not this one's bounds.
+compiler named in THRESHOLDS_TAKEN_ON.  Both checks are STRUCTURAL -- "no full wait inside the tile-load phase" holds or does not,
+and the measured-good / measured-bad counts of reloads inside the steps are 0-8 against 237 -- so another hipcc is judged by the
+same bounds (round 6; round 5 printed "not judged" there and left the two slow forms unguarded on every other toolchain): the
+verdict then says which compiler the bounds come from, and a violation is a reason to MEASURE, as it is on the known compiler
+(the test only warns unless PV_ISA_GUARD_STRICT=1).
 
     python tools/check_kernel_isa.py [file.s]      (exit code 1 on a violation)"""
 import collections
@@ -77,7 +80,8 @@ def compiler_version():
 def main():
     ver = compiler_version()
     judged = ver.startswith(THRESHOLDS_TAKEN_ON)
-    print("compiler: %s (thresholds taken on '%s...': %s)" % (ver, THRESHOLDS_TAKEN_ON, "judged" if judged else "NOT JUDGED, numbers only"))
+    print("compiler: %s (thresholds taken on '%s...': %s)" % (ver, THRESHOLDS_TAKEN_ON,
+                                                              "judged" if judged else "judged by the same structural bounds; another register allocator -- measure before trusting either verdict"))
     if len(sys.argv) > 1:
         asm = open(sys.argv[1]).read()
     else:
@@ -87,7 +91,7 @@ def main():
                                   cwd=CSRC, stderr=subprocess.DEVNULL)
             asm = open(out).read()
     ok = check(asm)
-    return 0 if (ok or not judged) else 1
+    return 0 if ok else 1
 
 
 if __name__ == "__main__":
