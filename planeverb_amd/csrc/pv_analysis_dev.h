@@ -269,10 +269,10 @@ __device__ __forceinline__ void rt60WaveBody(const AnalyzeArgs& a, const TabF& t
     for (int off = 16; off < 64; off <<= 1) n = max(n, __shfl_xor(n, off));
     n = __builtin_amdgcn_readfirstlane(n);
     float edc = 0.f, xysum = 0.f, ysum = 0.f;  // lane 15 of the row carries them from chunk to chunk
-    // kRt60Ahead chunks of loads in flight (round 6; one until then): a chunk's chains and logarithm take ~0.3 us of a wave's
-    // time, a load from a plane 150 KB - 3 MB further down ~1 us -- the pass waited a memory round trip per chunk (30 us for the
-    // 27 chunks of T = 435: profiles/r06_analysis_chain.txt).  A ring of fixed registers, the loop unrolled over it, every load
-    // issued in consumption order (the wait counts then retire one chunk at a time).  Same additions in the same order.
+    // kRt60Ahead chunks of loads in flight (round 6; one until then): a ring of fixed registers, the loop unrolled over it, every
+    // load issued in consumption order (the wait counts then retire one chunk at a time).  Same additions in the same order.
+    // Measured: no change -- the pass is bound by its dependent DPP chains and the logarithm, not by the loads (what did help is
+    // the logarithm's table in LDS: profiles/r06_analysis_chain.txt); kept, it costs nothing and takes the loads off the table.
     float ring[kRt60Ahead];
 #pragma unroll
     for (int b = 0; b < kRt60Ahead; ++b) {
@@ -392,8 +392,8 @@ __device__ __forceinline__ void rt60BlockedBody(const AnalyzeArgs& a, const LogT
     for (int off = 1; off < 64; off <<= 1) n = max(n, __shfl_xor(n, off));
     n = __builtin_amdgcn_readfirstlane(n);  // (wave-uniform by value: scalar loop counters and branches)
     float edc = 0.f, xysum = 0.f, ysum = 0.f;
-    // kRt60Ahead chunks of loads in flight, as in rt60WaveBody (round 6; one until then: 124 us for 36 000 cells at T = 1187, two
-    // waves per SIMD waiting a memory round trip per chunk of 16 samples)
+    // kRt60Ahead chunks of loads in flight, as in rt60WaveBody (round 6; one until then).  Measured: no change -- 125 us for 36 000
+    // cells at T = 1187 either way: 2 176 waves of ~21 000 dependent instructions on 1 024 SIMDs, two or three waves per SIMD decide
     float ring[kRt60Ahead][S];
 #pragma unroll
     for (int b = 0; b < kRt60Ahead; ++b) {

@@ -317,11 +317,12 @@ struct AnalyzeArgs {
     // T = 435), a closed room reaches a few thousand of them -- and the far frame and the listener-direction passes moved 62 MB
     // per run for them (profiles/r05_analysis_pmc.md).  box = four device words {r0, c0, r1, c1}, the inclusive bounding box of
     // the cells pv_onset_kernel finds an onset in (atomics; empty = {INT_MAX, INT_MAX, -1, -1}); prevBox = the same of the
-    // previous analysed run of this solver.  With them the first launch resets only prevBox's cells to "no onset"
-    // (pv_near_reset_kernel), the direction passes cover the box grown by one cell (a cell further away has no neighbour with
-    // an onset: its walk stays put, Analyzer.cpp:365-391 -- the closed form), and every other cell of the window is a far cell
-    // like the ones outside it (FarInfo::box).  pv_onset_kernel empties prevBox for the run after the next.  NULL: the
-    // window-wide passes (slabs, whole-grid windows, the experimental one-launch analysis).
+    // previous analysed run of this solver.  With them there is no far-frame launch: pv_onset_kernel itself gives "no onset" back
+    // to prevBox's cells that this run does not reach (every other cell of the map holds it already); the direction passes cover
+    // the box grown by one cell (a cell further away has no neighbour with an onset: its walk stays put, Analyzer.cpp:365-391 --
+    // the closed form), and every other cell of the window is a far cell like the ones outside it (FarInfo::box).  The decay-time
+    // launch behind the onsets (pv_rt60_groups_kernel) empties prevBox: it is the box of the run after this one.  NULL: the
+    // window-wide passes (slabs, whole-grid windows, the experimental one-launch analysis, PLANEVERB_AMD_NEAR_BOX=0).
     int* box;
     int* prevBox;
     unsigned long long* stamp;  // pinned host words, or NULL: stamp[1] = the 100 MHz counter when the analysis' first kernel starts
