@@ -205,6 +205,9 @@ typedef struct PvAmdSlabInfo {
     long long haloBytesPerLaunch;        /* pr, vx, vy boundary rows moved between slabs per K-step launch */
     long long exchangeBytesPerRun;       /* boundary histories + result blocks of the last run */
     long long deviceBytes[16];           /* HBM held by slab i (whole-grid result maps: see PvAmdGetInfo) */
+    int handoffWords;                    /* 1: slabs of one device hand over through words in device memory, 0: stream events */
+    int streamRedeals;                   /* times every slab was given another stream at creation: the hand-off's dry run timed out or was slow */
+    float dryRunUsPerSweep;              /* how long a sweep of that dry run took (launches and sync included; ~4 us per slab when the streams run beside each other) */
 } PvAmdSlabInfo;
 PVA_EXPORT int PvAmdGetSlabInfo(PvAmdSolver* s, PvAmdSlabInfo* out);
 /* The same decomposition with the slabs in DIFFERENT PROCESSES (one rank per GPU): a rank creates ITS slab, the host

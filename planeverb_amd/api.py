@@ -84,7 +84,8 @@ class PvAmdInfo(C.Structure):
 class PvAmdSlabInfo(C.Structure):
     _fields_ = [("nslabs", C.c_int), ("row0", C.c_int * 16), ("rows", C.c_int * 16), ("device", C.c_int * 16),
                 ("haloBytesPerLaunch", C.c_longlong), ("exchangeBytesPerRun", C.c_longlong),
-                ("deviceBytes", C.c_longlong * 16)]
+                ("deviceBytes", C.c_longlong * 16), ("handoffWords", C.c_int), ("streamRedeals", C.c_int),
+                ("dryRunUsPerSweep", C.c_float)]
 
 
 class PvAmdTimings(C.Structure):

@@ -315,6 +315,9 @@ int PvAmdGetSlabInfo(PvAmdSolver* h, PvAmdSlabInfo* out) try {
     }
     out->haloBytesPerLaunch = h->g->haloBytesPerLaunch();
     out->exchangeBytesPerRun = h->g->exchangeBytesPerRun();
+    out->handoffWords = h->g->handoffWords() ? 1 : 0;
+    out->streamRedeals = h->g->streamRedeals();
+    out->dryRunUsPerSweep = h->g->dryRunUsPerSweep();
     return 0;
 } PV_API_CATCH(-1)
 

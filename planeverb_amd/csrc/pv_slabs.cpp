@@ -134,7 +134,10 @@ bool SlabGroup::init(const GridSpec& spec, const std::vector<int>& devices, cons
             // 5.0-7.3 instead of 2.6-6.2 ms (profiles/r06_slabs.txt; the pairwise sleeper / stamp probe of QueueClaim sees nothing there)
             bool ok = forced || probeHandoff();
             const float slowUs = 6.5f * (float)S;
-            for (int attempt = 0; !forced && (!ok || probeUsPerSweep_ > slowUs) && attempt < 3; ++attempt) {
+            const char* fr = getenv("PLANEVERB_AMD_SLAB_REDEAL");  // (tests: 1 = one re-deal whatever the dry run said)
+            const bool forceRedeal = fr && atoi(fr) == 1;
+            for (int attempt = 0; !forced && (!ok || probeUsPerSweep_ > slowUs || (forceRedeal && attempt == 0)) && attempt < 3; ++attempt) {
+                ++redeals_;
                 bool dealt = true;
                 for (Solver* sv : slabs_) {
                     hipSetDevice(sv->device_);

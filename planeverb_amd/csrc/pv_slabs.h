@@ -30,9 +30,13 @@ public:
     ~SlabGroup();
     static constexpr int kProbeSweeps = 16;  // sweeps of the hand-off's dry run (probeHandoff)
     float probeUsPerSweep_ = 0.f;            // how long one of them took, launches and sync included
+    int redeals_ = 0;                        // times every slab was given another stream because the dry run was slow or timed out
 
     const GridSpec& spec() const { return g_; }
     int numSlabs() const { return (int)slabs_.size(); }
+    bool handoffWords() const { return handoff_ != nullptr; }
+    int streamRedeals() const { return redeals_; }
+    float dryRunUsPerSweep() const { return probeUsPerSweep_; }
     const Solver* slab(int s) const { return slabs_[(size_t)s]; }
     int slabRow0(int s) const { return slabs_[(size_t)s]->x0_; }
     int slabRows(int s) const { return slabs_[(size_t)s]->lNX_; }

@@ -225,3 +225,28 @@ def test_slab_handoff_words_equal_events(pvlib, nslabs, monkeypatch):
                     assert same_bits(ra[..., k], r[..., k]).all(), "result plane %d, hand-off %s, run %d" % (k, mode, i)
                 for fa, fb in zip(a.fields(), f):
                     assert same_bits(fa, fb).all(), "final fields, hand-off %s, run %d" % (mode, i)
+
+
+def test_slab_streams_redealt_at_creation(pvlib, monkeypatch):
+    """Round 6: a slab group whose hand-off's dry run times out OR comes through slowly (its slabs' streams take turns instead of running
+    beside each other: 5.0-7.3 instead of 2.6-6.2 ms per run, profiles/r06_slabs.txt) gives every slab another stream and tries
+    again (QueueClaim::replace).  PLANEVERB_AMD_SLAB_REDEAL=1 forces one such re-deal: the group must come up with the hand-off words
+    on, report the re-deal, and give one solver's bits over consecutive runs."""
+    n = 1024
+    Ls = [cell(300, 400), cell(511, 700), cell(800, 90)]
+    monkeypatch.setenv("PLANEVERB_AMD_SLAB_REDEAL", "1")
+    with pvlib.Solver(size_of(n), size_of(n), 275) as a, pvlib.Solver(size_of(n), size_of(n), 275, slabs=[0, 0]) as b:
+        si = b.slab_info()
+        assert si.handoffWords == 1 and si.streamRedeals >= 1 and 0.0 < si.dryRunUsPerSweep < 1000.0, (si.handoffWords, si.streamRedeals, si.dryRunUsPerSweep)
+        for s in (a, b):
+            s.add_geometry([Ls[0][0] + 2.0, Ls[0][2] + 7.0, 60.0, 1.5, 0.8])
+        for i, L in enumerate(Ls):
+            a.run(L)
+            b.run(L)
+            ra, da = a.results()
+            rb, db = b.results()
+            assert same_bits(da, db).all(), "delay map, run %d" % i
+            for k in range(8):
+                assert same_bits(ra[..., k], rb[..., k]).all(), "result plane %d, run %d" % (k, i)
+            for fa, fb in zip(a.fields(), b.fields()):
+                assert same_bits(fa, fb).all(), "final fields, run %d" % i
